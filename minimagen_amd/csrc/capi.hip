@@ -1,0 +1,34 @@
+// C-ABI plumbing: error reporting, version, HIP-graph helpers.
+#include "common.hip.h"
+#include <cstdarg>
+#include <cstdio>
+
+static thread_local char g_err[512] = "";
+
+void mi_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int mi_check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        mi_set_error("%s: %s", what, hipGetErrorString(e));
+        return MI_ERR_LAUNCH;
+    }
+    return MI_OK;
+}
+
+extern "C" int mi_abi_version(void) { return MI_ABI_VERSION; }
+extern "C" const char* mi_last_error(void) { return g_err; }
+extern "C" const char* mi_backend(void) { return MI_BACKEND_STRING; }   // set by the build line
+extern "C" int mi_struct_size(int which) {
+    switch (which) {
+        case 0: return (int)sizeof(mi_act);
+        case 1: return (int)sizeof(mi_conv_params);
+        case 2: return (int)sizeof(mi_crossembed_params);
+    }
+    return -1;
+}

@@ -1,0 +1,305 @@
+// K4 / K6 / K7 / K8 / final conv: the direct-convolution family for narrow NCHW fp32
+// activations (8..32 channels), MinImagen layers.py:107-145 (Block), :308-319 (Downsample),
+// :346-356 (Parallel, 1x1 folded into the 3x3 centre tap by the host), :502-515 (Upsample),
+// :415/:439 (ResnetBlock residual).  HBM-bound by design: one pass over the input (halo tile
+// staged once through LDS with GroupNorm-apply + scale/shift + SiLU fused into the staging),
+// all output channels of a channel tile held in VGPRs per work-item, weights broadcast from
+// SGPRs (wave-uniform addresses), and the NEXT GroupNorm's per-channel partial statistics
+// emitted from the epilogue so no tensor is ever re-read for normalisation.
+#include "common.hip.h"
+
+namespace {
+
+template <int NT_, int TW_, int COUT_T_, int KS_, int S_, bool UP2_>
+struct ConvCfg {
+    static constexpr int NT = NT_, TW = TW_, COUT_T = COUT_T_, KS = KS_, S = S_;
+    static constexpr bool UP2 = UP2_;
+    static constexpr int TXN = TW / 4;            // work-items along x (4 output pixels each)
+    static constexpr int TH = NT / TXN;           // output rows per tile (1 row per work-item)
+    static constexpr int IH = TH * S + KS - S;    // staged input rows / cols (with halo)
+    static constexpr int IW = TW * S + KS - S;
+    static constexpr int IWP = (IW + 3) & ~3;     // LDS row pitch (16-byte aligned rows)
+    static constexpr int CK = (S == 2) ? 2 : 8;   // input channels staged per round
+    static constexpr int NIN = 4 * S + KS - S;    // input floats per row a work-item consumes
+    static constexpr int STAGE_FLOATS = CK * IH * IWP;
+    static constexpr int RED_FLOATS = 2 * COUT_T * (NT + 1);
+    static constexpr int SMEM_FLOATS = STAGE_FLOATS > RED_FLOATS ? STAGE_FLOATS : RED_FLOATS;
+};
+
+template <class CFG>
+__global__ __launch_bounds__(CFG::NT) void conv_tile_kernel(const mi_conv_params p, const int CoutPad) {
+    constexpr int NT = CFG::NT, TW = CFG::TW, TH = CFG::TH, TXN = CFG::TXN, COUT_T = CFG::COUT_T;
+    constexpr int KS = CFG::KS, S = CFG::S, IH = CFG::IH, IW = CFG::IW, IWP = CFG::IWP, CK = CFG::CK, NIN = CFG::NIN;
+    constexpr bool UP2 = CFG::UP2;
+
+    __shared__ __attribute__((aligned(16))) float smem[CFG::SMEM_FLOATS];
+    __shared__ float chA[MI_MAX_CIN], chB[MI_MAX_CIN];
+    __shared__ double chS[MI_MAX_CIN], chQ[MI_MAX_CIN];
+    __shared__ float gMean[MI_MAX_GROUPS], gRstd[MI_MAX_GROUPS];
+
+    const int tid = threadIdx.x;
+    const int tiles_x = (p.W + TW - 1) / TW;
+    const int tile = blockIdx.x;
+    const int oy0 = (tile / tiles_x) * TH, ox0 = (tile % tiles_x) * TW;
+    const int b = blockIdx.y;
+    const int co0 = blockIdx.z * COUT_T;
+    const int C0 = p.in0.C, C1 = p.in1.data ? p.in1.C : 0, Cin = C0 + C1;
+    // real input extent, and the extent of the (virtual) image the taps address
+    const int Hin = UP2 ? p.H / 2 : p.H * S, Win = UP2 ? p.W / 2 : p.W * S;
+    const int Hv = UP2 ? p.H : Hin, Wv = UP2 ? p.W : Win;
+
+    // ---------------- prologue: per-channel affine for the fused GroupNorm / scale-shift
+    if (p.gn_groups > 0) {
+        for (int base = 0; base < Cin; base += NT / 4) {
+            const int c = base + (tid >> 2), sub = tid & 3;
+            double s = 0.0, q = 0.0;
+            if (c < Cin) {
+                const bool second = c >= C0;
+                const mi_act& a = second ? p.in1 : p.in0;
+                const int cc = second ? c - C0 : c;
+                const float* st = a.stats + ((size_t)(b * a.C + cc) * a.nt) * 2;
+                for (int t = sub; t < a.nt; t += 4) {
+                    const float2 v = *reinterpret_cast<const float2*>(st + 2 * t);
+                    s += (double)v.x;
+                    q += (double)v.y;
+                }
+                s *= (double)a.scale;
+                q *= (double)a.scale * (double)a.scale;
+            }
+            s += __shfl_xor(s, 1); s += __shfl_xor(s, 2);
+            q += __shfl_xor(q, 1); q += __shfl_xor(q, 2);
+            if (c < Cin && sub == 0) { chS[c] = s; chQ[c] = q; }
+        }
+        __syncthreads();
+        const int cpg = Cin / p.gn_groups;
+        for (int g = tid; g < p.gn_groups; g += NT) {
+            double s = 0.0, q = 0.0;
+            for (int c = g * cpg; c < (g + 1) * cpg; ++c) { s += chS[c]; q += chQ[c]; }
+            const double n = (double)cpg * (double)Hin * (double)Win;
+            const double mean = s / n;
+            double var = q / n - mean * mean;
+            var = var > 0.0 ? var : 0.0;
+            gMean[g] = (float)mean;
+            gRstd[g] = (float)(1.0 / sqrt(var + (double)p.gn_eps));
+        }
+        __syncthreads();
+        for (int c = tid; c < Cin; c += NT) {
+            const int g = c / cpg;
+            float A = gRstd[g] * p.gn_gamma[c];
+            float Bc = p.gn_beta[c] - gMean[g] * A;
+            if (p.scale_shift) {
+                const float* ss = p.scale_shift + (size_t)b * p.ss_stride + p.ss_off;
+                const float sc = ss[c] + 1.0f, sh = ss[Cin + c];
+                A *= sc;
+                Bc = Bc * sc + sh;
+            }
+            if (c >= C0) A *= p.in1.scale; else A *= p.in0.scale;
+            chA[c] = A;
+            chB[c] = Bc;
+        }
+    } else {
+        for (int c = tid; c < Cin; c += NT) { chA[c] = (c >= C0) ? p.in1.scale : p.in0.scale; chB[c] = 0.0f; }
+    }
+
+    const int ty = tid / TXN, tx = tid % TXN;
+    float acc[4][COUT_T];
+#pragma unroll
+    for (int px = 0; px < 4; ++px)
+#pragma unroll
+        for (int co = 0; co < COUT_T; ++co) acc[px][co] = 0.0f;
+
+    const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;   // pad = 1 for every member of the family
+    const bool gn = p.gn_groups > 0;
+
+    for (int c0 = 0; c0 < Cin; c0 += CK) {
+        __syncthreads();   // previous round fully consumed (and chA/chB visible on the first round)
+        // ---- stage CK channels of the activated input tile (zero outside the image: padding follows the activation)
+        for (int idx = tid; idx < CK * IH * IW; idx += NT) {
+            const int ix = idx % IW, r = idx / IW;
+            const int iy = r % IH, ck = r / IH;
+            const int c = c0 + ck;
+            const int gy = iy0 + iy, gx = ix0 + ix;
+            float v = 0.0f;
+            if (c < Cin && gy >= 0 && gy < Hv && gx >= 0 && gx < Wv) {
+                const int sy = UP2 ? (gy >> 1) : gy, sx = UP2 ? (gx >> 1) : gx;
+                const float* src = (c < C0) ? p.in0.data + ((size_t)(b * C0 + c) * Hin + sy) * Win + sx
+                                            : p.in1.data + ((size_t)(b * C1 + (c - C0)) * Hin + sy) * Win + sx;
+                const float x = *src;
+                v = gn ? mi_silu(fmaf(x, chA[c], chB[c])) : x * chA[c];
+            }
+            smem[(ck * IH + iy) * IWP + ix] = v;
+        }
+        __syncthreads();
+        // ---- accumulate
+        const int nck = (Cin - c0) < CK ? (Cin - c0) : CK;
+        for (int ck = 0; ck < nck; ++ck) {
+            const float* wc = p.w + (size_t)(c0 + ck) * KS * KS * CoutPad + co0;
+#pragma unroll
+            for (int ky = 0; ky < KS; ++ky) {
+                float in[NIN];
+                const float* row = &smem[(ck * IH + ty * S + ky) * IWP + tx * 4 * S];
+#pragma unroll
+                for (int j = 0; j < NIN; ++j) in[j] = row[j];
+#pragma unroll
+                for (int kx = 0; kx < KS; ++kx) {
+                    const float* wk = wc + (ky * KS + kx) * CoutPad;
+#pragma unroll
+                    for (int co = 0; co < COUT_T; ++co) {
+                        const float wv = wk[co];
+#pragma unroll
+                        for (int px = 0; px < 4; ++px) acc[px][co] = fmaf(in[px * S + kx], wv, acc[px][co]);
+                    }
+                }
+            }
+        }
+    }
+
+    // ---------------- epilogue: bias, residual, store, statistics of the output
+    const int oy = oy0 + ty, ox = ox0 + tx * 4;
+    const bool row_ok = oy < p.H;
+    const int Cres0 = p.res0.data ? p.res0.C : 0, Cres1 = (p.res0.data && p.res1.data) ? p.res1.C : 0;
+#pragma unroll
+    for (int co = 0; co < COUT_T; ++co) {
+        const float bv = (p.bias && (co0 + co) < p.Cout) ? p.bias[co0 + co] : 0.0f;
+#pragma unroll
+        for (int px = 0; px < 4; ++px) acc[px][co] += bv;
+    }
+    if (p.res0.data && row_ok) {
+        if (p.res_w) {
+            for (int cr = 0; cr < Cres0 + Cres1; ++cr) {
+                const bool second = cr >= Cres0;
+                const float* src = second ? p.res1.data + ((size_t)(b * Cres1 + (cr - Cres0)) * p.H + oy) * p.W
+                                          : p.res0.data + ((size_t)(b * Cres0 + cr) * p.H + oy) * p.W;
+                const float sc = second ? p.res1.scale : p.res0.scale;
+                float xv[4];
+#pragma unroll
+                for (int px = 0; px < 4; ++px) xv[px] = (ox + px < p.W) ? src[ox + px] * sc : 0.0f;
+                const float* wr = p.res_w + (size_t)cr * CoutPad + co0;
+#pragma unroll
+                for (int co = 0; co < COUT_T; ++co) {
+                    const float wv = wr[co];
+#pragma unroll
+                    for (int px = 0; px < 4; ++px) acc[px][co] = fmaf(xv[px], wv, acc[px][co]);
+                }
+            }
+#pragma unroll
+            for (int co = 0; co < COUT_T; ++co) {
+                const float bv = (p.res_b && (co0 + co) < p.Cout) ? p.res_b[co0 + co] : 0.0f;
+#pragma unroll
+                for (int px = 0; px < 4; ++px) acc[px][co] += bv;
+            }
+        } else {
+#pragma unroll
+            for (int co = 0; co < COUT_T; ++co) {
+                if (co0 + co < p.Cout) {
+                    const float* src = p.res0.data + ((size_t)(b * Cres0 + co0 + co) * p.H + oy) * p.W;
+#pragma unroll
+                    for (int px = 0; px < 4; ++px)
+                        if (ox + px < p.W) acc[px][co] += src[ox + px] * p.res0.scale;
+                }
+            }
+        }
+    }
+    float ssum[COUT_T], ssq[COUT_T];
+#pragma unroll
+    for (int co = 0; co < COUT_T; ++co) {
+        float s = 0.0f, q = 0.0f;
+        if (row_ok && (co0 + co) < p.Cout) {
+            float* dst = p.out + ((size_t)(b * p.Cout + co0 + co) * p.H + oy) * p.W + ox;
+            if (ox + 3 < p.W && (p.W & 3) == 0) {
+                *reinterpret_cast<float4*>(dst) = make_float4(acc[0][co], acc[1][co], acc[2][co], acc[3][co]);
+#pragma unroll
+                for (int px = 0; px < 4; ++px) { s += acc[px][co]; q = fmaf(acc[px][co], acc[px][co], q); }
+            } else {
+#pragma unroll
+                for (int px = 0; px < 4; ++px)
+                    if (ox + px < p.W) { dst[px] = acc[px][co]; s += acc[px][co]; q = fmaf(acc[px][co], acc[px][co], q); }
+            }
+        }
+        ssum[co] = s;
+        ssq[co] = q;
+    }
+    if (p.out_stats) {
+        constexpr int R = 2 * COUT_T, SEG = NT / R;
+        __syncthreads();   // staging buffer no longer read
+#pragma unroll
+        for (int co = 0; co < COUT_T; ++co) {
+            smem[(2 * co) * (NT + 1) + tid] = ssum[co];
+            smem[(2 * co + 1) * (NT + 1) + tid] = ssq[co];
+        }
+        __syncthreads();
+        const int rrow = tid / SEG, seg = tid % SEG;
+        float a = 0.0f;
+        for (int i = seg; i < NT; i += SEG) a += smem[rrow * (NT + 1) + i];
+#pragma unroll
+        for (int o = SEG / 2; o > 0; o >>= 1) a += __shfl_xor(a, o);
+        const int co = co0 + (rrow >> 1);
+        if (seg == 0 && co < p.Cout) {
+            const int nt = gridDim.x;
+            p.out_stats[((size_t)(b * p.Cout + co) * nt + tile) * 2 + (rrow & 1)] = a;
+        }
+    }
+}
+
+template <int NT, int TW, int COUT_T, int KS, int S, bool UP2>
+int launch_conv(const mi_conv_params& p, hipStream_t st) {
+    using CFG = ConvCfg<NT, TW, COUT_T, KS, S, UP2>;
+    const int tiles = ((p.H + CFG::TH - 1) / CFG::TH) * ((p.W + TW - 1) / TW);
+    const int cz = (p.Cout + COUT_T - 1) / COUT_T;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_tile_kernel<CFG>), dim3(tiles, p.B, cz), dim3(NT), 0, st, p, cz * COUT_T);
+    return mi_check_launch("conv_tile_kernel");
+}
+
+template <int COUT_T, int KS, int S, bool UP2>
+int dispatch_tile(const mi_conv_params& p, hipStream_t st) {
+    switch (p.tile_cfg) {
+        case 0: return launch_conv<256, 64, COUT_T, KS, S, UP2>(p, st);
+        case 1: return launch_conv<256, 32, COUT_T, KS, S, UP2>(p, st);
+        case 2: return launch_conv<64, 32, COUT_T, KS, S, UP2>(p, st);
+    }
+    mi_set_error("mi_conv_fwd: bad tile_cfg %d", p.tile_cfg);
+    return MI_ERR_INVALID;
+}
+
+}  // namespace
+
+extern "C" int mi_conv_tile_shape(int tile_cfg, int* th, int* tw) {
+    switch (tile_cfg) {
+        case 0: *th = 16; *tw = 64; return MI_OK;
+        case 1: *th = 32; *tw = 32; return MI_OK;
+        case 2: *th = 8; *tw = 32; return MI_OK;
+    }
+    return MI_ERR_INVALID;
+}
+
+extern "C" int mi_conv_cout_tile(int Cout) { return Cout <= 4 ? 4 : (Cout % 16 == 0 ? 16 : 8); }
+
+extern "C" int mi_conv_fwd(const mi_conv_params* pp, void* stream) {
+    const mi_conv_params& p = *pp;
+    hipStream_t st = (hipStream_t)stream;
+    const int Cin = p.in0.C + (p.in1.data ? p.in1.C : 0);
+    if (Cin > MI_MAX_CIN || p.gn_groups > MI_MAX_GROUPS) { mi_set_error("mi_conv_fwd: Cin %d / groups %d too large for the direct-conv family", Cin, p.gn_groups); return MI_ERR_UNSUPPORTED; }
+    if (p.gn_groups > 0 && (Cin % p.gn_groups) != 0) { mi_set_error("mi_conv_fwd: Cin %d not divisible by groups %d", Cin, p.gn_groups); return MI_ERR_INVALID; }
+    if (p.gn_groups > 0 && (!p.in0.stats || (p.in1.data && !p.in1.stats))) { mi_set_error("mi_conv_fwd: GroupNorm input without channel statistics"); return MI_ERR_INVALID; }
+    if (p.res0.data && !p.res_w && p.res0.C != p.Cout) { mi_set_error("mi_conv_fwd: identity residual needs Cres == Cout"); return MI_ERR_INVALID; }
+    if (p.B <= 0 || p.H <= 0 || p.W <= 0 || p.Cout <= 0) { mi_set_error("mi_conv_fwd: empty problem"); return MI_ERR_INVALID; }
+    if (p.up2 && ((p.H | p.W) & 1)) { mi_set_error("mi_conv_fwd: up2 needs even output size"); return MI_ERR_INVALID; }
+    const int ct = mi_conv_cout_tile(p.Cout);
+    if (p.ksize == 3 && p.stride == 1 && !p.up2) {
+        if (ct == 4) return dispatch_tile<4, 3, 1, false>(p, st);
+        if (ct == 8) return dispatch_tile<8, 3, 1, false>(p, st);
+        return dispatch_tile<16, 3, 1, false>(p, st);
+    }
+    if (p.ksize == 3 && p.stride == 1 && p.up2) {
+        if (ct == 16) return dispatch_tile<16, 3, 1, true>(p, st);
+        if (ct == 8) return dispatch_tile<8, 3, 1, true>(p, st);
+        return dispatch_tile<4, 3, 1, true>(p, st);
+    }
+    if (p.ksize == 4 && p.stride == 2 && !p.up2) {
+        if (ct == 16) return dispatch_tile<16, 4, 2, false>(p, st);
+        if (ct == 8) return dispatch_tile<8, 4, 2, false>(p, st);
+        return dispatch_tile<4, 4, 2, false>(p, st);
+    }
+    mi_set_error("mi_conv_fwd: unsupported conv k%d s%d up%d", p.ksize, p.stride, p.up2);
+    return MI_ERR_UNSUPPORTED;
+}
