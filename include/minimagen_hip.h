@@ -49,6 +49,8 @@ typedef struct mi_act {
     const float* stats;  /* [B][C][nt][2] partial (sum, sumsq); may be NULL when no GroupNorm consumes it */
     int nt;
     float scale;         /* multiplies the data when consumed (skip connections: 2^-1/2, Unet.py:445) */
+    int bmod;            /* >0: the tensor has only `bmod` batch rows, row b%bmod is used (tensors shared by the
+                            conditional and null halves of a classifier-free-guidance batch) */
 } mi_act;
 
 /* ---- K4/K6/K7/K8/K11: the conv family --------------------------------------------------
@@ -101,6 +103,174 @@ typedef struct mi_crossembed_params {
     int tile_cfg;
 } mi_crossembed_params;
 int mi_crossembed_fwd(const mi_crossembed_params* p, void* stream);
+
+/* ---- conditioning --------------------------------------------------------------------- */
+typedef struct mi_linear {   /* torch nn.Linear layout: w[out][in], b[out] (b may be NULL) */
+    const float* w; const float* b; int in, out;
+} mi_linear;
+
+/* K2: text conditioning, once per sample() (Unet._text_condition, Unet.py:571-634, minus the
+ * time-token rows): text_to_cond -> truncate/pad to max_len -> mask / CFG-drop to null_text_embed
+ * -> mean-pool -> to_text_non_attn_cond (LayerNorm, Linear, SiLU, Linear) -> null_text_hidden
+ * select; and norm_cond (LayerNorm, per row) of the text rows of c.  Row b' of the outputs uses
+ * text row b' % B and keep[b'] (the all-True / all-False prob_mask_like of Unet.py:587). */
+typedef struct mi_text_cond_params {
+    int B2, B, L, E, cd, tcd, max_len;
+    const float* text_embeds;       /* [B][L][E] */
+    const uint8_t* text_mask;       /* [B][L] or NULL (all valid) */
+    const uint8_t* keep;            /* [B2] */
+    mi_linear text_to_cond;
+    const float* null_text_embed;   /* [max_len][cd] */
+    const float* ln_w; const float* ln_b;   /* to_text_non_attn_cond.0 */
+    mi_linear h1, h2;               /* to_text_non_attn_cond.1 / .3 */
+    const float* null_text_hidden;  /* [tcd] */
+    const float* norm_w; const float* norm_b;  /* norm_cond */
+    float* c_text;                  /* out [B2][max_len][cd] */
+    float* text_hiddens;            /* out [B2][tcd] */
+} mi_text_cond_params;
+int mi_text_cond_fwd(const mi_text_cond_params* p, void* stream);
+
+/* K1 + K5, every denoising step: sinusoidal embedding -> to_time_hiddens -> {to_time_cond,
+ * to_time_tokens} (+ the lowres trio, Unet.py:508-536), t += text_hiddens (Unet.py:626),
+ * norm_cond of the time-token rows (Unet.py:629-632), and every ResnetBlock's
+ * time_mlp = Linear(SiLU(t)) (layers.py:395-399,425-429) in one launch. */
+typedef struct mi_cond_step_params {
+    int B2, B, dim, cd, tcd, ntok;
+    const int64_t* time;            /* [B] */
+    const int64_t* lowres_time;     /* [B] or NULL */
+    const float* freq;              /* [dim/2] = exp(arange(dim/2) * -(ln 1e4/(dim/2-1)))  (layers.py:461-463) */
+    mi_linear th, tc, tt;           /* to_time_hiddens.1, to_time_cond.0, to_time_tokens.0 */
+    mi_linear lth, ltc, ltt;        /* to_lowres_time_* (w == NULL when not lowres_cond) */
+    const float* text_hiddens;      /* [B2][tcd] or NULL */
+    const float* norm_w; const float* norm_b;
+    mi_linear time_mlps;            /* all ResnetBlock time_mlp.1 stacked: [R][tcd] */
+    float* ss;                      /* out [B2][R] */
+    float* c_time;                  /* out [B2][ntok_total][cd], ntok_total = ntok * (1 + lowres) */
+    float* t_out;                   /* out [B2][tcd] or NULL */
+} mi_cond_step_params;
+int mi_cond_step_fwd(const mi_cond_step_params* p, void* stream);
+
+/* ---- K9: bottleneck cross-attention, folded form ---------------------------------------
+ * CrossAttention (layers.py:220-251) inside ResnetBlock (layers.py:433-435) when
+ * C (=dim_out) and cond_dim are below dim_head=64: with x^ = LN(x),
+ *     sim_h = x^ . (scale * Wq_h^T Wk_h) . c^T           (C x cond_dim matrix per head)
+ *     out   = sum_h softmax(sim_h) . (c . Wv_h^T Wo_h^T)
+ * so the 512-wide q/k/v/out tensors never exist.  mi_attn_fold_rows turns context rows into
+ * MFMA A-operand fragments ("gv"); mi_cross_attn_fwd does LN -> QK^T -> softmax -> PV ->
+ * to_out.1 LayerNorm -> + residual with v_mfma_f32_16x16x4_f32 (exact fp32).
+ *   gv layout: [B2][heads][JT][64 lanes][FR], FR = max(4, C/4) + 4*ceil(C/16); context row j
+ *   lives in tile j/16.  Row 0 is the null key/value, rows 1.. the time tokens, then 256 text rows. */
+#define MI_ATTN_MAX_BLOCKS 8
+typedef struct mi_attn_fold_params {
+    int B2, C, cd, heads, JT;
+    const float* c_rows;            /* [B2][nrows][cd] rows (already norm_cond-ed) */
+    int c_stride_b;                 /* floats between consecutive b' in c_rows */
+    int row0, nrows;                /* they become context rows row0 .. row0+nrows-1 */
+    int write_null;                 /* also write context row 0 from g0 / v0 */
+    int n_blocks;
+    struct {
+        const float* mg;            /* [heads][C][cd]  log2(e) * scale * Wq_h^T Wk_h */
+        const float* mv;            /* [heads][C][cd]  Wo_h Wv_h */
+        const float* g0;            /* [heads][C]      log2(e) * scale * Wq_h^T null_k */
+        const float* v0;            /* [heads][C]      Wo_h null_v */
+        float* gv;
+    } blk[MI_ATTN_MAX_BLOCKS];
+} mi_attn_fold_params;
+int mi_attn_fold_rows(const mi_attn_fold_params* p, void* stream);
+int mi_attn_fragment_floats(int C);     /* FR */
+
+typedef struct mi_cross_attn_params {
+    int B2, C, HW, heads, J;        /* J = 1 + time tokens + 256 */
+    mi_act x;                       /* block1 output h [B2][C][HW]; also the residual */
+    const float* gv;
+    const float* n1_g; const float* n1_b;   /* CrossAttention.norm   gamma / beta */
+    const float* n2_g; const float* n2_b;   /* to_out.1              gamma / beta */
+    float* out; float* out_stats;   /* [B2][C][HW]; stats [B2][C][ceil(HW/128)][2] */
+} mi_cross_attn_params;
+int mi_cross_attn_fwd(const mi_cross_attn_params* p, void* stream);
+#define MI_ATTN_TOKENS_PER_WG 128
+
+/* ---- sampler (Imagen._p_mean_variance / _p_sample, Imagen.py:261-370) ------------------
+ * Per-stage device state so that one HIP graph can be replayed for every timestep:
+ *   int   t_state[1]   current timestep t (T-1 .. 0)
+ *   float coef[T][8]   { sqrt_recip_alphas_cumprod, sqrt_recipm1_alphas_cumprod, posterior_mean_coef1,
+ *                        posterior_mean_coef2, [t != 0] * exp(0.5 * posterior_log_variance_clipped), 0, 0, 0 }
+ *                      (tables built by the host in fp64 then cast, exactly as diffusion_model.py:28-66)
+ */
+/* K11 epilogue: classifier-free-guidance combine (Unet.py:506) + predict_start_from_noise
+ * (diffusion_model.py:159-162).  pred2 holds the conditional rows [0,B) and, when cond_scale != 1,
+ * the null rows [B,2B). */
+typedef struct mi_cfg_x0_params {
+    int B, n;                     /* n = C*H*W elements per image */
+    const float* pred2;
+    int two;                      /* 1: pred2 has 2B rows and the combine runs */
+    float cond_scale;
+    const float* x_t;             /* [B][n]; may be NULL when only pred_out is wanted */
+    const float* coef; const int* t_state;
+    float* pred_out;              /* [B][n] guided prediction or NULL */
+    float* x0;                    /* [B][n] or NULL */
+} mi_cfg_x0_params;
+int mi_cfg_x0_fwd(const mi_cfg_x0_params* p, void* stream);
+
+/* K12: dynamic-threshold quantile (Imagen.py:313-317 -> torch.quantile, linear interpolation):
+ * exact selection of the order statistics k_lo and k_hi of |x0| per image by a 3-pass radix
+ * select over the fp32 bit patterns (11+11+9 bits), integer atomics only -> deterministic and
+ * bit-exact.  The rank arithmetic (k_lo, w in fp32) is torch's and is done by the host. */
+#define MI_Q_BINS 2048
+typedef struct mi_quantile_params {
+    int B, n;
+    const float* x0;              /* [B][n] */
+    int k_lo, k_hi; float w;
+    unsigned* hist;               /* [3][B][2][MI_Q_BINS], zeroed by mi_quantile_fwd itself */
+    float* s_out;                 /* [B]  lerp(v_lo, v_hi, w) -- NOT yet clamped to >= 1 */
+    float* v_out;                 /* [B][2] the two selected order statistics, or NULL */
+} mi_quantile_params;
+int mi_quantile_fwd(const mi_quantile_params* p, void* stream);
+
+/* K13: threshold, posterior mean and the reverse-diffusion draw (Imagen.py:320-326,361-370):
+ *   s = max(1, s_q); x0 = clamp(x0,-s,s)/s; mean = c1*x0 + c2*x_t; x_{t-1} = mean + sigma_t * eps
+ * eps comes from `noise` (parity runs: host-generated, step k = T-1-t at noise + k*B*n) or, when
+ * noise == NULL, from Philox4x32-10 + Box-Muller keyed by (seed, global sample index, stream, element). */
+typedef struct mi_posterior_params {
+    int B, n, T;
+    const float* x0; const float* s_q;
+    float* x;                     /* in: x_t, out: x_{t-1} */
+    const float* coef; const int* t_state;
+    const float* noise;
+    uint64_t seed; int sample0; int stream_base;
+} mi_posterior_params;
+int mi_posterior_fwd(const mi_posterior_params* p, void* stream);
+
+/* t -= 1 ; times[b] = t  (diffusion_model.py:81-87, one step of the list) */
+int mi_step_advance(int* t_state, int64_t* times, int B, void* stream);
+/* t = value ; times[b] = value */
+int mi_step_set(int* t_state, int64_t* times, int B, int value, void* stream);
+
+/* N(0,1) fill with the same generator as mi_posterior_fwd (x_T, low-res augmentation noise) */
+int mi_randn_fill(float* out, int B, int n, uint64_t seed, int sample0, int stream_id, void* stream);
+
+/* img.clamp_(-1,1); (img+1)*0.5   (Imagen.py:418-420) */
+int mi_finalize_images(const float* x, float* out, int64_t total, void* stream);
+
+/* K14: separable cubic resize with host-built tap tables (helpers.py:138-164 -> resize_right), H pass
+ * then W pass; idx tables already contain the reflect-padded source indices. */
+typedef struct mi_resize_params {
+    int planes, Hin, Win, Hout, Wout, KH, KW;
+    const float* in; float* out;
+    const int* idx_h; const float* w_h;   /* [Hout][KH] */
+    const int* idx_w; const float* w_w;   /* [Wout][KW] */
+} mi_resize_params;
+int mi_resize_fwd(const mi_resize_params* p, void* stream);
+
+/* low-res conditioning augmentation (Imagen.py:483-485 q_sample, then the *2-1 of Imagen.py:393):
+ * out = (a*img + b*noise)*2 - 1 */
+int mi_lowres_augment(const float* img, const float* noise, float* out, int64_t total, float a, float b, int normalize, void* stream);
+
+/* ---- HIP graphs: capture a sequence of the calls above once, replay it per timestep ------- */
+int mi_graph_begin(void* stream);
+int mi_graph_end(void* stream, void** graph_exec);
+int mi_graph_launch(void* graph_exec, void* stream);
+int mi_graph_destroy(void* graph_exec);
 
 #ifdef __cplusplus
 }

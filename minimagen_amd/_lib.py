@@ -18,7 +18,7 @@ c_float_p = C.c_void_p   # raw device pointers travel as integers
 
 
 class MiAct(C.Structure):
-    _fields_ = [("data", C.c_void_p), ("C", C.c_int), ("stats", C.c_void_p), ("nt", C.c_int), ("scale", C.c_float)]
+    _fields_ = [("data", C.c_void_p), ("C", C.c_int), ("stats", C.c_void_p), ("nt", C.c_int), ("scale", C.c_float), ("bmod", C.c_int)]
 
 
 class MiConvParams(C.Structure):
@@ -44,7 +44,74 @@ class MiCrossEmbedParams(C.Structure):
     ]
 
 
-_STRUCTS = {0: MiAct, 1: MiConvParams, 2: MiCrossEmbedParams}
+class MiLinear(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("b", C.c_void_p), ("in_", C.c_int), ("out", C.c_int)]
+
+
+class MiTextCondParams(C.Structure):
+    _fields_ = [
+        ("B2", C.c_int), ("B", C.c_int), ("L", C.c_int), ("E", C.c_int), ("cd", C.c_int), ("tcd", C.c_int), ("max_len", C.c_int),
+        ("text_embeds", C.c_void_p), ("text_mask", C.c_void_p), ("keep", C.c_void_p),
+        ("text_to_cond", MiLinear), ("null_text_embed", C.c_void_p), ("ln_w", C.c_void_p), ("ln_b", C.c_void_p),
+        ("h1", MiLinear), ("h2", MiLinear), ("null_text_hidden", C.c_void_p), ("norm_w", C.c_void_p), ("norm_b", C.c_void_p),
+        ("c_text", C.c_void_p), ("text_hiddens", C.c_void_p),
+    ]
+
+
+class MiCondStepParams(C.Structure):
+    _fields_ = [
+        ("B2", C.c_int), ("B", C.c_int), ("dim", C.c_int), ("cd", C.c_int), ("tcd", C.c_int), ("ntok", C.c_int),
+        ("time", C.c_void_p), ("lowres_time", C.c_void_p), ("freq", C.c_void_p),
+        ("th", MiLinear), ("tc", MiLinear), ("tt", MiLinear), ("lth", MiLinear), ("ltc", MiLinear), ("ltt", MiLinear),
+        ("text_hiddens", C.c_void_p), ("norm_w", C.c_void_p), ("norm_b", C.c_void_p), ("time_mlps", MiLinear),
+        ("ss", C.c_void_p), ("c_time", C.c_void_p), ("t_out", C.c_void_p),
+    ]
+
+
+class MiAttnFoldBlk(C.Structure):
+    _fields_ = [("mg", C.c_void_p), ("mv", C.c_void_p), ("g0", C.c_void_p), ("v0", C.c_void_p), ("gv", C.c_void_p)]
+
+
+class MiAttnFoldParams(C.Structure):
+    _fields_ = [
+        ("B2", C.c_int), ("C", C.c_int), ("cd", C.c_int), ("heads", C.c_int), ("JT", C.c_int),
+        ("c_rows", C.c_void_p), ("c_stride_b", C.c_int), ("row0", C.c_int), ("nrows", C.c_int), ("write_null", C.c_int),
+        ("n_blocks", C.c_int), ("blk", MiAttnFoldBlk * 8),
+    ]
+
+
+class MiCrossAttnParams(C.Structure):
+    _fields_ = [
+        ("B2", C.c_int), ("C", C.c_int), ("HW", C.c_int), ("heads", C.c_int), ("J", C.c_int),
+        ("x", MiAct), ("gv", C.c_void_p), ("n1_g", C.c_void_p), ("n1_b", C.c_void_p), ("n2_g", C.c_void_p), ("n2_b", C.c_void_p),
+        ("out", C.c_void_p), ("out_stats", C.c_void_p),
+    ]
+
+
+class MiCfgX0Params(C.Structure):
+    _fields_ = [("B", C.c_int), ("n", C.c_int), ("pred2", C.c_void_p), ("two", C.c_int), ("cond_scale", C.c_float),
+                ("x_t", C.c_void_p), ("coef", C.c_void_p), ("t_state", C.c_void_p), ("pred_out", C.c_void_p), ("x0", C.c_void_p)]
+
+
+class MiQuantileParams(C.Structure):
+    _fields_ = [("B", C.c_int), ("n", C.c_int), ("x0", C.c_void_p), ("k_lo", C.c_int), ("k_hi", C.c_int), ("w", C.c_float),
+                ("hist", C.c_void_p), ("s_out", C.c_void_p), ("v_out", C.c_void_p)]
+
+
+class MiPosteriorParams(C.Structure):
+    _fields_ = [("B", C.c_int), ("n", C.c_int), ("T", C.c_int), ("x0", C.c_void_p), ("s_q", C.c_void_p), ("x", C.c_void_p),
+                ("coef", C.c_void_p), ("t_state", C.c_void_p), ("noise", C.c_void_p),
+                ("seed", C.c_uint64), ("sample0", C.c_int), ("stream_base", C.c_int)]
+
+
+class MiResizeParams(C.Structure):
+    _fields_ = [("planes", C.c_int), ("Hin", C.c_int), ("Win", C.c_int), ("Hout", C.c_int), ("Wout", C.c_int), ("KH", C.c_int), ("KW", C.c_int),
+                ("in_", C.c_void_p), ("out", C.c_void_p), ("idx_h", C.c_void_p), ("w_h", C.c_void_p), ("idx_w", C.c_void_p), ("w_w", C.c_void_p)]
+
+
+_STRUCTS = {0: MiAct, 1: MiConvParams, 2: MiCrossEmbedParams, 3: MiLinear, 4: MiTextCondParams, 5: MiCondStepParams,
+            6: MiAttnFoldParams, 7: MiCrossAttnParams, 8: MiCfgX0Params, 9: MiQuantileParams, 10: MiPosteriorParams,
+            11: MiResizeParams}
 
 _lib = None
 _backend = None
@@ -59,8 +126,23 @@ def _bind(lib):
     lib.mi_last_error.restype = C.c_char_p
     lib.mi_backend.restype = C.c_char_p
     lib.mi_struct_size.argtypes = [C.c_int]
-    for name in dir(lib.__class__):
-        pass
+    vp, i32, i64, u64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float
+    for name in ("mi_conv_fwd", "mi_crossembed_fwd", "mi_text_cond_fwd", "mi_cond_step_fwd", "mi_attn_fold_rows", "mi_cross_attn_fwd",
+                 "mi_cfg_x0_fwd", "mi_quantile_fwd", "mi_posterior_fwd", "mi_resize_fwd"):
+        getattr(lib, name).argtypes = [vp, vp]
+        getattr(lib, name).restype = i32
+    lib.mi_step_advance.argtypes = [vp, vp, i32, vp]
+    lib.mi_step_set.argtypes = [vp, vp, i32, i32, vp]
+    lib.mi_randn_fill.argtypes = [vp, i32, i32, u64, i32, i32, vp]
+    lib.mi_finalize_images.argtypes = [vp, vp, i64, vp]
+    lib.mi_lowres_augment.argtypes = [vp, vp, vp, i64, f32, f32, i32, vp]
+    lib.mi_graph_begin.argtypes = [vp]
+    lib.mi_graph_end.argtypes = [vp, C.POINTER(vp)]
+    lib.mi_graph_launch.argtypes = [vp, vp]
+    lib.mi_graph_destroy.argtypes = [vp]
+    lib.mi_conv_tile_shape.argtypes = [i32, C.POINTER(i32), C.POINTER(i32)]
+    lib.mi_conv_cout_tile.argtypes = [i32]
+    lib.mi_attn_fragment_floats.argtypes = [i32]
     for which, st in _STRUCTS.items():
         n = lib.mi_struct_size(which)
         if n != C.sizeof(st):

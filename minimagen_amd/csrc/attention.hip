@@ -1,0 +1,221 @@
+// K9: the bottleneck cross-attention of MinImagen's ResnetBlock (layers.py:220-251, 433-435) in
+// folded form (see minimagen_hip.h).  One wave owns 16*NQ image tokens; for every head it
+// computes S^T = G_h . x^^T (swapped operands, so a token's scores over all context rows j sit in
+// ONE lane's accumulators + the 3 lanes 16/32/48 away -> row max / row sum are in-register plus two
+// cross-lane steps), exponentiates in place, and feeds the accumulators straight back as the B
+// operand of O^T += VW_h^T . P^T: the C/D layout of v_mfma_f32_16x16x4_f32 (row = 4*(lane>>4)+reg)
+// IS the B layout (k = lane>>4) for the k-order j = 4k + reg, so P never moves.  The whole
+// (tokens x 261) score row lives in registers: no online-softmax rescaling, no LDS, no barriers in
+// the main loop; A fragments come pre-arranged from mi_attn_fold_rows through L2.
+#include "common.hip.h"
+
+namespace {
+
+template <int C, int NQ, int JT>
+__global__ __launch_bounds__(256) void cross_attn_folded_kernel(const mi_cross_attn_params p) {
+    constexpr int KK = C / 4;                       // k-steps of QK^T
+    constexpr int NGP = KK < 4 ? 4 : KK;
+    constexpr int MT = (C + 15) / 16;               // M tiles of PV (output channels)
+    constexpr int FR = NGP + 4 * MT;
+    constexpr int CPL = (C < 16 ? C : 16) / 4;      // (unused rows are zero when C < 16)
+    (void)CPL;
+    __shared__ float red[4][2 * 16 * MT];
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int lq = lane & 15, lg = lane >> 4;
+    const int b = blockIdx.y;
+    const int bx = p.x.bmod > 0 ? b % p.x.bmod : b;
+    const int i0 = (blockIdx.x * 4 + wave) * 16 * NQ;
+    const float* xb = p.x.data + (size_t)bx * C * p.HW;
+
+    // ---- LayerNorm(x) per token -> B operand of QK^T: lane supplies x^[a = 4kk + lg][token lq]
+    float xh[NQ][KK];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int i = i0 + 16 * q + lq;
+        const bool ok = i < p.HW;
+        float s = 0.0f;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            xh[q][kk] = ok ? xb[(size_t)(4 * kk + lg) * p.HW + i] * p.x.scale : 0.0f;
+            s += xh[q][kk];
+        }
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        const float mean = s / (float)C;
+        float v = 0.0f;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) { const float d = xh[q][kk] - mean; v = fmaf(d, d, v); }
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        const float rstd = 1.0f / sqrtf(v / (float)C + 1e-5f);
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            const int a = 4 * kk + lg;
+            xh[q][kk] = (xh[q][kk] - mean) * rstd * p.n1_g[a] + p.n1_b[a];
+        }
+    }
+
+    f32x4 oacc[NQ][MT];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) oacc[q][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const float* gvb = p.gv + (size_t)b * p.heads * JT * 64 * FR + (size_t)lane * FR;
+    const int jlast = p.J - 1;
+
+    for (int h = 0; h < p.heads; ++h) {
+        const float* gvh = gvb + (size_t)h * JT * 64 * FR;
+        f32x4 s[JT][NQ];
+        // ---- S^T tiles
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) {
+            float g[NGP];
+#pragma unroll
+            for (int v4 = 0; v4 < NGP / 4; ++v4) {
+                const float4 t = *reinterpret_cast<const float4*>(gvh + (size_t)jt * 64 * FR + 4 * v4);
+                g[4 * v4 + 0] = t.x; g[4 * v4 + 1] = t.y; g[4 * v4 + 2] = t.z; g[4 * v4 + 3] = t.w;
+            }
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kk = 0; kk < KK; ++kk) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(g[kk], xh[q][kk], acc, 0, 0, 0);
+                s[jt][q] = acc;
+            }
+        }
+        // ---- softmax over j (rows of S^T): this lane holds j = 16jt + 4lg + r
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            float m = -INFINITY;
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (jt == JT - 1 && (16 * jt + 4 * lg + r) > jlast) s[jt][q][r] = -INFINITY;   // padded context rows
+                    m = fmaxf(m, s[jt][q][r]);
+                }
+            m = fmaxf(m, __shfl_xor(m, 16));
+            m = fmaxf(m, __shfl_xor(m, 32));
+            float l = 0.0f;
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = __builtin_amdgcn_exp2f(s[jt][q][r] - m);
+                    s[jt][q][r] = e;
+                    l += e;
+                }
+            l += __shfl_xor(l, 16);
+            l += __shfl_xor(l, 32);
+            const float inv = 1.0f / l;
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s[jt][q][r] *= inv;
+        }
+        // ---- O^T += VW_h^T . P^T
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) {
+            float vw[4 * MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const float4 t = *reinterpret_cast<const float4*>(gvh + (size_t)jt * 64 * FR + NGP + 4 * mt);
+                vw[4 * mt + 0] = t.x; vw[4 * mt + 1] = t.y; vw[4 * mt + 2] = t.z; vw[4 * mt + 3] = t.w;
+            }
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        oacc[q][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vw[4 * mt + r], s[jt][q][r], oacc[q][mt], 0, 0, 0);
+        }
+    }
+
+    // ---- to_out.1 LayerNorm over channels, + residual, store, statistics.
+    // This lane holds channels a = 16mt + 4lg + r of token lq (rows >= C are exact zeros).
+    float csum[4 * MT], csq[4 * MT];
+#pragma unroll
+    for (int e = 0; e < 4 * MT; ++e) { csum[e] = 0.0f; csq[e] = 0.0f; }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int i = i0 + 16 * q + lq;
+        const bool ok = i < p.HW;
+        float s1 = 0.0f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s1 += oacc[q][mt][r];
+        s1 += __shfl_xor(s1, 16);
+        s1 += __shfl_xor(s1, 32);
+        const float mean = s1 / (float)C;
+        float v = 0.0f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int a = 16 * mt + 4 * lg + r;
+                const float d = (a < C) ? oacc[q][mt][r] - mean : 0.0f;
+                v = fmaf(d, d, v);
+            }
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        const float rstd = 1.0f / sqrtf(v / (float)C + 1e-5f);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int a = 16 * mt + 4 * lg + r;
+                if (a < C && ok) {
+                    const float res = xb[(size_t)a * p.HW + i] * p.x.scale;
+                    const float y = (oacc[q][mt][r] - mean) * rstd * p.n2_g[a] + p.n2_b[a] + res;
+                    p.out[((size_t)b * C + a) * p.HW + i] = y;
+                    csum[4 * mt + r] += y;
+                    csq[4 * mt + r] = fmaf(y, y, csq[4 * mt + r]);
+                }
+            }
+    }
+    if (p.out_stats) {
+        // reduce over the 16 tokens held by lanes with the same lg, then over the 4 waves
+#pragma unroll
+        for (int e = 0; e < 4 * MT; ++e) {
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) { csum[e] += __shfl_xor(csum[e], o); csq[e] += __shfl_xor(csq[e], o); }
+        }
+        if (lq == 0) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int a = 16 * mt + 4 * lg + r;
+                    red[wave][2 * a] = csum[4 * mt + r];
+                    red[wave][2 * a + 1] = csq[4 * mt + r];
+                }
+        }
+        __syncthreads();
+        if (tid < 2 * C) {
+            const float a4 = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+            p.out_stats[((size_t)(b * C + (tid >> 1)) * gridDim.x + blockIdx.x) * 2 + (tid & 1)] = a4;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int mi_cross_attn_fwd(const mi_cross_attn_params* pp, void* stream) {
+    const mi_cross_attn_params& p = *pp;
+    hipStream_t st = (hipStream_t)stream;
+    const int JT = (p.J + 15) / 16;
+    if (JT != 17) { mi_set_error("mi_cross_attn_fwd: context of %d rows (%d tiles) not instantiated (MinImagen: 1 + time tokens + 256)", p.J, JT); return MI_ERR_UNSUPPORTED; }
+    if (p.B2 <= 0 || p.HW <= 0) { mi_set_error("mi_cross_attn_fwd: empty problem"); return MI_ERR_INVALID; }
+    const dim3 grid((p.HW + MI_ATTN_TOKENS_PER_WG - 1) / MI_ATTN_TOKENS_PER_WG, p.B2);
+    switch (p.C) {
+        case 8: hipLaunchKernelGGL(HIP_KERNEL_NAME(cross_attn_folded_kernel<8, 2, 17>), grid, dim3(256), 0, st, p); break;
+        case 16: hipLaunchKernelGGL(HIP_KERNEL_NAME(cross_attn_folded_kernel<16, 2, 17>), grid, dim3(256), 0, st, p); break;
+        case 32: hipLaunchKernelGGL(HIP_KERNEL_NAME(cross_attn_folded_kernel<32, 2, 17>), grid, dim3(256), 0, st, p); break;
+        default: mi_set_error("mi_cross_attn_fwd: folded path instantiated for C in {8,16,32}, got %d", p.C); return MI_ERR_UNSUPPORTED;
+    }
+    return mi_check_launch("cross_attn_folded_kernel");
+}

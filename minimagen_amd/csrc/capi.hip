@@ -29,6 +29,15 @@ extern "C" int mi_struct_size(int which) {
         case 0: return (int)sizeof(mi_act);
         case 1: return (int)sizeof(mi_conv_params);
         case 2: return (int)sizeof(mi_crossembed_params);
+        case 3: return (int)sizeof(mi_linear);
+        case 4: return (int)sizeof(mi_text_cond_params);
+        case 5: return (int)sizeof(mi_cond_step_params);
+        case 6: return (int)sizeof(mi_attn_fold_params);
+        case 7: return (int)sizeof(mi_cross_attn_params);
+        case 8: return (int)sizeof(mi_cfg_x0_params);
+        case 9: return (int)sizeof(mi_quantile_params);
+        case 10: return (int)sizeof(mi_posterior_params);
+        case 11: return (int)sizeof(mi_resize_params);
     }
     return -1;
 }

@@ -57,7 +57,8 @@ __global__ __launch_bounds__(CFG::NT) void conv_tile_kernel(const mi_conv_params
                 const bool second = c >= C0;
                 const mi_act& a = second ? p.in1 : p.in0;
                 const int cc = second ? c - C0 : c;
-                const float* st = a.stats + ((size_t)(b * a.C + cc) * a.nt) * 2;
+                const int ba = a.bmod > 0 ? b % a.bmod : b;
+                const float* st = a.stats + ((size_t)(ba * a.C + cc) * a.nt) * 2;
                 for (int t = sub; t < a.nt; t += 4) {
                     const float2 v = *reinterpret_cast<const float2*>(st + 2 * t);
                     s += (double)v.x;
@@ -109,6 +110,8 @@ __global__ __launch_bounds__(CFG::NT) void conv_tile_kernel(const mi_conv_params
         for (int co = 0; co < COUT_T; ++co) acc[px][co] = 0.0f;
 
     const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;   // pad = 1 for every member of the family
+    const int b0 = p.in0.bmod > 0 ? b % p.in0.bmod : b, b1 = p.in1.bmod > 0 ? b % p.in1.bmod : b;
+    const int br0 = p.res0.bmod > 0 ? b % p.res0.bmod : b, br1 = p.res1.bmod > 0 ? b % p.res1.bmod : b;
     const bool gn = p.gn_groups > 0;
 
     for (int c0 = 0; c0 < Cin; c0 += CK) {
@@ -122,8 +125,8 @@ __global__ __launch_bounds__(CFG::NT) void conv_tile_kernel(const mi_conv_params
             float v = 0.0f;
             if (c < Cin && gy >= 0 && gy < Hv && gx >= 0 && gx < Wv) {
                 const int sy = UP2 ? (gy >> 1) : gy, sx = UP2 ? (gx >> 1) : gx;
-                const float* src = (c < C0) ? p.in0.data + ((size_t)(b * C0 + c) * Hin + sy) * Win + sx
-                                            : p.in1.data + ((size_t)(b * C1 + (c - C0)) * Hin + sy) * Win + sx;
+                const float* src = (c < C0) ? p.in0.data + ((size_t)(b0 * C0 + c) * Hin + sy) * Win + sx
+                                            : p.in1.data + ((size_t)(b1 * C1 + (c - C0)) * Hin + sy) * Win + sx;
                 const float x = *src;
                 v = gn ? mi_silu(fmaf(x, chA[c], chB[c])) : x * chA[c];
             }
@@ -168,8 +171,8 @@ __global__ __launch_bounds__(CFG::NT) void conv_tile_kernel(const mi_conv_params
         if (p.res_w) {
             for (int cr = 0; cr < Cres0 + Cres1; ++cr) {
                 const bool second = cr >= Cres0;
-                const float* src = second ? p.res1.data + ((size_t)(b * Cres1 + (cr - Cres0)) * p.H + oy) * p.W
-                                          : p.res0.data + ((size_t)(b * Cres0 + cr) * p.H + oy) * p.W;
+                const float* src = second ? p.res1.data + ((size_t)(br1 * Cres1 + (cr - Cres0)) * p.H + oy) * p.W
+                                          : p.res0.data + ((size_t)(br0 * Cres0 + cr) * p.H + oy) * p.W;
                 const float sc = second ? p.res1.scale : p.res0.scale;
                 float xv[4];
 #pragma unroll
@@ -192,7 +195,7 @@ __global__ __launch_bounds__(CFG::NT) void conv_tile_kernel(const mi_conv_params
 #pragma unroll
             for (int co = 0; co < COUT_T; ++co) {
                 if (co0 + co < p.Cout) {
-                    const float* src = p.res0.data + ((size_t)(b * Cres0 + co0 + co) * p.H + oy) * p.W;
+                    const float* src = p.res0.data + ((size_t)(br0 * Cres0 + co0 + co) * p.H + oy) * p.W;
 #pragma unroll
                     for (int px = 0; px < 4; ++px)
                         if (ox + px < p.W) acc[px][co] += src[ox + px] * p.res0.scale;

@@ -1,0 +1,330 @@
+// Sampler epilogue kernels: K11 (CFG combine + x0), K12 (bit-exact dynamic-threshold quantile),
+// K13/K15 (posterior step, final clamp), K14 (cubic resize + low-res augmentation) and the
+// counter-based normal generator.  All elementwise math keeps the reference's operation order
+// with un-fused multiplies/adds (__fmul_rn/__fadd_rn) so the only differences to the reference's
+// fp32 results come from the U-Net's summation order.
+#include "common.hip.h"
+
+namespace {
+
+// ------------------------------------------------------------------ K11 epilogue
+__global__ __launch_bounds__(256) void cfg_x0_kernel(const mi_cfg_x0_params p) {
+    const int b = blockIdx.y;
+    const int t = p.t_state ? *p.t_state : 0;
+    const float ca = p.coef ? p.coef[t * 8 + 0] : 0.0f, cb = p.coef ? p.coef[t * 8 + 1] : 0.0f;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < p.n; i += gridDim.x * 256) {
+        const float c = p.pred2[(size_t)b * p.n + i];
+        float pred = c;
+        if (p.two) {
+            const float nl = p.pred2[(size_t)(b + p.B) * p.n + i];
+            pred = __fadd_rn(nl, __fmul_rn(__fsub_rn(c, nl), p.cond_scale));     // Unet.py:506
+        }
+        if (p.pred_out) p.pred_out[(size_t)b * p.n + i] = pred;
+        if (p.x0) {
+            const float xt = p.x_t[(size_t)b * p.n + i];
+            p.x0[(size_t)b * p.n + i] = __fsub_rn(__fmul_rn(ca, xt), __fmul_rn(cb, pred));   // diffusion_model.py:159-162
+        }
+    }
+}
+
+// ------------------------------------------------------------------ K12 radix select
+// digit layout of a non-negative float's bit pattern (bit 31 = 0): pass 0 -> bits 30..20, pass 1 -> 19..9, pass 2 -> 8..0
+__device__ __forceinline__ int q_shift(int pass) { return pass == 0 ? 20 : (pass == 1 ? 9 : 0); }
+__device__ __forceinline__ int q_bits(int pass) { return pass == 2 ? 9 : 11; }
+
+// Block-wide: locate the bin of `hist` (MI_Q_BINS entries) that holds 0-based rank r; returns bin and the
+// rank inside the bin.  All 256 work-items call it; result broadcast through LDS.
+__device__ void q_find_bin(const unsigned* hist, unsigned r, int* sh_scratch, unsigned& bin_out, unsigned& r_out) {
+    unsigned* wsum = reinterpret_cast<unsigned*>(sh_scratch);       // [4] wave totals, [4..5] result
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned c[8], tot = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { c[k] = hist[tid * 8 + k]; tot += c[k]; }
+    unsigned inc = tot;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned v = __shfl_up(inc, o);
+        if (lane >= o) inc += v;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    unsigned base = 0;
+    for (int w = 0; w < wave; ++w) base += wsum[w];
+    unsigned excl = base + inc - tot;
+    if (r >= excl && r < excl + tot) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (r < excl + c[k]) { wsum[4] = (unsigned)(tid * 8 + k); wsum[5] = r - excl; break; }
+            excl += c[k];
+        }
+    }
+    __syncthreads();
+    bin_out = wsum[4];
+    r_out = wsum[5];
+    __syncthreads();
+}
+
+template <int PASS>
+__global__ __launch_bounds__(256) void quantile_hist_kernel(const mi_quantile_params p) {
+    __shared__ unsigned lh[2][MI_Q_BINS];
+    __shared__ int scratch[8];
+    const int tid = threadIdx.x, b = blockIdx.y;
+    // resolve the prefixes chosen by the earlier passes (every workgroup redoes this tiny scan)
+    unsigned prefix[2] = {0u, 0u}, rk[2] = {(unsigned)p.k_lo, (unsigned)p.k_hi};
+#pragma unroll
+    for (int ps = 0; ps < PASS; ++ps) {
+#pragma unroll
+        for (int sel = 0; sel < 2; ++sel) {
+            unsigned bin, rr;
+            q_find_bin(p.hist + (((size_t)ps * p.B + b) * 2 + sel) * MI_Q_BINS, rk[sel], scratch, bin, rr);
+            prefix[sel] = (prefix[sel] << q_bits(ps)) | bin;
+            rk[sel] = rr;
+        }
+    }
+    for (int i = tid; i < 2 * MI_Q_BINS; i += 256) (&lh[0][0])[i] = 0u;
+    __syncthreads();
+    const int shift = q_shift(PASS), nb = q_bits(PASS);
+    const unsigned mask = (1u << nb) - 1u;
+    const float* xb = p.x0 + (size_t)b * p.n;
+    for (int i = blockIdx.x * 256 + tid; i < p.n; i += gridDim.x * 256) {
+        const unsigned key = __float_as_uint(fabsf(xb[i]));
+        const unsigned hi = PASS == 0 ? 0u : (key >> (shift + nb));
+        const unsigned bin = (key >> shift) & mask;
+        if (hi == prefix[0]) atomicAdd(&lh[0][bin], 1u);
+        if (hi == prefix[1]) atomicAdd(&lh[1][bin], 1u);
+    }
+    __syncthreads();
+    unsigned* gh = p.hist + (((size_t)PASS * p.B + b) * 2) * MI_Q_BINS;
+    for (int i = tid; i < 2 * MI_Q_BINS; i += 256) {
+        const unsigned v = (&lh[0][0])[i];
+        if (v) atomicAdd(&gh[i], v);
+    }
+}
+
+__global__ __launch_bounds__(256) void quantile_finish_kernel(const mi_quantile_params p) {
+    __shared__ int scratch[8];
+    const int b = blockIdx.x;
+    unsigned prefix[2] = {0u, 0u}, rk[2] = {(unsigned)p.k_lo, (unsigned)p.k_hi};
+#pragma unroll
+    for (int ps = 0; ps < 3; ++ps) {
+#pragma unroll
+        for (int sel = 0; sel < 2; ++sel) {
+            unsigned bin, rr;
+            q_find_bin(p.hist + (((size_t)ps * p.B + b) * 2 + sel) * MI_Q_BINS, rk[sel], scratch, bin, rr);
+            prefix[sel] = (prefix[sel] << q_bits(ps)) | bin;
+            rk[sel] = rr;
+        }
+    }
+    if (threadIdx.x == 0) {
+        const float a = __uint_as_float(prefix[0]), bb = __uint_as_float(prefix[1]);
+        const float d = __fsub_rn(bb, a);
+        // ATen lerp: weight < 0.5 ? a + w*d : b - d*(1-w), multiply-add fused
+        const float s = (fabsf(p.w) < 0.5f) ? fmaf(p.w, d, a) : fmaf(__fsub_rn(p.w, 1.0f), d, bb);
+        p.s_out[b] = s;
+        if (p.v_out) { p.v_out[2 * b] = a; p.v_out[2 * b + 1] = bb; }
+    }
+}
+
+// ------------------------------------------------------------------ Philox4x32-10 + Box-Muller
+__device__ __forceinline__ void philox_round(unsigned (&c)[4], unsigned k0, unsigned k1) {
+    const unsigned M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+    const unsigned hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
+    const unsigned hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
+    const unsigned n0 = hi1 ^ c[1] ^ k0, n1 = lo1, n2 = hi0 ^ c[3] ^ k1, n3 = lo0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+__device__ __forceinline__ void philox4x32_10(unsigned (&c)[4], unsigned k0, unsigned k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        philox_round(c, k0, k1);
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+}
+// four N(0,1) draws for (seed, sample, stream, quad index)
+__device__ __forceinline__ void randn4(unsigned long long seed, unsigned sample, unsigned stream, unsigned quad, float (&z)[4]) {
+    unsigned c[4] = {quad, sample, stream, 0x4D494E49u};
+    philox4x32_10(c, (unsigned)seed, (unsigned)(seed >> 32));
+    const float u0 = ((float)(c[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float u1 = ((float)(c[1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float u2 = ((float)(c[2] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float u3 = ((float)(c[3] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float r0 = sqrtf(-2.0f * logf(u0)), r1 = sqrtf(-2.0f * logf(u2));
+    const float a0 = 6.28318530717958647692f * u1, a1 = 6.28318530717958647692f * u3;
+    z[0] = r0 * cosf(a0); z[1] = r0 * sinf(a0);
+    z[2] = r1 * cosf(a1); z[3] = r1 * sinf(a1);
+}
+
+__global__ __launch_bounds__(256) void randn_fill_kernel(float* out, int n, unsigned long long seed, int sample0, int stream_id) {
+    const int b = blockIdx.y;
+    const int nq = (n + 3) / 4;
+    for (int qd = blockIdx.x * 256 + threadIdx.x; qd < nq; qd += gridDim.x * 256) {
+        float z[4];
+        randn4(seed, (unsigned)(sample0 + b), (unsigned)stream_id, (unsigned)qd, z);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (4 * qd + k < n) out[(size_t)b * n + 4 * qd + k] = z[k];
+    }
+}
+
+// ------------------------------------------------------------------ K13
+__global__ __launch_bounds__(256) void posterior_kernel(const mi_posterior_params p) {
+    const int b = blockIdx.y;
+    const int t = *p.t_state;
+    const float c1 = p.coef[t * 8 + 2], c2 = p.coef[t * 8 + 3], sigma = p.coef[t * 8 + 4];
+    const float s = fmaxf(p.s_q[b], 1.0f);                                       // Imagen.py:320
+    const int k = (p.T - 1) - t;
+    const float* nz = p.noise ? p.noise + ((size_t)k * p.B + b) * p.n : nullptr;
+    const int nq = (p.n + 3) / 4;
+    for (int qd = blockIdx.x * 256 + threadIdx.x; qd < nq; qd += gridDim.x * 256) {
+        float z[4];
+        if (nz) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) z[e] = (4 * qd + e < p.n) ? nz[4 * qd + e] : 0.0f;
+        } else {
+            randn4(p.seed, (unsigned)(p.sample0 + b), (unsigned)(p.stream_base + k), (unsigned)qd, z);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int i = 4 * qd + e;
+            if (i < p.n) {
+                const size_t o = (size_t)b * p.n + i;
+                float x0 = p.x0[o];
+                x0 = __fdiv_rn(fminf(fmaxf(x0, -s), s), s);                       // Imagen.py:323
+                const float mean = __fadd_rn(__fmul_rn(c1, x0), __fmul_rn(c2, p.x[o]));   // diffusion_model.py:118-121
+                p.x[o] = __fadd_rn(mean, __fmul_rn(sigma, z[e]));               // Imagen.py:370
+            }
+        }
+    }
+}
+
+__global__ void step_advance_kernel(int* t_state, long long* times, int B, int set, int value) {
+    const int t = set ? value : (*t_state - 1);
+    __syncthreads();
+    for (int b = threadIdx.x; b < B; b += blockDim.x) times[b] = (long long)t;
+    if (threadIdx.x == 0) *t_state = t;
+}
+
+__global__ __launch_bounds__(256) void finalize_kernel(const float* x, float* out, long long total) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const float v = fminf(fmaxf(x[i], -1.0f), 1.0f);
+        out[i] = __fmul_rn(__fadd_rn(v, 1.0f), 0.5f);
+    }
+}
+
+__global__ __launch_bounds__(256) void lowres_augment_kernel(const float* img, const float* noise, float* out, long long total, float a, float b, int normalize) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        float v = img[i];
+        if (noise) v = __fadd_rn(__fmul_rn(a, v), __fmul_rn(b, noise[i]));       // diffusion_model.py:142-147
+        if (normalize) v = __fsub_rn(__fmul_rn(v, 2.0f), 1.0f);                  // helpers.py:105-110 via Imagen.py:393
+        out[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void resize_kernel(const mi_resize_params p) {
+    const int plane = blockIdx.y;
+    const float* src = p.in + (size_t)plane * p.Hin * p.Win;
+    float* dst = p.out + (size_t)plane * p.Hout * p.Wout;
+    for (int o = blockIdx.x * 256 + threadIdx.x; o < p.Hout * p.Wout; o += gridDim.x * 256) {
+        const int oy = o / p.Wout, ox = o % p.Wout;
+        float acc = 0.0f;
+        for (int kx = 0; kx < p.KW; ++kx) {
+            const int sx = p.idx_w[ox * p.KW + kx];
+            float col = 0.0f;                                   // H pass value at (oy, sx)
+            for (int ky = 0; ky < p.KH; ++ky) {
+                const float v = __fmul_rn(src[(size_t)p.idx_h[oy * p.KH + ky] * p.Win + sx], p.w_h[oy * p.KH + ky]);
+                col = ky == 0 ? v : __fadd_rn(col, v);
+            }
+            const float v = __fmul_rn(col, p.w_w[ox * p.KW + kx]);
+            acc = kx == 0 ? v : __fadd_rn(acc, v);
+        }
+        dst[o] = acc;
+    }
+}
+
+inline int grid_for(long long n, int cap = 2048) {
+    long long g = (n + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+}  // namespace
+
+extern "C" int mi_cfg_x0_fwd(const mi_cfg_x0_params* p, void* stream) {
+    if (p->B <= 0 || p->n <= 0) { mi_set_error("mi_cfg_x0_fwd: empty"); return MI_ERR_INVALID; }
+    if (p->x0 && (!p->x_t || !p->coef || !p->t_state)) { mi_set_error("mi_cfg_x0_fwd: x0 needs x_t, coef, t_state"); return MI_ERR_INVALID; }
+    hipLaunchKernelGGL(cfg_x0_kernel, dim3(grid_for(p->n, 256), p->B), dim3(256), 0, (hipStream_t)stream, *p);
+    return mi_check_launch("cfg_x0_kernel");
+}
+
+extern "C" int mi_quantile_fwd(const mi_quantile_params* p, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (p->B <= 0 || p->n <= 0 || p->k_lo < 0 || p->k_hi >= p->n || p->k_lo > p->k_hi) { mi_set_error("mi_quantile_fwd: bad ranks"); return MI_ERR_INVALID; }
+    if (hipMemsetAsync(p->hist, 0, (size_t)3 * p->B * 2 * MI_Q_BINS * sizeof(unsigned), st) != hipSuccess) { mi_set_error("mi_quantile_fwd: memset failed"); return MI_ERR_LAUNCH; }
+    const dim3 grid(grid_for((p->n + 15) / 16, 64), p->B);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(quantile_hist_kernel<0>), grid, dim3(256), 0, st, *p);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(quantile_hist_kernel<1>), grid, dim3(256), 0, st, *p);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(quantile_hist_kernel<2>), grid, dim3(256), 0, st, *p);
+    hipLaunchKernelGGL(quantile_finish_kernel, dim3(p->B), dim3(256), 0, st, *p);
+    return mi_check_launch("quantile kernels");
+}
+
+extern "C" int mi_posterior_fwd(const mi_posterior_params* p, void* stream) {
+    if (p->B <= 0 || p->n <= 0) { mi_set_error("mi_posterior_fwd: empty"); return MI_ERR_INVALID; }
+    hipLaunchKernelGGL(posterior_kernel, dim3(grid_for((p->n + 3) / 4, 256), p->B), dim3(256), 0, (hipStream_t)stream, *p);
+    return mi_check_launch("posterior_kernel");
+}
+
+extern "C" int mi_step_advance(int* t_state, int64_t* times, int B, void* stream) {
+    hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, t_state, (long long*)times, B, 0, 0);
+    return mi_check_launch("step_advance_kernel");
+}
+extern "C" int mi_step_set(int* t_state, int64_t* times, int B, int value, void* stream) {
+    hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, t_state, (long long*)times, B, 1, value);
+    return mi_check_launch("step_advance_kernel");
+}
+
+extern "C" int mi_randn_fill(float* out, int B, int n, uint64_t seed, int sample0, int stream_id, void* stream) {
+    hipLaunchKernelGGL(randn_fill_kernel, dim3(grid_for((n + 3) / 4, 256), B), dim3(256), 0, (hipStream_t)stream, out, n, (unsigned long long)seed, sample0, stream_id);
+    return mi_check_launch("randn_fill_kernel");
+}
+
+extern "C" int mi_finalize_images(const float* x, float* out, int64_t total, void* stream) {
+    hipLaunchKernelGGL(finalize_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, out, (long long)total);
+    return mi_check_launch("finalize_kernel");
+}
+
+extern "C" int mi_lowres_augment(const float* img, const float* noise, float* out, int64_t total, float a, float b, int normalize, void* stream) {
+    hipLaunchKernelGGL(lowres_augment_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, img, noise, out, (long long)total, a, b, normalize);
+    return mi_check_launch("lowres_augment_kernel");
+}
+
+extern "C" int mi_resize_fwd(const mi_resize_params* p, void* stream) {
+    if (p->planes <= 0 || p->KH <= 0 || p->KW <= 0) { mi_set_error("mi_resize_fwd: bad params"); return MI_ERR_INVALID; }
+    hipLaunchKernelGGL(resize_kernel, dim3(grid_for((long long)p->Hout * p->Wout, 1024), p->planes), dim3(256), 0, (hipStream_t)stream, *p);
+    return mi_check_launch("resize_kernel");
+}
+
+// ------------------------------------------------------------------ HIP graphs
+extern "C" int mi_graph_begin(void* stream) {
+    if (hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeRelaxed) != hipSuccess) { mi_set_error("hipStreamBeginCapture failed"); return MI_ERR_LAUNCH; }
+    return MI_OK;
+}
+extern "C" int mi_graph_end(void* stream, void** graph_exec) {
+    hipGraph_t g = nullptr;
+    if (hipStreamEndCapture((hipStream_t)stream, &g) != hipSuccess || g == nullptr) { mi_set_error("hipStreamEndCapture failed"); return MI_ERR_LAUNCH; }
+    hipGraphExec_t ge = nullptr;
+    const hipError_t e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (e != hipSuccess) { mi_set_error("hipGraphInstantiate failed: %s", hipGetErrorString(e)); return MI_ERR_LAUNCH; }
+    *graph_exec = (void*)ge;
+    return MI_OK;
+}
+extern "C" int mi_graph_launch(void* graph_exec, void* stream) {
+    const hipError_t e = hipGraphLaunch((hipGraphExec_t)graph_exec, (hipStream_t)stream);
+    if (e != hipSuccess) { mi_set_error("hipGraphLaunch failed: %s", hipGetErrorString(e)); return MI_ERR_LAUNCH; }
+    return MI_OK;
+}
+extern "C" int mi_graph_destroy(void* graph_exec) {
+    if (graph_exec) (void)hipGraphExecDestroy((hipGraphExec_t)graph_exec);
+    return MI_OK;
+}

@@ -1,0 +1,59 @@
+"""Host-side weight re-layout for the HIP kernels (done once per state-dict version).
+
+Nothing here is on the per-step path; everything is derived from the reference's own parameter
+tensors (state-dict layout of SURVEY.md Appendix B-9) so reference checkpoints load unchanged.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+LOG2E = 1.4426950408889634
+
+
+def pack_conv_weight(w: torch.Tensor, cout_tile: int) -> torch.Tensor:
+    """[Cout][Cin][k][k] -> [Cin][k][k][Cout_pad] (all output channels of a tap contiguous)."""
+    cout = w.shape[0]
+    pad = (cout + cout_tile - 1) // cout_tile * cout_tile
+    out = torch.zeros(w.shape[1], w.shape[2], w.shape[3], pad, dtype=torch.float32, device=w.device)
+    out[..., :cout] = w.detach().permute(1, 2, 3, 0)
+    return out.contiguous()
+
+
+def fold_parallel_1x1(w3: torch.Tensor, b3, w1: torch.Tensor, b1):
+    """Parallel(conv3x3, conv1x1) (layers.py:346-356, Unet.py:233-234) == one 3x3 conv whose centre tap
+    carries the 1x1 weights (exact in real arithmetic)."""
+    w = w3.detach().clone()
+    w[:, :, 1, 1] += w1.detach()[:, :, 0, 0]
+    return w, (b3.detach() + b1.detach())
+
+
+def fold_cross_attention(to_q, to_kv, to_out, null_kv, heads: int, dim_head: int = 64):
+    """Folded matrices of the bottleneck cross-attention (see include/minimagen_hip.h, K9).
+
+    to_q [H*D][C], to_kv [2*H*D][cd] (k rows first, layers.py:226), to_out [C][H*D], null_kv [2][D].
+    Returns mg, mv [H][C][cd] and g0, v0 [H][C] (fp32), computed in fp64.
+    """
+    dev = to_q.device
+    H, D = heads, dim_head
+    q = to_q.detach().double().reshape(H, D, -1)               # [H][D][C]
+    kv = to_kv.detach().double()
+    k = kv[:H * D].reshape(H, D, -1)                            # [H][D][cd]
+    v = kv[H * D:].reshape(H, D, -1)
+    o = to_out.detach().double().reshape(-1, H, D).permute(1, 0, 2)   # [H][C][D]
+    nk, nv = null_kv.detach().double().unbind(0)
+    scale = D ** -0.5
+    mg = torch.einsum('hda,hdb->hab', q, k) * (scale * LOG2E)
+    mv = torch.einsum('had,hdb->hab', o, v)
+    g0 = torch.einsum('hda,d->ha', q, nk) * (scale * LOG2E)
+    v0 = torch.einsum('had,d->ha', o, nv)
+    f = lambda t: t.float().contiguous().to(dev)
+    return f(mg), f(mv), f(g0), f(v0)
+
+
+def sinusoid_freq(dim: int, device) -> torch.Tensor:
+    """exp(arange(dim/2) * -(ln 1e4 / (dim/2 - 1))) exactly as SinusoidalPosEmb builds it (layers.py:461-463)."""
+    half = dim // 2
+    k = math.log(10000) / (half - 1)
+    return torch.exp(torch.arange(half) * -k).float().contiguous().to(device)
