@@ -249,8 +249,8 @@ int mi_step_set(int* t_state, int64_t* times, int B, int value, void* stream);
 /* N(0,1) fill with the same generator as mi_posterior_fwd (x_T, low-res augmentation noise) */
 int mi_randn_fill(float* out, int B, int n, uint64_t seed, int sample0, int stream_id, void* stream);
 
-/* img.clamp_(-1,1); (img+1)*0.5   (Imagen.py:418-420) */
-int mi_finalize_images(const float* x, float* out, int64_t total, void* stream);
+/* img.clamp_(-1,1); then (img+1)*0.5 when unnormalize != 0   (Imagen.py:418-420) */
+int mi_finalize_images(const float* x, float* out, int64_t total, int unnormalize, void* stream);
 
 /* K14: separable cubic resize with host-built tap tables (helpers.py:138-164 -> resize_right), H pass
  * then W pass; idx tables already contain the reflect-padded source indices. */

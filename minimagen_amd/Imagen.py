@@ -1,0 +1,242 @@
+"""``Imagen`` with the reference's constructor and ``sample`` API (minimagen/Imagen.py), whose cascaded
+reverse-diffusion loop runs as HIP kernels replayed from a HIP graph on MI355X."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Callable, List, Literal, Tuple, Union
+
+import torch
+from torch import nn
+
+from . import _lib as L
+from .Unet import Unet
+from .diffusion_model import GaussianDiffusion
+from .helpers import cast_tuple, cubic_taps, default, eval_decorator, exists, module_device, quantile_rank
+from .t5 import get_encoded_dim, t5_encode_text
+
+
+class Imagen(nn.Module):
+    """minimagen/Imagen.py:22-131."""
+
+    def __init__(
+            self,
+            unets: Union[Unet, List[Unet], Tuple[Unet, ...]],
+            *,
+            text_encoder_name: str,
+            image_sizes: Union[int, List[int], Tuple[int, ...]],
+            text_embed_dim: int = None,
+            channels: int = 3,
+            timesteps: Union[int, List[int], Tuple[int, ...]] = 1000,
+            cond_drop_prob: float = 0.1,
+            loss_type: Literal["l1", "l2", "huber"] = 'l2',
+            lowres_sample_noise_level: float = 0.2,
+            auto_normalize_img: bool = True,
+            dynamic_thresholding_percentile: float = 0.9,
+            only_train_unet_number: int = None
+    ):
+        super().__init__()
+        if loss_type not in ('l1', 'l2', 'huber'):
+            raise NotImplementedError()
+        self.loss_type = loss_type
+        self.channels = channels
+        unets = cast_tuple(unets)
+        num_unets = len(unets)
+        self.noise_schedulers = nn.ModuleList([GaussianDiffusion(timesteps=t) for t in cast_tuple(timesteps, num_unets)])
+        # built from the RAW argument like Imagen.py:78 (so only an int works, as in the reference)
+        self.lowres_noise_schedule = GaussianDiffusion(timesteps=timesteps)
+        self.text_encoder_name = text_encoder_name
+        self.text_embed_dim = default(text_embed_dim, lambda: get_encoded_dim(text_encoder_name))
+        self.unet_being_trained_index = -1
+        self.only_train_unet_number = only_train_unet_number
+        self.unets = nn.ModuleList([])
+        for ind, one_unet in enumerate(unets):
+            assert isinstance(one_unet, Unet)
+            one_unet = one_unet._cast_model_parameters(lowres_cond=not ind == 0, text_embed_dim=self.text_embed_dim,
+                                                       channels=self.channels, channels_out=self.channels)
+            self.unets.append(one_unet)
+        self.image_sizes = cast_tuple(image_sizes)
+        assert num_unets == len(image_sizes), f'you did not supply the correct number of u-nets ({len(self.unets)}) for resolutions {image_sizes}'
+        self.sample_channels = cast_tuple(self.channels, num_unets)
+        self.lowres_sample_noise_level = lowres_sample_noise_level
+        self.cond_drop_prob = cond_drop_prob
+        self.can_classifier_guidance = cond_drop_prob > 0.
+        self.auto_normalize_img = auto_normalize_img
+        self.input_image_range = (0. if auto_normalize_img else -1., 1.)
+        self.dynamic_thresholding_percentile = dynamic_thresholding_percentile
+        self.register_buffer('_temp', torch.tensor([0.]), persistent=False)
+        self.to(next(self.unets.parameters()).device)
+        self._sampler_state = {}
+
+    @property
+    def device(self) -> torch.device:
+        return self._temp.device
+
+    def _reset_unets_all_one_device(self, device: torch.device = None):
+        """Imagen.py:205-219.  All U-Nets stay resident on the GPU (288 GB of HBM: nothing is swapped to the host)."""
+        device = default(device, self.device)
+        self.unets = nn.ModuleList([*self.unets])
+        self.unets.to(device)
+        self.unet_being_trained_index = -1
+
+    def state_dict(self, *args, **kwargs):
+        self._reset_unets_all_one_device()
+        return super().state_dict(*args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        self._reset_unets_all_one_device()
+        return super().load_state_dict(*args, **kwargs)
+
+    def forward(self, images, texts=None, text_embeds=None, text_masks=None, unet_number=None):
+        raise NotImplementedError("Imagen.forward is the training loss path (Imagen.py:575-650): out of scope for the sampling hot path")
+
+    # ------------------------------------------------------------------ sampling
+    def _stage_state(self, ws, sched: GaussianDiffusion, B: int, n: int):
+        key = (id(ws), sched.num_timesteps)
+        st = self._sampler_state.get(key)
+        if st is None:
+            dev = ws.dev
+            st = type("StageState", (), {})()
+            st.coef = sched.sampler_coef_table().to(dev).contiguous()
+            st.t_state = torch.zeros(1, dtype=torch.int32, device=dev)
+            st.x0 = torch.empty(B, n, dtype=torch.float32, device=dev)
+            st.hist = torch.zeros(3 * B * 2 * 2048, dtype=torch.int32, device=dev)
+            st.s_q = torch.zeros(B, dtype=torch.float32, device=dev)
+            st.v_q = torch.zeros(B, 2, dtype=torch.float32, device=dev)
+            self._sampler_state[key] = st
+        return st
+
+    def _p_sample_loop(self, unet: Unet, shape, *, noise_scheduler: GaussianDiffusion, ws, cond_scale: float,
+                       noise_fn: Callable = None, seed: int = 0, sample0: int = 0, stage: int = 0, use_graph: bool = True):
+        """Imagen.py:373-420 + :329-370 + :261-326: T replays of
+        [U-Net (both guidance halves) -> CFG combine + x0 -> dynamic-threshold quantile -> posterior draw -> t -= 1]."""
+        lib = L.lib()
+        stream = L.current_stream()
+        eng = unet.engine()
+        B, Cc, H, W = shape
+        n = Cc * H * W
+        T = noise_scheduler.num_timesteps
+        st = self._stage_state(ws, noise_scheduler, B, n)
+        two = ws.B2 != ws.B
+
+        noise_dev = None
+        if noise_fn is not None:
+            ws.x.copy_(noise_fn(shape))                                          # Imagen.py:400
+            noise_dev = torch.stack([noise_fn(shape) for _ in range(T)]).to(ws.dev).contiguous()   # Imagen.py:361, in step order
+        else:
+            L.check(lib.mi_randn_fill(L.ptr(ws.x), B, n, seed, sample0, (stage << 20) | (1 << 19) | 1, stream), "mi_randn_fill")
+        L.check(lib.mi_step_set(L.ptr(st.t_state), L.ptr(ws.times), B, T - 1, stream), "mi_step_set")
+
+        cp = L.MiCfgX0Params(B, n, L.ptr(ws.pred), 1 if two else 0, float(cond_scale), L.ptr(ws.x), L.ptr(st.coef), L.ptr(st.t_state), 0, L.ptr(st.x0))
+        k_lo, k_hi, w = quantile_rank(n, self.dynamic_thresholding_percentile)
+        qp = L.MiQuantileParams(B, n, L.ptr(st.x0), k_lo, k_hi, w, L.ptr(st.hist), L.ptr(st.s_q), L.ptr(st.v_q))
+        pp = L.MiPosteriorParams(B, n, T, L.ptr(st.x0), L.ptr(st.s_q), L.ptr(ws.x), L.ptr(st.coef), L.ptr(st.t_state),
+                                 L.ptr(noise_dev), seed, sample0, stage << 20)
+
+        def one_step():
+            eng.run(ws, stream)
+            L.check(lib.mi_cfg_x0_fwd(C.byref(cp), stream), "mi_cfg_x0_fwd")
+            L.check(lib.mi_quantile_fwd(C.byref(qp), stream), "mi_quantile_fwd")
+            L.check(lib.mi_posterior_fwd(C.byref(pp), stream), "mi_posterior_fwd")
+            L.check(lib.mi_step_advance(L.ptr(st.t_state), L.ptr(ws.times), B, stream), "mi_step_advance")
+
+        if use_graph:
+            L.check(lib.mi_graph_begin(stream), "mi_graph_begin")
+            try:
+                one_step()
+            finally:
+                g = C.c_void_p()
+                rc = lib.mi_graph_end(stream, C.byref(g))
+            L.check(rc, "mi_graph_end")
+            try:
+                for _ in range(T):
+                    L.check(lib.mi_graph_launch(g, stream), "mi_graph_launch")
+            finally:
+                if L.backend() == "hip-gfx950":
+                    torch.cuda.current_stream().synchronize()
+                lib.mi_graph_destroy(g)
+        else:
+            for _ in range(T):
+                one_step()
+        img = torch.empty(shape, dtype=torch.float32, device=ws.dev)
+        L.check(lib.mi_finalize_images(L.ptr(ws.x), L.ptr(img), B * n, 1 if self.auto_normalize_img else 0, stream), "mi_finalize_images")
+        return img
+
+    def _lowres_conditioning(self, img, image_size: int, ws, lowres_noise_level: float, noise_fn, seed, sample0, stage):
+        """Imagen.py:479-485 + :393: cubic resize (reflect pad) -> q_sample at int(T*level) -> *2-1."""
+        lib = L.lib()
+        stream = L.current_stream()
+        B, Cc, Hin, Win = img.shape
+        t_low = int(self.lowres_noise_schedule.num_timesteps * lowres_noise_level)          # diffusion_model.py:68-69
+        ws.lowres_times.fill_(t_low)
+        if Hin != image_size:
+            _, idx_h, w_h = cubic_taps(Hin, image_size)
+            _, idx_w, w_w = cubic_taps(Win, image_size)
+            tabs = [t.to(ws.dev) for t in (idx_h, w_h, idx_w, w_w)]
+            up = torch.empty(B, Cc, image_size, image_size, dtype=torch.float32, device=ws.dev)
+            rp = L.MiResizeParams(B * Cc, Hin, Win, image_size, image_size, idx_h.shape[1], idx_w.shape[1], L.ptr(img), L.ptr(up),
+                                  L.ptr(tabs[0]), L.ptr(tabs[1]), L.ptr(tabs[2]), L.ptr(tabs[3]))
+            L.check(lib.mi_resize_fwd(C.byref(rp), stream), "mi_resize_fwd")
+            ws.resize_keepalive = tabs
+        else:
+            up = img
+        n = Cc * image_size * image_size
+        if noise_fn is not None:
+            noise = noise_fn(up.shape).to(ws.dev).contiguous()                  # Imagen.py:485 randn_like
+        else:
+            noise = torch.empty_like(up)
+            L.check(lib.mi_randn_fill(L.ptr(noise), B, n, seed, sample0, (stage << 20) | (1 << 19), stream), "mi_randn_fill")
+        a = float(self.lowres_noise_schedule.sqrt_alphas_cumprod[t_low])
+        b = float(self.lowres_noise_schedule.sqrt_one_minus_alphas_cumprod[t_low])
+        L.check(lib.mi_lowres_augment(L.ptr(up), L.ptr(noise), L.ptr(ws.lowres), B * n, a, b, 1 if self.auto_normalize_img else 0, stream), "mi_lowres_augment")
+        ws.lowres_keepalive = (up, noise)
+
+    @torch.no_grad()
+    @eval_decorator
+    def sample(self, texts: List[str] = None, text_masks: torch.Tensor = None, text_embeds: torch.Tensor = None,
+               cond_scale: float = 1., lowres_sample_noise_level: float = None, return_pil_images: bool = False,
+               device: torch.device = None, *, _noise: Callable = None, _seed: int = 1234, _sample_offset: int = 0,
+               _use_graph: bool = True):
+        """minimagen/Imagen.py:424-510.  Private keyword-only extras (not in the reference): ``_noise(shape)`` injects a
+        host noise stream in the reference's draw order (parity runs); otherwise noise is Philox keyed by
+        (``_seed``, ``_sample_offset`` + row, stage, step, element) so a sharded batch reproduces the unsharded one."""
+        device = default(device, self.device)
+        self._reset_unets_all_one_device(device=device)
+        if exists(texts) and not exists(text_embeds):
+            text_embeds, text_masks = t5_encode_text(texts, name=self.text_encoder_name)
+            text_embeds, text_masks = map(lambda t: t.to(device), (text_embeds, text_masks))
+        assert exists(text_embeds), 'text or text encodings must be passed into Imagen'
+        assert not (exists(text_embeds) and text_embeds.shape[-1] != self.text_embed_dim), \
+            f'invalid text embedding dimension being passed in (should be {self.text_embed_dim})'
+        assert not (cond_scale != 1. and not self.can_classifier_guidance), \
+            'imagen was not trained with conditional dropout, and thus one cannot use classifier free guidance (cond_scale anything other than 1)'
+        batch_size = text_embeds.shape[0]
+        device = next(self.parameters()).device
+        lowres_sample_noise_level = default(lowres_sample_noise_level, self.lowres_sample_noise_level)
+        two = cond_scale != 1.
+        B2 = 2 * batch_size if two else batch_size
+        keep = torch.cat((torch.ones(batch_size, dtype=torch.bool), torch.zeros(B2 - batch_size, dtype=torch.bool)))
+        text_embeds = text_embeds.to(device)
+        text_masks = text_masks.to(device) if exists(text_masks) else None
+
+        img = None
+        for stage, (unet, channel, image_size, noise_scheduler) in enumerate(
+                zip(self.unets, self.sample_channels, self.image_sizes, self.noise_schedulers)):
+            eng = unet.engine()
+            ws = eng.workspace(batch_size, B2, image_size, image_size)
+            eng.set_text(ws, text_embeds, text_masks, keep)
+            if unet.lowres_cond:
+                self._lowres_conditioning(img, image_size, ws, lowres_sample_noise_level, _noise, _seed, _sample_offset, stage)
+            img = self._p_sample_loop(unet, (batch_size, self.channels, image_size, image_size), noise_scheduler=noise_scheduler,
+                                      ws=ws, cond_scale=cond_scale, noise_fn=_noise, seed=_seed, sample0=_sample_offset,
+                                      stage=stage, use_graph=_use_graph)
+        if not return_pil_images:
+            return img
+        return _to_pil_images(img)
+
+
+def _to_pil_images(img: torch.Tensor):
+    """torchvision.transforms.ToPILImage on a float CHW tensor (Imagen.py:508): mul(255) then truncate to uint8."""
+    import numpy as np
+    from PIL import Image
+    arr = img.detach().to('cpu').mul(255).to(torch.uint8).permute(0, 2, 3, 1).contiguous().numpy()
+    return [Image.fromarray(np.ascontiguousarray(a)) for a in arr]

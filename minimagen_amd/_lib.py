@@ -134,7 +134,7 @@ def _bind(lib):
     lib.mi_step_advance.argtypes = [vp, vp, i32, vp]
     lib.mi_step_set.argtypes = [vp, vp, i32, i32, vp]
     lib.mi_randn_fill.argtypes = [vp, i32, i32, u64, i32, i32, vp]
-    lib.mi_finalize_images.argtypes = [vp, vp, i64, vp]
+    lib.mi_finalize_images.argtypes = [vp, vp, i64, i32, vp]
     lib.mi_lowres_augment.argtypes = [vp, vp, vp, i64, f32, f32, i32, vp]
     lib.mi_graph_begin.argtypes = [vp]
     lib.mi_graph_end.argtypes = [vp, C.POINTER(vp)]

@@ -205,10 +205,10 @@ __global__ void step_advance_kernel(int* t_state, long long* times, int B, int s
     if (threadIdx.x == 0) *t_state = t;
 }
 
-__global__ __launch_bounds__(256) void finalize_kernel(const float* x, float* out, long long total) {
+__global__ __launch_bounds__(256) void finalize_kernel(const float* x, float* out, long long total, int unnormalize) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const float v = fminf(fmaxf(x[i], -1.0f), 1.0f);
-        out[i] = __fmul_rn(__fadd_rn(v, 1.0f), 0.5f);
+        out[i] = unnormalize ? __fmul_rn(__fadd_rn(v, 1.0f), 0.5f) : v;
     }
 }
 
@@ -288,8 +288,8 @@ extern "C" int mi_randn_fill(float* out, int B, int n, uint64_t seed, int sample
     return mi_check_launch("randn_fill_kernel");
 }
 
-extern "C" int mi_finalize_images(const float* x, float* out, int64_t total, void* stream) {
-    hipLaunchKernelGGL(finalize_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, out, (long long)total);
+extern "C" int mi_finalize_images(const float* x, float* out, int64_t total, int unnormalize, void* stream) {
+    hipLaunchKernelGGL(finalize_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, out, (long long)total, unnormalize);
     return mi_check_launch("finalize_kernel");
 }
 

@@ -1,0 +1,72 @@
+"""Noise schedule with the reference's class name and buffers (minimagen/diffusion_model.py)."""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+
+class GaussianDiffusion(nn.Module):
+    """Linear-beta DDPM schedule.  The twelve tables are computed in fp64 and stored as fp32
+    non-persistent buffers exactly as diffusion_model.py:28-66 does, so every look-up value is
+    bit-identical to the reference's.  The per-timestep arithmetic that consumes them
+    (predict_start_from_noise / q_posterior / q_sample) runs inside the HIP sampler kernels."""
+
+    def __init__(self, *, timesteps: int):
+        super().__init__()
+        assert not timesteps < 20, f'timsteps must be at least 20'
+        self.num_timesteps = timesteps
+        scale = 1000 / timesteps
+        betas = torch.linspace(scale * 0.0001, scale * 0.02, timesteps, dtype=torch.float64)
+        alphas = 1. - betas
+        alphas_cumprod = torch.cumprod(alphas, dim=0)
+        alphas_cumprod_prev = F.pad(alphas_cumprod[:-1], (1, 0), value=1.)
+        reg = lambda name, val: self.register_buffer(name, val.to(torch.float32), persistent=False)
+        reg('betas', betas)
+        reg('alphas_cumprod', alphas_cumprod)
+        reg('alphas_cumprod_prev', alphas_cumprod_prev)
+        reg('sqrt_alphas_cumprod', torch.sqrt(alphas_cumprod))
+        reg('sqrt_one_minus_alphas_cumprod', torch.sqrt(1. - alphas_cumprod))
+        reg('log_one_minus_alphas_cumprod', torch.log(1. - alphas_cumprod))
+        reg('sqrt_recip_alphas_cumprod', torch.sqrt(1. / alphas_cumprod))
+        reg('sqrt_recipm1_alphas_cumprod', torch.sqrt(1. / alphas_cumprod - 1))
+        posterior_variance = betas * (1. - alphas_cumprod_prev) / (1. - alphas_cumprod)
+        reg('posterior_variance', posterior_variance)
+        reg('posterior_log_variance_clipped', torch.log(posterior_variance.clamp(min=1e-20)))
+        reg('posterior_mean_coef1', betas * torch.sqrt(alphas_cumprod_prev) / (1. - alphas_cumprod))
+        reg('posterior_mean_coef2', (1. - alphas_cumprod_prev) * torch.sqrt(alphas) / (1. - alphas_cumprod))
+
+    def _get_times(self, batch_size: int, noise_level: float, *, device) -> torch.Tensor:
+        """diffusion_model.py:68-69"""
+        return torch.full((batch_size,), int(self.num_timesteps * noise_level), device=device, dtype=torch.long)
+
+    def _sample_random_times(self, batch_size: int, *, device) -> torch.Tensor:
+        return torch.randint(0, self.num_timesteps, (batch_size,), device=device, dtype=torch.long)
+
+    def _get_sampling_timesteps(self, batch: int, *, device):
+        """diffusion_model.py:81-87"""
+        return [torch.full((batch,), i, device=device, dtype=torch.long) for i in reversed(range(self.num_timesteps))]
+
+    def sampler_coef_table(self) -> torch.Tensor:
+        """[T][8] table consumed by mi_cfg_x0_fwd / mi_posterior_fwd: per-timestep scalars gathered from the
+        buffers above; column 4 is [t != 0] * exp(0.5 * posterior_log_variance_clipped) (Imagen.py:364-370)."""
+        T = self.num_timesteps
+        tab = torch.zeros(T, 8, dtype=torch.float32)
+        cpu = lambda v: v.detach().to('cpu', torch.float32)
+        tab[:, 0] = cpu(self.sqrt_recip_alphas_cumprod)
+        tab[:, 1] = cpu(self.sqrt_recipm1_alphas_cumprod)
+        tab[:, 2] = cpu(self.posterior_mean_coef1)
+        tab[:, 3] = cpu(self.posterior_mean_coef2)
+        nonzero = torch.ones(T)
+        nonzero[0] = 0.
+        tab[:, 4] = nonzero * (0.5 * cpu(self.posterior_log_variance_clipped)).exp()
+        return tab
+
+    def q_sample(self, *a, **k):
+        raise NotImplementedError("q_sample is fused into mi_lowres_augment on the sampling path; the training path is out of scope")
+
+    def q_posterior(self, *a, **k):
+        raise NotImplementedError("q_posterior is fused into mi_posterior_fwd on the sampling path")
+
+    def predict_start_from_noise(self, *a, **k):
+        raise NotImplementedError("predict_start_from_noise is fused into mi_cfg_x0_fwd on the sampling path")

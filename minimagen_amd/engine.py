@@ -1,0 +1,428 @@
+"""Launch-plan builder for ``Unet``: turns the module tree into a fixed sequence of C-ABI kernel calls.
+
+For one (batch, resolution) the engine allocates every intermediate tensor once (a ``Workspace``),
+pre-builds every parameter struct, and ``run`` just replays the list -- no allocation, no host
+synchronisation, pointer-stable, so the sampler can capture it in a HIP graph.
+
+Classifier-free guidance runs as ONE batch of 2B rows (conditional rows then null rows).  Tensors that
+do not depend on the conditioning (the input image, CrossEmbed output, pre-downsample convs, the first
+Block of a level) are computed once for B rows and read by both halves (``mi_act.bmod``).
+
+The op order follows minimagen/Unet.py:355-472 and minimagen/layers.py:417-439.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional
+
+import torch
+from torch import nn
+
+from . import _lib as L
+from . import packing as P
+from .layers import CrossAttention, EinopsToAndFrom, Identity, Parallel, ResnetBlock, TransformerBlock
+
+MAX_TEXT_LEN = 256
+JT = 17     # context tiles of 16 rows: 1 null + (2|4) time tokens + 256 text rows <= 272
+
+
+class Act:
+    """An NCHW fp32 activation plus the per-channel partial statistics its producer emitted."""
+    __slots__ = ("t", "stats", "nt", "C", "H", "W", "batch")
+
+    def __init__(self, t, stats, nt, C_, H, W, batch):
+        self.t, self.stats, self.nt, self.C, self.H, self.W, self.batch = t, stats, nt, C_, H, W, batch
+
+    def c(self, consumer_batch: int, scale: float = 1.0) -> L.MiAct:
+        bmod = self.batch if self.batch != consumer_batch else 0
+        return L.MiAct(L.ptr(self.t), self.C, L.ptr(self.stats), self.nt, scale, bmod)
+
+
+def _lin(m: Optional[nn.Linear]) -> L.MiLinear:
+    if m is None:
+        return L.MiLinear(0, 0, 0, 0)
+    return L.MiLinear(L.ptr(m.weight), L.ptr(m.bias) if m.bias is not None else 0, m.in_features, m.out_features)
+
+
+class Workspace:
+    pass
+
+
+class UnetEngine:
+    def __init__(self, unet):
+        self.unet = unet
+        self._pack = None
+        self._pack_key = None
+        self._ws = {}
+
+    # ------------------------------------------------------------------ weights
+    def _param_key(self):
+        u = self.unet
+        first = next(u.parameters())
+        ver = sum(p._version for p in u.parameters()) + sum(b._version for b in u.buffers())
+        return (str(first.device), first.data_ptr(), ver)
+
+    def _check_params(self):
+        for name, t in list(self.unet.named_parameters()) + list(self.unet.named_buffers()):
+            if t.dtype != torch.float32:
+                raise L.MinImagenHipError(f"parameter {name} is {t.dtype}; the HIP path computes in fp32 like the reference")
+            if not t.is_contiguous():
+                raise L.MinImagenHipError(f"parameter {name} is not contiguous")
+        L.require_device(next(self.unet.parameters()))
+
+    def pack(self):
+        key = self._param_key()
+        if self._pack is not None and key == self._pack_key:
+            return self._pack
+        self._check_params()
+        u = self.unet
+        dev = next(u.parameters()).device
+        lib = L.lib()
+        pk = Workspace()
+        pk.keep = []           # keeps packed tensors alive
+        pk.freq = P.sinusoid_freq(u.dim, dev)
+        pk.conv = {}
+        pk.attn = {}
+
+        def conv_pack(mod: nn.Conv2d, w=None, b=None):
+            w = mod.weight if w is None else w
+            ct = lib.mi_conv_cout_tile(w.shape[0])
+            wp = P.pack_conv_weight(w.to(dev), ct)
+            pk.keep.append(wp)
+            return wp
+
+        resblocks: List[ResnetBlock] = [m for m in u.modules() if isinstance(m, ResnetBlock)]
+        # every time_mlp stacked into one [R][tcd] matrix (layers.py:395-399)
+        rows, biases, off = [], [], 0
+        pk.ss_off = {}
+        for rb in resblocks:
+            if rb.time_mlp is not None:
+                lin = rb.time_mlp[1]
+                pk.ss_off[id(rb)] = off
+                rows.append(lin.weight.detach())
+                biases.append(lin.bias.detach())
+                off += lin.out_features
+        pk.R = off
+        pk.tm_w = torch.cat(rows, 0).contiguous() if rows else torch.zeros(1, u.time_cond_dim, device=dev)
+        pk.tm_b = torch.cat(biases, 0).contiguous() if rows else torch.zeros(1, device=dev)
+        for rb in resblocks:
+            pk.conv[id(rb.block1.project)] = conv_pack(rb.block1.project)
+            pk.conv[id(rb.block2.project)] = conv_pack(rb.block2.project)
+            if isinstance(rb.res_conv, nn.Conv2d):
+                ct = lib.mi_conv_cout_tile(rb.res_conv.weight.shape[0])
+                rw = P.pack_conv_weight(rb.res_conv.weight, ct).reshape(rb.res_conv.weight.shape[1], -1).contiguous()
+                pk.keep.append(rw)
+                pk.conv[id(rb.res_conv)] = rw
+            if rb.cross_attn is not None:
+                ca: CrossAttention = rb.cross_attn.fn
+                Cc = ca.to_q.in_features
+                if Cc not in (8, 16, 32) or ca.dim_head != 64:
+                    raise NotImplementedError(f"cross-attention over {Cc} channels: only the folded path (C in 8/16/32, dim_head 64) is built")
+                if not isinstance(ca.norm_context, Identity):
+                    raise NotImplementedError("norm_context=True cross-attention is not on the MinImagen hot path")
+                mg, mv, g0, v0 = P.fold_cross_attention(ca.to_q.weight, ca.to_kv.weight, ca.to_out[0].weight, ca.null_kv, ca.heads, ca.dim_head)
+                pk.attn[id(ca)] = (mg, mv, g0, v0)
+        # plain convs: down/up-sample, final
+        for level in u.downs:
+            pre, _, _, _, post = level
+            if isinstance(pre, nn.Conv2d):
+                pk.conv[id(pre)] = conv_pack(pre)
+            if isinstance(post, nn.Conv2d):
+                pk.conv[id(post)] = conv_pack(post)
+            elif isinstance(post, Parallel):
+                w, b = P.fold_parallel_1x1(post.fns[0].weight, post.fns[0].bias, post.fns[1].weight, post.fns[1].bias)
+                b = b.contiguous()
+                pk.keep.append(b)
+                pk.conv[id(post)] = (conv_pack(None, w=w), b)
+        for level in u.ups:
+            up = level[3]
+            if isinstance(up, nn.Sequential):
+                pk.conv[id(up[1])] = conv_pack(up[1])
+        pk.conv[id(u.final_conv)] = conv_pack(u.final_conv)
+        pk.ce_w = [c.weight.detach().permute(1, 2, 3, 0).contiguous() for c in u.init_conv.convs]
+        self._pack, self._pack_key = pk, key
+        self._ws = {}
+        return pk
+
+    # ------------------------------------------------------------------ workspace / program
+    def workspace(self, B: int, B2: int, H: int, W: int) -> Workspace:
+        pk = self.pack()
+        dev = next(self.unet.parameters()).device
+        key = (B, B2, H, W, str(dev))
+        ws = self._ws.get(key)
+        if ws is not None:
+            return ws
+        u = self.unet
+        ws = Workspace()
+        ws.B, ws.B2, ws.H, ws.W, ws.dev = B, B2, H, W, dev
+        f = lambda *shape: torch.zeros(*shape, dtype=torch.float32, device=dev)
+        ws.x = f(B, u.channels, H, W)
+        ws.lowres = f(B, u.channels, H, W) if u.lowres_cond else None
+        ws.times = torch.zeros(B, dtype=torch.int64, device=dev)
+        ws.lowres_times = torch.zeros(B, dtype=torch.int64, device=dev) if u.lowres_cond else None
+        ws.keep = torch.ones(B2, dtype=torch.uint8, device=dev)
+        ws.c_text = f(B2, MAX_TEXT_LEN, u.cond_dim)
+        ws.text_hiddens = f(B2, u.time_cond_dim)
+        ws.ntot = u.num_time_tokens * (2 if u.lowres_cond else 1)
+        ws.J = 1 + ws.ntot + MAX_TEXT_LEN
+        ws.ss = f(B2, max(pk.R, 1))
+        ws.c_time = f(B2, ws.ntot, u.cond_dim)
+        ws.t_out = f(B2, u.time_cond_dim)
+        ws.gv = {}
+        ws.tensors = []
+        ws.text_L = None
+        ws.prog = []
+        self._build_program(ws, pk)
+        self._ws[key] = ws
+        return ws
+
+    def _tile_cfg(self, H, W, batch, cz=1):
+        lib = L.lib()
+        cands = ([0] if W >= 64 else []) + [1, 2]
+        best = cands[-1]
+        for cfg in cands:
+            th, tw = C.c_int(), C.c_int()
+            lib.mi_conv_tile_shape(cfg, C.byref(th), C.byref(tw))
+            tiles = -(-H // th.value) * -(-W // tw.value)
+            if tiles * batch * cz >= 512:
+                best = cfg
+                break
+        th, tw = C.c_int(), C.c_int()
+        lib.mi_conv_tile_shape(best, C.byref(th), C.byref(tw))
+        return best, -(-H // th.value) * -(-W // tw.value)
+
+    def _new_act(self, ws, batch, Cc, H, W, nt) -> Act:
+        t = torch.empty(batch, Cc, H, W, dtype=torch.float32, device=ws.dev)
+        st = torch.zeros(batch, Cc, max(nt, 1), 2, dtype=torch.float32, device=ws.dev) if nt else None
+        ws.tensors += [t, st]
+        return Act(t, st, nt, Cc, H, W, batch)
+
+    def _emit_conv(self, ws, pk, in0: Act, in1: Optional[Act], *, wpack, bias, Cout, ksize=3, stride=1, up2=0,
+                   gn: Optional[nn.GroupNorm] = None, ss_off: Optional[int] = None, res=None, conditioned=False,
+                   want_stats=True, skip_scale=1.0) -> Act:
+        lib = L.lib()
+        Ho = in0.H * 2 if up2 else in0.H // stride
+        Wo = in0.W * 2 if up2 else in0.W // stride
+        if stride == 2 and ((in0.H | in0.W) & 1):
+            raise NotImplementedError("stride-2 conv on an odd-sized image")
+        ins = [a for a in (in0, in1) if a is not None] + ([r for r in res[:2] if r is not None] if res else [])
+        batch = ws.B2 if (conditioned or any(a.batch == ws.B2 for a in ins)) else ws.B
+        ct = lib.mi_conv_cout_tile(Cout)
+        cfg, nt = self._tile_cfg(Ho, Wo, batch, -(-Cout // ct))
+        out = self._new_act(ws, batch, Cout, Ho, Wo, nt if want_stats else 0)
+        p = L.MiConvParams()
+        p.B, p.H, p.W = batch, Ho, Wo
+        p.in0 = in0.c(batch)
+        if in1 is not None:
+            p.in1 = in1.c(batch, skip_scale)
+        p.Cout, p.ksize, p.stride, p.up2 = Cout, ksize, stride, up2
+        p.w, p.bias = L.ptr(wpack), L.ptr(bias)
+        if gn is not None:
+            p.gn_groups, p.gn_gamma, p.gn_beta, p.gn_eps = gn.num_groups, L.ptr(gn.weight), L.ptr(gn.bias), gn.eps
+            if ss_off is not None:
+                p.scale_shift, p.ss_stride, p.ss_off = L.ptr(ws.ss), ws.ss.shape[1], ss_off
+        if res is not None:
+            r0, r1, rw, rb = res
+            p.res0 = r0.c(batch)
+            if r1 is not None:
+                p.res1 = r1.c(batch, skip_scale)
+            p.res_w, p.res_b = L.ptr(rw), L.ptr(rb)
+        p.out, p.out_stats, p.tile_cfg = L.ptr(out.t), L.ptr(out.stats), cfg
+        ws.prog.append((lib.mi_conv_fwd, p, "conv"))
+        return out
+
+    def _emit_resnet(self, ws, pk, rb: ResnetBlock, in0: Act, in1: Optional[Act]) -> Act:
+        """layers.py:417-439"""
+        u = self.unet
+        s = u.skip_connect_scale
+        Cout = rb.block1.project.out_channels
+        has_cross = rb.cross_attn is not None
+        h = self._emit_conv(ws, pk, in0, in1, wpack=pk.conv[id(rb.block1.project)], bias=rb.block1.project.bias, Cout=Cout,
+                            gn=rb.block1.groupnorm, want_stats=not has_cross, skip_scale=s)
+        if has_cross:
+            h = self._emit_cross_attn(ws, pk, rb.cross_attn.fn, h)
+        ss_off = pk.ss_off.get(id(rb))
+        if isinstance(rb.res_conv, nn.Conv2d):
+            res = (in0, in1, pk.conv[id(rb.res_conv)], rb.res_conv.bias)
+        else:
+            assert in1 is None
+            res = (in0, None, None, None)
+        return self._emit_conv(ws, pk, h, None, wpack=pk.conv[id(rb.block2.project)], bias=rb.block2.project.bias, Cout=Cout,
+                               gn=rb.block2.groupnorm, ss_off=ss_off, res=res, conditioned=ss_off is not None, skip_scale=s)
+
+    def _emit_cross_attn(self, ws, pk, ca: CrossAttention, h: Act) -> Act:
+        lib = L.lib()
+        Cc, HW = h.C, h.H * h.W
+        FR = lib.mi_attn_fragment_floats(Cc)
+        gv = torch.zeros(ws.B2, ca.heads, JT, 64, FR, dtype=torch.float32, device=ws.dev)
+        ws.gv[id(ca)] = gv
+        nt = -(-HW // 128)
+        out = self._new_act(ws, ws.B2, Cc, h.H, h.W, nt)
+        p = L.MiCrossAttnParams()
+        p.B2, p.C, p.HW, p.heads, p.J = ws.B2, Cc, HW, ca.heads, ws.J
+        p.x = h.c(ws.B2)
+        p.gv = L.ptr(gv)
+        p.n1_g, p.n1_b = L.ptr(ca.norm.gamma), L.ptr(ca.norm.beta)
+        p.n2_g, p.n2_b = L.ptr(ca.to_out[1].gamma), L.ptr(ca.to_out[1].beta)
+        p.out, p.out_stats = L.ptr(out.t), L.ptr(out.stats)
+        ws.prog.append((lib.mi_cross_attn_fwd, p, "cross_attn"))
+        return out
+
+    def _fold_params(self, ws, pk, rows_t, stride_b, row0, nrows, write_null):
+        """one mi_attn_fold_rows launch covering every cross-attention block (they share C in practice; else one per C)"""
+        lib = L.lib()
+        calls = []
+        by_c = {}
+        for ca_id, gv in ws.gv.items():
+            by_c.setdefault(gv.shape[-1], []).append(ca_id)
+        cas = {id(m): m for m in self.unet.modules() if isinstance(m, CrossAttention)}
+        for _, ids in by_c.items():
+            for i0 in range(0, len(ids), 8):
+                chunk = ids[i0:i0 + 8]
+                ca0 = cas[chunk[0]]
+                p = L.MiAttnFoldParams()
+                p.B2, p.C, p.cd, p.heads, p.JT = ws.B2, ca0.to_q.in_features, self.unet.cond_dim, ca0.heads, JT
+                p.c_rows, p.c_stride_b, p.row0, p.nrows, p.write_null = L.ptr(rows_t), stride_b, row0, nrows, write_null
+                p.n_blocks = len(chunk)
+                for k, cid in enumerate(chunk):
+                    mg, mv, g0, v0 = pk.attn[cid]
+                    p.blk[k].mg, p.blk[k].mv, p.blk[k].g0, p.blk[k].v0 = L.ptr(mg), L.ptr(mv), L.ptr(g0), L.ptr(v0)
+                    p.blk[k].gv = L.ptr(ws.gv[cid])
+                calls.append((lib.mi_attn_fold_rows, p, "fold"))
+        return calls
+
+    def _build_program(self, ws, pk):
+        u = self.unet
+        lib = L.lib()
+        for m in u.modules():
+            if isinstance(m, TransformerBlock):
+                raise NotImplementedError("self-attention TransformerBlocks (layer_attns=True, SURVEY K10) are not built yet in the HIP engine")
+        if u.mid_attn is not None:
+            raise NotImplementedError("attend_at_middle=True (SURVEY K10) is not built yet in the HIP engine")
+        B, B2, H, W = ws.B, ws.B2, ws.H, ws.W
+        # ---- K1/K5: per-step conditioning
+        cp = L.MiCondStepParams()
+        cp.B2, cp.B, cp.dim, cp.cd, cp.tcd, cp.ntok = B2, B, u.dim, u.cond_dim, u.time_cond_dim, u.num_time_tokens
+        cp.time, cp.lowres_time, cp.freq = L.ptr(ws.times), L.ptr(ws.lowres_times), L.ptr(pk.freq)
+        cp.th, cp.tc, cp.tt = _lin(u.to_time_hiddens[1]), _lin(u.to_time_cond[0]), _lin(u.to_time_tokens[0])
+        if u.lowres_cond:
+            cp.lth, cp.ltc, cp.ltt = _lin(u.to_lowres_time_hiddens[1]), _lin(u.to_lowres_time_cond[0]), _lin(u.to_lowres_time_tokens[0])
+        cp.text_hiddens = L.ptr(ws.text_hiddens)
+        cp.norm_w, cp.norm_b = L.ptr(u.norm_cond.weight), L.ptr(u.norm_cond.bias)
+        cp.time_mlps = L.MiLinear(L.ptr(pk.tm_w), L.ptr(pk.tm_b), u.time_cond_dim, pk.R)
+        cp.ss, cp.c_time, cp.t_out = L.ptr(ws.ss), L.ptr(ws.c_time), L.ptr(ws.t_out)
+        ws.prog.append((lib.mi_cond_step_fwd, cp, "cond_step"))
+        fold_slot = len(ws.prog)        # the time-row fold is inserted here once the attention blocks are known
+
+        # ---- K3: init conv
+        cin = u.init_conv.convs[0].in_channels
+        cfg, nt = self._tile_cfg(H, W, B)
+        cur = self._new_act(ws, B, sum(u.init_conv.dim_scales), H, W, nt)
+        ce = L.MiCrossEmbedParams()
+        ce.B, ce.H, ce.W = B, H, W
+        ce.in0, ce.C0 = L.ptr(ws.x), u.channels
+        if u.lowres_cond:
+            ce.in1, ce.C1 = L.ptr(ws.lowres), u.channels
+        assert cin == u.channels * (2 if u.lowres_cond else 1)
+        ce.n_kernels = len(u.init_conv.convs)
+        if ce.n_kernels > 3:
+            raise NotImplementedError("CrossEmbedLayer with more than 3 kernel sizes")
+        for i, cv in enumerate(u.init_conv.convs):
+            ce.ksize[i], ce.cout[i] = cv.kernel_size[0], cv.out_channels
+            ce.w[i], ce.bias[i] = L.ptr(pk.ce_w[i]), L.ptr(cv.bias)
+        ce.out, ce.out_stats, ce.tile_cfg = L.ptr(cur.t), L.ptr(cur.stats), cfg
+        ws.prog.append((lib.mi_crossembed_fwd, ce, "crossembed"))
+
+        hiddens: List[Act] = []
+        for pre, init_block, resnet_blocks, attn_block, post in u.downs:
+            if isinstance(pre, nn.Conv2d):
+                cur = self._emit_conv(ws, pk, cur, None, wpack=pk.conv[id(pre)], bias=pre.bias, Cout=pre.out_channels, ksize=4, stride=2)
+            cur = self._emit_resnet(ws, pk, init_block, cur, None)
+            for rb in resnet_blocks:
+                cur = self._emit_resnet(ws, pk, rb, cur, None)
+                hiddens.append(cur)
+            hiddens.append(cur)          # attn_block is Identity here (TransformerBlock rejected above)
+            if isinstance(post, nn.Conv2d):
+                cur = self._emit_conv(ws, pk, cur, None, wpack=pk.conv[id(post)], bias=post.bias, Cout=post.out_channels, ksize=4, stride=2)
+            elif isinstance(post, Parallel):
+                wp, bsum = pk.conv[id(post)]
+                cur = self._emit_conv(ws, pk, cur, None, wpack=wp, bias=bsum, Cout=post.fns[0].out_channels)
+        cur = self._emit_resnet(ws, pk, u.mid_block1, cur, None)
+        cur = self._emit_resnet(ws, pk, u.mid_block2, cur, None)
+        for init_block, resnet_blocks, attn_block, upsample in u.ups:
+            cur = self._emit_resnet(ws, pk, init_block, cur, hiddens.pop())
+            for rb in resnet_blocks:
+                cur = self._emit_resnet(ws, pk, rb, cur, hiddens.pop())
+            if isinstance(upsample, nn.Sequential):
+                cv = upsample[1]
+                cur = self._emit_conv(ws, pk, cur, None, wpack=pk.conv[id(cv)], bias=cv.bias, Cout=cv.out_channels, up2=1)
+        cur = self._emit_resnet(ws, pk, u.final_res_block, cur, None)
+        out = self._emit_conv(ws, pk, cur, None, wpack=pk.conv[id(u.final_conv)], bias=u.final_conv.bias, Cout=u.channels_out,
+                              want_stats=False, conditioned=True)
+        ws.pred = out.t
+        if (out.H, out.W) != (H, W):
+            raise L.MinImagenHipError(f"U-Net output is {out.H}x{out.W} for a {H}x{W} input (image size must be divisible by the down-sampling factor)")
+        # time-token rows of the folded context, every step
+        if ws.gv:
+            ws.prog[fold_slot:fold_slot] = self._fold_params(ws, pk, ws.c_time, ws.ntot * u.cond_dim, 1, ws.ntot, 0)
+
+    # ------------------------------------------------------------------ execution
+    def set_text(self, ws, text_embeds: torch.Tensor, text_mask: Optional[torch.Tensor], keep: torch.Tensor):
+        """K2 + the step-invariant part of the context fold.  Once per ``sample()`` / ``forward``."""
+        u, pk, lib = self.unet, self.pack(), L.lib()
+        if text_embeds is None:
+            raise NotImplementedError("text_embeds=None (time-token-only context) is not on the MinImagen sampling path")
+        text_embeds = text_embeds.to(device=ws.dev, dtype=torch.float32).contiguous()
+        assert text_embeds.shape[0] == ws.B and text_embeds.shape[-1] == u.text_embed_dim
+        mask8 = None if text_mask is None else text_mask.to(device=ws.dev).to(torch.uint8).contiguous()
+        ws.keep.copy_(keep.to(torch.uint8))
+        ws.text_keepalive = (text_embeds, mask8)
+        L.require_device(text_embeds, mask8)
+        p = L.MiTextCondParams()
+        p.B2, p.B, p.L, p.E, p.cd, p.tcd, p.max_len = ws.B2, ws.B, text_embeds.shape[1], u.text_embed_dim, u.cond_dim, u.time_cond_dim, MAX_TEXT_LEN
+        p.text_embeds, p.text_mask, p.keep = L.ptr(text_embeds), L.ptr(mask8), L.ptr(ws.keep)
+        p.text_to_cond = _lin(u.text_to_cond)
+        p.null_text_embed = L.ptr(u.null_text_embed)
+        ln = u.to_text_non_attn_cond[0]
+        p.ln_w, p.ln_b = L.ptr(ln.weight), L.ptr(ln.bias)
+        p.h1, p.h2 = _lin(u.to_text_non_attn_cond[1]), _lin(u.to_text_non_attn_cond[3])
+        p.null_text_hidden = L.ptr(u.null_text_hidden)
+        p.norm_w, p.norm_b = L.ptr(u.norm_cond.weight), L.ptr(u.norm_cond.bias)
+        p.c_text, p.text_hiddens = L.ptr(ws.c_text), L.ptr(ws.text_hiddens)
+        st = L.current_stream()
+        L.check(lib.mi_text_cond_fwd(C.byref(p), st), "mi_text_cond_fwd")
+        for fn, fp, name in self._fold_params(ws, pk, ws.c_text, MAX_TEXT_LEN * u.cond_dim, 1 + ws.ntot, MAX_TEXT_LEN, 1):
+            L.check(fn(C.byref(fp), st), name)
+
+    def run(self, ws, stream=None):
+        """Enqueue one U-Net evaluation (all conditioning rows) on the current stream: ws.x / ws.times /
+        ws.lowres / ws.lowres_times -> ws.pred."""
+        st = L.current_stream() if stream is None else stream
+        for fn, p, name in ws.prog:
+            rc = fn(C.byref(p), st)
+            if rc != 0:
+                L.check(rc, name)
+
+    def forward_once(self, x, time, *, lowres_cond_img, lowres_noise_times, text_embeds, text_mask, keep, cond_scale=None):
+        u, lib = self.unet, L.lib()
+        self.pack()
+        L.require_device(x)
+        B, Cc, H, W = x.shape
+        assert Cc == u.channels
+        two = cond_scale is not None
+        ws = self.workspace(B, 2 * B if two else B, H, W)
+        ws.x.copy_(x)
+        ws.times.copy_(time.to(torch.int64))
+        if u.lowres_cond:
+            ws.lowres.copy_(lowres_cond_img)
+            ws.lowres_times.copy_(lowres_noise_times.to(torch.int64))
+        if two:
+            keep = torch.cat((torch.ones(B, dtype=torch.bool), torch.zeros(B, dtype=torch.bool)))
+        self.set_text(ws, text_embeds, text_mask, keep)
+        self.run(ws)
+        if not two:
+            return ws.pred.clone()
+        out = torch.empty(B, u.channels_out, H, W, dtype=torch.float32, device=ws.dev)
+        p = L.MiCfgX0Params(B, u.channels_out * H * W, L.ptr(ws.pred), 1, float(cond_scale), 0, 0, 0, L.ptr(out), 0)
+        L.check(lib.mi_cfg_x0_fwd(C.byref(p), L.current_stream()), "mi_cfg_x0_fwd")
+        return out
