@@ -1,0 +1,239 @@
+#!/usr/bin/env python
+"""bench.py -- MinImagen cascaded-diffusion sampling on MI355X (the BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" is one full ``Imagen.sample()`` over one batch of synthetic text embeddings: the hot path named by
+BASELINE.json (``Imagen.sample -> _p_sample_loop -> _p_sample -> Unet.forward_with_cond_scale``), i.e.
+T denoising steps per stage, classifier-free guidance (2 U-Net evaluations per step), dynamic thresholding
+and the posterior draw, all stages.  value = denoising-steps/s = (images x sum_stages T) / wall time, summed
+over all ranks (weak scaling: the per-GPU batch is fixed, every rank samples its own rows, one RCCL
+all_gather of the finished images inside the timed region).
+
+Also printed in the same JSON line:
+  roofline      the dominant kernel launch of the dominant stage, timed live with HIP events on the launch stream
+  cpu_baseline  the oracle (a CPU port of the reference's algorithm) timed on this host's cores on a bounded sample
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3  # v_mfma_f32_16x16x4_f32, dense
+
+
+def synthetic_text(batch, length=64, dim=512, seed=7, row0=0):
+    """randn(B,L,512) seed 7, row r keeps L-(r mod 24) leading tokens, masked rows zeroed (t5.py:82)."""
+    gen = torch.Generator(device="cpu").manual_seed(seed)
+    emb = torch.randn(row0 + batch, length, dim, generator=gen)[row0:]
+    keep = torch.tensor([max(1, length - ((row0 + r) % 24)) for r in range(batch)])
+    mask = torch.arange(length)[None, :] < keep[:, None]
+    return emb.masked_fill(~mask[:, :, None], 0.).contiguous(), mask.contiguous()
+
+
+def build_imagen(workload, timesteps, dev):
+    from minimagen_amd.Imagen import Imagen
+    from minimagen_amd.Unet import Unet
+    p = json.load(open(os.path.join(ROOT, "tests", "golden", "unet_params.json")))   # = the reference's parameters/*.json
+    torch.manual_seed(0)
+    if workload == "base64":
+        unets, sizes = [Unet(**p["unet0"])], (64,)
+    else:
+        unets, sizes = [Unet(**p["unet0"]), Unet(**p["unet1"])], (64, 256)
+    im = Imagen(unets, text_encoder_name="t5_small", image_sizes=sizes, timesteps=timesteps, cond_drop_prob=0.15)
+    return im.to(dev), sizes
+
+
+# ---- algorithmic bytes / flops of one program entry (SURVEY.md 8(d) definition: every Conv2d / Linear call counts
+# input + output + weights&bias elements, an attention core counts q + k + v + out; norms/activations/adds count zero)
+def entry_cost(name, p):
+    from minimagen_amd import _lib as L
+    if name == "conv":
+        cin = p.in0.C + (p.in1.C if p.in1.data else 0)
+        hin, win = (p.H // 2, p.W // 2) if p.up2 else (p.H * p.stride, p.W * p.stride)
+        elems = p.B * cin * hin * win + p.B * p.Cout * p.H * p.W + p.Cout * cin * p.ksize * p.ksize + p.Cout
+        flops = 2.0 * p.B * p.H * p.W * p.Cout * cin * p.ksize * p.ksize
+        if p.res0.data and p.res_w:
+            cres = p.res0.C + (p.res1.C if p.res1.data else 0)
+            elems += p.B * cres * p.H * p.W + p.B * p.Cout * p.H * p.W + p.Cout * cres + p.Cout
+            flops += 2.0 * p.B * p.H * p.W * p.Cout * cres
+        return elems * 4.0, flops, "hbm"
+    if name == "crossembed":
+        cin = p.C0 + (p.C1 if p.in1 else 0)
+        elems, flops = 0, 0.0
+        for i in range(p.n_kernels):
+            k, co = p.ksize[i], p.cout[i]
+            elems += p.B * cin * p.H * p.W + p.B * co * p.H * p.W + co * cin * k * k + co
+            flops += 2.0 * p.B * p.H * p.W * co * cin * k * k
+        return elems * 4.0, flops, "hbm"
+    if name == "cross_attn":
+        inner, j, i = p.heads * 64, p.J, p.HW
+        cd = 8
+        lin = (p.B2 * i * p.C + p.B2 * i * inner + inner * p.C) + (p.B2 * (j - 1) * cd + p.B2 * (j - 1) * 2 * inner + 2 * inner * cd) \
+            + (p.B2 * i * inner + p.B2 * i * p.C + inner * p.C)
+        core = 2 * p.B2 * i * inner + 2 * p.B2 * j * inner
+        flops = p.B2 * (4.0 * p.heads * i * j * 64 + 2 * 2.0 * i * p.C * inner)
+        return (lin + core) * 4.0, flops, "mfma"
+    return 0.0, 0.0, "hbm"
+
+
+def op_breakdown(im, stage, B, cond_scale, reps=20):
+    """Time every kernel launch of one U-Net evaluation of `stage` standalone with HIP events on the launch stream."""
+    from minimagen_amd import _lib as L
+    unet = im.unets[stage]
+    S = im.image_sizes[stage]
+    eng = unet.engine()
+    ws = eng.workspace(B, 2 * B if cond_scale != 1 else B, S, S)
+    stream = L.current_stream()
+    rows = []
+    for fn, p, name in ws.prog:
+        for _ in range(3):
+            fn(C.byref(p), stream)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn(C.byref(p), stream)
+        e1.record()
+        e1.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        by, fl, bound = entry_cost(name, p)
+        desc = name
+        if name == "conv":
+            cin = p.in0.C + (p.in1.C if p.in1.data else 0)
+            desc = f"conv k{p.ksize}s{p.stride}{'u' if p.up2 else ''} {cin}->{p.Cout} @{p.H}x{p.W} B{p.B}{' gn' if p.gn_groups else ''}{' res' if p.res0.data else ''}"
+        elif name == "cross_attn":
+            desc = f"cross_attn C{p.C} tokens{p.HW} ctx{p.J} B{p.B2}"
+        elif name == "crossembed":
+            desc = f"crossembed {p.C0 + (p.C1 if p.in1 else 0)}->8 @{p.H}x{p.W} B{p.B}"
+        rows.append(dict(op=desc, kernel=name, ms=ms, alg_bytes=by, alg_flops=fl, bound=bound))
+    return rows
+
+
+def cpu_baseline():
+    """Config 1 of BASELINE.json on this host: base U-Net 64x64, B=4, T=100, cond_scale 3, oracle (CPU port)."""
+    from oracle import restated as R
+    ncores = os.cpu_count()
+    torch.set_num_threads(ncores)
+    sd = torch.load(os.path.join(ROOT, "tests", "golden", "unet0_sd.pt"), weights_only=False)
+    emb, mask = synthetic_text(4)
+    B, T = 4, 100
+    t0 = time.time()
+    R.sample([sd], [64], T, text_embeds=emb, text_masks=mask, cond_scale=3., randn=R.make_randn(1234))
+    dt = time.time() - t0
+    return dict(value=B * T / dt, unit="denoising-steps/s", cores=ncores, kind="port",
+                sample=f"oracle/restated.py sample(): base U-Net (unet_0 params) 64x64, B=4, T=100, cond_scale=3 (BASELINE config 1), {dt:.1f}s on {ncores} host threads")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="cascade64_256", choices=["cascade64_256", "base64"])
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
+    ap.add_argument("--timesteps", type=int, default=100)
+    ap.add_argument("--cond-scale", type=float, default=3.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-breakdown", action="store_true")
+    ap.add_argument("--breakdown-out", default="")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (there is no CPU path)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from minimagen_amd import _lib as L
+    from minimagen_amd.distributed import gather_samples
+    L.use_library(L.DEFAULT_LIB)
+    im, sizes = build_imagen(args.workload, args.timesteps, dev)
+    B = args.batch
+    gB = B * world
+    emb, mask = synthetic_text(B, row0=rank * B)
+    emb, mask = emb.to(dev), mask.to(dev)
+
+    def one_step(k):
+        out = im.sample(text_embeds=emb, text_masks=mask, cond_scale=args.cond_scale, _seed=1234 + k, _sample_offset=rank * B)
+        if world > 1:
+            pad = [torch.empty_like(out) for _ in range(world)]
+            dist.all_gather(pad, out)
+            out = torch.cat(pad, 0)
+        return out
+
+    for k in range(args.warmup):
+        one_step(k)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        out = one_step(100 + k)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    assert torch.isfinite(out).all() and out.shape[0] == gB
+
+    n_stages = len(sizes)
+    steps_per_sample = args.timesteps * n_stages
+    value = gB * steps_per_sample * args.steps / dt
+    res = {
+        "metric": "denoising-steps/sec (images/sec x T), base 64^2 + SR 64->256 cascade" if n_stages == 2 else "denoising-steps/sec (images/sec x T), base 64^2",
+        "value": value, "unit": "denoising-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic (random-init weights seed 0, randn text embeddings seed 7 with ragged masks, Philox noise)",
+        "config": {"workload": f"{args.workload}: unet_0 params @64x64" + (" + unet_1 params (lowres_cond) @256x256" if n_stages == 2 else "")
+                   + f", T={args.timesteps}/stage, cond_scale={args.cond_scale} (2 U-Net evals/step), dynamic thresholding 0.9, fp32",
+                   "per_gpu_batch": B, "global_batch": gB, "timesteps": args.timesteps, "parallelism": f"dp{world}"},
+        "images_per_s": gB * args.steps / dt,
+    }
+
+    if rank == 0 and not args.no_breakdown:
+        stage = n_stages - 1
+        rows = op_breakdown(im, stage, B, args.cond_scale)
+        total_ms = sum(r["ms"] for r in rows)
+        dom = max(rows, key=lambda r: r["ms"])
+        if dom["bound"] == "hbm":
+            ach, peak, unit = dom["alg_bytes"] / (dom["ms"] * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
+        else:
+            ach, peak, unit = dom["alg_flops"] / (dom["ms"] * 1e-3) / 1e12, MFMA_F32_PEAK_TFLOPS, "TFLOP/s"
+        res["roofline"] = {"bound": dom["bound"], "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak, "traffic": None,
+                           "kernel": dom["op"], "kernel_ms": dom["ms"], "stage": f"stage {stage} U-Net evaluation ({sizes[stage]}x{sizes[stage]})"}
+        alg_fwd_mb = {64: 28.82, 256: 124.97}.get(sizes[stage])
+        nfwd = 2 if args.cond_scale != 1 else 1
+        res["unet_eval"] = {"stage": stage, "sum_kernel_ms": total_ms, "launches": len(rows),
+                            "alg_bytes_MB_per_image_forward": alg_fwd_mb,
+                            "hbm_frac_whole_forward": (alg_fwd_mb * 1e6 * B * nfwd / (total_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if alg_fwd_mb else None,
+                            "by_kernel_ms": {k: sum(r["ms"] for r in rows if r["kernel"] == k) for k in sorted({r["kernel"] for r in rows})}}
+        if args.breakdown_out:
+            with open(args.breakdown_out, "w") as f:
+                json.dump(rows, f, indent=1)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline()
+    if rank == 0:
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -152,7 +152,7 @@ class Imagen(nn.Module):
                     L.check(lib.mi_graph_launch(g, stream), "mi_graph_launch")
             finally:
                 if L.backend() == "hip-gfx950":
-                    torch.cuda.current_stream().synchronize()
+                    torch.cuda.current_stream().synchronize()     # the exec must outlive its replays
                 lib.mi_graph_destroy(g)
         else:
             for _ in range(T):
@@ -218,17 +218,32 @@ class Imagen(nn.Module):
         text_embeds = text_embeds.to(device)
         text_masks = text_masks.to(device) if exists(text_masks) else None
 
+        # HIP graphs cannot be captured on the legacy default stream: the whole cascade runs on a dedicated stream
+        on_gpu = L.backend() == "hip-gfx950"
+        if on_gpu:
+            if getattr(self, "_stream", None) is None or self._stream.device != device:
+                self._stream = torch.cuda.Stream(device=device)
+            caller_stream = torch.cuda.current_stream(device)
+            self._stream.wait_stream(caller_stream)
+            ctx = torch.cuda.stream(self._stream)
+        else:
+            from .helpers import null_context
+            ctx = null_context()
         img = None
-        for stage, (unet, channel, image_size, noise_scheduler) in enumerate(
-                zip(self.unets, self.sample_channels, self.image_sizes, self.noise_schedulers)):
-            eng = unet.engine()
-            ws = eng.workspace(batch_size, B2, image_size, image_size)
-            eng.set_text(ws, text_embeds, text_masks, keep)
-            if unet.lowres_cond:
-                self._lowres_conditioning(img, image_size, ws, lowres_sample_noise_level, _noise, _seed, _sample_offset, stage)
-            img = self._p_sample_loop(unet, (batch_size, self.channels, image_size, image_size), noise_scheduler=noise_scheduler,
-                                      ws=ws, cond_scale=cond_scale, noise_fn=_noise, seed=_seed, sample0=_sample_offset,
-                                      stage=stage, use_graph=_use_graph)
+        with ctx:
+            for stage, (unet, channel, image_size, noise_scheduler) in enumerate(
+                    zip(self.unets, self.sample_channels, self.image_sizes, self.noise_schedulers)):
+                eng = unet.engine()
+                ws = eng.workspace(batch_size, B2, image_size, image_size)
+                eng.set_text(ws, text_embeds, text_masks, keep)
+                if unet.lowres_cond:
+                    self._lowres_conditioning(img, image_size, ws, lowres_sample_noise_level, _noise, _seed, _sample_offset, stage)
+                img = self._p_sample_loop(unet, (batch_size, self.channels, image_size, image_size), noise_scheduler=noise_scheduler,
+                                          ws=ws, cond_scale=cond_scale, noise_fn=_noise, seed=_seed, sample0=_sample_offset,
+                                          stage=stage, use_graph=_use_graph)
+        if on_gpu:
+            caller_stream.wait_stream(self._stream)
+            img.record_stream(caller_stream)
         if not return_pil_images:
             return img
         return _to_pil_images(img)

@@ -1,0 +1,52 @@
+"""Data-parallel sampling over the GPUs of one node (one process per GPU, RCCL through torch.distributed).
+
+The cascade has no cross-sample coupling (GroupNorm, attention, the dynamic-threshold quantile and the
+schedule look-ups are all per sample), so each rank samples a contiguous slice of the batch with ZERO
+communication and the only collective is one all_gather of the finished images.
+Noise is keyed by the GLOBAL sample index, so the gathered result is bit-identical to a single-GPU run.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(batch: int, world_size: int, rank: int) -> Tuple[int, int]:
+    """Contiguous slice [lo, hi) of the batch owned by `rank` (first `batch % world_size` ranks get one extra row)."""
+    base, rem = divmod(batch, world_size)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def gather_samples(local: torch.Tensor, batch: int, group=None) -> torch.Tensor:
+    """all_gather of per-rank image slices (possibly ragged by one row) into the full (batch, C, H, W) tensor."""
+    ws = dist.get_world_size(group)
+    if ws == 1:
+        return local
+    sizes = [shard_bounds(batch, ws, r) for r in range(ws)]
+    maxn = max(hi - lo for lo, hi in sizes)
+    pad = local
+    if local.shape[0] < maxn:
+        pad = torch.cat((local, local.new_zeros(maxn - local.shape[0], *local.shape[1:])), 0)
+    out = [torch.empty_like(pad) for _ in range(ws)]
+    dist.all_gather(out, pad.contiguous(), group=group)
+    return torch.cat([o[:hi - lo] for o, (lo, hi) in zip(out, sizes)], 0)
+
+
+def sample_distributed(imagen, *, text_embeds: torch.Tensor, text_masks: Optional[torch.Tensor] = None, gather: bool = True,
+                       group=None, **sample_kwargs) -> torch.Tensor:
+    """Every rank passes the SAME full-batch ``text_embeds``/``text_masks``; rank r samples rows shard_bounds(B, N, r)
+    and (if ``gather``) all ranks return the full batch."""
+    ws = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    batch = text_embeds.shape[0]
+    lo, hi = shard_bounds(batch, ws, rank)
+    seed_off = sample_kwargs.pop("_sample_offset", 0)
+    local = imagen.sample(text_embeds=text_embeds[lo:hi].contiguous(),
+                          text_masks=None if text_masks is None else text_masks[lo:hi].contiguous(),
+                          _sample_offset=seed_off + lo, **sample_kwargs)
+    if not gather or ws == 1:
+        return local
+    return gather_samples(local, batch, group)

@@ -1,0 +1,316 @@
+"""Op-level parity of every HIP kernel, called through the C ABI, against the oracle / plain torch fp32 ops
+(the arithmetic spec the reference itself uses).  Tolerances: fp32, op-level atol 2e-5 (+4e-6 relative for
+the long k15 sums); bit-exact for the quantile selection and the elementwise sampler math."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from minimagen_amd import _lib as L, packing as P
+from minimagen_amd.helpers import quantile_rank
+from oracle import restated as R
+from tests._backend import BACKENDS, GPU_ONLY, setup
+
+
+def chan_stats(x):
+    st = torch.zeros(x.shape[0], x.shape[1], 1, 2)
+    st[:, :, 0, 0] = x.double().sum((2, 3)).float()
+    st[:, :, 0, 1] = (x.double() ** 2).sum((2, 3)).float()
+    return st.contiguous()
+
+
+def tile_nt(lib, cfg, H, W):
+    th, tw = C.c_int(), C.c_int()
+    lib.mi_conv_tile_shape(cfg, C.byref(th), C.byref(tw))
+    return -(-H // th.value) * -(-W // tw.value)
+
+
+def check_stats(ost, ref):
+    dims = tuple(range(2, ref.dim()))
+    es = (ost[..., 0].sum(-1) - ref.sum(dims)).abs().max().item() / max(ref.abs().sum(dims).max().item(), 1e-6)
+    eq = (ost[..., 1].sum(-1) - (ref ** 2).sum(dims)).abs().max().item() / max((ref ** 2).sum(dims).max().item(), 1e-6)
+    assert es < 1e-5 and eq < 1e-5, (es, eq)
+
+
+CONV_CASES = [
+    # B, C0, C1, Cout, H, W, ks, stride, up2, gn, ss, res, tile_cfg
+    (2, 8, 0, 8, 16, 64, 3, 1, 0, True, True, 'none', 0),
+    (2, 16, 8, 16, 32, 32, 3, 1, 0, True, True, 'conv2', 1),
+    (1, 8, 8, 8, 20, 36, 3, 1, 0, True, False, 'conv', 2),          # ragged tile edges
+    (2, 16, 0, 16, 32, 32, 3, 1, 0, True, True, 'id', 2),
+    (1, 8, 0, 3, 24, 64, 3, 1, 0, False, False, 'none', 0),          # final conv (Cout 3 -> padded tile)
+    (2, 16, 0, 8, 32, 64, 3, 1, 1, False, False, 'none', 0),         # nearest x2 + conv
+    (2, 8, 0, 16, 16, 32, 4, 2, 0, False, False, 'none', 1),         # downsample k4 s2
+    (1, 32, 0, 16, 16, 64, 3, 1, 0, True, True, 'none', 0),
+]
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_family(backend, case):
+    dev = setup(backend)
+    lib = L.lib()
+    B, C0, C1, Cout, H, W, ks, stride, up2, gn, ss, res, cfg = case
+    g = torch.Generator().manual_seed(hash(case) & 0xffff)
+    rn = lambda *s: torch.randn(*s, generator=g)
+    Hin, Win = (H // 2, W // 2) if up2 else (H * stride, W * stride)
+    x0 = rn(B, C0, Hin, Win) * 1.5 + 0.3
+    x1 = rn(B, C1, Hin, Win) if C1 else None
+    Cin = C0 + C1
+    w, bias = rn(Cout, Cin, ks, ks) * 0.2, rn(Cout)
+    gamma, beta = 1 + 0.2 * rn(Cin), 0.1 * rn(Cin)
+    sst = rn(B, 7 + 2 * Cin) * 0.3 if ss else None
+    sk = 2 ** -0.5
+    xin = torch.cat((x0, x1 * sk), 1) if C1 else x0
+    h = xin
+    if gn:
+        h = F.group_norm(h, 8, gamma, beta, 1e-5)
+        if ss:
+            h = h * (sst[:, 7:7 + Cin, None, None] + 1) + sst[:, 7 + Cin:7 + 2 * Cin, None, None]
+        h = F.silu(h)
+    if up2:
+        h = F.interpolate(h, scale_factor=2, mode='nearest')
+    ref = F.conv2d(h, w, bias, stride=stride, padding=1)
+    ct = lib.mi_conv_cout_tile(Cout)
+    keep = {}
+    d = lambda name, t: keep.setdefault(name, t.to(dev).contiguous())
+    p = L.MiConvParams()
+    p.B, p.H, p.W = B, H, W
+    p.in0 = L.MiAct(d("x0", x0).data_ptr(), C0, d("s0", chan_stats(x0)).data_ptr(), 1, 1.0, 0)
+    if C1:
+        p.in1 = L.MiAct(d("x1", x1).data_ptr(), C1, d("s1", chan_stats(x1)).data_ptr(), 1, sk, 0)
+    p.Cout, p.ksize, p.stride, p.up2 = Cout, ks, stride, up2
+    p.w, p.bias = d("w", P.pack_conv_weight(w, ct)).data_ptr(), d("b", bias).data_ptr()
+    if gn:
+        p.gn_groups, p.gn_gamma, p.gn_beta, p.gn_eps = 8, d("g", gamma).data_ptr(), d("be", beta).data_ptr(), 1e-5
+        if ss:
+            p.scale_shift, p.ss_stride, p.ss_off = d("ss", sst).data_ptr(), sst.shape[1], 7
+    if res != 'none':
+        r0 = rn(B, Cout if res == 'id' else 5, H, W)
+        r1 = rn(B, 3, H, W) if res == 'conv2' else None
+        p.res0 = L.MiAct(d("r0", r0).data_ptr(), r0.shape[1], 0, 0, 1.0, 0)
+        if res == 'id':
+            ref = ref + r0
+        else:
+            rin = torch.cat((r0, r1 * sk), 1) if r1 is not None else r0
+            rw, rb = rn(Cout, rin.shape[1], 1, 1) * 0.3, rn(Cout)
+            ref = ref + F.conv2d(rin, rw, rb)
+            p.res_w = d("rw", P.pack_conv_weight(rw, ct).reshape(rin.shape[1], -1)).data_ptr()
+            p.res_b = d("rb", rb).data_ptr()
+            if r1 is not None:
+                p.res1 = L.MiAct(d("r1", r1).data_ptr(), 3, 0, 0, sk, 0)
+    nt = tile_nt(lib, cfg, H, W)
+    out = torch.full((B, Cout, H, W), float('nan'), device=dev)
+    ost = torch.zeros(B, Cout, nt, 2, device=dev)
+    p.out, p.out_stats, p.tile_cfg = out.data_ptr(), ost.data_ptr(), cfg
+    L.check(lib.mi_conv_fwd(C.byref(p), L.current_stream()), "conv")
+    assert (out.cpu() - ref).abs().max().item() < 2e-5
+    check_stats(ost.cpu(), ref)
+
+
+def test_conv_rejects_bad_arguments():
+    setup("emu")
+    lib = L.lib()
+    p = L.MiConvParams()
+    p.B, p.H, p.W, p.Cout, p.ksize, p.stride = 1, 8, 8, 8, 5, 1
+    p.in0 = L.MiAct(1, 8, 0, 0, 1.0, 0)
+    assert lib.mi_conv_fwd(C.byref(p), None) == -3 and b"unsupported" in lib.mi_last_error()
+    p.ksize, p.gn_groups = 3, 8          # GroupNorm without statistics
+    assert lib.mi_conv_fwd(C.byref(p), None) == -1
+    p.gn_groups, p.B = 0, 0              # empty batch
+    assert lib.mi_conv_fwd(C.byref(p), None) == -1
+
+
+CE_CASES = [(2, 3, 0, 64, 64, (3, 7, 15), (4, 2, 2), 0, 0), (2, 3, 3, 40, 72, (3, 7, 15), (4, 2, 2), 1, 0),
+            (4, 3, 3, 16, 32, (3, 7, 15), (4, 2, 2), 2, 2), (1, 3, 0, 24, 40, (3, 7, 15), (8, 4, 4), 2, 0),
+            (1, 3, 3, 16, 64, (3, 5), (4, 4), 0, 0)]
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("case", CE_CASES)
+def test_crossembed(backend, case):
+    dev = setup(backend)
+    lib = L.lib()
+    B, C0, C1, H, W, ks, cout, cfg, mod = case
+    g = torch.Generator().manual_seed(3)
+    rn = lambda *s: torch.randn(*s, generator=g)
+    Bx = mod if mod else B
+    x0, x1 = rn(Bx, C0, H, W), (rn(B, C1, H, W) if C1 else None)
+    ws = [rn(co, C0 + C1, k, k) * 0.1 for k, co in zip(ks, cout)]
+    bs = [rn(co) for co in cout]
+    x0e = x0.repeat(B // Bx, 1, 1, 1)
+    xin = torch.cat((x0e, x1), 1) if C1 else x0e
+    ref = torch.cat([F.conv2d(xin, w, b, padding=(k - 1) // 2) for w, b, k in zip(ws, bs, ks)], 1)
+    p = L.MiCrossEmbedParams()
+    p.B, p.H, p.W = B, H, W
+    x0d = x0.to(dev); x1d = x1.to(dev) if C1 else None
+    p.in0, p.C0, p.in0_batch_mod = x0d.data_ptr(), C0, mod
+    if C1:
+        p.in1, p.C1 = x1d.data_ptr(), C1
+    p.n_kernels = len(ks)
+    wp = [w.permute(1, 2, 3, 0).contiguous().to(dev) for w in ws]
+    bd = [b.to(dev) for b in bs]
+    for i in range(len(ks)):
+        p.ksize[i], p.cout[i], p.w[i], p.bias[i] = ks[i], cout[i], wp[i].data_ptr(), bd[i].data_ptr()
+    nt = tile_nt(lib, cfg, H, W)
+    out = torch.full(ref.shape, float('nan'), device=dev)
+    ost = torch.zeros(B, ref.shape[1], nt, 2, device=dev)
+    p.out, p.out_stats, p.tile_cfg = out.data_ptr(), ost.data_ptr(), cfg
+    L.check(lib.mi_crossembed_fwd(C.byref(p), L.current_stream()), "crossembed")
+    assert (out.cpu() - ref).abs().max().item() < 2e-5 + 4e-6 * ref.abs().max().item()
+    check_stats(ost.cpu(), ref)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("case", [(2, 16, 256, 8, 2), (1, 16, 200, 8, 4), (1, 8, 128, 8, 2), (1, 32, 128, 16, 2)])
+def test_cross_attention_folded(backend, case):
+    """K9 against the oracle's unfolded CrossAttention (+ residual), incl. a ragged token count and both context lengths."""
+    dev = setup(backend)
+    lib = L.lib()
+    B2, Cc, HW, cd, ntok = case
+    heads, J = 8, 1 + ntok + 256
+    g = torch.Generator().manual_seed(1)
+    rn = lambda *s: torch.randn(*s, generator=g)
+    sd = {"a.norm.gamma": 1 + 0.2 * rn(Cc), "a.norm.beta": 0.1 * rn(Cc),
+          "a.to_q.weight": rn(heads * 64, Cc) * Cc ** -0.5, "a.to_kv.weight": rn(2 * heads * 64, cd) * cd ** -0.5,
+          "a.null_kv": rn(2, 64), "a.to_out.0.weight": rn(Cc, heads * 64) * (heads * 64) ** -0.5,
+          "a.to_out.1.gamma": 1 + 0.2 * rn(Cc), "a.to_out.1.beta": 0.1 * rn(Cc)}
+    x, c = rn(B2, Cc, HW) * 1.3, rn(B2, J - 1, cd)
+    xt = x.permute(0, 2, 1)
+    ref = (R.cross_attention(xt, c, sd, "a") + xt).permute(0, 2, 1).contiguous()
+    mg, mv, g0, v0 = [t.to(dev) for t in P.fold_cross_attention(sd["a.to_q.weight"], sd["a.to_kv.weight"], sd["a.to_out.0.weight"], sd["a.null_kv"], heads)]
+    FR = lib.mi_attn_fragment_floats(Cc)
+    gv = torch.zeros(B2, heads, 17, 64, FR, device=dev)
+    fp = L.MiAttnFoldParams()
+    fp.B2, fp.C, fp.cd, fp.heads, fp.JT, fp.n_blocks = B2, Cc, cd, heads, 17, 1
+    fp.blk[0].mg, fp.blk[0].mv, fp.blk[0].g0, fp.blk[0].v0, fp.blk[0].gv = mg.data_ptr(), mv.data_ptr(), g0.data_ptr(), v0.data_ptr(), gv.data_ptr()
+    ct, cx = c[:, :ntok].contiguous().to(dev), c[:, ntok:].contiguous().to(dev)
+    fp.c_rows, fp.c_stride_b, fp.row0, fp.nrows, fp.write_null = cx.data_ptr(), 256 * cd, 1 + ntok, 256, 1
+    L.check(lib.mi_attn_fold_rows(C.byref(fp), L.current_stream()))
+    fp.c_rows, fp.c_stride_b, fp.row0, fp.nrows, fp.write_null = ct.data_ptr(), ntok * cd, 1, ntok, 0
+    L.check(lib.mi_attn_fold_rows(C.byref(fp), L.current_stream()))
+    ap = L.MiCrossAttnParams()
+    ap.B2, ap.C, ap.HW, ap.heads, ap.J = B2, Cc, HW, heads, J
+    xd = x.to(dev)
+    sdd = {k: v.to(dev) for k, v in sd.items()}
+    ap.x, ap.gv = L.MiAct(xd.data_ptr(), Cc, 0, 0, 1.0, 0), gv.data_ptr()
+    ap.n1_g, ap.n1_b = sdd["a.norm.gamma"].data_ptr(), sdd["a.norm.beta"].data_ptr()
+    ap.n2_g, ap.n2_b = sdd["a.to_out.1.gamma"].data_ptr(), sdd["a.to_out.1.beta"].data_ptr()
+    nt = -(-HW // 128)
+    out = torch.full(x.shape, float('nan'), device=dev)
+    ost = torch.zeros(B2, Cc, nt, 2, device=dev)
+    ap.out, ap.out_stats = out.data_ptr(), ost.data_ptr()
+    L.check(lib.mi_cross_attn_fwd(C.byref(ap), L.current_stream()))
+    assert (out.cpu() - ref).abs().max().item() < 3e-5
+    check_stats(ost.cpu(), ref)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_quantile_bit_exact(backend):
+    """K12: exact order statistics + torch's fp32 rank arithmetic + fused lerp == torch.quantile, incl. ties and n = 3*256^2."""
+    dev = setup(backend)
+    lib = L.lib()
+    g = torch.Generator().manual_seed(5)
+    sizes = (48, 1000, 12288, 196608) + ((3145728,) if backend == "gpu" else ())
+    for n in sizes:
+        for ties in (False, True):
+            B = 3
+            x0 = torch.randn(B, n, generator=g) * 2
+            if ties:
+                x0 = (x0 * 4).round() / 4
+            k_lo, k_hi, w = quantile_rank(n, 0.9)
+            assert (k_lo, w) == tuple(float(v) if i else v for i, v in enumerate(R.quantile_rank(n, 0.9)))
+            x0d = x0.to(dev)
+            hist = torch.zeros(3 * B * 2 * 2048, dtype=torch.int32, device=dev)
+            s, v = torch.zeros(B, device=dev), torch.zeros(B, 2, device=dev)
+            p = L.MiQuantileParams(B, n, x0d.data_ptr(), k_lo, k_hi, w, hist.data_ptr(), s.data_ptr(), v.data_ptr())
+            L.check(lib.mi_quantile_fwd(C.byref(p), L.current_stream()))
+            srt = x0.abs().sort(-1).values
+            assert torch.equal(s.cpu(), torch.quantile(x0.abs(), 0.9, dim=-1)), (n, ties)
+            assert torch.equal(v.cpu()[:, 0], srt[:, k_lo]) and torch.equal(v.cpu()[:, 1], srt[:, k_hi])
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_sampler_elementwise_bit_exact(backend):
+    """K11 epilogue + K13 + schedule look-ups against the oracle, bit for bit (t = 13 and the t = 0 no-noise step)."""
+    dev = setup(backend)
+    lib = L.lib()
+    from minimagen_amd.diffusion_model import GaussianDiffusion
+    T, B, n = 25, 2, 3 * 16 * 16
+    sched = R.Schedule(T)
+    gd = GaussianDiffusion(timesteps=T)
+    for k in ("sqrt_recip_alphas_cumprod", "posterior_mean_coef1", "posterior_log_variance_clipped", "sqrt_alphas_cumprod"):
+        assert torch.equal(getattr(gd, k), getattr(sched, k))
+    coef = gd.sampler_coef_table().to(dev)
+    g = torch.Generator().manual_seed(9)
+    for t in (13, 0):
+        tstate = torch.tensor([t], dtype=torch.int32, device=dev)
+        pred2, xt, noise = torch.randn(2 * B, n, generator=g), torch.randn(B, n, generator=g), torch.randn(T, B, n, generator=g)
+        pred2d, xtd, noised = pred2.to(dev), xt.to(dev), noise.to(dev)
+        x0, pg = torch.zeros(B, n, device=dev), torch.zeros(B, n, device=dev)
+        p = L.MiCfgX0Params(B, n, pred2d.data_ptr(), 1, 3.0, xtd.data_ptr(), coef.data_ptr(), tstate.data_ptr(), pg.data_ptr(), x0.data_ptr())
+        L.check(lib.mi_cfg_x0_fwd(C.byref(p), L.current_stream()))
+        pred = pred2[B:] + (pred2[:B] - pred2[B:]) * 3.0
+        assert torch.equal(pg.cpu(), pred)
+        assert torch.equal(x0.cpu(), sched.predict_start_from_noise(xt, t, pred))
+        k_lo, k_hi, w = quantile_rank(n, 0.9)
+        hist = torch.zeros(3 * B * 2 * 2048, dtype=torch.int32, device=dev)
+        s = torch.zeros(B, device=dev)
+        qp = L.MiQuantileParams(B, n, x0.data_ptr(), k_lo, k_hi, w, hist.data_ptr(), s.data_ptr(), None)
+        L.check(lib.mi_quantile_fwd(C.byref(qp), L.current_stream()))
+        x = xtd.clone()
+        pp = L.MiPosteriorParams(B, n, T, x0.data_ptr(), s.data_ptr(), x.data_ptr(), coef.data_ptr(), tstate.data_ptr(), noised.data_ptr(), 0, 0, 0)
+        L.check(lib.mi_posterior_fwd(C.byref(pp), L.current_stream()))
+        xr, _ = R.p_sample(None, sched, xt.reshape(B, 3, 16, 16), t, noise[T - 1 - t].reshape(B, 3, 16, 16), pred=pred.reshape(B, 3, 16, 16))
+        assert torch.equal(x.cpu().reshape(B, 3, 16, 16), xr)
+    # timestep bookkeeping (bit-exact integers)
+    times = torch.zeros(5, dtype=torch.int64, device=dev)
+    ts = torch.zeros(1, dtype=torch.int32, device=dev)
+    lib.mi_step_set(ts.data_ptr(), times.data_ptr(), 5, 24, L.current_stream())
+    assert ts.item() == 24 and times.tolist() == [24] * 5
+    lib.mi_step_advance(ts.data_ptr(), times.data_ptr(), 5, L.current_stream())
+    assert ts.item() == 23 and times.tolist() == [23] * 5
+    xx = torch.randn(1000, generator=g) * 2
+    oo = torch.zeros(1000, device=dev)
+    lib.mi_finalize_images(xx.to(dev).data_ptr(), oo.data_ptr(), 1000, 1, L.current_stream())
+    assert torch.equal(oo.cpu(), (xx.clamp(-1, 1) + 1) * 0.5)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_randn_keyed_by_global_sample(backend):
+    dev = setup(backend)
+    lib = L.lib()
+    z = torch.zeros(4, 50001, device=dev)
+    lib.mi_randn_fill(z.data_ptr(), 4, 50001, 1234, 0, 7, L.current_stream())
+    z2 = torch.zeros(2, 50001, device=dev)
+    lib.mi_randn_fill(z2.data_ptr(), 2, 50001, 1234, 2, 7, L.current_stream())
+    assert torch.equal(z2, z[2:])                      # a shard starting at global row 2 reproduces rows 2..3
+    zc = z.cpu()
+    assert abs(zc.mean()) < 0.01 and abs(zc.std() - 1) < 0.01 and abs((zc ** 4).mean() / zc.var() ** 2 - 3) < 0.1
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_resize_and_lowres_augment(backend):
+    """K14 against the oracle's restatement of resize_right (PARITY UNPINNED upstream) and q_sample, bit for bit."""
+    dev = setup(backend)
+    lib = L.lib()
+    from minimagen_amd.helpers import cubic_taps
+    from oracle import resize_restated as RR
+    g = torch.Generator().manual_seed(2)
+    img = torch.rand(2, 3, 16, 16, generator=g)
+    for out_sz in (32, 64):
+        _, ih, wh = cubic_taps(16, out_sz)
+        ref = RR.resize(img, scale_factors=out_sz / 16, pad_mode='reflect')
+        tabs = [t.to(dev) for t in (ih, wh, ih, wh)]
+        imgd, up = img.to(dev), torch.zeros(2, 3, out_sz, out_sz, device=dev)
+        rp = L.MiResizeParams(6, 16, 16, out_sz, out_sz, ih.shape[1], ih.shape[1], imgd.data_ptr(), up.data_ptr(),
+                              tabs[0].data_ptr(), tabs[1].data_ptr(), tabs[2].data_ptr(), tabs[3].data_ptr())
+        L.check(lib.mi_resize_fwd(C.byref(rp), L.current_stream()))
+        assert torch.equal(up.cpu(), ref)
+    sched = R.Schedule(100)
+    noise = torch.randn(2, 3, 64, 64, generator=g)
+    out = torch.zeros(2, 3, 64, 64, device=dev)
+    a, b = float(sched.sqrt_alphas_cumprod[20]), float(sched.sqrt_one_minus_alphas_cumprod[20])
+    lib.mi_lowres_augment(up.data_ptr(), noise.to(dev).data_ptr(), out.data_ptr(), up.numel(), a, b, 1, L.current_stream())
+    assert torch.equal(out.cpu(), sched.q_sample(ref, 20, noise) * 2 - 1)
