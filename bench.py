@@ -120,16 +120,24 @@ def op_breakdown(im, stage, B, cond_scale, reps=20):
 def cpu_baseline():
     """Config 1 of BASELINE.json on this host: base U-Net 64x64, B=4, T=100, cond_scale 3, oracle (CPU port)."""
     from oracle import restated as R
-    ncores = os.cpu_count()
+    ncores = min(os.cpu_count(), 16)     # tiny-channel convs do not scale further; more threads only add sync cost
     torch.set_num_threads(ncores)
     sd = torch.load(os.path.join(ROOT, "tests", "golden", "unet0_sd.pt"), weights_only=False)
     emb, mask = synthetic_text(4)
     B, T = 4, 100
-    t0 = time.time()
-    R.sample([sd], [64], T, text_embeds=emb, text_masks=mask, cond_scale=3., randn=R.make_randn(1234))
+    sched = R.Schedule(T)
+    randn = R.make_randn(1234)
+    img = randn((B, 3, 64, 64))
+    done, t0 = 0, time.time()
+    for t in sched.sampling_timesteps():          # the reference's own loop order; stop after ~20 s of CPU work
+        img, _ = R.p_sample(sd, sched, img, t, randn((B, 3, 64, 64)), text_embeds=emb, text_mask=mask, cond_scale=3.)
+        done += 1
+        if time.time() - t0 > 20.0:
+            break
     dt = time.time() - t0
-    return dict(value=B * T / dt, unit="denoising-steps/s", cores=ncores, kind="port",
-                sample=f"oracle/restated.py sample(): base U-Net (unet_0 params) 64x64, B=4, T=100, cond_scale=3 (BASELINE config 1), {dt:.1f}s on {ncores} host threads")
+    return dict(value=B * done / dt, unit="denoising-steps/s", cores=ncores, kind="port",
+                sample=f"oracle/restated.py p_sample loop: base U-Net (unet_0 params) 64x64, B=4, cond_scale=3 (BASELINE config 1), "
+                       f"{done} of {T} timesteps in {dt:.1f}s on {ncores} host threads")
 
 
 def main():

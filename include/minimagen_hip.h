@@ -79,8 +79,9 @@ typedef struct mi_conv_params {
     const float* res_b;     /* [Cout] or NULL */
     float* out;             /* [B][Cout][H][W] */
     float* out_stats;       /* [B][Cout][out_nt][2] or NULL */
-    int tile_cfg;           /* see mi_conv_tile_shape */
+    int tile_cfg;           /* see mi_conv_tile_shape; | MI_CONV_SPLIT16: 16-channel outputs as two 8-channel workgroups */
 } mi_conv_params;
+#define MI_CONV_SPLIT16 0x100
 
 /* tile_cfg -> output tile (th x tw) handled by one workgroup; out_nt = ceil(H/th)*ceil(W/tw) */
 int mi_conv_tile_shape(int tile_cfg, int* th, int* tw);
@@ -185,7 +186,8 @@ typedef struct mi_cross_attn_params {
     const float* gv;
     const float* n1_g; const float* n1_b;   /* CrossAttention.norm   gamma / beta */
     const float* n2_g; const float* n2_b;   /* to_out.1              gamma / beta */
-    float* out; float* out_stats;   /* [B2][C][HW]; stats [B2][C][ceil(HW/128)][2] */
+    float* out; float* out_stats;   /* [B2][C][HW]; stats [B2][C][ceil(HW/tok)][2], tok = 128 (variant 0) or 64 (variant 1) */
+    int variant;                    /* 0: 32 tokens per wave, 1: 16 tokens per wave (more waves per SIMD) */
 } mi_cross_attn_params;
 int mi_cross_attn_fwd(const mi_cross_attn_params* p, void* stream);
 #define MI_ATTN_TOKENS_PER_WG 128

@@ -84,7 +84,7 @@ class MiCrossAttnParams(C.Structure):
     _fields_ = [
         ("B2", C.c_int), ("C", C.c_int), ("HW", C.c_int), ("heads", C.c_int), ("J", C.c_int),
         ("x", MiAct), ("gv", C.c_void_p), ("n1_g", C.c_void_p), ("n1_b", C.c_void_p), ("n2_g", C.c_void_p), ("n2_b", C.c_void_p),
-        ("out", C.c_void_p), ("out_stats", C.c_void_p),
+        ("out", C.c_void_p), ("out_stats", C.c_void_p), ("variant", C.c_int),
     ]
 
 

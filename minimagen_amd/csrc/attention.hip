@@ -17,15 +17,25 @@ __global__ __launch_bounds__(256) void cross_attn_folded_kernel(const mi_cross_a
     constexpr int NGP = KK < 4 ? 4 : KK;
     constexpr int MT = (C + 15) / 16;               // M tiles of PV (output channels)
     constexpr int FR = NGP + 4 * MT;
-    constexpr int CPL = (C < 16 ? C : 16) / 4;      // (unused rows are zero when C < 16)
-    (void)CPL;
+    constexpr int TOK_WG = 4 * 16 * NQ;             // tokens per workgroup
     __shared__ float red[4][2 * 16 * MT];
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int lq = lane & 15, lg = lane >> 4;
-    const int b = blockIdx.y;
+    // XCD-aware placement: workgroup L runs on XCD L%8 (observed dispatch order); give each XCD whole samples so the
+    // folded context fragments (267 KB per sample) stay in that XCD's L2.  Pure speed: any placement is correct.
+    const int tiles = (p.HW + TOK_WG - 1) / TOK_WG;
+    int b, tile;
+    if ((p.B2 & 7) == 0) {
+        const int L = blockIdx.x, k = L >> 3;
+        b = (L & 7) + 8 * (k / tiles);
+        tile = k % tiles;
+    } else {
+        b = blockIdx.x / tiles;
+        tile = blockIdx.x % tiles;
+    }
     const int bx = p.x.bmod > 0 ? b % p.x.bmod : b;
-    const int i0 = (blockIdx.x * 4 + wave) * 16 * NQ;
+    const int i0 = (tile * 4 + wave) * 16 * NQ;
     const float* xb = p.x.data + (size_t)bx * C * p.HW;
 
     // ---- LayerNorm(x) per token -> B operand of QK^T: lane supplies x^[a = 4kk + lg][token lq]
@@ -85,7 +95,9 @@ __global__ __launch_bounds__(256) void cross_attn_folded_kernel(const mi_cross_a
                 s[jt][q] = acc;
             }
         }
-        // ---- softmax over j (rows of S^T): this lane holds j = 16jt + 4lg + r
+        // ---- softmax over j (rows of S^T): this lane holds j = 16jt + 4lg + r.  P stays un-normalised; the 1/l of
+        // this head is applied to its 16*MT-row PV result instead of to the 272 probabilities.
+        float linv[NQ];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             float m = -INFINITY;
@@ -109,13 +121,14 @@ __global__ __launch_bounds__(256) void cross_attn_folded_kernel(const mi_cross_a
                 }
             l += __shfl_xor(l, 16);
             l += __shfl_xor(l, 32);
-            const float inv = 1.0f / l;
-#pragma unroll
-            for (int jt = 0; jt < JT; ++jt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) s[jt][q][r] *= inv;
+            linv[q] = 1.0f / l;
         }
-        // ---- O^T += VW_h^T . P^T
+        // ---- O_h^T = VW_h^T . P^T
+        f32x4 oh[NQ][MT];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) oh[q][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int jt = 0; jt < JT; ++jt) {
             float vw[4 * MT];
@@ -130,8 +143,14 @@ __global__ __launch_bounds__(256) void cross_attn_folded_kernel(const mi_cross_a
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        oacc[q][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vw[4 * mt + r], s[jt][q][r], oacc[q][mt], 0, 0, 0);
+                        oh[q][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vw[4 * mt + r], s[jt][q][r], oh[q][mt], 0, 0, 0);
         }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) oacc[q][mt][r] = fmaf(oh[q][mt][r], linv[q], oacc[q][mt][r]);
     }
 
     // ---- to_out.1 LayerNorm over channels, + residual, store, statistics.
@@ -197,7 +216,7 @@ __global__ __launch_bounds__(256) void cross_attn_folded_kernel(const mi_cross_a
         __syncthreads();
         if (tid < 2 * C) {
             const float a4 = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
-            p.out_stats[((size_t)(b * C + (tid >> 1)) * gridDim.x + blockIdx.x) * 2 + (tid & 1)] = a4;
+            p.out_stats[((size_t)(b * C + (tid >> 1)) * tiles + tile) * 2 + (tid & 1)] = a4;
         }
     }
 }
@@ -210,7 +229,19 @@ extern "C" int mi_cross_attn_fwd(const mi_cross_attn_params* pp, void* stream) {
     const int JT = (p.J + 15) / 16;
     if (JT != 17) { mi_set_error("mi_cross_attn_fwd: context of %d rows (%d tiles) not instantiated (MinImagen: 1 + time tokens + 256)", p.J, JT); return MI_ERR_UNSUPPORTED; }
     if (p.B2 <= 0 || p.HW <= 0) { mi_set_error("mi_cross_attn_fwd: empty problem"); return MI_ERR_INVALID; }
-    const dim3 grid((p.HW + MI_ATTN_TOKENS_PER_WG - 1) / MI_ATTN_TOKENS_PER_WG, p.B2);
+    // out_stats tiles are MI_ATTN_TOKENS_PER_WG tokens (NQ = 2); p.variant = 1 selects NQ = 1 (64-token tiles)
+    const int nq = p.variant == 1 ? 1 : 2;
+    const int tok = 64 * nq;
+    const dim3 grid(((p.HW + tok - 1) / tok) * p.B2);
+    if (nq == 1) {
+        switch (p.C) {
+            case 8: hipLaunchKernelGGL(HIP_KERNEL_NAME(cross_attn_folded_kernel<8, 1, 17>), grid, dim3(256), 0, st, p); break;
+            case 16: hipLaunchKernelGGL(HIP_KERNEL_NAME(cross_attn_folded_kernel<16, 1, 17>), grid, dim3(256), 0, st, p); break;
+            case 32: hipLaunchKernelGGL(HIP_KERNEL_NAME(cross_attn_folded_kernel<32, 1, 17>), grid, dim3(256), 0, st, p); break;
+            default: mi_set_error("mi_cross_attn_fwd: folded path instantiated for C in {8,16,32}, got %d", p.C); return MI_ERR_UNSUPPORTED;
+        }
+        return mi_check_launch("cross_attn_folded_kernel");
+    }
     switch (p.C) {
         case 8: hipLaunchKernelGGL(HIP_KERNEL_NAME(cross_attn_folded_kernel<8, 2, 17>), grid, dim3(256), 0, st, p); break;
         case 16: hipLaunchKernelGGL(HIP_KERNEL_NAME(cross_attn_folded_kernel<16, 2, 17>), grid, dim3(256), 0, st, p); break;

@@ -10,16 +10,16 @@
 
 namespace {
 
-template <int NT_, int TW_, int COUT_T_, int KS_, int S_, bool UP2_>
+template <int NT_, int TW_, int COUT_T_, int KS_, int S_, bool UP2_, bool VEC_>
 struct ConvCfg {
     static constexpr int NT = NT_, TW = TW_, COUT_T = COUT_T_, KS = KS_, S = S_;
-    static constexpr bool UP2 = UP2_;
+    static constexpr bool UP2 = UP2_, VEC = VEC_;
     static constexpr int TXN = TW / 4;            // work-items along x (4 output pixels each)
     static constexpr int TH = NT / TXN;           // output rows per tile (1 row per work-item)
     static constexpr int IH = TH * S + KS - S;    // staged input rows / cols (with halo)
     static constexpr int IW = TW * S + KS - S;
     static constexpr int IWP = (IW + 3) & ~3;     // LDS row pitch (16-byte aligned rows)
-    static constexpr int CK = (S == 2) ? 2 : 8;   // input channels staged per round
+    static constexpr int CK = (S == 2) ? 2 : 4;   // input channels staged per round
     static constexpr int NIN = 4 * S + KS - S;    // input floats per row a work-item consumes
     static constexpr int STAGE_FLOATS = CK * IH * IWP;
     static constexpr int RED_FLOATS = 2 * COUT_T * (NT + 1);
@@ -27,10 +27,13 @@ struct ConvCfg {
 };
 
 template <class CFG>
-__global__ __launch_bounds__(CFG::NT) void conv_tile_kernel(const mi_conv_params p, const int CoutPad) {
+__global__ __launch_bounds__(CFG::NT) void conv_tile_kernel(const mi_conv_params p, const int CoutPad,
+                                                            const float* __restrict__ wts, const float* __restrict__ res_wts) {
+    // wts / res_wts repeat p.w / p.res_w as `const __restrict__` kernel arguments: only then does the compiler prove the
+    // (wave-uniform) weight reads invariant and issue them as scalar s_load instead of per-lane global loads
     constexpr int NT = CFG::NT, TW = CFG::TW, TH = CFG::TH, TXN = CFG::TXN, COUT_T = CFG::COUT_T;
     constexpr int KS = CFG::KS, S = CFG::S, IH = CFG::IH, IW = CFG::IW, IWP = CFG::IWP, CK = CFG::CK, NIN = CFG::NIN;
-    constexpr bool UP2 = CFG::UP2;
+    constexpr bool UP2 = CFG::UP2, VEC = CFG::VEC;
 
     __shared__ __attribute__((aligned(16))) float smem[CFG::SMEM_FLOATS];
     __shared__ float chA[MI_MAX_CIN], chB[MI_MAX_CIN];
@@ -48,10 +51,119 @@ __global__ __launch_bounds__(CFG::NT) void conv_tile_kernel(const mi_conv_params
     const int Hin = UP2 ? p.H / 2 : p.H * S, Win = UP2 ? p.W / 2 : p.W * S;
     const int Hv = UP2 ? p.H : Hin, Wv = UP2 ? p.W : Win;
 
+    const int ty = tid / TXN, tx = tid % TXN;
+    float acc[4][COUT_T];
+#pragma unroll
+    for (int px = 0; px < 4; ++px)
+#pragma unroll
+        for (int co = 0; co < COUT_T; ++co) acc[px][co] = 0.0f;
+
+    const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;   // pad = 1 for every member of the family
+    const int b0 = p.in0.bmod > 0 ? b % p.in0.bmod : b, b1 = p.in1.bmod > 0 ? b % p.in1.bmod : b;
+    const int br0 = p.res0.bmod > 0 ? b % p.res0.bmod : b, br1 = p.res1.bmod > 0 ? b % p.res1.bmod : b;
+    const bool gn = p.gn_groups > 0;
+
+    // Staging is split (T14): a round's global loads are issued back-to-back into registers with clamped
+    // (always legal) addresses and no branches; the activation + LDS write happens after the barrier, and on
+    // the vector path the NEXT round's loads fly under the FMA loop.
+    //   VEC  (k3 s1, W % 4 == 0): aligned float4 loads of the window [ox0-4, ox0+TW+4)
+    //   !VEC (stride 2, nearest-upsample, ragged W): scalar loads, U at a time
+    constexpr int WIN4 = (TW + 8) / 4;
+    constexpr int PER4 = (CK * IH * WIN4 + NT - 1) / NT;
+    float4 xq4[VEC ? PER4 : 1];
+    // per-work-item staging slots (tile geometry only -> identical for every channel round):
+    //   msrc = element offset of the float4 inside one channel plane, or -1 when the slot is outside the image / unused
+    //   mdst = LDS index of its first float, mck = channel within the round
+    int msrc[VEC ? PER4 : 1], mdst[VEC ? PER4 : 1], mck[VEC ? PER4 : 1];
+    if constexpr (VEC) {
+#pragma unroll
+        for (int u = 0; u < PER4; ++u) {
+            const int q = tid + u * NT;
+            const int rowid = q / WIN4, xq = q % WIN4;
+            const int ck = rowid / IH, iy = rowid % IH;
+            const int gy = iy0 + iy, gx0 = ox0 - 4 + 4 * xq;
+            const bool in = (ck < CK) && gy >= 0 && gy < Hv && gx0 >= 0 && gx0 < Wv;
+            msrc[u] = in ? gy * Win + gx0 : -1;
+            mdst[u] = (ck < CK) ? (ck * IH + iy) * IWP + 4 * xq - 3 : -(1 << 20);
+            mck[u] = ck | (xq << 8);
+        }
+    }
+    auto stage_load = [&](int c0) {
+        if constexpr (VEC) {
+#pragma unroll
+            for (int u = 0; u < PER4; ++u) {
+                const int c = c0 + (mck[u] & 255);
+                const bool inimg = msrc[u] >= 0 && c < Cin;
+                const bool second = inimg && c >= C0;
+                const float* base = second ? p.in1.data : p.in0.data;
+                const int cc = second ? (b1 * C1 + (c - C0)) : (b0 * C0 + c);
+                const unsigned off = inimg ? (unsigned)(cc * Hin * Win + msrc[u]) : 0u;
+                xq4[u] = *reinterpret_cast<const float4*>(base + off);
+            }
+        }
+    };
+    auto stage_write = [&](int c0) {
+        if constexpr (VEC) {
+#pragma unroll
+            for (int u = 0; u < PER4; ++u) {
+                const int c = c0 + (mck[u] & 255);
+                const bool inimg = msrc[u] >= 0 && c < Cin;
+                const float A = inimg ? chA[c] : 0.0f, Bc = inimg ? chB[c] : 0.0f;
+                const float xe[4] = {xq4[u].x, xq4[u].y, xq4[u].z, xq4[u].w};
+                const int ixb = 4 * (mck[u] >> 8) - 3;             // column of the first float (-3 .. IW)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = 0.0f;      // zero outside the image: the padding follows the activation
+                    if (inimg) v = gn ? mi_silu(fmaf(xe[e], A, Bc)) : xe[e] * A;
+                    if (mdst[u] >= -3 && ixb + e >= 0 && ixb + e < IW) smem[mdst[u] + e] = v;
+                }
+            }
+        } else {
+            constexpr int TOT = CK * IH * IW, U = 8;
+#pragma unroll 1
+            for (int it = 0; it < TOT; it += U * NT) {
+                float xs[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int idx = it + tid + u * NT;
+                    const int ix = idx % IW, r = idx / IW;
+                    const int iy = r % IH, ck = r / IH;
+                    const int c = c0 + ck;
+                    const int gy = iy0 + iy, gx = ix0 + ix;
+                    const bool inimg = idx < TOT && c < Cin && gy >= 0 && gy < Hv && gx >= 0 && gx < Wv;
+                    const int sy = UP2 ? (gy >> 1) : gy, sx = UP2 ? (gx >> 1) : gx;
+                    const bool second = inimg && c >= C0;
+                    const float* base = second ? p.in1.data : p.in0.data;
+                    const int cc = second ? (b1 * C1 + (c - C0)) : (b0 * C0 + c);
+                    const unsigned off = inimg ? (unsigned)((cc * Hin + sy) * Win + sx) : 0u;
+                    xs[u] = base[off];
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int idx = it + tid + u * NT;
+                    const int ix = idx % IW, r = idx / IW;
+                    const int iy = r % IH, ck = r / IH;
+                    const int c = c0 + ck;
+                    const int gy = iy0 + iy, gx = ix0 + ix;
+                    const bool inimg = idx < TOT && c < Cin && gy >= 0 && gy < Hv && gx >= 0 && gx < Wv;
+                    float v = 0.0f;
+                    if (inimg) v = gn ? mi_silu(fmaf(xs[u], chA[c], chB[c])) : xs[u] * chA[c];
+                    if (idx < TOT) smem[(ck * IH + iy) * IWP + ix] = v;
+                }
+            }
+        }
+    };
+
+    stage_load(0);      // first round's loads fly under the statistics prologue
+
     // ---------------- prologue: per-channel affine for the fused GroupNorm / scale-shift
     if (p.gn_groups > 0) {
-        for (int base = 0; base < Cin; base += NT / 4) {
-            const int c = base + (tid >> 2), sub = tid & 3;
+        // per-channel totals of the producer's per-tile partial sums: TPC lanes per channel, fixed-order fp64 tree
+        int TPC = 1;
+        while (TPC < 64 && TPC * 2 * Cin <= NT) TPC *= 2;
+        const int CPP = NT / TPC;                       // channels per pass
+        for (int base = 0; base < Cin; base += CPP) {
+            const int c = base + tid / TPC, sub = tid % TPC;
             double s = 0.0, q = 0.0;
             if (c < Cin) {
                 const bool second = c >= C0;
@@ -59,7 +171,7 @@ __global__ __launch_bounds__(CFG::NT) void conv_tile_kernel(const mi_conv_params
                 const int cc = second ? c - C0 : c;
                 const int ba = a.bmod > 0 ? b % a.bmod : b;
                 const float* st = a.stats + ((size_t)(ba * a.C + cc) * a.nt) * 2;
-                for (int t = sub; t < a.nt; t += 4) {
+                for (int t = sub; t < a.nt; t += TPC) {
                     const float2 v = *reinterpret_cast<const float2*>(st + 2 * t);
                     s += (double)v.x;
                     q += (double)v.y;
@@ -67,8 +179,7 @@ __global__ __launch_bounds__(CFG::NT) void conv_tile_kernel(const mi_conv_params
                 s *= (double)a.scale;
                 q *= (double)a.scale * (double)a.scale;
             }
-            s += __shfl_xor(s, 1); s += __shfl_xor(s, 2);
-            q += __shfl_xor(q, 1); q += __shfl_xor(q, 2);
+            for (int o = TPC >> 1; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
             if (c < Cin && sub == 0) { chS[c] = s; chQ[c] = q; }
         }
         __syncthreads();
@@ -102,41 +213,14 @@ __global__ __launch_bounds__(CFG::NT) void conv_tile_kernel(const mi_conv_params
         for (int c = tid; c < Cin; c += NT) { chA[c] = (c >= C0) ? p.in1.scale : p.in0.scale; chB[c] = 0.0f; }
     }
 
-    const int ty = tid / TXN, tx = tid % TXN;
-    float acc[4][COUT_T];
-#pragma unroll
-    for (int px = 0; px < 4; ++px)
-#pragma unroll
-        for (int co = 0; co < COUT_T; ++co) acc[px][co] = 0.0f;
-
-    const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;   // pad = 1 for every member of the family
-    const int b0 = p.in0.bmod > 0 ? b % p.in0.bmod : b, b1 = p.in1.bmod > 0 ? b % p.in1.bmod : b;
-    const int br0 = p.res0.bmod > 0 ? b % p.res0.bmod : b, br1 = p.res1.bmod > 0 ? b % p.res1.bmod : b;
-    const bool gn = p.gn_groups > 0;
-
     for (int c0 = 0; c0 < Cin; c0 += CK) {
         __syncthreads();   // previous round fully consumed (and chA/chB visible on the first round)
-        // ---- stage CK channels of the activated input tile (zero outside the image: padding follows the activation)
-        for (int idx = tid; idx < CK * IH * IW; idx += NT) {
-            const int ix = idx % IW, r = idx / IW;
-            const int iy = r % IH, ck = r / IH;
-            const int c = c0 + ck;
-            const int gy = iy0 + iy, gx = ix0 + ix;
-            float v = 0.0f;
-            if (c < Cin && gy >= 0 && gy < Hv && gx >= 0 && gx < Wv) {
-                const int sy = UP2 ? (gy >> 1) : gy, sx = UP2 ? (gx >> 1) : gx;
-                const float* src = (c < C0) ? p.in0.data + ((size_t)(b0 * C0 + c) * Hin + sy) * Win + sx
-                                            : p.in1.data + ((size_t)(b1 * C1 + (c - C0)) * Hin + sy) * Win + sx;
-                const float x = *src;
-                v = gn ? mi_silu(fmaf(x, chA[c], chB[c])) : x * chA[c];
-            }
-            smem[(ck * IH + iy) * IWP + ix] = v;
-        }
+        stage_write(c0);
         __syncthreads();
-        // ---- accumulate
+        if (c0 + CK < Cin) stage_load(c0 + CK);       // in flight during the FMA loop below
         const int nck = (Cin - c0) < CK ? (Cin - c0) : CK;
         for (int ck = 0; ck < nck; ++ck) {
-            const float* wc = p.w + (size_t)(c0 + ck) * KS * KS * CoutPad + co0;
+            const float* wc = wts + (size_t)(c0 + ck) * KS * KS * CoutPad + co0;
 #pragma unroll
             for (int ky = 0; ky < KS; ++ky) {
                 float in[NIN];
@@ -174,15 +258,20 @@ __global__ __launch_bounds__(CFG::NT) void conv_tile_kernel(const mi_conv_params
                 const float* src = second ? p.res1.data + ((size_t)(br1 * Cres1 + (cr - Cres0)) * p.H + oy) * p.W
                                           : p.res0.data + ((size_t)(br0 * Cres0 + cr) * p.H + oy) * p.W;
                 const float sc = second ? p.res1.scale : p.res0.scale;
-                float xv[4];
+                float rv[4];
+                if (ox + 3 < p.W && (p.W & 3) == 0) {
+                    const float4 t4 = *reinterpret_cast<const float4*>(src + ox);
+                    rv[0] = t4.x * sc; rv[1] = t4.y * sc; rv[2] = t4.z * sc; rv[3] = t4.w * sc;
+                } else {
 #pragma unroll
-                for (int px = 0; px < 4; ++px) xv[px] = (ox + px < p.W) ? src[ox + px] * sc : 0.0f;
-                const float* wr = p.res_w + (size_t)cr * CoutPad + co0;
+                    for (int px = 0; px < 4; ++px) rv[px] = (ox + px < p.W) ? src[ox + px] * sc : 0.0f;
+                }
+                const float* wr = res_wts + (size_t)cr * CoutPad + co0;
 #pragma unroll
                 for (int co = 0; co < COUT_T; ++co) {
                     const float wv = wr[co];
 #pragma unroll
-                    for (int px = 0; px < 4; ++px) acc[px][co] = fmaf(xv[px], wv, acc[px][co]);
+                    for (int px = 0; px < 4; ++px) acc[px][co] = fmaf(rv[px], wv, acc[px][co]);
                 }
             }
 #pragma unroll
@@ -196,9 +285,15 @@ __global__ __launch_bounds__(CFG::NT) void conv_tile_kernel(const mi_conv_params
             for (int co = 0; co < COUT_T; ++co) {
                 if (co0 + co < p.Cout) {
                     const float* src = p.res0.data + ((size_t)(br0 * Cres0 + co0 + co) * p.H + oy) * p.W;
+                    if (ox + 3 < p.W && (p.W & 3) == 0) {
+                        const float4 t4 = *reinterpret_cast<const float4*>(src + ox);
+                        acc[0][co] += t4.x * p.res0.scale; acc[1][co] += t4.y * p.res0.scale;
+                        acc[2][co] += t4.z * p.res0.scale; acc[3][co] += t4.w * p.res0.scale;
+                    } else {
 #pragma unroll
-                    for (int px = 0; px < 4; ++px)
-                        if (ox + px < p.W) acc[px][co] += src[ox + px] * p.res0.scale;
+                        for (int px = 0; px < 4; ++px)
+                            if (ox + px < p.W) acc[px][co] += src[ox + px] * p.res0.scale;
+                    }
                 }
             }
         }
@@ -244,18 +339,27 @@ __global__ __launch_bounds__(CFG::NT) void conv_tile_kernel(const mi_conv_params
     }
 }
 
-template <int NT, int TW, int COUT_T, int KS, int S, bool UP2>
-int launch_conv(const mi_conv_params& p, hipStream_t st) {
-    using CFG = ConvCfg<NT, TW, COUT_T, KS, S, UP2>;
+template <int NT, int TW, int COUT_T, int KS, int S, bool UP2, bool VEC>
+int launch_conv_v(const mi_conv_params& p, hipStream_t st) {
+    using CFG = ConvCfg<NT, TW, COUT_T, KS, S, UP2, VEC>;
     const int tiles = ((p.H + CFG::TH - 1) / CFG::TH) * ((p.W + TW - 1) / TW);
     const int cz = (p.Cout + COUT_T - 1) / COUT_T;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_tile_kernel<CFG>), dim3(tiles, p.B, cz), dim3(NT), 0, st, p, cz * COUT_T);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_tile_kernel<CFG>), dim3(tiles, p.B, cz), dim3(NT), 0, st, p, cz * COUT_T, p.w, p.res_w);
     return mi_check_launch("conv_tile_kernel");
+}
+
+template <int NT, int TW, int COUT_T, int KS, int S, bool UP2>
+int launch_conv(const mi_conv_params& p, hipStream_t st) {
+    if constexpr (KS == 3 && S == 1 && !UP2) {
+        if ((p.W & 3) == 0 && (size_t)p.B * (p.in0.C > p.in1.C ? p.in0.C : p.in1.C) * p.H * p.W < (1ull << 31))
+            return launch_conv_v<NT, TW, COUT_T, KS, S, UP2, true>(p, st);
+    }
+    return launch_conv_v<NT, TW, COUT_T, KS, S, UP2, false>(p, st);
 }
 
 template <int COUT_T, int KS, int S, bool UP2>
 int dispatch_tile(const mi_conv_params& p, hipStream_t st) {
-    switch (p.tile_cfg) {
+    switch (p.tile_cfg & 0xff) {
         case 0: return launch_conv<256, 64, COUT_T, KS, S, UP2>(p, st);
         case 1: return launch_conv<256, 32, COUT_T, KS, S, UP2>(p, st);
         case 2: return launch_conv<64, 32, COUT_T, KS, S, UP2>(p, st);
@@ -290,7 +394,7 @@ extern "C" int mi_conv_fwd(const mi_conv_params* pp, void* stream) {
     const int ct = mi_conv_cout_tile(p.Cout);
     if (p.ksize == 3 && p.stride == 1 && !p.up2) {
         if (ct == 4) return dispatch_tile<4, 3, 1, false>(p, st);
-        if (ct == 8) return dispatch_tile<8, 3, 1, false>(p, st);
+        if (ct == 8 || (p.tile_cfg & MI_CONV_SPLIT16)) return dispatch_tile<8, 3, 1, false>(p, st);
         return dispatch_tile<16, 3, 1, false>(p, st);
     }
     if (p.ksize == 3 && p.stride == 1 && p.up2) {
@@ -299,7 +403,7 @@ extern "C" int mi_conv_fwd(const mi_conv_params* pp, void* stream) {
         return dispatch_tile<4, 3, 1, true>(p, st);
     }
     if (p.ksize == 4 && p.stride == 2 && !p.up2) {
-        if (ct == 16) return dispatch_tile<16, 4, 2, false>(p, st);
+        if (ct == 16) return dispatch_tile<8, 4, 2, false>(p, st);     // 16 taps x 16 channels would not fit the SGPR file: 2 channel tiles
         if (ct == 8) return dispatch_tile<8, 4, 2, false>(p, st);
         return dispatch_tile<4, 4, 2, false>(p, st);
     }

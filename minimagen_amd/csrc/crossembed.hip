@@ -11,11 +11,15 @@ namespace {
 
 // ---- specialised: dim_scales (4,2,2), kernel sizes (3,7,15) -- every U-Net with dim=8 ----
 template <int NT, int TW>
-__global__ __launch_bounds__(NT) void crossembed_422_kernel(const mi_crossembed_params p) {
+__global__ __launch_bounds__(NT) void crossembed_422_kernel(const mi_crossembed_params p, const float* __restrict__ w3g,
+                                                            const float* __restrict__ w7g, const float* __restrict__ w15g) {
+    // (w3g/w7g/w15g repeat p.w[] as const __restrict__ kernel arguments so the wave-uniform weight reads become s_load)
     constexpr int TXN = TW / 4, TH = NT / TXN, HALO = 7;
     constexpr int IH = TH + 2 * HALO, IW = TW + 2 * HALO, IWP = (IW + 3) & ~3;
     constexpr int COUT = 8;
     constexpr int STAGE = IH * IWP, RED = 2 * COUT * (NT + 1);
+    constexpr int WIN4 = (TW + 16) / 4;                 // aligned float4 window [ox0-8, ox0+TW+8)
+    constexpr int PER4 = (IH * WIN4 + NT - 1) / NT;
     __shared__ __attribute__((aligned(16))) float smem[STAGE > RED ? STAGE : RED];
 
     const int tid = threadIdx.x;
@@ -27,6 +31,7 @@ __global__ __launch_bounds__(NT) void crossembed_422_kernel(const mi_crossembed_
     const int b0 = p.in0_batch_mod > 0 ? b % p.in0_batch_mod : b;
     const int b1 = p.in1_batch_mod > 0 ? b % p.in1_batch_mod : b;
     const int ty = tid / TXN, tx = tid % TXN;
+    const bool vec = (p.W & 3) == 0;
 
     float acc[4][COUT];
 #pragma unroll
@@ -34,21 +39,61 @@ __global__ __launch_bounds__(NT) void crossembed_422_kernel(const mi_crossembed_
 #pragma unroll
         for (int co = 0; co < COUT; ++co) acc[px][co] = 0.0f;
 
+    // split staging: one channel's loads are issued into registers and fly under the previous channel's FMAs
+    float4 xq4[PER4];
+    int msrc[PER4], mdst[PER4];
+#pragma unroll
+    for (int u = 0; u < PER4; ++u) {
+        const int q = tid + u * NT;
+        const int iy = q / WIN4, xq = q % WIN4;
+        const int gy = oy0 - HALO + iy, gx0 = ox0 - 8 + 4 * xq;
+        const bool in = iy < IH && gy >= 0 && gy < p.H && gx0 >= 0 && gx0 < p.W;
+        msrc[u] = in ? gy * p.W + gx0 : -1;
+        mdst[u] = iy < IH ? (iy * IWP + 4 * xq) | (xq << 20) : -1;
+    }
+    auto plane = [&](int c) { return (c < C0) ? p.in0 + (size_t)(b0 * C0 + c) * p.H * p.W : p.in1 + (size_t)(b1 * C1 + (c - C0)) * p.H * p.W; };
+    auto stage_load = [&](int c) {
+        const float* src = plane(c);
+        if (vec) {
+#pragma unroll
+            for (int u = 0; u < PER4; ++u) xq4[u] = *reinterpret_cast<const float4*>(src + (msrc[u] >= 0 ? msrc[u] : 0));
+        }
+    };
+    auto stage_write = [&](int c) {
+        if (vec) {
+#pragma unroll
+            for (int u = 0; u < PER4; ++u) {
+                if (mdst[u] >= 0) {
+                    const int d = mdst[u] & 0xfffff, xq = mdst[u] >> 20;
+                    const float xe[4] = {xq4[u].x, xq4[u].y, xq4[u].z, xq4[u].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int ix = 4 * xq - 1 + e;
+                        if (ix >= 0 && ix < IW) smem[d - 1 + e] = msrc[u] >= 0 ? xe[e] : 0.0f;
+                    }
+                }
+            }
+        } else {
+            const float* src = plane(c);
+            for (int idx = tid; idx < IH * IW; idx += NT) {
+                const int ix = idx % IW, iy = idx / IW;
+                const int gy = oy0 - HALO + iy, gx = ox0 - HALO + ix;
+                float v = 0.0f;
+                if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) v = src[(size_t)gy * p.W + gx];
+                smem[iy * IWP + ix] = v;
+            }
+        }
+    };
+
+    stage_load(0);
     for (int c = 0; c < Cin; ++c) {
         __syncthreads();
-        const float* src = (c < C0) ? p.in0 + (size_t)(b0 * C0 + c) * p.H * p.W
-                                    : p.in1 + (size_t)(b1 * C1 + (c - C0)) * p.H * p.W;
-        for (int idx = tid; idx < IH * IW; idx += NT) {
-            const int ix = idx % IW, iy = idx / IW;
-            const int gy = oy0 - HALO + iy, gx = ox0 - HALO + ix;
-            float v = 0.0f;
-            if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) v = src[(size_t)gy * p.W + gx];
-            smem[iy * IWP + ix] = v;
-        }
+        stage_write(c);
         __syncthreads();
-        const float* w3 = p.w[0] + (size_t)c * 9 * 4;
-        const float* w7 = p.w[1] + (size_t)c * 49 * 2;
-        const float* w15 = p.w[2] + (size_t)c * 225 * 2;
+        if (c + 1 < Cin) stage_load(c + 1);
+        const float* w3 = w3g + (size_t)c * 9 * 4;
+        const float* w7 = w7g + (size_t)c * 49 * 2;
+        const float* w15 = w15g + (size_t)c * 225 * 2;
 #pragma unroll
         for (int ky = 0; ky < 15; ++ky) {
             float in[18];
@@ -191,9 +236,9 @@ extern "C" int mi_crossembed_fwd(const mi_crossembed_params* pp, void* stream) {
     const int tiles = ((p.H + th - 1) / th) * ((p.W + tw - 1) / tw);
     if (fast) {
         switch (p.tile_cfg) {
-            case 0: hipLaunchKernelGGL(HIP_KERNEL_NAME(crossembed_422_kernel<256, 64>), dim3(tiles, p.B), dim3(256), 0, st, p); break;
-            case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(crossembed_422_kernel<256, 32>), dim3(tiles, p.B), dim3(256), 0, st, p); break;
-            default: hipLaunchKernelGGL(HIP_KERNEL_NAME(crossembed_422_kernel<64, 32>), dim3(tiles, p.B), dim3(64), 0, st, p); break;
+            case 0: hipLaunchKernelGGL(HIP_KERNEL_NAME(crossembed_422_kernel<256, 64>), dim3(tiles, p.B), dim3(256), 0, st, p, p.w[0], p.w[1], p.w[2]); break;
+            case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(crossembed_422_kernel<256, 32>), dim3(tiles, p.B), dim3(256), 0, st, p, p.w[0], p.w[1], p.w[2]); break;
+            default: hipLaunchKernelGGL(HIP_KERNEL_NAME(crossembed_422_kernel<64, 32>), dim3(tiles, p.B), dim3(64), 0, st, p, p.w[0], p.w[1], p.w[2]); break;
         }
     } else {
         // generic tiles: same (th x tw) footprint so out_nt matches mi_conv_tile_shape; th*tw work-items <= 1024

@@ -5,6 +5,10 @@
 // fp32 results come from the U-Net's summation order.
 #include "common.hip.h"
 
+// hipcc contracts a*b+c into FMA by default and its __fmul_rn/__fadd_rn are plain operators: switch contraction
+// off for this file so the elementwise sampler math rounds exactly like the reference's separate torch ops.
+#pragma clang fp contract(off)
+
 namespace {
 
 // ------------------------------------------------------------------ K11 epilogue

@@ -13,6 +13,7 @@ The op order follows minimagen/Unet.py:355-472 and minimagen/layers.py:417-439.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import List, Optional
 
 import torch
@@ -23,6 +24,9 @@ from . import packing as P
 from .layers import CrossAttention, EinopsToAndFrom, Identity, Parallel, ResnetBlock, TransformerBlock
 
 MAX_TEXT_LEN = 256
+# kernel-shape tuning knobs (A/B measurements; the defaults are what profiles/ was measured with)
+ATTN_VARIANT = int(os.environ.get("MINIMAGEN_ATTN_VARIANT", "0"))       # 0: 32 tokens per wave, 1: 16 tokens per wave
+CONV_SPLIT16 = int(os.environ.get("MINIMAGEN_CONV_SPLIT16", "0"))       # 1: 16-channel 3x3 outputs as two 8-channel workgroups
 JT = 17     # context tiles of 16 rows: 1 null + (2|4) time tokens + 256 text rows <= 272
 
 
@@ -176,17 +180,11 @@ class UnetEngine:
         self._ws[key] = ws
         return ws
 
-    def _tile_cfg(self, H, W, batch, cz=1):
+    def _tile_cfg(self, H, W, batch=None, cz=1):
+        """Tile shape by image size ONLY: the per-tile partial statistics must reduce in the same order whatever the
+        batch is, so that a sharded batch reproduces the unsharded rows bit for bit."""
         lib = L.lib()
-        cands = ([0] if W >= 64 else []) + [1, 2]
-        best = cands[-1]
-        for cfg in cands:
-            th, tw = C.c_int(), C.c_int()
-            lib.mi_conv_tile_shape(cfg, C.byref(th), C.byref(tw))
-            tiles = -(-H // th.value) * -(-W // tw.value)
-            if tiles * batch * cz >= 512:
-                best = cfg
-                break
+        best = 0 if (W >= 64 and H * W > 64 * 64) else 2
         th, tw = C.c_int(), C.c_int()
         lib.mi_conv_tile_shape(best, C.byref(th), C.byref(tw))
         return best, -(-H // th.value) * -(-W // tw.value)
@@ -227,7 +225,7 @@ class UnetEngine:
             if r1 is not None:
                 p.res1 = r1.c(batch, skip_scale)
             p.res_w, p.res_b = L.ptr(rw), L.ptr(rb)
-        p.out, p.out_stats, p.tile_cfg = L.ptr(out.t), L.ptr(out.stats), cfg
+        p.out, p.out_stats, p.tile_cfg = L.ptr(out.t), L.ptr(out.stats), cfg | (0x100 if CONV_SPLIT16 else 0)
         ws.prog.append((lib.mi_conv_fwd, p, "conv"))
         return out
 
@@ -256,7 +254,7 @@ class UnetEngine:
         FR = lib.mi_attn_fragment_floats(Cc)
         gv = torch.zeros(ws.B2, ca.heads, JT, 64, FR, dtype=torch.float32, device=ws.dev)
         ws.gv[id(ca)] = gv
-        nt = -(-HW // 128)
+        nt = -(-HW // (64 if ATTN_VARIANT == 1 else 128))
         out = self._new_act(ws, ws.B2, Cc, h.H, h.W, nt)
         p = L.MiCrossAttnParams()
         p.B2, p.C, p.HW, p.heads, p.J = ws.B2, Cc, HW, ca.heads, ws.J
@@ -264,7 +262,7 @@ class UnetEngine:
         p.gv = L.ptr(gv)
         p.n1_g, p.n1_b = L.ptr(ca.norm.gamma), L.ptr(ca.norm.beta)
         p.n2_g, p.n2_b = L.ptr(ca.to_out[1].gamma), L.ptr(ca.to_out[1].beta)
-        p.out, p.out_stats = L.ptr(out.t), L.ptr(out.stats)
+        p.out, p.out_stats, p.variant = L.ptr(out.t), L.ptr(out.stats), ATTN_VARIANT
         ws.prog.append((lib.mi_cross_attn_fwd, p, "cross_attn"))
         return out
 

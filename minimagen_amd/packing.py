@@ -37,6 +37,8 @@ def fold_cross_attention(to_q, to_kv, to_out, null_kv, heads: int, dim_head: int
     """
     dev = to_q.device
     H, D = heads, dim_head
+    # host arithmetic (once per weight version): keeps library GEMMs off the GPU timeline
+    to_q, to_kv, to_out, null_kv = (t.detach().to('cpu') for t in (to_q, to_kv, to_out, null_kv))
     q = to_q.detach().double().reshape(H, D, -1)               # [H][D][C]
     kv = to_kv.detach().double()
     k = kv[:H * D].reshape(H, D, -1)                            # [H][D][cd]

@@ -163,12 +163,13 @@ def test_crossembed(backend, case):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
-@pytest.mark.parametrize("case", [(2, 16, 256, 8, 2), (1, 16, 200, 8, 4), (1, 8, 128, 8, 2), (1, 32, 128, 16, 2)])
+@pytest.mark.parametrize("case", [(2, 16, 256, 8, 2, 0), (1, 16, 200, 8, 4, 0), (1, 8, 128, 8, 2, 0), (1, 32, 128, 16, 2, 0),
+                                  (8, 16, 200, 8, 4, 1), (1, 8, 128, 8, 2, 1)])
 def test_cross_attention_folded(backend, case):
     """K9 against the oracle's unfolded CrossAttention (+ residual), incl. a ragged token count and both context lengths."""
     dev = setup(backend)
     lib = L.lib()
-    B2, Cc, HW, cd, ntok = case
+    B2, Cc, HW, cd, ntok, variant = case
     heads, J = 8, 1 + ntok + 256
     g = torch.Generator().manual_seed(1)
     rn = lambda *s: torch.randn(*s, generator=g)
@@ -197,10 +198,10 @@ def test_cross_attention_folded(backend, case):
     ap.x, ap.gv = L.MiAct(xd.data_ptr(), Cc, 0, 0, 1.0, 0), gv.data_ptr()
     ap.n1_g, ap.n1_b = sdd["a.norm.gamma"].data_ptr(), sdd["a.norm.beta"].data_ptr()
     ap.n2_g, ap.n2_b = sdd["a.to_out.1.gamma"].data_ptr(), sdd["a.to_out.1.beta"].data_ptr()
-    nt = -(-HW // 128)
+    nt = -(-HW // (64 if variant else 128))
     out = torch.full(x.shape, float('nan'), device=dev)
     ost = torch.zeros(B2, Cc, nt, 2, device=dev)
-    ap.out, ap.out_stats = out.data_ptr(), ost.data_ptr()
+    ap.out, ap.out_stats, ap.variant = out.data_ptr(), ost.data_ptr(), variant
     L.check(lib.mi_cross_attn_fwd(C.byref(ap), L.current_stream()))
     assert (out.cpu() - ref).abs().max().item() < 3e-5
     check_stats(ost.cpu(), ref)
