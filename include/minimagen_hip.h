@@ -102,6 +102,8 @@ typedef struct mi_crossembed_params {
     const float* bias[3];
     float* out; float* out_stats;  /* [B][sum cout][H][W], [B][C][nt][2] */
     int tile_cfg;
+    const float* addend;           /* [B][sum cout][H][W] added to the result (the step-invariant low-res half of the
+                                      convolution, computed once per sample()), or NULL; bias[] entries may be NULL */
 } mi_crossembed_params;
 int mi_crossembed_fwd(const mi_crossembed_params* p, void* stream);
 

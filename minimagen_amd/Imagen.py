@@ -189,6 +189,8 @@ class Imagen(nn.Module):
         b = float(self.lowres_noise_schedule.sqrt_one_minus_alphas_cumprod[t_low])
         L.check(lib.mi_lowres_augment(L.ptr(up), L.ptr(noise), L.ptr(ws.lowres), B * n, a, b, 1 if self.auto_normalize_img else 0, stream), "mi_lowres_augment")
         ws.lowres_keepalive = (up, noise)
+        unet = [u for u in self.unets if u.engine()._ws and ws in u.engine()._ws.values()][0]
+        unet.engine().prepare_lowres(ws, stream)
 
     @torch.no_grad()
     @eval_decorator

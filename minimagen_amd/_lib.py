@@ -12,7 +12,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-DEFAULT_LIB = os.path.join(_HERE, "libminimagen_hip.so")
+# MINIMAGEN_HIP_LIB selects another gfx950 build of the same C ABI (kernel A/B experiments); never a CPU library
+DEFAULT_LIB = os.environ.get("MINIMAGEN_HIP_LIB") or os.path.join(_HERE, "libminimagen_hip.so")
 
 c_float_p = C.c_void_p   # raw device pointers travel as integers
 
@@ -40,7 +41,7 @@ class MiCrossEmbedParams(C.Structure):
         ("in0", C.c_void_p), ("C0", C.c_int), ("in1", C.c_void_p), ("C1", C.c_int),
         ("in1_batch_mod", C.c_int), ("in0_batch_mod", C.c_int), ("n_kernels", C.c_int),
         ("ksize", C.c_int * 3), ("cout", C.c_int * 3), ("w", C.c_void_p * 3), ("bias", C.c_void_p * 3),
-        ("out", C.c_void_p), ("out_stats", C.c_void_p), ("tile_cfg", C.c_int),
+        ("out", C.c_void_p), ("out_stats", C.c_void_p), ("tile_cfg", C.c_int), ("addend", C.c_void_p),
     ]
 
 

@@ -8,8 +8,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define MI_MAX_CIN 256      // direct-conv family: input channels (after concat) per launch
 #define MI_MAX_GROUPS 32
 
-// SiLU as layers.py:128/144 computes it (x * sigmoid(x)); accurate exp, 1-ulp reciprocal.
+// SiLU as layers.py:128/144 computes it (x * sigmoid(x)).  MI_SILU_EXP2=1: sigmoid through the hardware exp2
+// (v_exp_f32, ~1 ulp on the exponential, argument scaled by -log2(e)); 0: libm expf.  1-ulp reciprocal either way.
+#ifndef MI_SILU_EXP2
+#define MI_SILU_EXP2 1
+#endif
 __device__ __forceinline__ float mi_silu(float v) {
+    if (MI_SILU_EXP2) return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.44269504088896340736f));
     return v * __builtin_amdgcn_rcpf(1.0f + expf(-v));
 }
 

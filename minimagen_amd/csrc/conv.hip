@@ -18,7 +18,9 @@ struct ConvCfg {
     static constexpr int TH = NT / TXN;           // output rows per tile (1 row per work-item)
     static constexpr int IH = TH * S + KS - S;    // staged input rows / cols (with halo)
     static constexpr int IW = TW * S + KS - S;
-    static constexpr int IWP = (IW + 3) & ~3;     // LDS row pitch (16-byte aligned rows)
+    static constexpr int WIN4 = (TW_ + 8) / 4;    // vector path: aligned float4 window [ox0-4, ox0+TW+4) per staged row
+    static constexpr int IWP = VEC_ ? 4 * WIN4 : ((IW + 3) & ~3);   // LDS row pitch (16-byte aligned rows)
+    static constexpr int XOFF = VEC_ ? 3 : 0;     // LDS column of the tile's first halo pixel (gx = ox0-1)
     static constexpr int CK = (S == 2) ? 2 : 4;   // input channels staged per round
     static constexpr int NIN = 4 * S + KS - S;    // input floats per row a work-item consumes
     static constexpr int STAGE_FLOATS = CK * IH * IWP;
@@ -34,9 +36,10 @@ __global__ __launch_bounds__(CFG::NT) void conv_tile_kernel(const mi_conv_params
     constexpr int NT = CFG::NT, TW = CFG::TW, TH = CFG::TH, TXN = CFG::TXN, COUT_T = CFG::COUT_T;
     constexpr int KS = CFG::KS, S = CFG::S, IH = CFG::IH, IW = CFG::IW, IWP = CFG::IWP, CK = CFG::CK, NIN = CFG::NIN;
     constexpr bool UP2 = CFG::UP2, VEC = CFG::VEC;
+    constexpr int XOFF = CFG::XOFF;
 
     __shared__ __attribute__((aligned(16))) float smem[CFG::SMEM_FLOATS];
-    __shared__ float chA[MI_MAX_CIN], chB[MI_MAX_CIN];
+    __shared__ __attribute__((aligned(16))) float4 chP[MI_MAX_CIN + 1];   // {A, B, -log2(e)A, -log2(e)B}; last entry = zeros
     __shared__ double chS[MI_MAX_CIN], chQ[MI_MAX_CIN];
     __shared__ float gMean[MI_MAX_GROUPS], gRstd[MI_MAX_GROUPS];
 
@@ -68,12 +71,12 @@ __global__ __launch_bounds__(CFG::NT) void conv_tile_kernel(const mi_conv_params
     // the vector path the NEXT round's loads fly under the FMA loop.
     //   VEC  (k3 s1, W % 4 == 0): aligned float4 loads of the window [ox0-4, ox0+TW+4)
     //   !VEC (stride 2, nearest-upsample, ragged W): scalar loads, U at a time
-    constexpr int WIN4 = (TW + 8) / 4;
+    constexpr int WIN4 = CFG::WIN4;
     constexpr int PER4 = (CK * IH * WIN4 + NT - 1) / NT;
     float4 xq4[VEC ? PER4 : 1];
     // per-work-item staging slots (tile geometry only -> identical for every channel round):
-    //   msrc = element offset of the float4 inside one channel plane, or -1 when the slot is outside the image / unused
-    //   mdst = LDS index of its first float, mck = channel within the round
+    //   msrc = element offset of the float4 inside one channel plane, or -1 when the slot is outside the image
+    //   mdst = LDS index of the float4 (16-byte aligned), or -1 for an unused slot; mck = channel within the round
     int msrc[VEC ? PER4 : 1], mdst[VEC ? PER4 : 1], mck[VEC ? PER4 : 1];
     if constexpr (VEC) {
 #pragma unroll
@@ -84,20 +87,20 @@ __global__ __launch_bounds__(CFG::NT) void conv_tile_kernel(const mi_conv_params
             const int gy = iy0 + iy, gx0 = ox0 - 4 + 4 * xq;
             const bool in = (ck < CK) && gy >= 0 && gy < Hv && gx0 >= 0 && gx0 < Wv;
             msrc[u] = in ? gy * Win + gx0 : -1;
-            mdst[u] = (ck < CK) ? (ck * IH + iy) * IWP + 4 * xq - 3 : -(1 << 20);
-            mck[u] = ck | (xq << 8);
+            mdst[u] = (ck < CK) ? (ck * IH + iy) * IWP + 4 * xq : -1;
+            mck[u] = ck;
         }
     }
     auto stage_load = [&](int c0) {
         if constexpr (VEC) {
 #pragma unroll
             for (int u = 0; u < PER4; ++u) {
-                const int c = c0 + (mck[u] & 255);
-                const bool inimg = msrc[u] >= 0 && c < Cin;
+                const int c = c0 + mck[u];            // the vector path requires Cin % CK == 0, so c < Cin
+                const bool inimg = msrc[u] >= 0;
                 const bool second = inimg && c >= C0;
                 const float* base = second ? p.in1.data : p.in0.data;
                 const int cc = second ? (b1 * C1 + (c - C0)) : (b0 * C0 + c);
-                const unsigned off = inimg ? (unsigned)(cc * Hin * Win + msrc[u]) : 0u;
+                const unsigned off = inimg ? (unsigned)(cc * Hin * Win + msrc[u]) : 0u;   // unused slots read element 0 (legal, ignored)
                 xq4[u] = *reinterpret_cast<const float4*>(base + off);
             }
         }
@@ -106,17 +109,22 @@ __global__ __launch_bounds__(CFG::NT) void conv_tile_kernel(const mi_conv_params
         if constexpr (VEC) {
 #pragma unroll
             for (int u = 0; u < PER4; ++u) {
-                const int c = c0 + (mck[u] & 255);
-                const bool inimg = msrc[u] >= 0 && c < Cin;
-                const float A = inimg ? chA[c] : 0.0f, Bc = inimg ? chB[c] : 0.0f;
+                // slots outside the image use the all-zero parameter entry: 0*x+0 -> SiLU(0) = 0 = the zero padding,
+                // which (as in the reference) follows the activation
+                const float4 P = chP[msrc[u] >= 0 ? c0 + mck[u] : MI_MAX_CIN];
                 const float xe[4] = {xq4[u].x, xq4[u].y, xq4[u].z, xq4[u].w};
-                const int ixb = 4 * (mck[u] >> 8) - 3;             // column of the first float (-3 .. IW)
+                float o[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float v = 0.0f;      // zero outside the image: the padding follows the activation
-                    if (inimg) v = gn ? mi_silu(fmaf(xe[e], A, Bc)) : xe[e] * A;
-                    if (mdst[u] >= -3 && ixb + e >= 0 && ixb + e < IW) smem[mdst[u] + e] = v;
+                    if (gn) {
+                        const float v = fmaf(xe[e], P.x, P.y);
+                        const float ex = __builtin_amdgcn_exp2f(fmaf(xe[e], P.z, P.w));     // exp(-v)
+                        o[e] = v * __builtin_amdgcn_rcpf(1.0f + ex);
+                    } else {
+                        o[e] = xe[e] * P.x;
+                    }
                 }
+                if (mdst[u] >= 0) *reinterpret_cast<float4*>(&smem[mdst[u]]) = make_float4(o[0], o[1], o[2], o[3]);
             }
         } else {
             constexpr int TOT = CK * IH * IW, U = 8;
@@ -147,7 +155,7 @@ __global__ __launch_bounds__(CFG::NT) void conv_tile_kernel(const mi_conv_params
                     const int gy = iy0 + iy, gx = ix0 + ix;
                     const bool inimg = idx < TOT && c < Cin && gy >= 0 && gy < Hv && gx >= 0 && gx < Wv;
                     float v = 0.0f;
-                    if (inimg) v = gn ? mi_silu(fmaf(xs[u], chA[c], chB[c])) : xs[u] * chA[c];
+                    if (inimg) { const float4 P = chP[c]; v = gn ? mi_silu(fmaf(xs[u], P.x, P.y)) : xs[u] * P.x; }
                     if (idx < TOT) smem[(ck * IH + iy) * IWP + ix] = v;
                 }
             }
@@ -206,12 +214,12 @@ __global__ __launch_bounds__(CFG::NT) void conv_tile_kernel(const mi_conv_params
                 Bc = Bc * sc + sh;
             }
             if (c >= C0) A *= p.in1.scale; else A *= p.in0.scale;
-            chA[c] = A;
-            chB[c] = Bc;
+            chP[c] = make_float4(A, Bc, A * -1.44269504088896340736f, Bc * -1.44269504088896340736f);
         }
     } else {
-        for (int c = tid; c < Cin; c += NT) { chA[c] = (c >= C0) ? p.in1.scale : p.in0.scale; chB[c] = 0.0f; }
+        for (int c = tid; c < Cin; c += NT) chP[c] = make_float4((c >= C0) ? p.in1.scale : p.in0.scale, 0.0f, 0.0f, 0.0f);
     }
+    if (tid == 0) chP[MI_MAX_CIN] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 
     for (int c0 = 0; c0 < Cin; c0 += CK) {
         __syncthreads();   // previous round fully consumed (and chA/chB visible on the first round)
@@ -224,18 +232,26 @@ __global__ __launch_bounds__(CFG::NT) void conv_tile_kernel(const mi_conv_params
 #pragma unroll
             for (int ky = 0; ky < KS; ++ky) {
                 float in[NIN];
-                const float* row = &smem[(ck * IH + ty * S + ky) * IWP + tx * 4 * S];
+                const float* row = &smem[(ck * IH + ty * S + ky) * IWP + tx * 4 * S + XOFF];
+                if constexpr (VEC) {
+                    in[0] = row[0];
+                    const float4 m4 = *reinterpret_cast<const float4*>(row + 1);      // 16-byte aligned: column 4tx+4
+                    in[1] = m4.x; in[2] = m4.y; in[3] = m4.z; in[4] = m4.w;
+                    in[5] = row[5];
+                } else {
 #pragma unroll
-                for (int j = 0; j < NIN; ++j) in[j] = row[j];
+                    for (int j = 0; j < NIN; ++j) in[j] = row[j];
+                }
 #pragma unroll
                 for (int kx = 0; kx < KS; ++kx) {
                     const float* wk = wc + (ky * KS + kx) * CoutPad;
+                    float wv[COUT_T];
 #pragma unroll
-                    for (int co = 0; co < COUT_T; ++co) {
-                        const float wv = wk[co];
+                    for (int co = 0; co < COUT_T; ++co) wv[co] = wk[co];
 #pragma unroll
-                        for (int px = 0; px < 4; ++px) acc[px][co] = fmaf(in[px * S + kx], wv, acc[px][co]);
-                    }
+                    for (int px = 0; px < 4; ++px)
+#pragma unroll
+                        for (int co = 0; co < COUT_T; ++co) acc[px][co] = fmaf(in[px * S + kx], wv[co], acc[px][co]);
                 }
             }
         }
@@ -351,7 +367,9 @@ int launch_conv_v(const mi_conv_params& p, hipStream_t st) {
 template <int NT, int TW, int COUT_T, int KS, int S, bool UP2>
 int launch_conv(const mi_conv_params& p, hipStream_t st) {
     if constexpr (KS == 3 && S == 1 && !UP2) {
-        if ((p.W & 3) == 0 && (size_t)p.B * (p.in0.C > p.in1.C ? p.in0.C : p.in1.C) * p.H * p.W < (1ull << 31))
+        const int Cin = p.in0.C + (p.in1.data ? p.in1.C : 0);
+        if ((p.W & 3) == 0 && (Cin & 3) == 0 && (p.in0.C & 3) == 0 &&
+            (size_t)p.B * (p.in0.C > p.in1.C ? p.in0.C : p.in1.C) * p.H * p.W < (1ull << 31))
             return launch_conv_v<NT, TW, COUT_T, KS, S, UP2, true>(p, st);
     }
     return launch_conv_v<NT, TW, COUT_T, KS, S, UP2, false>(p, st);

@@ -139,13 +139,15 @@ __global__ __launch_bounds__(NT) void crossembed_422_kernel(const mi_crossembed_
     float ssum[COUT], ssq[COUT];
 #pragma unroll
     for (int co = 0; co < COUT; ++co) {
-        const float bv = co < 4 ? p.bias[0][co] : (co < 6 ? p.bias[1][co - 4] : p.bias[2][co - 6]);
+        const float* bp = co < 4 ? p.bias[0] : (co < 6 ? p.bias[1] : p.bias[2]);
+        const float bv = bp ? bp[co < 4 ? co : (co < 6 ? co - 4 : co - 6)] : 0.0f;
         float s = 0.0f, q = 0.0f;
         if (row_ok) {
             float* dst = p.out + ((size_t)(b * COUT + co) * p.H + oy) * p.W + ox;
+            const float* add = p.addend ? p.addend + ((size_t)(b * COUT + co) * p.H + oy) * p.W + ox : nullptr;
 #pragma unroll
             for (int px = 0; px < 4; ++px) {
-                const float v = acc[px][co] + bv;
+                const float v = acc[px][co] + bv + ((add && ox + px < p.W) ? add[px] : 0.0f);
                 if (ox + px < p.W) { dst[px] = v; s += v; q = fmaf(v, v, q); }
             }
         }
@@ -204,7 +206,8 @@ __global__ __launch_bounds__(NT) void crossembed_generic_kernel(const mi_crossem
                 }
             }
         }
-        acc += p.bias[ki][co];
+        if (p.bias[ki]) acc += p.bias[ki][co];
+        if (p.addend) acc += p.addend[((size_t)(b * Ctot + co_g) * p.H + oy) * p.W + ox];
         p.out[((size_t)(b * Ctot + co_g) * p.H + oy) * p.W + ox] = acc;
     }
     if (p.out_stats) {

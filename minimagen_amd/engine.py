@@ -312,24 +312,37 @@ class UnetEngine:
         ws.prog.append((lib.mi_cond_step_fwd, cp, "cond_step"))
         fold_slot = len(ws.prog)        # the time-row fold is inserted here once the attention blocks are known
 
-        # ---- K3: init conv
+        # ---- K3: init conv.  For super-resolution U-Nets the low-res conditioning image is constant over the T steps and
+        # the convolution is linear, so conv(cat(x, lr)) = conv_x(x) + conv_lr(lr): the lr half runs once per sample()
+        # (ws.prog_pre, see prepare_lowres) and is added back by the per-step kernel.
         cin = u.init_conv.convs[0].in_channels
-        cfg, nt = self._tile_cfg(H, W, B)
-        cur = self._new_act(ws, B, sum(u.init_conv.dim_scales), H, W, nt)
-        ce = L.MiCrossEmbedParams()
-        ce.B, ce.H, ce.W = B, H, W
-        ce.in0, ce.C0 = L.ptr(ws.x), u.channels
-        if u.lowres_cond:
-            ce.in1, ce.C1 = L.ptr(ws.lowres), u.channels
         assert cin == u.channels * (2 if u.lowres_cond else 1)
-        ce.n_kernels = len(u.init_conv.convs)
-        if ce.n_kernels > 3:
+        cfg, nt = self._tile_cfg(H, W, B)
+        ctot = sum(u.init_conv.dim_scales)
+        cur = self._new_act(ws, B, ctot, H, W, nt)
+        if len(u.init_conv.convs) > 3:
             raise NotImplementedError("CrossEmbedLayer with more than 3 kernel sizes")
-        for i, cv in enumerate(u.init_conv.convs):
-            ce.ksize[i], ce.cout[i] = cv.kernel_size[0], cv.out_channels
-            ce.w[i], ce.bias[i] = L.ptr(pk.ce_w[i]), L.ptr(cv.bias)
-        ce.out, ce.out_stats, ce.tile_cfg = L.ptr(cur.t), L.ptr(cur.stats), cfg
-        ws.prog.append((lib.mi_crossembed_fwd, ce, "crossembed"))
+
+        def ce_params(src, chan0, with_bias, out_t, out_stats, addend):
+            ce = L.MiCrossEmbedParams()
+            ce.B, ce.H, ce.W = B, H, W
+            ce.in0, ce.C0 = L.ptr(src), u.channels
+            ce.n_kernels = len(u.init_conv.convs)
+            for i, cv in enumerate(u.init_conv.convs):
+                k, co = cv.kernel_size[0], cv.out_channels
+                ce.ksize[i], ce.cout[i] = k, co
+                ce.w[i] = L.ptr(pk.ce_w[i]) + 4 * chan0 * k * k * co        # packed [Cin][k][k][co]: a channel offset is a pointer offset
+                ce.bias[i] = L.ptr(cv.bias) if with_bias else 0
+            ce.out, ce.out_stats, ce.tile_cfg, ce.addend = L.ptr(out_t), L.ptr(out_stats), cfg, L.ptr(addend)
+            return ce
+
+        ws.prog_pre = []
+        if u.lowres_cond:
+            ws.ce_lr = torch.zeros(B, ctot, H, W, dtype=torch.float32, device=ws.dev)
+            ws.prog_pre.append((lib.mi_crossembed_fwd, ce_params(ws.lowres, u.channels, False, ws.ce_lr, None, None), "crossembed_lowres"))
+            ws.prog.append((lib.mi_crossembed_fwd, ce_params(ws.x, 0, True, cur.t, cur.stats, ws.ce_lr), "crossembed"))
+        else:
+            ws.prog.append((lib.mi_crossembed_fwd, ce_params(ws.x, 0, True, cur.t, cur.stats, None), "crossembed"))
 
         hiddens: List[Act] = []
         for pre, init_block, resnet_blocks, attn_block, post in u.downs:
@@ -392,6 +405,12 @@ class UnetEngine:
         for fn, fp, name in self._fold_params(ws, pk, ws.c_text, MAX_TEXT_LEN * u.cond_dim, 1 + ws.ntot, MAX_TEXT_LEN, 1):
             L.check(fn(C.byref(fp), st), name)
 
+    def prepare_lowres(self, ws, stream=None):
+        """Once per ``sample()`` stage / ``forward``: everything that depends only on ws.lowres (the low-res half of CrossEmbed)."""
+        st = L.current_stream() if stream is None else stream
+        for fn, p, name in ws.prog_pre:
+            L.check(fn(C.byref(p), st), name)
+
     def run(self, ws, stream=None):
         """Enqueue one U-Net evaluation (all conditioning rows) on the current stream: ws.x / ws.times /
         ws.lowres / ws.lowres_times -> ws.pred."""
@@ -414,6 +433,7 @@ class UnetEngine:
         if u.lowres_cond:
             ws.lowres.copy_(lowres_cond_img)
             ws.lowres_times.copy_(lowres_noise_times.to(torch.int64))
+            self.prepare_lowres(ws)
         if two:
             keep = torch.cat((torch.ones(B, dtype=torch.bool), torch.zeros(B, dtype=torch.bool)))
         self.set_text(ws, text_embeds, text_mask, keep)
