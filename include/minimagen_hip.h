@@ -270,6 +270,19 @@ int mi_resize_fwd(const mi_resize_params* p, void* stream);
  * out = (a*img + b*noise)*2 - 1 */
 int mi_lowres_augment(const float* img, const float* noise, float* out, int64_t total, float a, float b, int normalize, void* stream);
 
+/* ---- K16: T5 encoder (minimagen/t5.py:71-84 -> transformers T5Stack, third party) -------
+ * fp32; dense contractions on v_mfma_f32_16x16x4_f32.  All matrices in torch nn.Linear layout. */
+/* C[M][N] = act(A[M][K] . W[N][K]^T) + R[M][N]   (R may be NULL; act: 0 none, 1 ReLU, 2 gelu_new)
+ * gate != NULL (gated-gelu FF of T5 v1.1): C = act(A.W^T) * (A.gate^T).   N % 64 == 0, K % 16 == 0. */
+int mi_gemm_f32(const float* A, const float* W, const float* gate, const float* R, float* Cout, int M, int N, int K, int act, void* stream);
+/* y = x * rsqrt(mean(x^2) + eps) * w per row (T5LayerNorm); zero_mask != NULL: rows with zero_mask[row]==0 are zeroed (t5.py:82) */
+int mi_rmsnorm(const float* x, const float* w, float* y, int rows, int dim, float eps, const uint8_t* zero_mask, void* stream);
+/* out[row][:] = table[ids[row]][:] */
+int mi_embed_rows(const int64_t* ids, const float* table, float* out, int rows, int dim, void* stream);
+/* T5 self-attention core for one layer: qkv [B*L][3*inner] (q | k | v, head h at columns h*64), unscaled q.k^T
+ * + bias_tab[heads][2L-1] (relative position bias indexed by (j - i) + L-1) + key mask, softmax, .v -> ctx [B*L][inner] */
+int mi_t5_attention(const float* qkv, const float* bias_tab, const uint8_t* key_mask, float* ctx, int B, int L, int heads, void* stream);
+
 /* ---- HIP graphs: capture a sequence of the calls above once, replay it per timestep ------- */
 int mi_graph_begin(void* stream);
 int mi_graph_end(void* stream, void** graph_exec);

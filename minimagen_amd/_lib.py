@@ -137,6 +137,10 @@ def _bind(lib):
     lib.mi_randn_fill.argtypes = [vp, i32, i32, u64, i32, i32, vp]
     lib.mi_finalize_images.argtypes = [vp, vp, i64, i32, vp]
     lib.mi_lowres_augment.argtypes = [vp, vp, vp, i64, f32, f32, i32, vp]
+    lib.mi_gemm_f32.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
+    lib.mi_rmsnorm.argtypes = [vp, vp, vp, i32, i32, f32, vp, vp]
+    lib.mi_embed_rows.argtypes = [vp, vp, vp, i32, i32, vp]
+    lib.mi_t5_attention.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp]
     lib.mi_graph_begin.argtypes = [vp]
     lib.mi_graph_end.argtypes = [vp, C.POINTER(vp)]
     lib.mi_graph_launch.argtypes = [vp, vp]

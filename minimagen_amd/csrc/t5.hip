@@ -1,0 +1,203 @@
+// K16: T5 encoder building blocks (minimagen/t5.py:71-84 calls transformers' T5Stack): embedding gather,
+// T5LayerNorm (RMS), fp32 MFMA GEMM with fused ReLU / gated-GELU / residual epilogues, and the self-attention core
+// (unscaled q.k^T + bucketed relative position bias + key mask, softmax, .v) on v_mfma_f32_16x16x4_f32.
+#include "common.hip.h"
+
+namespace {
+
+__device__ __forceinline__ float gelu_new(float x) {       // transformers' NewGELUActivation (tanh form)
+    const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+    return 0.5f * x * (1.0f + tanhf(u));
+}
+
+// ---- C = act(A.W^T) [* (A.G^T)] + R ; 64x64 block tile, 4 waves of 32x32 (2x2 MFMA tiles), K step 16 through LDS
+template <bool GATED>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, const float* __restrict__ W, const float* __restrict__ G,
+                                                       const float* __restrict__ R, float* __restrict__ Cout, int M, int N, int K, int act) {
+    constexpr int BM = 64, BN = 64, BK = 16, LD = BK + 1;
+    __shared__ float As[BM][LD], Ws[BN][LD], Gs[GATED ? BN : 1][LD];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int lr = tid >> 2, lc = (tid & 3) * 4;            // staging: one float4 per work-item and matrix
+    f32x4 acc[2][2], accg[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; accg[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    for (int k0 = 0; k0 < K; k0 += BK) {
+        float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (m0 + lr < M) a4 = *reinterpret_cast<const float4*>(A + (size_t)(m0 + lr) * K + k0 + lc);
+        const float4 w4 = *reinterpret_cast<const float4*>(W + (size_t)(n0 + lr) * K + k0 + lc);
+        float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (GATED) g4 = *reinterpret_cast<const float4*>(G + (size_t)(n0 + lr) * K + k0 + lc);
+        __syncthreads();
+        As[lr][lc] = a4.x; As[lr][lc + 1] = a4.y; As[lr][lc + 2] = a4.z; As[lr][lc + 3] = a4.w;
+        Ws[lr][lc] = w4.x; Ws[lr][lc + 1] = w4.y; Ws[lr][lc + 2] = w4.z; Ws[lr][lc + 3] = w4.w;
+        if (GATED) { Gs[lr][lc] = g4.x; Gs[lr][lc + 1] = g4.y; Gs[lr][lc + 2] = g4.z; Gs[lr][lc + 3] = g4.w; }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < BK / 4; ++kk) {
+            float a[2], b[2], g[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i] = As[wm * 32 + i * 16 + (lane & 15)][kk * 4 + (lane >> 4)];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                b[j] = Ws[wn * 32 + j * 16 + (lane & 15)][kk * 4 + (lane >> 4)];
+                g[j] = GATED ? Gs[wn * 32 + j * 16 + (lane & 15)][kk * 4 + (lane >> 4)] : 0.0f;
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                    if (GATED) accg[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], g[j], accg[i][j], 0, 0, 0);
+                }
+        }
+    }
+    // D layout: column (n) = lane & 15, row (m) = 4 * (lane >> 4) + r
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm * 32 + i * 16 + 4 * (lane >> 4) + r, n = n0 + wn * 32 + j * 16 + (lane & 15);
+                if (m < M) {
+                    float v = acc[i][j][r];
+                    if (act == 1) v = fmaxf(v, 0.0f);
+                    else if (act == 2) v = gelu_new(v);
+                    if (GATED) v *= accg[i][j][r];
+                    if (R) v += R[(size_t)m * N + n];
+                    Cout[(size_t)m * N + n] = v;
+                }
+            }
+}
+
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const float* x, const float* w, float* y, int rows, int dim, float eps, const uint8_t* zero_mask) {
+    __shared__ float red[4];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const float* xr = x + (size_t)row * dim;
+    float s = 0.0f;
+    for (int i = tid; i < dim; i += 256) s = fmaf(xr[i], xr[i], s);
+    s = mi_wave_sum(s);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    const float tot = red[0] + red[1] + red[2] + red[3];
+    const float rs = 1.0f / sqrtf(tot / (float)dim + eps);
+    const bool zero = zero_mask && zero_mask[row] == 0;
+    for (int i = tid; i < dim; i += 256) y[(size_t)row * dim + i] = zero ? 0.0f : xr[i] * rs * w[i];
+}
+
+__global__ __launch_bounds__(256) void embed_rows_kernel(const long long* ids, const float* table, float* out, int rows, int dim) {
+    const int row = blockIdx.x;
+    const float* src = table + (size_t)ids[row] * dim;
+    for (int i = threadIdx.x; i < dim; i += 256) out[(size_t)row * dim + i] = src[i];
+}
+
+// one wave = 16 queries of one (batch, head); the whole (<=256)-key score row lives in registers like K9
+template <int JT>
+__global__ __launch_bounds__(256) void t5_attention_kernel(const float* __restrict__ qkv, const float* __restrict__ bias_tab,
+                                                           const uint8_t* __restrict__ key_mask, float* __restrict__ ctx, int L, int heads) {
+    constexpr int D = 64;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lq = lane & 15, lg = lane >> 4;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int inner = heads * D, ld = 3 * inner;
+    const int i0 = (blockIdx.x * 4 + wave) * 16;
+    if (i0 >= L) return;
+    const int iq = i0 + lq;
+    const bool qok = iq < L;
+    const int iqc = qok ? iq : L - 1;                       // rows past the sequence end compute (and discard) row L-1's bias
+    const float* base = qkv + (size_t)b * L * ld;
+    float qf[16];                                            // B operand: Q[i][d = 4kk + lg]
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) qf[kk] = qok ? base[(size_t)iq * ld + h * D + 4 * kk + lg] : 0.0f;
+    f32x4 s[JT];
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt) {
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int jr = 16 * jt + lq;                         // A operand: K[j = 16jt + lq][d = 4kk + lg]
+        const float* kp = base + (size_t)(jr < L ? jr : 0) * ld + inner + h * D + lg;
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kp[4 * kk], qf[kk], acc, 0, 0, 0);
+        s[jt] = acc;
+    }
+    float m = -INFINITY;
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = 16 * jt + 4 * lg + r;
+            float v = -INFINITY;
+            if (j < L) {
+                v = s[jt][r] + bias_tab[(size_t)h * (2 * L - 1) + (j - iqc) + (L - 1)];
+                if (key_mask && key_mask[(size_t)b * L + j] == 0) v += -3.4028234663852886e38f;     // (1 - mask) * finfo.min
+            }
+            s[jt][r] = v;
+            m = fmaxf(m, v);
+        }
+    m = fmaxf(m, __shfl_xor(m, 16));
+    m = fmaxf(m, __shfl_xor(m, 32));
+    float l = 0.0f;
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float e = __builtin_amdgcn_exp2f((s[jt][r] - m) * 1.44269504088896340736f);
+            s[jt][r] = e;
+            l += e;
+        }
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+    f32x4 o[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) o[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = 16 * jt + 4 * lg + r;              // A operand of PV: V[j][d = 16mt + lq]
+            const float* vp = base + (size_t)(j < L ? j : 0) * ld + 2 * inner + h * D + lq;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) o[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vp[16 * mt], s[jt][r], o[mt], 0, 0, 0);
+        }
+    const float inv = 1.0f / l;
+    if (qok) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ctx[((size_t)b * L + iq) * inner + h * D + 16 * mt + 4 * lg + r] = o[mt][r] * inv;
+    }
+}
+
+}  // namespace
+
+extern "C" int mi_gemm_f32(const float* A, const float* W, const float* gate, const float* R, float* Cout, int M, int N, int K, int act, void* stream) {
+    if (M <= 0 || (N % 64) != 0 || (K % 16) != 0) { mi_set_error("mi_gemm_f32: need M>0, N%%64==0, K%%16==0 (got %d,%d,%d)", M, N, K); return MI_ERR_INVALID; }
+    const dim3 grid(N / 64, (M + 63) / 64);
+    if (gate) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_f32_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, A, W, gate, R, Cout, M, N, K, act);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_f32_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, A, W, gate, R, Cout, M, N, K, act);
+    return mi_check_launch("gemm_f32_kernel");
+}
+
+extern "C" int mi_rmsnorm(const float* x, const float* w, float* y, int rows, int dim, float eps, const uint8_t* zero_mask, void* stream) {
+    if (rows <= 0 || dim <= 0) { mi_set_error("mi_rmsnorm: empty"); return MI_ERR_INVALID; }
+    hipLaunchKernelGGL(rmsnorm_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, x, w, y, rows, dim, eps, zero_mask);
+    return mi_check_launch("rmsnorm_kernel");
+}
+
+extern "C" int mi_embed_rows(const int64_t* ids, const float* table, float* out, int rows, int dim, void* stream) {
+    if (rows <= 0) { mi_set_error("mi_embed_rows: empty"); return MI_ERR_INVALID; }
+    hipLaunchKernelGGL(embed_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, (const long long*)ids, table, out, rows, dim);
+    return mi_check_launch("embed_rows_kernel");
+}
+
+extern "C" int mi_t5_attention(const float* qkv, const float* bias_tab, const uint8_t* key_mask, float* ctx, int B, int L, int heads, void* stream) {
+    if (B <= 0 || L <= 0 || L > 256) { mi_set_error("mi_t5_attention: sequence length %d outside (0, 256] (t5.py MAX_LENGTH)", L); return MI_ERR_INVALID; }
+    const dim3 grid((L + 63) / 64, heads, B);
+    hipStream_t st = (hipStream_t)stream;
+    if (L <= 64) hipLaunchKernelGGL(HIP_KERNEL_NAME(t5_attention_kernel<4>), grid, dim3(256), 0, st, qkv, bias_tab, key_mask, ctx, L, heads);
+    else if (L <= 128) hipLaunchKernelGGL(HIP_KERNEL_NAME(t5_attention_kernel<8>), grid, dim3(256), 0, st, qkv, bias_tab, key_mask, ctx, L, heads);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(t5_attention_kernel<16>), grid, dim3(256), 0, st, qkv, bias_tab, key_mask, ctx, L, heads);
+    return mi_check_launch("t5_attention_kernel");
+}

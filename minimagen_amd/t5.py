@@ -1,5 +1,13 @@
-"""Text-encoder front-end with the reference's names (minimagen/t5.py)."""
+"""Text-encoder front-end with the reference's names (minimagen/t5.py), T5 encoder stack on HIP kernels (K16)."""
 from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, Optional
+
+import torch
+
+from . import _lib as L
 
 MAX_LENGTH = 256
 DEFAULT_T5_NAME = 't5_small'
@@ -24,7 +32,106 @@ def get_encoded_dim(name: str) -> int:
     return T5_VERSIONS[name]['dim']
 
 
+def relative_position_bucket(relative_position: torch.Tensor, num_buckets: int = 32, max_distance: int = 128) -> torch.Tensor:
+    """T5's bidirectional bucket function (transformers T5Attention._relative_position_bucket), same integer / fp32
+    operations so the bucket indices are identical."""
+    num_buckets //= 2
+    buckets = (relative_position > 0).to(torch.long) * num_buckets
+    rp = torch.abs(relative_position)
+    max_exact = num_buckets // 2
+    is_small = rp < max_exact
+    if_large = max_exact + (torch.log(rp.float() / max_exact) / math.log(max_distance / max_exact) * (num_buckets - max_exact)).to(torch.long)
+    if_large = torch.min(if_large, torch.full_like(if_large, num_buckets - 1))
+    return buckets + torch.where(is_small, rp, if_large)
+
+
+class T5EncoderHIP:
+    """The T5 encoder stack (embedding -> N x {RMSNorm, self-attention with shared relative-position bias, RMSNorm,
+    feed-forward} -> final RMSNorm) executed by the kernels of csrc/t5.hip from a transformers ``T5EncoderModel``
+    state dict.  fp32; no biases; attention is unscaled (T5)."""
+
+    def __init__(self, state_dict: Dict[str, torch.Tensor], *, d_model: int, d_kv: int, num_heads: int, d_ff: int, num_layers: int,
+                 relative_attention_num_buckets: int = 32, relative_attention_max_distance: int = 128,
+                 layer_norm_epsilon: float = 1e-6, feed_forward_proj: str = "relu", device="cuda"):
+        if d_kv != 64:
+            raise NotImplementedError("T5 attention kernel is instantiated for d_kv = 64")
+        self.cfg = dict(d_model=d_model, d_kv=d_kv, heads=num_heads, d_ff=d_ff, layers=num_layers, nb=relative_attention_num_buckets,
+                        md=relative_attention_max_distance, eps=layer_norm_epsilon)
+        self.gated = feed_forward_proj.startswith("gated")
+        self.act = 1 if feed_forward_proj == "relu" else 2
+        dev = torch.device(device)
+        f = lambda k: state_dict[k].detach().to(dev, torch.float32).contiguous()
+        self.emb = f("shared.weight") if "shared.weight" in state_dict else f("encoder.embed_tokens.weight")
+        self.rel_emb_cpu = state_dict["encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight"].detach().to("cpu", torch.float32)
+        self.layers = []
+        for i in range(num_layers):
+            p = f"encoder.block.{i}.layer."
+            ff = p + "1.DenseReluDense."
+            self.layers.append(dict(
+                ln0=f(p + "0.layer_norm.weight"),
+                wqkv=torch.cat([f(p + f"0.SelfAttention.{n}.weight") for n in "qkv"], 0).contiguous(),
+                wo=f(p + "0.SelfAttention.o.weight"), ln1=f(p + "1.layer_norm.weight"),
+                wi=f(ff + ("wi_0.weight" if self.gated else "wi.weight")), wg=f(ff + "wi_1.weight") if self.gated else None,
+                wo2=f(ff + "wo.weight")))
+        self.final_ln = f("encoder.final_layer_norm.weight")
+        self.dev = dev
+        L.require_device(self.emb)
+
+    @classmethod
+    def from_hf(cls, model, device="cuda"):
+        c = model.config
+        return cls(model.state_dict(), d_model=c.d_model, d_kv=c.d_kv, num_heads=c.num_heads, d_ff=c.d_ff, num_layers=c.num_layers,
+                   relative_attention_num_buckets=c.relative_attention_num_buckets,
+                   relative_attention_max_distance=getattr(c, "relative_attention_max_distance", 128),
+                   layer_norm_epsilon=c.layer_norm_epsilon, feed_forward_proj=c.feed_forward_proj, device=device)
+
+    def bias_table(self, Lq: int) -> torch.Tensor:
+        """[heads][2L-1]: relative_attention_bias[bucket(j - i)] for j - i = -(L-1) .. L-1 (layer 0's table, shared by all layers)"""
+        rel = torch.arange(-(Lq - 1), Lq)
+        b = relative_position_bucket(rel, self.cfg["nb"], self.cfg["md"])
+        return self.rel_emb_cpu[b].t().contiguous().to(self.dev)
+
+    @torch.no_grad()
+    def encode(self, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor] = None):
+        """-> (last_hidden_state with masked rows zeroed (t5.py:82), bool mask)"""
+        lib, st, c = L.lib(), L.current_stream(), self.cfg
+        B, Lq = input_ids.shape
+        if Lq > MAX_LENGTH:
+            raise ValueError(f"sequence length {Lq} exceeds MAX_LENGTH {MAX_LENGTH} (t5.py:5)")
+        M, d, inner = B * Lq, c["d_model"], c["heads"] * c["d_kv"]
+        ids = input_ids.to(self.dev, torch.int64).contiguous()
+        mask = torch.ones(B, Lq, dtype=torch.uint8, device=self.dev) if attention_mask is None else attention_mask.to(self.dev).to(torch.uint8).contiguous()
+        L.require_device(ids, mask)
+        e = lambda *s: torch.empty(*s, dtype=torch.float32, device=self.dev)
+        h, x, qkv, ctx, ff, h2 = e(M, d), e(M, d), e(M, 3 * inner), e(M, inner), e(M, c["d_ff"]), e(M, d)
+        bias = self.bias_table(Lq)
+        L.check(lib.mi_embed_rows(L.ptr(ids), L.ptr(self.emb), L.ptr(h), M, d, st), "mi_embed_rows")
+        for ly in self.layers:
+            L.check(lib.mi_rmsnorm(L.ptr(h), L.ptr(ly["ln0"]), L.ptr(x), M, d, c["eps"], None, st), "mi_rmsnorm")
+            L.check(lib.mi_gemm_f32(L.ptr(x), L.ptr(ly["wqkv"]), None, None, L.ptr(qkv), M, 3 * inner, d, 0, st), "mi_gemm_f32 qkv")
+            L.check(lib.mi_t5_attention(L.ptr(qkv), L.ptr(bias), L.ptr(mask), L.ptr(ctx), B, Lq, c["heads"], st), "mi_t5_attention")
+            L.check(lib.mi_gemm_f32(L.ptr(ctx), L.ptr(ly["wo"]), None, L.ptr(h), L.ptr(h2), M, d, inner, 0, st), "mi_gemm_f32 o")
+            L.check(lib.mi_rmsnorm(L.ptr(h2), L.ptr(ly["ln1"]), L.ptr(x), M, d, c["eps"], None, st), "mi_rmsnorm")
+            L.check(lib.mi_gemm_f32(L.ptr(x), L.ptr(ly["wi"]), L.ptr(ly["wg"]), None, L.ptr(ff), M, c["d_ff"], d, self.act, st), "mi_gemm_f32 wi")
+            L.check(lib.mi_gemm_f32(L.ptr(ff), L.ptr(ly["wo2"]), None, L.ptr(h2), L.ptr(h), M, d, c["d_ff"], 0, st), "mi_gemm_f32 wo")
+        out = e(M, d)
+        L.check(lib.mi_rmsnorm(L.ptr(h), L.ptr(self.final_ln), L.ptr(out), M, d, c["eps"], L.ptr(mask), st), "mi_rmsnorm final")
+        return out.reshape(B, Lq, d), mask.bool()
+
+
+def _check_downloads(name):
+    """minimagen/t5.py:24-28 (needs the Hugging Face files on disk; there is no network here)"""
+    from transformers import T5EncoderModel, T5Tokenizer
+    if T5_VERSIONS[name]['tokenizer'] is None:
+        T5_VERSIONS[name]['tokenizer'] = T5Tokenizer.from_pretrained(T5_VERSIONS[name]['handle'])
+    if T5_VERSIONS[name]['model'] is None:
+        T5_VERSIONS[name]['model'] = T5EncoderHIP.from_hf(T5EncoderModel.from_pretrained(T5_VERSIONS[name]['handle']).eval())
+
+
 def t5_encode_text(text, name: str = 't5_base', max_length=MAX_LENGTH):
-    """minimagen/t5.py:31-84.  The HIP T5 encoder (K16) is not built yet in this round and there are no
-    tokenizer/checkpoint files offline; pass ``text_embeds`` / ``text_masks`` to ``Imagen.sample`` instead."""
-    raise NotImplementedError("t5_encode_text: HIP T5 encoder (SURVEY K16) not built yet; supply text_embeds/text_masks")
+    """minimagen/t5.py:31-84: tokenise (pad longest, truncate to max_length), encode with the HIP T5 stack, zero the
+    masked positions, return (embeds, bool mask)."""
+    _check_downloads(name)
+    tokenizer, model = T5_VERSIONS[name]['tokenizer'], T5_VERSIONS[name]['model']
+    tokenized = tokenizer.batch_encode_plus(text, padding='longest', max_length=max_length, truncation=True, return_tensors="pt")
+    return model.encode(tokenized.input_ids, tokenized.attention_mask)

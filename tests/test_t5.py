@@ -1,0 +1,58 @@
+"""K16: the HIP T5 encoder against transformers' T5EncoderModel (the third-party code minimagen/t5.py calls) with
+random-init weights and synthetic ids (no checkpoints / tokenizer offline: parity unpinned for pretrained weights)."""
+import pytest
+import torch
+
+from tests._backend import BACKENDS, setup
+
+
+def hf_model(ff="relu", layers=2, seed=0):
+    from transformers import T5Config, T5EncoderModel
+    torch.manual_seed(seed)
+    cfg = T5Config(num_layers=layers, feed_forward_proj=ff, d_ff=1024 if ff != "relu" else 2048)    # other fields = t5-small
+    m = T5EncoderModel(cfg).eval()
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if "layer_norm" in n:
+                p.copy_(1 + 0.2 * torch.randn(p.shape))
+            elif "relative_attention_bias" in n:
+                p.copy_(torch.randn(p.shape))
+            elif "shared" not in n and "embed" not in n:
+                p.mul_(0.5)
+    return m
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("case", [("relu", 3, 40), ("gated-gelu", 2, 70), ("relu", 1, 200)])
+def test_t5_encoder_matches_transformers(backend, case):
+    ff, B, Lq = case
+    if backend == "emu" and Lq > 100:
+        pytest.skip("long sequences only on the GPU (emulator time)")
+    dev = setup(backend)
+    from minimagen_amd.t5 import T5EncoderHIP
+    m = hf_model(ff)
+    g = torch.Generator().manual_seed(1)
+    ids = torch.randint(0, 32128, (B, Lq), generator=g)
+    mask = torch.arange(Lq)[None, :] < torch.tensor([Lq - 7 * r for r in range(B)])[:, None]
+    with torch.no_grad():
+        ref = m(input_ids=ids, attention_mask=mask.long()).last_hidden_state
+    ref = ref.masked_fill(~mask[:, :, None], 0.)                      # minimagen/t5.py:82
+    enc = T5EncoderHIP.from_hf(m, device=dev)
+    out, mk = enc.encode(ids.to(dev), mask.to(dev))
+    assert torch.equal(mk.cpu(), mask)
+    d = (out.cpu() - ref).abs()
+    assert d.max() < 2e-4 and d.mean() < 2e-5, (d.max(), d.mean(), ref.abs().max())
+
+
+def test_relative_position_bucket_matches_transformers():
+    from transformers.models.t5.modeling_t5 import T5Attention
+    from minimagen_amd.t5 import relative_position_bucket
+    rel = torch.arange(-255, 256)
+    assert torch.equal(relative_position_bucket(rel), T5Attention._relative_position_bucket(rel, bidirectional=True, num_buckets=32, max_distance=128))
+
+
+def test_t5_api_surface():
+    from minimagen_amd import t5
+    assert t5.get_encoded_dim("t5_small") == 512 and t5.get_encoded_dim("xxl1.1") == 4096 and t5.MAX_LENGTH == 256
+    with pytest.raises(Exception):          # no tokenizer / checkpoint files offline: must fail loudly, never silently stub
+        t5.t5_encode_text(["a cat"], name="t5_small")
