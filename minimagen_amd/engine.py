@@ -25,8 +25,8 @@ from .layers import CrossAttention, EinopsToAndFrom, Identity, Parallel, ResnetB
 
 MAX_TEXT_LEN = 256
 # kernel-shape tuning knobs (A/B measurements; the defaults are what profiles/ was measured with)
-ATTN_VARIANT = int(os.environ.get("MINIMAGEN_ATTN_VARIANT", "0"))       # 0: 32 tokens per wave, 1: 16 tokens per wave
-CONV_SPLIT16 = int(os.environ.get("MINIMAGEN_CONV_SPLIT16", "0"))       # 1: 16-channel 3x3 outputs as two 8-channel workgroups
+ATTN_VARIANT = int(os.environ.get("MINIMAGEN_ATTN_VARIANT", "1"))       # 0: 32 tokens per wave, 1: 16 tokens per wave
+CONV_SPLIT16 = int(os.environ.get("MINIMAGEN_CONV_SPLIT16", "1"))       # 1: 16-channel 3x3 outputs as two 8-channel workgroups
 JT = 17     # context tiles of 16 rows: 1 null + (2|4) time tokens + 256 text rows <= 272
 
 
