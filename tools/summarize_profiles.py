@@ -46,7 +46,8 @@ for key, c in a.items():
         active_valu_pct=round(100 * m["SQ_ACTIVE_INST_VALU"] / wc, 1), wait_inst_any_pct=round(100 * m["SQ_WAIT_INST_ANY"] / wc, 1),
         wait_any_pct=round(100 * m2.get("SQ_WAIT_ANY", 0) / wc, 1),
         lds_bank_conflict_pct=round(100 * m2.get("SQ_LDS_BANK_CONFLICT", 0) / max(m2.get("SQ_LDS_IDX_ACTIVE", 1), 1), 1),
-        mfma_busy_pct=round(100 * m2.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / max(m2.get("SQ_BUSY_CYCLES", 1), 1), 2),
+        # SQ_VALU_MFMA_BUSY_CYCLES sums SIMD-cycles (32 per v_mfma_f32_16x16x4_f32); GRBM_GUI_ACTIVE sums the 8 XCDs' clocks
+        mfma_pipe_util_pct=round(100 * m2.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / max(m2.get("GRBM_GUI_ACTIVE", 1) / 8 * 1024, 1), 1),
         # gfx950: FETCH_SIZE counts 64 B per 128-B request on wide coalesced reads -> doubled (MI355X_MICROARCH.md, HBM section); KiB -> MB
         fetch_MB_x2=round(2 * st.mean(f[key]["FETCH_SIZE"]) / 1024, 1) if key in f and "FETCH_SIZE" in f[key] else None,
         write_MB=round(st.mean(w[key]["WRITE_SIZE"]) / 1024, 1) if key in w and "WRITE_SIZE" in w[key] else None))
