@@ -95,6 +95,8 @@ def op_breakdown(im, stage, B, cond_scale, reps=20):
     stream = L.current_stream()
     rows = []
     for fn, p, name in ws.prog:
+        if p is None:
+            continue
         for _ in range(3):
             fn(C.byref(p), stream)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

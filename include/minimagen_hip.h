@@ -270,6 +270,31 @@ int mi_resize_fwd(const mi_resize_params* p, void* stream);
  * out = (a*img + b*noise)*2 - 1 */
 int mi_lowres_augment(const float* img, const float* noise, float* out, int64_t total, float a, float b, int normalize, void* stream);
 
+/* ---- K10: self-attention TransformerBlock for narrow layers (C in {8,16,32}) -------------
+ * Attention (layers.py:52-104, multi-query: one shared 64-wide k/v head, null k/v) in the same folded form as K9 with
+ * the image tokens as their own context: sim_h = x^ (s Wq_h^T Wk) x^^T, out = sum_h softmax(sim_h) (x^ Wv^T Wo_h^T).
+ * Context length = H*W + 1, so the score row is processed in chunks with an online softmax (running max / sum). */
+/* x^ = LayerNorm_C(x) written token-major: out[B][HW][C]  (Attention.norm, layers.py:57) */
+int mi_ln_tokens_fwd(const mi_act* x, int B, int HW, const float* gamma, const float* beta, float* out, void* stream);
+typedef struct mi_self_attn_params {
+    int B2, C, HW, heads, J;        /* J = HW + 1 context rows (null k/v first) */
+    mi_act x;                       /* [B2][C][HW]; also the residual (TransformerBlock :497 / Residual :368) */
+    const float* gv;                /* fragments from mi_attn_fold_rows with JT = ceil(J/16) */
+    const float* n1_g; const float* n1_b;   /* Attention.norm */
+    const float* n2_g; const float* n2_b;   /* to_out.1 */
+    float* out; float* out_stats;   /* stats [B2][C][ceil(HW/64)][2] or NULL */
+} mi_self_attn_params;
+int mi_self_attn_fwd(const mi_self_attn_params* p, void* stream);
+/* ChanFeedForward + residual (layers.py:148-161, 498): y = x + W2 . CLN(gelu(W1 . CLN(x)))  (1x1 convs, no bias) */
+typedef struct mi_chan_ff_params {
+    int B, C, Chid, HW;
+    mi_act x;
+    const float* g1; const float* w1;   /* ChanLayerNorm g [C]; conv [Chid][C] */
+    const float* g2; const float* w2;   /* ChanLayerNorm g [Chid]; conv [C][Chid] */
+    float* out; float* out_stats;       /* stats [B][C][ceil(HW/256)][2] or NULL */
+} mi_chan_ff_params;
+int mi_chan_ff_fwd(const mi_chan_ff_params* p, void* stream);
+
 /* ---- K16: T5 encoder (minimagen/t5.py:71-84 -> transformers T5Stack, third party) -------
  * fp32; dense contractions on v_mfma_f32_16x16x4_f32.  All matrices in torch nn.Linear layout. */
 /* C[M][N] = act(A[M][K] . W[N][K]^T) + R[M][N]   (R may be NULL; act: 0 none, 1 ReLU, 2 gelu_new)

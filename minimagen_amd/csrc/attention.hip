@@ -250,3 +250,269 @@ extern "C" int mi_cross_attn_fwd(const mi_cross_attn_params* pp, void* stream) {
     }
     return mi_check_launch("cross_attn_folded_kernel");
 }
+
+// =====================================================================================================
+// K10: folded multi-query self-attention (layers.py:52-104) + ChanFeedForward (layers.py:148-161) for narrow layers
+namespace {
+
+__global__ __launch_bounds__(256) void ln_tokens_kernel(const mi_act x, int HW, const float* gamma, const float* beta, float* out) {
+    const int b = blockIdx.y, C = x.C;
+    const int bx = x.bmod > 0 ? b % x.bmod : b;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= HW) return;
+    const float* xb = x.data + (size_t)bx * C * HW + i;
+    float s = 0.0f;
+    for (int c = 0; c < C; ++c) s += xb[(size_t)c * HW] * x.scale;
+    const float mean = s / (float)C;
+    float v = 0.0f;
+    for (int c = 0; c < C; ++c) { const float d = xb[(size_t)c * HW] * x.scale - mean; v = fmaf(d, d, v); }
+    const float rstd = 1.0f / sqrtf(v / (float)C + 1e-5f);
+    float* o = out + ((size_t)b * HW + i) * C;
+    for (int c = 0; c < C; ++c) o[c] = (xb[(size_t)c * HW] * x.scale - mean) * rstd * gamma[c] + beta[c];
+}
+
+// Same operand scheme as cross_attn_folded_kernel (16 tokens per wave), but the context (HW+1 rows) is walked in
+// chunks of JTC tiles with an online softmax: running max m, running sum l, O_h rescaled by 2^(m_old - m_new).
+template <int C, int JTC>
+__global__ __launch_bounds__(256) void self_attn_folded_kernel(const mi_self_attn_params p, const int JT) {
+    constexpr int KK = C / 4, NGP = KK < 4 ? 4 : KK, MT = (C + 15) / 16, FR = NGP + 4 * MT;
+    __shared__ float red[4][2 * 16 * MT];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lq = lane & 15, lg = lane >> 4;
+    const int tiles = (p.HW + 63) / 64;
+    const int b = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+    const int bx = p.x.bmod > 0 ? b % p.x.bmod : b;
+    const int i = (tile * 4 + wave) * 16 + lq;
+    const bool ok = i < p.HW;
+    const float* xb = p.x.data + (size_t)bx * C * p.HW;
+    float xh[KK];
+    {
+        float s = 0.0f;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) { xh[kk] = ok ? xb[(size_t)(4 * kk + lg) * p.HW + i] * p.x.scale : 0.0f; s += xh[kk]; }
+        s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
+        const float mean = s / (float)C;
+        float v = 0.0f;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) { const float d = xh[kk] - mean; v = fmaf(d, d, v); }
+        v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+        const float rstd = 1.0f / sqrtf(v / (float)C + 1e-5f);
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) { const int a = 4 * kk + lg; xh[kk] = (xh[kk] - mean) * rstd * p.n1_g[a] + p.n1_b[a]; }
+    }
+    f32x4 oacc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) oacc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float* gvb = p.gv + (size_t)b * p.heads * JT * 64 * FR + (size_t)lane * FR;
+    const int jlast = p.J - 1;
+    for (int h = 0; h < p.heads; ++h) {
+        const float* gvh = gvb + (size_t)h * JT * 64 * FR;
+        f32x4 oh[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) oh[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        float m = -INFINITY, l = 0.0f;
+        for (int jt0 = 0; jt0 < JT; jt0 += JTC) {
+            f32x4 s[JTC];
+#pragma unroll
+            for (int t = 0; t < JTC; ++t) {
+                f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (jt0 + t < JT) {
+                    float g[NGP];
+#pragma unroll
+                    for (int v4 = 0; v4 < NGP / 4; ++v4) {
+                        const float4 q4 = *reinterpret_cast<const float4*>(gvh + (size_t)(jt0 + t) * 64 * FR + 4 * v4);
+                        g[4 * v4] = q4.x; g[4 * v4 + 1] = q4.y; g[4 * v4 + 2] = q4.z; g[4 * v4 + 3] = q4.w;
+                    }
+#pragma unroll
+                    for (int kk = 0; kk < KK; ++kk) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(g[kk], xh[kk], acc, 0, 0, 0);
+                }
+                s[t] = acc;
+            }
+            float cm = -INFINITY;
+#pragma unroll
+            for (int t = 0; t < JTC; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (16 * (jt0 + t) + 4 * lg + r > jlast) s[t][r] = -INFINITY;
+                    cm = fmaxf(cm, s[t][r]);
+                }
+            cm = fmaxf(cm, __shfl_xor(cm, 16));
+            cm = fmaxf(cm, __shfl_xor(cm, 32));
+            const float mn = fmaxf(m, cm);                    // finite from the first chunk on (row 0 is always valid)
+            const float alpha = __builtin_amdgcn_exp2f(m - mn);
+            float cl = 0.0f;
+#pragma unroll
+            for (int t = 0; t < JTC; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float e = __builtin_amdgcn_exp2f(s[t][r] - mn); s[t][r] = e; cl += e; }
+            cl += __shfl_xor(cl, 16);
+            cl += __shfl_xor(cl, 32);
+            l = l * alpha + cl;
+            m = mn;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) oh[mt][r] *= alpha;
+#pragma unroll
+            for (int t = 0; t < JTC; ++t) {
+                if (jt0 + t < JT) {
+                    float vw[4 * MT];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        const float4 q4 = *reinterpret_cast<const float4*>(gvh + (size_t)(jt0 + t) * 64 * FR + NGP + 4 * mt);
+                        vw[4 * mt] = q4.x; vw[4 * mt + 1] = q4.y; vw[4 * mt + 2] = q4.z; vw[4 * mt + 3] = q4.w;
+                    }
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) oh[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vw[4 * mt + r], s[t][r], oh[mt], 0, 0, 0);
+                }
+            }
+        }
+        const float linv = 1.0f / l;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) oacc[mt][r] = fmaf(oh[mt][r], linv, oacc[mt][r]);
+    }
+    // to_out.1 LayerNorm + residual + statistics (as in cross_attn_folded_kernel)
+    float csum[4 * MT], csq[4 * MT];
+#pragma unroll
+    for (int e = 0; e < 4 * MT; ++e) { csum[e] = 0.0f; csq[e] = 0.0f; }
+    {
+        float s1 = 0.0f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s1 += oacc[mt][r];
+        s1 += __shfl_xor(s1, 16); s1 += __shfl_xor(s1, 32);
+        const float mean = s1 / (float)C;
+        float v = 0.0f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const int a = 16 * mt + 4 * lg + r; const float d = (a < C) ? oacc[mt][r] - mean : 0.0f; v = fmaf(d, d, v); }
+        v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+        const float rstd = 1.0f / sqrtf(v / (float)C + 1e-5f);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int a = 16 * mt + 4 * lg + r;
+                if (a < C && ok) {
+                    const float y = (oacc[mt][r] - mean) * rstd * p.n2_g[a] + p.n2_b[a] + xb[(size_t)a * p.HW + i] * p.x.scale;
+                    p.out[((size_t)b * C + a) * p.HW + i] = y;
+                    csum[4 * mt + r] = y;
+                    csq[4 * mt + r] = y * y;
+                }
+            }
+    }
+    if (p.out_stats) {
+#pragma unroll
+        for (int e = 0; e < 4 * MT; ++e) {
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) { csum[e] += __shfl_xor(csum[e], o); csq[e] += __shfl_xor(csq[e], o); }
+        }
+        if (lq == 0) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const int a = 16 * mt + 4 * lg + r; red[wave][2 * a] = csum[4 * mt + r]; red[wave][2 * a + 1] = csq[4 * mt + r]; }
+        }
+        __syncthreads();
+        if (tid < 2 * C) p.out_stats[((size_t)(b * C + (tid >> 1)) * tiles + tile) * 2 + (tid & 1)] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+    }
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// one work-item = one pixel; the (tiny) 1x1 weights are wave-uniform reads
+template <int C, int CH>
+__global__ __launch_bounds__(256) void chan_ff_kernel(const mi_chan_ff_params p, const float* __restrict__ w1, const float* __restrict__ w2,
+                                                      const float* __restrict__ g1, const float* __restrict__ g2) {
+    __shared__ float red[2 * C][4];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int bx = p.x.bmod > 0 ? b % p.x.bmod : b;
+    const int i = blockIdx.x * 256 + tid;
+    const bool ok = i < p.HW;
+    const float* xb = p.x.data + (size_t)bx * C * p.HW + (ok ? i : 0);
+    float x[C], hdn[CH];
+    float s = 0.0f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) { x[c] = xb[(size_t)c * p.HW] * p.x.scale; s += x[c]; }
+    float mean = s / (float)C, v = 0.0f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) { const float d = x[c] - mean; v = fmaf(d, d, v); }
+    float rs = 1.0f / sqrtf(v / (float)C + 1e-5f);           // (x - mean) / sqrt(var + eps) * g   (layers.py:174-177)
+    float xn[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) xn[c] = (x[c] - mean) * rs * g1[c];
+    s = 0.0f;
+#pragma unroll
+    for (int o = 0; o < CH; ++o) {
+        float a = 0.0f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) a = fmaf(w1[o * C + c], xn[c], a);
+        hdn[o] = gelu_erf(a);
+        s += hdn[o];
+    }
+    mean = s / (float)CH; v = 0.0f;
+#pragma unroll
+    for (int o = 0; o < CH; ++o) { const float d = hdn[o] - mean; v = fmaf(d, d, v); }
+    rs = 1.0f / sqrtf(v / (float)CH + 1e-5f);
+#pragma unroll
+    for (int o = 0; o < CH; ++o) hdn[o] = (hdn[o] - mean) * rs * g2[o];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        float a = 0.0f;
+#pragma unroll
+        for (int o = 0; o < CH; ++o) a = fmaf(w2[c * CH + o], hdn[o], a);
+        const float y = a + x[c];
+        if (ok) p.out[((size_t)b * C + c) * p.HW + i] = y;
+        if (p.out_stats) {
+            float ys = ok ? y : 0.0f, yq = ok ? y * y : 0.0f;
+            ys = mi_wave_sum(ys); yq = mi_wave_sum(yq);
+            if ((tid & 63) == 0) { red[2 * c][tid >> 6] = ys; red[2 * c + 1][tid >> 6] = yq; }
+        }
+    }
+    if (p.out_stats) {
+        __syncthreads();
+        if (tid < 2 * C) p.out_stats[((size_t)(b * C + (tid >> 1)) * gridDim.x + blockIdx.x) * 2 + (tid & 1)] = red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3];
+    }
+}
+
+}  // namespace
+
+extern "C" int mi_ln_tokens_fwd(const mi_act* x, int B, int HW, const float* gamma, const float* beta, float* out, void* stream) {
+    if (B <= 0 || HW <= 0) { mi_set_error("mi_ln_tokens_fwd: empty"); return MI_ERR_INVALID; }
+    hipLaunchKernelGGL(ln_tokens_kernel, dim3((HW + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, *x, HW, gamma, beta, out);
+    return mi_check_launch("ln_tokens_kernel");
+}
+
+extern "C" int mi_self_attn_fwd(const mi_self_attn_params* pp, void* stream) {
+    const mi_self_attn_params& p = *pp;
+    hipStream_t st = (hipStream_t)stream;
+    if (p.B2 <= 0 || p.HW <= 0 || p.J != p.HW + 1) { mi_set_error("mi_self_attn_fwd: bad sizes (J must be HW+1)"); return MI_ERR_INVALID; }
+    const int JT = (p.J + 15) / 16;
+    const dim3 grid(((p.HW + 63) / 64) * p.B2);
+    switch (p.C) {
+        case 8: hipLaunchKernelGGL(HIP_KERNEL_NAME(self_attn_folded_kernel<8, 16>), grid, dim3(256), 0, st, p, JT); break;
+        case 16: hipLaunchKernelGGL(HIP_KERNEL_NAME(self_attn_folded_kernel<16, 16>), grid, dim3(256), 0, st, p, JT); break;
+        case 32: hipLaunchKernelGGL(HIP_KERNEL_NAME(self_attn_folded_kernel<32, 16>), grid, dim3(256), 0, st, p, JT); break;
+        default: mi_set_error("mi_self_attn_fwd: folded path instantiated for C in {8,16,32}, got %d", p.C); return MI_ERR_UNSUPPORTED;
+    }
+    return mi_check_launch("self_attn_folded_kernel");
+}
+
+extern "C" int mi_chan_ff_fwd(const mi_chan_ff_params* pp, void* stream) {
+    const mi_chan_ff_params& p = *pp;
+    hipStream_t st = (hipStream_t)stream;
+    if (p.B <= 0 || p.HW <= 0 || p.Chid != 2 * p.C) { mi_set_error("mi_chan_ff_fwd: bad sizes (hidden must be 2*C)"); return MI_ERR_INVALID; }
+    const dim3 grid((p.HW + 255) / 256, p.B);
+    switch (p.C) {
+        case 8: hipLaunchKernelGGL(HIP_KERNEL_NAME(chan_ff_kernel<8, 16>), grid, dim3(256), 0, st, p, p.w1, p.w2, p.g1, p.g2); break;
+        case 16: hipLaunchKernelGGL(HIP_KERNEL_NAME(chan_ff_kernel<16, 32>), grid, dim3(256), 0, st, p, p.w1, p.w2, p.g1, p.g2); break;
+        case 32: hipLaunchKernelGGL(HIP_KERNEL_NAME(chan_ff_kernel<32, 64>), grid, dim3(256), 0, st, p, p.w1, p.w2, p.g1, p.g2); break;
+        default: mi_set_error("mi_chan_ff_fwd: instantiated for C in {8,16,32}, got %d", p.C); return MI_ERR_UNSUPPORTED;
+    }
+    return mi_check_launch("chan_ff_kernel");
+}

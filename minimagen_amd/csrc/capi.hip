@@ -38,6 +38,8 @@ extern "C" int mi_struct_size(int which) {
         case 9: return (int)sizeof(mi_quantile_params);
         case 10: return (int)sizeof(mi_posterior_params);
         case 11: return (int)sizeof(mi_resize_params);
+        case 12: return (int)sizeof(mi_self_attn_params);
+        case 13: return (int)sizeof(mi_chan_ff_params);
     }
     return -1;
 }

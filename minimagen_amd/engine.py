@@ -21,7 +21,7 @@ from torch import nn
 
 from . import _lib as L
 from . import packing as P
-from .layers import CrossAttention, EinopsToAndFrom, Identity, Parallel, ResnetBlock, TransformerBlock
+from .layers import Attention, CrossAttention, EinopsToAndFrom, Identity, Parallel, ResnetBlock, TransformerBlock
 
 MAX_TEXT_LEN = 256
 # kernel-shape tuning knobs (A/B measurements; the defaults are what profiles/ was measured with)
@@ -126,6 +126,16 @@ class UnetEngine:
                     raise NotImplementedError("norm_context=True cross-attention is not on the MinImagen hot path")
                 mg, mv, g0, v0 = P.fold_cross_attention(ca.to_q.weight, ca.to_kv.weight, ca.to_out[0].weight, ca.null_kv, ca.heads, ca.dim_head)
                 pk.attn[id(ca)] = (mg, mv, g0, v0)
+        # K10: multi-query self-attention (one shared 64-wide k/v head, layers.py:42) folded like K9 with the k/v rows repeated per head
+        for m in u.modules():
+            if isinstance(m, Attention):
+                Cc = m.to_q.in_features
+                dh = m.to_kv.out_features // 2
+                if Cc not in (8, 16, 32) or dh != 64:
+                    raise NotImplementedError(f"self-attention over {Cc} channels: only the folded path (C in 8/16/32, dim_head 64) is built")
+                kv = m.to_kv.weight.detach()
+                kv_full = torch.cat((kv[:dh].repeat(m.heads, 1), kv[dh:].repeat(m.heads, 1)), 0)
+                pk.attn[id(m)] = P.fold_cross_attention(m.to_q.weight, kv_full, m.to_out[0].weight, m.null_kv, m.heads, dh)
         # plain convs: down/up-sample, final
         for level in u.downs:
             pre, _, _, _, post = level
@@ -266,6 +276,52 @@ class UnetEngine:
         ws.prog.append((lib.mi_cross_attn_fwd, p, "cross_attn"))
         return out
 
+    def _emit_self_attn(self, ws, pk, at: Attention, x: Act, want_stats: bool) -> Act:
+        """layers.py:52-104 + residual: LayerNorm tokens -> fold them as their own context -> chunked online-softmax attention"""
+        lib = L.lib()
+        Cc, HW, batch = x.C, x.H * x.W, x.batch
+        xh = torch.empty(batch, HW, Cc, dtype=torch.float32, device=ws.dev)
+        J = HW + 1
+        jt = -(-J // 16)
+        FR = lib.mi_attn_fragment_floats(Cc)
+        gv = torch.zeros(batch, at.heads, jt, 64, FR, dtype=torch.float32, device=ws.dev)
+        ws.tensors += [xh, gv]
+        xa = x.c(batch)
+        ws.tensors.append(xa)
+
+        def ln_call(_p, st, xa=xa, xh=xh):
+            return lib.mi_ln_tokens_fwd(C.byref(xa), batch, HW, L.ptr(at.norm.gamma), L.ptr(at.norm.beta), L.ptr(xh), st)
+        ws.prog.append((lambda p_, st: ln_call(p_, st), None, "ln_tokens"))
+        mg, mv, g0, v0 = pk.attn[id(at)]
+        fp = L.MiAttnFoldParams()
+        fp.B2, fp.C, fp.cd, fp.heads, fp.JT = batch, Cc, Cc, at.heads, jt
+        fp.c_rows, fp.c_stride_b, fp.row0, fp.nrows, fp.write_null, fp.n_blocks = L.ptr(xh), HW * Cc, 1, HW, 1, 1
+        fp.blk[0].mg, fp.blk[0].mv, fp.blk[0].g0, fp.blk[0].v0, fp.blk[0].gv = L.ptr(mg), L.ptr(mv), L.ptr(g0), L.ptr(v0), L.ptr(gv)
+        ws.prog.append((lib.mi_attn_fold_rows, fp, "self_fold"))
+        out = self._new_act(ws, batch, Cc, x.H, x.W, -(-HW // 64) if want_stats else 0)
+        p = L.MiSelfAttnParams()
+        p.B2, p.C, p.HW, p.heads, p.J = batch, Cc, HW, at.heads, J
+        p.x, p.gv = xa, L.ptr(gv)
+        p.n1_g, p.n1_b = L.ptr(at.norm.gamma), L.ptr(at.norm.beta)
+        p.n2_g, p.n2_b = L.ptr(at.to_out[1].gamma), L.ptr(at.to_out[1].beta)
+        p.out, p.out_stats = L.ptr(out.t), L.ptr(out.stats)
+        ws.prog.append((lib.mi_self_attn_fwd, p, "self_attn"))
+        return out
+
+    def _emit_transformer_block(self, ws, pk, tb: TransformerBlock, x: Act) -> Act:
+        """layers.py:496-499: x = attn(x) + x ; x = ff(x) + x"""
+        lib = L.lib()
+        y = self._emit_self_attn(ws, pk, tb.attn.fn, x, want_stats=False)
+        HW = y.H * y.W
+        out = self._new_act(ws, y.batch, y.C, y.H, y.W, -(-HW // 256))
+        p = L.MiChanFFParams()
+        p.B, p.C, p.Chid, p.HW = y.batch, y.C, tb.ff[1].out_channels, HW
+        p.x = y.c(y.batch)
+        p.g1, p.w1, p.g2, p.w2 = L.ptr(tb.ff[0].g), L.ptr(tb.ff[1].weight), L.ptr(tb.ff[3].g), L.ptr(tb.ff[4].weight)
+        p.out, p.out_stats = L.ptr(out.t), L.ptr(out.stats)
+        ws.prog.append((lib.mi_chan_ff_fwd, p, "chan_ff"))
+        return out
+
     def _fold_params(self, ws, pk, rows_t, stride_b, row0, nrows, write_null):
         """one mi_attn_fold_rows launch covering every cross-attention block (they share C in practice; else one per C)"""
         lib = L.lib()
@@ -274,6 +330,8 @@ class UnetEngine:
         for ca_id, gv in ws.gv.items():
             by_c.setdefault(gv.shape[-1], []).append(ca_id)
         cas = {id(m): m for m in self.unet.modules() if isinstance(m, CrossAttention)}
+        by_c = {k: [i for i in v if i in cas] for k, v in by_c.items()}
+        by_c = {k: v for k, v in by_c.items() if v}
         for _, ids in by_c.items():
             for i0 in range(0, len(ids), 8):
                 chunk = ids[i0:i0 + 8]
@@ -292,11 +350,6 @@ class UnetEngine:
     def _build_program(self, ws, pk):
         u = self.unet
         lib = L.lib()
-        for m in u.modules():
-            if isinstance(m, TransformerBlock):
-                raise NotImplementedError("self-attention TransformerBlocks (layer_attns=True, SURVEY K10) are not built yet in the HIP engine")
-        if u.mid_attn is not None:
-            raise NotImplementedError("attend_at_middle=True (SURVEY K10) is not built yet in the HIP engine")
         B, B2, H, W = ws.B, ws.B2, ws.H, ws.W
         # ---- K1/K5: per-step conditioning
         cp = L.MiCondStepParams()
@@ -352,18 +405,24 @@ class UnetEngine:
             for rb in resnet_blocks:
                 cur = self._emit_resnet(ws, pk, rb, cur, None)
                 hiddens.append(cur)
-            hiddens.append(cur)          # attn_block is Identity here (TransformerBlock rejected above)
+            if isinstance(attn_block, TransformerBlock):
+                cur = self._emit_transformer_block(ws, pk, attn_block, cur)
+            hiddens.append(cur)
             if isinstance(post, nn.Conv2d):
                 cur = self._emit_conv(ws, pk, cur, None, wpack=pk.conv[id(post)], bias=post.bias, Cout=post.out_channels, ksize=4, stride=2)
             elif isinstance(post, Parallel):
                 wp, bsum = pk.conv[id(post)]
                 cur = self._emit_conv(ws, pk, cur, None, wpack=wp, bias=bsum, Cout=post.fns[0].out_channels)
         cur = self._emit_resnet(ws, pk, u.mid_block1, cur, None)
+        if u.mid_attn is not None:            # EinopsToAndFrom(Residual(Attention)), Unet.py:272-274
+            cur = self._emit_self_attn(ws, pk, u.mid_attn.fn.fn, cur, want_stats=True)
         cur = self._emit_resnet(ws, pk, u.mid_block2, cur, None)
         for init_block, resnet_blocks, attn_block, upsample in u.ups:
             cur = self._emit_resnet(ws, pk, init_block, cur, hiddens.pop())
             for rb in resnet_blocks:
                 cur = self._emit_resnet(ws, pk, rb, cur, hiddens.pop())
+            if isinstance(attn_block, TransformerBlock):
+                cur = self._emit_transformer_block(ws, pk, attn_block, cur)
             if isinstance(upsample, nn.Sequential):
                 cv = upsample[1]
                 cur = self._emit_conv(ws, pk, cur, None, wpack=pk.conv[id(cv)], bias=cv.bias, Cout=cv.out_channels, up2=1)
@@ -416,7 +475,7 @@ class UnetEngine:
         ws.lowres / ws.lowres_times -> ws.pred."""
         st = L.current_stream() if stream is None else stream
         for fn, p, name in ws.prog:
-            rc = fn(C.byref(p), st)
+            rc = fn(C.byref(p), st) if p is not None else fn(None, st)
             if rc != 0:
                 L.check(rc, name)
 

@@ -131,3 +131,41 @@ def test_constructor_api_and_state_dict_contract():
     for k in ("downs.1.3.attn.fn.to_kv.weight", "downs.1.3.ff.0.g", "downs.1.3.ff.4.weight", "mid_attn.fn.fn.null_kv",
               "downs.1.1.cross_attn.fn.to_out.1.beta", "ups.0.2.attn.fn.norm.gamma", "downs.1.4.fns.1.weight", "ups.0.3.1.weight"):
         assert k in keys, k
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_attention_bearing_unet_vs_oracle(backend):
+    """K10 + cross-attention at every level: layer_attns / layer_cross_attns / attend_at_middle on a narrow U-Net
+    (self-attention TransformerBlocks, ChanFeedForward, mid attention) against the oracle."""
+    dev = setup(backend)
+    torch.manual_seed(3)
+    u = Unet(dim=16, dim_mults=(1, 2), num_resnet_blocks=1, layer_attns=(False, True), layer_cross_attns=(True, True),
+             attend_at_middle=True, memory_efficient=False)
+    with torch.no_grad():
+        for n, p in u.named_parameters():
+            if n.endswith(("gamma", ".g")) or "norm" in n and n.endswith("weight"):
+                p.copy_(1 + 0.2 * torch.randn(p.shape))
+    sd = {k: v.clone() for k, v in u.state_dict().items()}
+    u = u.to(dev)
+    emb, mask = R.synthetic_text(2, length=12, seed=3)
+    x = I.seeded((2, 3, 32, 32), 6)
+    tm = torch.tensor([3, 9])
+    ref = R.unet_forward_with_cond_scale(sd, x, tm, cond_scale=2., text_embeds=emb, text_mask=mask)
+    out = u.forward_with_cond_scale(x.to(dev), tm.to(dev), text_embeds=emb.to(dev), text_mask=mask.to(dev), cond_scale=2.)
+    assert (out.cpu() - ref).abs().max() < 4e-5
+
+
+@pytest.mark.parametrize("backend", GPU_ONLY)
+def test_self_attention_4096_tokens(backend):
+    """K10 at full token count: layer_attns at the 64x64 level (4096 tokens + null row -> 17 context chunks of 256)"""
+    dev = setup(backend)
+    torch.manual_seed(5)
+    u = Unet(dim=8, dim_mults=(1, 2), num_resnet_blocks=1, layer_attns=(True, True), layer_cross_attns=False, memory_efficient=True, lowres_cond=True)
+    sd = {k: v.clone() for k, v in u.state_dict().items()}
+    u = u.to(dev)
+    emb, mask = R.synthetic_text(2, length=20, seed=3)
+    x, lr = I.seeded((2, 3, 128, 128), 6), I.seeded((2, 3, 128, 128), 7)
+    tm, lt = torch.tensor([3, 90]), torch.tensor([20, 20])
+    ref = R.unet_forward(sd, x, tm, lowres_cond_img=lr, lowres_noise_times=lt, text_embeds=emb, text_mask=mask)
+    out = u(x.to(dev), tm.to(dev), lowres_cond_img=lr.to(dev), lowres_noise_times=lt.to(dev), text_embeds=emb.to(dev), text_mask=mask.to(dev))
+    assert (out.cpu() - ref).abs().max() < 4e-5
