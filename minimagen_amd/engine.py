@@ -26,7 +26,9 @@ from .layers import Attention, CrossAttention, EinopsToAndFrom, Identity, Parall
 MAX_TEXT_LEN = 256
 # kernel-shape tuning knobs (A/B measurements; the defaults are what profiles/ was measured with)
 ATTN_VARIANT = int(os.environ.get("MINIMAGEN_ATTN_VARIANT", "1"))       # 0: 32 tokens per wave, 1: 16 tokens per wave
-CONV_SPLIT16 = int(os.environ.get("MINIMAGEN_CONV_SPLIT16", "1"))       # 1: 16-channel 3x3 outputs as two 8-channel workgroups
+CONV_SPLIT16 = int(os.environ.get("MINIMAGEN_CONV_SPLIT16", "1"))
+TILE64 = int(os.environ.get("MINIMAGEN_TILE64", "-1"))                  # force a conv tile shape at 64x64 / 128x128 (experiments)
+TILE128 = int(os.environ.get("MINIMAGEN_TILE128", "-1"))       # 1: 16-channel 3x3 outputs as two 8-channel workgroups
 JT = 17     # context tiles of 16 rows: 1 null + (2|4) time tokens + 256 text rows <= 272
 
 
@@ -195,6 +197,10 @@ class UnetEngine:
         batch is, so that a sharded batch reproduces the unsharded rows bit for bit."""
         lib = L.lib()
         best = 0 if (W >= 64 and H * W > 64 * 64) else 2
+        if H * W == 64 * 64 and TILE64 >= 0:
+            best = TILE64
+        if H * W == 128 * 128 and TILE128 >= 0:
+            best = TILE128
         th, tw = C.c_int(), C.c_int()
         lib.mi_conv_tile_shape(best, C.byref(th), C.byref(tw))
         return best, -(-H // th.value) * -(-W // tw.value)
