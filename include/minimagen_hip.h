@@ -170,6 +170,8 @@ typedef struct mi_attn_fold_params {
     int c_stride_b;                 /* floats between consecutive b' in c_rows */
     int row0, nrows;                /* they become context rows row0 .. row0+nrows-1 */
     int write_null;                 /* also write context row 0 from g0 / v0 */
+    int frag_f16;                   /* 1: fragments for the fp16x3 kernel (variant 6): every value split hi + lo into two halves,
+                                       per lane [G hi x4][G lo x4][VW hi x4][VW lo x4] per 16-channel chunk (same bytes as fp32) */
     int n_blocks;
     struct {
         const float* mg;            /* [heads][C][cd]  log2(e) * scale * Wq_h^T Wk_h */
@@ -189,7 +191,8 @@ typedef struct mi_cross_attn_params {
     const float* n1_g; const float* n1_b;   /* CrossAttention.norm   gamma / beta */
     const float* n2_g; const float* n2_b;   /* to_out.1              gamma / beta */
     float* out; float* out_stats;   /* [B2][C][HW]; stats [B2][C][ceil(HW/tok)][2], tok = 128 (variant 0) or 64 (variant 1) */
-    int variant;                    /* 0: 32 tokens per wave, 1: 16 tokens per wave (more waves per SIMD) */
+    int variant;                    /* 0: 32 tokens per wave; 1,3,4: 16 tokens per wave (fp32 MFMA, exact); 6: 16 tokens per wave with the
+                                       contractions as 3-term fp16 splits on v_mfma_f32_16x16x16_f16 (hi*hi + hi*lo + lo*hi, ~2^-21) */
 } mi_cross_attn_params;
 int mi_cross_attn_fwd(const mi_cross_attn_params* p, void* stream);
 #define MI_ATTN_TOKENS_PER_WG 128

@@ -76,7 +76,7 @@ class MiAttnFoldBlk(C.Structure):
 class MiAttnFoldParams(C.Structure):
     _fields_ = [
         ("B2", C.c_int), ("C", C.c_int), ("cd", C.c_int), ("heads", C.c_int), ("JT", C.c_int),
-        ("c_rows", C.c_void_p), ("c_stride_b", C.c_int), ("row0", C.c_int), ("nrows", C.c_int), ("write_null", C.c_int),
+        ("c_rows", C.c_void_p), ("c_stride_b", C.c_int), ("row0", C.c_int), ("nrows", C.c_int), ("write_null", C.c_int), ("frag_f16", C.c_int),
         ("n_blocks", C.c_int), ("blk", MiAttnFoldBlk * 8),
     ]
 

@@ -11,8 +11,10 @@
 
 namespace {
 
-template <int C, int NQ, int JT>
-__global__ __launch_bounds__(256) void cross_attn_folded_kernel(const mi_cross_attn_params p) {
+// WPS = waves per SIMD the register allocator must leave room for (hipcc's default heuristic spends 200 registers here;
+// 118 are enough, which doubles the resident waves and lets one wave's MFMAs run under another's softmax)
+template <int C, int NQ, int JT, bool PIPE, int WPS>
+__global__ __launch_bounds__(256, WPS) void cross_attn_folded_kernel(const mi_cross_attn_params p) {
     constexpr int KK = C / 4;                       // k-steps of QK^T
     constexpr int NGP = KK < 4 ? 4 : KK;
     constexpr int MT = (C + 15) / 16;               // M tiles of PV (output channels)
@@ -75,9 +77,8 @@ __global__ __launch_bounds__(256) void cross_attn_folded_kernel(const mi_cross_a
     const float* gvb = p.gv + (size_t)b * p.heads * JT * 64 * FR + (size_t)lane * FR;
     const int jlast = p.J - 1;
 
-    for (int h = 0; h < p.heads; ++h) {
+    auto qk = [&](int h, f32x4 (&s)[JT][NQ]) {
         const float* gvh = gvb + (size_t)h * JT * 64 * FR;
-        f32x4 s[JT][NQ];
         // ---- S^T tiles
 #pragma unroll
         for (int jt = 0; jt < JT; ++jt) {
@@ -95,6 +96,9 @@ __global__ __launch_bounds__(256) void cross_attn_folded_kernel(const mi_cross_a
                 s[jt][q] = acc;
             }
         }
+    };
+    auto softmax_pv = [&](int h, f32x4 (&s)[JT][NQ]) {
+        const float* gvh = gvb + (size_t)h * JT * 64 * FR;
         // ---- softmax over j (rows of S^T): this lane holds j = 16jt + 4lg + r.  P stays un-normalised; the 1/l of
         // this head is applied to its 16*MT-row PV result instead of to the 272 probabilities.
         float linv[NQ];
@@ -151,6 +155,26 @@ __global__ __launch_bounds__(256) void cross_attn_folded_kernel(const mi_cross_a
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) oacc[q][mt][r] = fmaf(oh[q][mt][r], linv[q], oacc[q][mt][r]);
+    };
+    if constexpr (PIPE) {
+        // two score sets: the QK^T MFMAs of head h+1 are issued before head h's softmax so the matrix pipe works under
+        // the exponentials of the same wave (named arrays, static indices only)
+        f32x4 sA[JT][NQ], sB[JT][NQ];
+        qk(0, sA);
+        for (int h = 0; h < p.heads; h += 2) {
+            if (h + 1 < p.heads) qk(h + 1, sB);
+            softmax_pv(h, sA);
+            if (h + 1 < p.heads) {
+                if (h + 2 < p.heads) qk(h + 2, sA);
+                softmax_pv(h + 1, sB);
+            }
+        }
+    } else {
+        for (int h = 0; h < p.heads; ++h) {
+            f32x4 s[JT][NQ];
+            qk(h, s);
+            softmax_pv(h, s);
+        }
     }
 
     // ---- to_out.1 LayerNorm over channels, + residual, store, statistics.
@@ -221,6 +245,186 @@ __global__ __launch_bounds__(256) void cross_attn_folded_kernel(const mi_cross_a
     }
 }
 
+
+// ---- variant 6: the same algorithm with both contractions as 3-term fp16 splits on the real matrix cores.
+// Measured on MI355X (profiles/r01_mfma_valu_overlap_ubench.txt): v_mfma_f32_16x16x4_f32 does not overlap with VALU work
+// (it runs at the VALU fp32 rate and serialises with it), v_mfma_f32_16x16x16_f16 takes ~0.6x its time for 4x the K and
+// hides 2-3 VALU instructions.  x = hi + lo with hi = fp16(x), lo = fp16(x - hi) keeps 22 mantissa bits; the dropped
+// lo*lo term is 2^-22 relative, so the result stays inside the fp32 parity tolerance.
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split_f16(const float (&x)[4], f16x4& hi, f16x4& lo) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const _Float16 h = (_Float16)x[e];
+        hi[e] = h;
+        lo[e] = (_Float16)(x[e] - (float)h);
+    }
+}
+
+template <int C, int JT, int WPS>
+__global__ __launch_bounds__(256, WPS) void cross_attn_f16x3_kernel(const mi_cross_attn_params p) {
+    constexpr int KC = (C + 15) / 16, MT = (C + 15) / 16, FRH = 8 * KC + 8 * MT, TOK_WG = 64;
+    __shared__ float red[4][2 * 16 * MT];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lq = lane & 15, lg = lane >> 4;
+    const int tiles = (p.HW + TOK_WG - 1) / TOK_WG;
+    int b, tile;
+    if ((p.B2 & 7) == 0) {
+        const int L = blockIdx.x, k = L >> 3;
+        b = (L & 7) + 8 * (k / tiles);
+        tile = k % tiles;
+    } else {
+        b = blockIdx.x / tiles;
+        tile = blockIdx.x % tiles;
+    }
+    const int bx = p.x.bmod > 0 ? b % p.x.bmod : b;
+    const int i = (tile * 4 + wave) * 16 + lq;
+    const bool ok = i < p.HW;
+    const float* xb = p.x.data + (size_t)bx * C * p.HW;
+
+    // LayerNorm(x) -> B operand of QK^T: this lane supplies channels a = 16kc + 4lg + e of token lq
+    f16x4 xhi[KC], xlo[KC];
+    {
+        float xf[KC][4];
+        float s = 0.0f;
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int a = 16 * kc + 4 * lg + e;
+                xf[kc][e] = (ok && a < C) ? xb[(size_t)a * p.HW + i] * p.x.scale : 0.0f;
+                s += xf[kc][e];
+            }
+        s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
+        const float mean = s / (float)C;
+        float v = 0.0f;
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = (16 * kc + 4 * lg + e < C) ? xf[kc][e] - mean : 0.0f; v = fmaf(d, d, v); }
+        v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+        const float rstd = 1.0f / sqrtf(v / (float)C + 1e-5f);
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+            float xn[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int a = 16 * kc + 4 * lg + e;
+                xn[e] = (a < C) ? (xf[kc][e] - mean) * rstd * p.n1_g[a] + p.n1_b[a] : 0.0f;
+            }
+            split_f16(xn, xhi[kc], xlo[kc]);
+        }
+    }
+    f32x4 oacc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) oacc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const _Float16* gvb = reinterpret_cast<const _Float16*>(p.gv) + (size_t)b * p.heads * JT * 64 * FRH + (size_t)lane * FRH;
+    const int jlast = p.J - 1;
+
+    for (int h = 0; h < p.heads; ++h) {
+        const _Float16* gvh = gvb + (size_t)h * JT * 64 * FRH;
+        f32x4 s[JT];
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) {
+            f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc) {
+                const f16x4 ghi = *reinterpret_cast<const f16x4*>(gvh + (size_t)jt * 64 * FRH + 8 * kc);
+                const f16x4 glo = *reinterpret_cast<const f16x4*>(gvh + (size_t)jt * 64 * FRH + 8 * kc + 4);
+                acc = __builtin_amdgcn_mfma_f32_16x16x16f16(glo, xhi[kc], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x16f16(ghi, xlo[kc], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x16f16(ghi, xhi[kc], acc, 0, 0, 0);
+            }
+            s[jt] = acc;
+        }
+        float m = -INFINITY;
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (jt == JT - 1 && (16 * jt + 4 * lg + r) > jlast) s[jt][r] = -INFINITY;
+                m = fmaxf(m, s[jt][r]);
+            }
+        m = fmaxf(m, __shfl_xor(m, 16));
+        m = fmaxf(m, __shfl_xor(m, 32));
+        float l = 0.0f;
+        f32x4 oh[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) oh[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) {
+            float pe[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { pe[r] = __builtin_amdgcn_exp2f(s[jt][r] - m); l += pe[r]; }
+            f16x4 phi, plo;                       // B operand of PV: P[j = 16jt + 4lg + e][token lq] -- the C/D layout as it is
+            split_f16(pe, phi, plo);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const f16x4 vhi = *reinterpret_cast<const f16x4*>(gvh + (size_t)jt * 64 * FRH + 8 * KC + 8 * mt);
+                const f16x4 vlo = *reinterpret_cast<const f16x4*>(gvh + (size_t)jt * 64 * FRH + 8 * KC + 8 * mt + 4);
+                oh[mt] = __builtin_amdgcn_mfma_f32_16x16x16f16(vlo, phi, oh[mt], 0, 0, 0);
+                oh[mt] = __builtin_amdgcn_mfma_f32_16x16x16f16(vhi, plo, oh[mt], 0, 0, 0);
+                oh[mt] = __builtin_amdgcn_mfma_f32_16x16x16f16(vhi, phi, oh[mt], 0, 0, 0);
+            }
+        }
+        l += __shfl_xor(l, 16);
+        l += __shfl_xor(l, 32);
+        const float linv = 1.0f / l;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) oacc[mt][r] = fmaf(oh[mt][r], linv, oacc[mt][r]);
+    }
+
+    // to_out.1 LayerNorm + residual + statistics (same as the fp32 kernel)
+    float csum[4 * MT], csq[4 * MT];
+#pragma unroll
+    for (int e = 0; e < 4 * MT; ++e) { csum[e] = 0.0f; csq[e] = 0.0f; }
+    {
+        float s1 = 0.0f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s1 += oacc[mt][r];
+        s1 += __shfl_xor(s1, 16); s1 += __shfl_xor(s1, 32);
+        const float mean = s1 / (float)C;
+        float v = 0.0f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const int a = 16 * mt + 4 * lg + r; const float d = (a < C) ? oacc[mt][r] - mean : 0.0f; v = fmaf(d, d, v); }
+        v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+        const float rstd = 1.0f / sqrtf(v / (float)C + 1e-5f);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int a = 16 * mt + 4 * lg + r;
+                if (a < C && ok) {
+                    const float y = (oacc[mt][r] - mean) * rstd * p.n2_g[a] + p.n2_b[a] + xb[(size_t)a * p.HW + i] * p.x.scale;
+                    p.out[((size_t)b * C + a) * p.HW + i] = y;
+                    csum[4 * mt + r] = y;
+                    csq[4 * mt + r] = y * y;
+                }
+            }
+    }
+    if (p.out_stats) {
+#pragma unroll
+        for (int e = 0; e < 4 * MT; ++e) {
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) { csum[e] += __shfl_xor(csum[e], o); csq[e] += __shfl_xor(csq[e], o); }
+        }
+        if (lq == 0) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const int a = 16 * mt + 4 * lg + r; red[wave][2 * a] = csum[4 * mt + r]; red[wave][2 * a + 1] = csq[4 * mt + r]; }
+        }
+        __syncthreads();
+        if (tid < 2 * C) p.out_stats[((size_t)(b * C + (tid >> 1)) * tiles + tile) * 2 + (tid & 1)] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+    }
+}
+
 }  // namespace
 
 extern "C" int mi_cross_attn_fwd(const mi_cross_attn_params* pp, void* stream) {
@@ -230,22 +434,56 @@ extern "C" int mi_cross_attn_fwd(const mi_cross_attn_params* pp, void* stream) {
     if (JT != 17) { mi_set_error("mi_cross_attn_fwd: context of %d rows (%d tiles) not instantiated (MinImagen: 1 + time tokens + 256)", p.J, JT); return MI_ERR_UNSUPPORTED; }
     if (p.B2 <= 0 || p.HW <= 0) { mi_set_error("mi_cross_attn_fwd: empty problem"); return MI_ERR_INVALID; }
     // out_stats tiles are MI_ATTN_TOKENS_PER_WG tokens (NQ = 2); p.variant = 1 selects NQ = 1 (64-token tiles)
+    if (p.variant == 6) {      // fp16x3 split on v_mfma_f32_16x16x16_f16 (fragments from mi_attn_fold_rows with frag_f16 = 1)
+        const dim3 g6(((p.HW + 63) / 64) * p.B2);
+        switch (p.C) {
+            case 8: hipLaunchKernelGGL(HIP_KERNEL_NAME(cross_attn_f16x3_kernel<8, 17, 3>), g6, dim3(256), 0, st, p); break;
+            case 16: hipLaunchKernelGGL(HIP_KERNEL_NAME(cross_attn_f16x3_kernel<16, 17, 3>), g6, dim3(256), 0, st, p); break;
+            case 32: hipLaunchKernelGGL(HIP_KERNEL_NAME(cross_attn_f16x3_kernel<32, 17, 3>), g6, dim3(256), 0, st, p); break;
+            default: mi_set_error("mi_cross_attn_fwd: folded path instantiated for C in {8,16,32}, got %d", p.C); return MI_ERR_UNSUPPORTED;
+        }
+        return mi_check_launch("cross_attn_f16x3_kernel");
+    }
+    if (p.variant >= 3 && p.variant <= 5) {      // 16 / 32 tokens per wave with a register cap for 3, 4 / 2 waves per SIMD
+        const int tok3 = p.variant == 5 ? 128 : 64;
+        const dim3 g3(((p.HW + tok3 - 1) / tok3) * p.B2);
+        if (p.C != 16 && p.C != 8 && p.C != 32) { mi_set_error("mi_cross_attn_fwd: folded path instantiated for C in {8,16,32}, got %d", p.C); return MI_ERR_UNSUPPORTED; }
+#define MI_ATTN_LAUNCH(CC) \
+        if (p.C == CC) { \
+            if (p.variant == 3) hipLaunchKernelGGL(HIP_KERNEL_NAME(cross_attn_folded_kernel<CC, 1, 17, false, 3>), g3, dim3(256), 0, st, p); \
+            else if (p.variant == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(cross_attn_folded_kernel<CC, 1, 17, false, 4>), g3, dim3(256), 0, st, p); \
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(cross_attn_folded_kernel<CC, 2, 17, false, 2>), g3, dim3(256), 0, st, p); \
+        }
+        MI_ATTN_LAUNCH(8) MI_ATTN_LAUNCH(16) MI_ATTN_LAUNCH(32)
+#undef MI_ATTN_LAUNCH
+        return mi_check_launch("cross_attn_folded_kernel");
+    }
+    if (p.variant == 2) {      // 16 tokens per wave, QK^T of the next head software-pipelined under the softmax
+        const dim3 g2(((p.HW + 63) / 64) * p.B2);
+        switch (p.C) {
+            case 8: hipLaunchKernelGGL(HIP_KERNEL_NAME(cross_attn_folded_kernel<8, 1, 17, true, 1>), g2, dim3(256), 0, st, p); break;
+            case 16: hipLaunchKernelGGL(HIP_KERNEL_NAME(cross_attn_folded_kernel<16, 1, 17, true, 1>), g2, dim3(256), 0, st, p); break;
+            case 32: hipLaunchKernelGGL(HIP_KERNEL_NAME(cross_attn_folded_kernel<32, 1, 17, true, 1>), g2, dim3(256), 0, st, p); break;
+            default: mi_set_error("mi_cross_attn_fwd: folded path instantiated for C in {8,16,32}, got %d", p.C); return MI_ERR_UNSUPPORTED;
+        }
+        return mi_check_launch("cross_attn_folded_kernel");
+    }
     const int nq = p.variant == 1 ? 1 : 2;
     const int tok = 64 * nq;
     const dim3 grid(((p.HW + tok - 1) / tok) * p.B2);
     if (nq == 1) {
         switch (p.C) {
-            case 8: hipLaunchKernelGGL(HIP_KERNEL_NAME(cross_attn_folded_kernel<8, 1, 17>), grid, dim3(256), 0, st, p); break;
-            case 16: hipLaunchKernelGGL(HIP_KERNEL_NAME(cross_attn_folded_kernel<16, 1, 17>), grid, dim3(256), 0, st, p); break;
-            case 32: hipLaunchKernelGGL(HIP_KERNEL_NAME(cross_attn_folded_kernel<32, 1, 17>), grid, dim3(256), 0, st, p); break;
+            case 8: hipLaunchKernelGGL(HIP_KERNEL_NAME(cross_attn_folded_kernel<8, 1, 17, false, 2>), grid, dim3(256), 0, st, p); break;
+            case 16: hipLaunchKernelGGL(HIP_KERNEL_NAME(cross_attn_folded_kernel<16, 1, 17, false, 2>), grid, dim3(256), 0, st, p); break;
+            case 32: hipLaunchKernelGGL(HIP_KERNEL_NAME(cross_attn_folded_kernel<32, 1, 17, false, 2>), grid, dim3(256), 0, st, p); break;
             default: mi_set_error("mi_cross_attn_fwd: folded path instantiated for C in {8,16,32}, got %d", p.C); return MI_ERR_UNSUPPORTED;
         }
         return mi_check_launch("cross_attn_folded_kernel");
     }
     switch (p.C) {
-        case 8: hipLaunchKernelGGL(HIP_KERNEL_NAME(cross_attn_folded_kernel<8, 2, 17>), grid, dim3(256), 0, st, p); break;
-        case 16: hipLaunchKernelGGL(HIP_KERNEL_NAME(cross_attn_folded_kernel<16, 2, 17>), grid, dim3(256), 0, st, p); break;
-        case 32: hipLaunchKernelGGL(HIP_KERNEL_NAME(cross_attn_folded_kernel<32, 2, 17>), grid, dim3(256), 0, st, p); break;
+        case 8: hipLaunchKernelGGL(HIP_KERNEL_NAME(cross_attn_folded_kernel<8, 2, 17, false, 1>), grid, dim3(256), 0, st, p); break;
+        case 16: hipLaunchKernelGGL(HIP_KERNEL_NAME(cross_attn_folded_kernel<16, 2, 17, false, 1>), grid, dim3(256), 0, st, p); break;
+        case 32: hipLaunchKernelGGL(HIP_KERNEL_NAME(cross_attn_folded_kernel<32, 2, 17, false, 1>), grid, dim3(256), 0, st, p); break;
         default: mi_set_error("mi_cross_attn_fwd: folded path instantiated for C in {8,16,32}, got %d", p.C); return MI_ERR_UNSUPPORTED;
     }
     return mi_check_launch("cross_attn_folded_kernel");

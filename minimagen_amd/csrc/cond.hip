@@ -153,6 +153,20 @@ __global__ __launch_bounds__(256) void attn_fold_rows_kernel(const mi_attn_fold_
             v = dot_row(mv + ((size_t)h * C + a) * p.cd, c, p.cd);
         }
         const int jt = j >> 4, jm = j & 15;
+        if (p.frag_f16) {
+            // fp16x3 fragments: per lane and tile KC x {4 halves G hi, 4 halves G lo} then MT x {4 VW hi, 4 VW lo}
+            const int KC = (C + 15) / 16, MTh = (C + 15) / 16, FRH = 8 * KC + 8 * MTh;          // halves per lane
+            _Float16* th = reinterpret_cast<_Float16*>(p.blk[blk].gv) + (((size_t)bb * p.heads + h) * p.JT + jt) * 64 * FRH;
+            const _Float16 ghi = (_Float16)g, glo = (_Float16)(g - (float)ghi);
+            const _Float16 vhi = (_Float16)v, vlo = (_Float16)(v - (float)vhi);
+            _Float16* lg = th + (size_t)(jm + 16 * ((a & 15) >> 2)) * FRH + 8 * (a >> 4);      // A[m=j][k=a]: lane (j, a/4), element a%4
+            lg[a & 3] = ghi;
+            lg[4 + (a & 3)] = glo;
+            _Float16* lv = th + (size_t)((a & 15) + 16 * (jm >> 2)) * FRH + 8 * KC + 8 * (a >> 4);   // A[m=a][k=j]: lane (a, j/4), element j%4
+            lv[jm & 3] = vhi;
+            lv[4 + (jm & 3)] = vlo;
+            continue;
+        }
         float* tilep = gv + ((size_t)h * p.JT + jt) * 64 * FR;
         tilep[(size_t)(jm + 16 * (a & 3)) * FR + (a >> 2)] = g;                           // A[m=j][k=a] of QK^T, k-step a/4
         tilep[(size_t)((a & 15) + 16 * (jm >> 2)) * FR + NGP + 4 * (a >> 4) + (jm & 3)] = v;   // A[m=a][k=j] of PV, step j%4

@@ -10,10 +10,10 @@
 
 namespace {
 
-template <int NT_, int TW_, int COUT_T_, int KS_, int S_, bool UP2_, bool VEC_>
+template <int NT_, int TW_, int COUT_T_, int KS_, int S_, bool UP2_, bool VEC_, bool GN_>
 struct ConvCfg {
     static constexpr int NT = NT_, TW = TW_, COUT_T = COUT_T_, KS = KS_, S = S_;
-    static constexpr bool UP2 = UP2_, VEC = VEC_;
+    static constexpr bool UP2 = UP2_, VEC = VEC_, GN = GN_;
     static constexpr int TXN = TW / 4;            // work-items along x (4 output pixels each)
     static constexpr int TH = NT / TXN;           // output rows per tile (1 row per work-item)
     static constexpr int IH = TH * S + KS - S;    // staged input rows / cols (with halo)
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(CFG::NT) void conv_tile_kernel(const mi_conv_params
     const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;   // pad = 1 for every member of the family
     const int b0 = p.in0.bmod > 0 ? b % p.in0.bmod : b, b1 = p.in1.bmod > 0 ? b % p.in1.bmod : b;
     const int br0 = p.res0.bmod > 0 ? b % p.res0.bmod : b, br1 = p.res1.bmod > 0 ? b % p.res1.bmod : b;
-    const bool gn = p.gn_groups > 0;
+    constexpr bool gn = CFG::GN;         // GroupNorm + SiLU prologue compiled in or out (no per-element branches)
 
     // Staging is split (T14): a round's global loads are issued back-to-back into registers with clamped
     // (always legal) addresses and no branches; the activation + LDS write happens after the barrier, and on
@@ -165,30 +165,33 @@ __global__ __launch_bounds__(CFG::NT) void conv_tile_kernel(const mi_conv_params
     stage_load(0);      // first round's loads fly under the statistics prologue
 
     // ---------------- prologue: per-channel affine for the fused GroupNorm / scale-shift
-    if (p.gn_groups > 0) {
-        // per-channel totals of the producer's per-tile partial sums: TPC lanes per channel, fixed-order fp64 tree
-        int TPC = 1;
-        while (TPC < 64 && TPC * 2 * Cin <= NT) TPC *= 2;
-        const int CPP = NT / TPC;                       // channels per pass
-        for (int base = 0; base < Cin; base += CPP) {
-            const int c = base + tid / TPC, sub = tid % TPC;
-            double s = 0.0, q = 0.0;
-            if (c < Cin) {
-                const bool second = c >= C0;
-                const mi_act& a = second ? p.in1 : p.in0;
-                const int cc = second ? c - C0 : c;
-                const int ba = a.bmod > 0 ? b % a.bmod : b;
-                const float* st = a.stats + ((size_t)(ba * a.C + cc) * a.nt) * 2;
-                for (int t = sub; t < a.nt; t += TPC) {
-                    const float2 v = *reinterpret_cast<const float2*>(st + 2 * t);
-                    s += (double)v.x;
-                    q += (double)v.y;
+    if constexpr (CFG::GN) {
+        // per-channel totals of the producer's per-tile partial sums: done by wave 0 only (the other waves go straight
+        // to the barrier), TPC lanes per channel, fixed-order fp64 tree
+        if (tid < 64) {
+            int TPC = 1;
+            while (TPC < 64 && TPC * 2 * Cin <= 64) TPC *= 2;
+            const int CPP = 64 / TPC;                       // channels per pass
+            for (int base = 0; base < Cin; base += CPP) {
+                const int c = base + tid / TPC, sub = tid % TPC;
+                double s = 0.0, q = 0.0;
+                if (c < Cin) {
+                    const bool second = c >= C0;
+                    const mi_act& a = second ? p.in1 : p.in0;
+                    const int cc = second ? c - C0 : c;
+                    const int ba = a.bmod > 0 ? b % a.bmod : b;
+                    const float* st = a.stats + ((size_t)(ba * a.C + cc) * a.nt) * 2;
+                    for (int t = sub; t < a.nt; t += TPC) {
+                        const float2 v = *reinterpret_cast<const float2*>(st + 2 * t);
+                        s += (double)v.x;
+                        q += (double)v.y;
+                    }
+                    s *= (double)a.scale;
+                    q *= (double)a.scale * (double)a.scale;
                 }
-                s *= (double)a.scale;
-                q *= (double)a.scale * (double)a.scale;
+                for (int o = TPC >> 1; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
+                if (c < Cin && sub == 0) { chS[c] = s; chQ[c] = q; }
             }
-            for (int o = TPC >> 1; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
-            if (c < Cin && sub == 0) { chS[c] = s; chQ[c] = q; }
         }
         __syncthreads();
         const int cpg = Cin / p.gn_groups;
@@ -355,13 +358,23 @@ __global__ __launch_bounds__(CFG::NT) void conv_tile_kernel(const mi_conv_params
     }
 }
 
-template <int NT, int TW, int COUT_T, int KS, int S, bool UP2, bool VEC>
-int launch_conv_v(const mi_conv_params& p, hipStream_t st) {
-    using CFG = ConvCfg<NT, TW, COUT_T, KS, S, UP2, VEC>;
+template <int NT, int TW, int COUT_T, int KS, int S, bool UP2, bool VEC, bool GN>
+int launch_conv_g(const mi_conv_params& p, hipStream_t st) {
+    using CFG = ConvCfg<NT, TW, COUT_T, KS, S, UP2, VEC, GN>;
     const int tiles = ((p.H + CFG::TH - 1) / CFG::TH) * ((p.W + TW - 1) / TW);
     const int cz = (p.Cout + COUT_T - 1) / COUT_T;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_tile_kernel<CFG>), dim3(tiles, p.B, cz), dim3(NT), 0, st, p, cz * COUT_T, p.w, p.res_w);
     return mi_check_launch("conv_tile_kernel");
+}
+
+template <int NT, int TW, int COUT_T, int KS, int S, bool UP2, bool VEC>
+int launch_conv_v(const mi_conv_params& p, hipStream_t st) {
+    if constexpr (KS == 3 && S == 1 && !UP2) {          // only the Block convs (layers.py:131-145) carry a GroupNorm prologue
+        if (p.gn_groups > 0) return launch_conv_g<NT, TW, COUT_T, KS, S, UP2, VEC, true>(p, st);
+    } else {
+        if (p.gn_groups > 0) { mi_set_error("mi_conv_fwd: GroupNorm prologue is only built for the k3 s1 family"); return MI_ERR_UNSUPPORTED; }
+    }
+    return launch_conv_g<NT, TW, COUT_T, KS, S, UP2, VEC, false>(p, st);
 }
 
 template <int NT, int TW, int COUT_T, int KS, int S, bool UP2>

@@ -25,7 +25,7 @@ from .layers import Attention, CrossAttention, EinopsToAndFrom, Identity, Parall
 
 MAX_TEXT_LEN = 256
 # kernel-shape tuning knobs (A/B measurements; the defaults are what profiles/ was measured with)
-ATTN_VARIANT = int(os.environ.get("MINIMAGEN_ATTN_VARIANT", "1"))       # 0: 32 tokens per wave, 1: 16 tokens per wave
+ATTN_VARIANT = int(os.environ.get("MINIMAGEN_ATTN_VARIANT", "6"))       # 6: fp16x3 MFMA (default); 0/1/3/4/5: exact-fp32 MFMA shapes
 CONV_SPLIT16 = int(os.environ.get("MINIMAGEN_CONV_SPLIT16", "1"))
 TILE64 = int(os.environ.get("MINIMAGEN_TILE64", "-1"))                  # force a conv tile shape at 64x64 / 128x128 (experiments)
 TILE128 = int(os.environ.get("MINIMAGEN_TILE128", "-1"))       # 1: 16-channel 3x3 outputs as two 8-channel workgroups
@@ -270,7 +270,7 @@ class UnetEngine:
         FR = lib.mi_attn_fragment_floats(Cc)
         gv = torch.zeros(ws.B2, ca.heads, JT, 64, FR, dtype=torch.float32, device=ws.dev)
         ws.gv[id(ca)] = gv
-        nt = -(-HW // (64 if ATTN_VARIANT == 1 else 128))
+        nt = -(-HW // (128 if ATTN_VARIANT in (0, 5) else 64))
         out = self._new_act(ws, ws.B2, Cc, h.H, h.W, nt)
         p = L.MiCrossAttnParams()
         p.B2, p.C, p.HW, p.heads, p.J = ws.B2, Cc, HW, ca.heads, ws.J
@@ -345,6 +345,7 @@ class UnetEngine:
                 p = L.MiAttnFoldParams()
                 p.B2, p.C, p.cd, p.heads, p.JT = ws.B2, ca0.to_q.in_features, self.unet.cond_dim, ca0.heads, JT
                 p.c_rows, p.c_stride_b, p.row0, p.nrows, p.write_null = L.ptr(rows_t), stride_b, row0, nrows, write_null
+                p.frag_f16 = 1 if ATTN_VARIANT == 6 else 0
                 p.n_blocks = len(chunk)
                 for k, cid in enumerate(chunk):
                     mg, mv, g0, v0 = pk.attn[cid]

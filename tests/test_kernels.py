@@ -164,7 +164,8 @@ def test_crossembed(backend, case):
 
 @pytest.mark.parametrize("backend", BACKENDS)
 @pytest.mark.parametrize("case", [(2, 16, 256, 8, 2, 0), (1, 16, 200, 8, 4, 0), (1, 8, 128, 8, 2, 0), (1, 32, 128, 16, 2, 0),
-                                  (8, 16, 200, 8, 4, 1), (1, 8, 128, 8, 2, 1)])
+                                  (8, 16, 200, 8, 4, 1), (1, 8, 128, 8, 2, 1), (2, 16, 256, 8, 4, 2), (2, 16, 256, 8, 4, 3), (1, 8, 200, 8, 2, 4), (1, 16, 256, 8, 4, 5),
+                                  (2, 16, 200, 8, 4, 6), (1, 8, 128, 8, 2, 6), (1, 32, 128, 16, 2, 6)])
 def test_cross_attention_folded(backend, case):
     """K9 against the oracle's unfolded CrossAttention (+ residual), incl. a ragged token count and both context lengths."""
     dev = setup(backend)
@@ -185,6 +186,7 @@ def test_cross_attention_folded(backend, case):
     gv = torch.zeros(B2, heads, 17, 64, FR, device=dev)
     fp = L.MiAttnFoldParams()
     fp.B2, fp.C, fp.cd, fp.heads, fp.JT, fp.n_blocks = B2, Cc, cd, heads, 17, 1
+    fp.frag_f16 = 1 if variant == 6 else 0
     fp.blk[0].mg, fp.blk[0].mv, fp.blk[0].g0, fp.blk[0].v0, fp.blk[0].gv = mg.data_ptr(), mv.data_ptr(), g0.data_ptr(), v0.data_ptr(), gv.data_ptr()
     ct, cx = c[:, :ntok].contiguous().to(dev), c[:, ntok:].contiguous().to(dev)
     fp.c_rows, fp.c_stride_b, fp.row0, fp.nrows, fp.write_null = cx.data_ptr(), 256 * cd, 1 + ntok, 256, 1
@@ -198,7 +200,7 @@ def test_cross_attention_folded(backend, case):
     ap.x, ap.gv = L.MiAct(xd.data_ptr(), Cc, 0, 0, 1.0, 0), gv.data_ptr()
     ap.n1_g, ap.n1_b = sdd["a.norm.gamma"].data_ptr(), sdd["a.norm.beta"].data_ptr()
     ap.n2_g, ap.n2_b = sdd["a.to_out.1.gamma"].data_ptr(), sdd["a.to_out.1.beta"].data_ptr()
-    nt = -(-HW // (64 if variant else 128))
+    nt = -(-HW // (128 if variant in (0, 5) else 64))
     out = torch.full(x.shape, float('nan'), device=dev)
     ost = torch.zeros(B2, Cc, nt, 2, device=dev)
     ap.out, ap.out_stats, ap.variant = out.data_ptr(), ost.data_ptr(), variant

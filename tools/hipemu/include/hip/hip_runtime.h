@@ -215,6 +215,31 @@ static inline hipemu_f32x16 hipemu_mfma_f32_32x32x2f32(float a, float b, hipemu_
     hipemu::wave_sync();
     return d;
 }
+typedef _Float16 hipemu_f16x4 __attribute__((ext_vector_type(4)));
+// v_mfma_f32_16x16x16_f16: A[i = l&15][k = 4*(l>>4) + e], B[k = 4*(l>>4) + e][j = l&15], D as the other 16x16 shapes
+static inline hipemu_f32x4 hipemu_mfma_f32_16x16x16f16(hipemu_f16x4 a, hipemu_f16x4 b, hipemu_f32x4 c, int, int, int) {
+    hipemu::Wave& w = hipemu::cur_wave();
+    int l = hipemu::g_cur->lane;
+    std::memcpy(&w.buf[l][0], &a, 8);
+    std::memcpy(&w.buf[l][2], &b, 8);
+    hipemu::wave_sync();
+    hipemu_f32x4 d = c;
+    int col = l & 15;
+    for (int r = 0; r < 4; ++r) {
+        int row = 4 * (l >> 4) + r;
+        float acc = c[r];
+        for (int k = 0; k < 16; ++k) {
+            hipemu_f16x4 av, bv;
+            std::memcpy(&av, &w.buf[row + 16 * (k >> 2)][0], 8);
+            std::memcpy(&bv, &w.buf[col + 16 * (k >> 2)][2], 8);
+            acc += (float)av[k & 3] * (float)bv[k & 3];      // exact products of halves, fp32 accumulation
+        }
+        d[r] = acc;
+    }
+    hipemu::wave_sync();
+    return d;
+}
+#define __builtin_amdgcn_mfma_f32_16x16x16f16 hipemu_mfma_f32_16x16x16f16
 #define __builtin_amdgcn_mfma_f32_16x16x4f32 hipemu_mfma_f32_16x16x4f32
 #define __builtin_amdgcn_mfma_f32_32x32x2f32 hipemu_mfma_f32_32x32x2f32
 #define __builtin_amdgcn_exp2f(x) exp2f(x)
