@@ -80,6 +80,10 @@ typedef struct mi_conv_params {
     float* out;             /* [B][Cout][H][W] */
     float* out_stats;       /* [B][Cout][out_nt][2] or NULL */
     int tile_cfg;           /* see mi_conv_tile_shape; | MI_CONV_SPLIT16: 16-channel outputs as two 8-channel workgroups */
+    /* matrix-core path (k3 s1 only, tile_cfg 3 or 4): weights as fp16 hi/lo MFMA A-fragments
+       [ceil(Cout/16)][ceil(Cin/16)][9 taps][64 lanes][4 hi | 4 lo halves]; res_w_f16 likewise with 1 tap over the residual channels */
+    const void* w_f16;
+    const void* res_w_f16;
 } mi_conv_params;
 #define MI_CONV_SPLIT16 0x100
 

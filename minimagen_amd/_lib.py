@@ -32,6 +32,7 @@ class MiConvParams(C.Structure):
         ("scale_shift", C.c_void_p), ("ss_stride", C.c_int), ("ss_off", C.c_int),
         ("res0", MiAct), ("res1", MiAct), ("res_w", C.c_void_p), ("res_b", C.c_void_p),
         ("out", C.c_void_p), ("out_stats", C.c_void_p), ("tile_cfg", C.c_int),
+        ("w_f16", C.c_void_p), ("res_w_f16", C.c_void_p),
     ]
 
 

@@ -29,6 +29,8 @@ __device__ __forceinline__ float mi_wave_max(float v) {
     return v;
 }
 
+int mi_conv_mfma_launch(const mi_conv_params& p, hipStream_t st);   // conv_mfma.hip
+
 // host-side error plumbing (capi.hip)
 void mi_set_error(const char* fmt, ...);
 int mi_check_launch(const char* what);

@@ -27,6 +27,7 @@ MAX_TEXT_LEN = 256
 # kernel-shape tuning knobs (A/B measurements; the defaults are what profiles/ was measured with)
 ATTN_VARIANT = int(os.environ.get("MINIMAGEN_ATTN_VARIANT", "6"))       # 6: fp16x3 MFMA (default); 0/1/3/4/5: exact-fp32 MFMA shapes
 CONV_SPLIT16 = int(os.environ.get("MINIMAGEN_CONV_SPLIT16", "1"))
+CONV_MFMA = int(os.environ.get("MINIMAGEN_CONV_MFMA", "0"))             # 1: k3 s1 convs on the matrix cores (fp16x3 split)
 TILE64 = int(os.environ.get("MINIMAGEN_TILE64", "-1"))                  # force a conv tile shape at 64x64 / 128x128 (experiments)
 TILE128 = int(os.environ.get("MINIMAGEN_TILE128", "-1"))       # 1: 16-channel 3x3 outputs as two 8-channel workgroups
 JT = 17     # context tiles of 16 rows: 1 null + (2|4) time tokens + 256 text rows <= 272
@@ -88,6 +89,7 @@ class UnetEngine:
         pk.keep = []           # keeps packed tensors alive
         pk.freq = P.sinusoid_freq(u.dim, dev)
         pk.conv = {}
+        pk.conv_f16 = {}
         pk.attn = {}
 
         def conv_pack(mod: nn.Conv2d, w=None, b=None):
@@ -95,6 +97,8 @@ class UnetEngine:
             ct = lib.mi_conv_cout_tile(w.shape[0])
             wp = P.pack_conv_weight(w.to(dev), ct)
             pk.keep.append(wp)
+            if w.shape[-1] in (1, 3):
+                pk.conv_f16[id(wp)] = P.pack_conv_weight_f16frag(w.to(dev))
             return wp
 
         resblocks: List[ResnetBlock] = [m for m in u.modules() if isinstance(m, ResnetBlock)]
@@ -118,6 +122,7 @@ class UnetEngine:
                 ct = lib.mi_conv_cout_tile(rb.res_conv.weight.shape[0])
                 rw = P.pack_conv_weight(rb.res_conv.weight, ct).reshape(rb.res_conv.weight.shape[1], -1).contiguous()
                 pk.keep.append(rw)
+                pk.conv_f16[id(rw)] = P.pack_conv_weight_f16frag(rb.res_conv.weight)
                 pk.conv[id(rb.res_conv)] = rw
             if rb.cross_attn is not None:
                 ca: CrossAttention = rb.cross_attn.fn
@@ -223,6 +228,12 @@ class UnetEngine:
         batch = ws.B2 if (conditioned or any(a.batch == ws.B2 for a in ins)) else ws.B
         ct = lib.mi_conv_cout_tile(Cout)
         cfg, nt = self._tile_cfg(Ho, Wo, batch, -(-Cout // ct))
+        cin_tot = in0.C + (in1.C if in1 is not None else 0)
+        mfma = bool(CONV_MFMA) and ksize == 3 and stride == 1 and not up2 and Wo % 4 == 0 and id(wpack) in pk.conv_f16
+        if mfma:
+            cfg = 3 if Wo >= 64 else 4
+            th, tw = (8, 64) if cfg == 3 else (16, 32)
+            nt = -(-Ho // th) * -(-Wo // tw)
         out = self._new_act(ws, batch, Cout, Ho, Wo, nt if want_stats else 0)
         p = L.MiConvParams()
         p.B, p.H, p.W = batch, Ho, Wo
@@ -242,6 +253,10 @@ class UnetEngine:
                 p.res1 = r1.c(batch, skip_scale)
             p.res_w, p.res_b = L.ptr(rw), L.ptr(rb)
         p.out, p.out_stats, p.tile_cfg = L.ptr(out.t), L.ptr(out.stats), cfg | (0x100 if CONV_SPLIT16 else 0)
+        if mfma:
+            p.w_f16 = L.ptr(pk.conv_f16[id(wpack)])
+            if res is not None and res[2] is not None:
+                p.res_w_f16 = L.ptr(pk.conv_f16[id(res[2])])
         ws.prog.append((lib.mi_conv_fwd, p, "conv"))
         return out
 

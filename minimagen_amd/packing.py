@@ -21,6 +21,23 @@ def pack_conv_weight(w: torch.Tensor, cout_tile: int) -> torch.Tensor:
     return out.contiguous()
 
 
+def pack_conv_weight_f16frag(w: torch.Tensor) -> torch.Tensor:
+    """[Cout][Cin][kh][kw] fp32 -> MFMA A-operand fragments of v_mfma_f32_16x16x16_f16 for the matrix-core conv path:
+    [ceil(Cout/16)][ceil(Cin/16)][kh*kw][64 lanes][4 hi | 4 lo] fp16, lane (lq, lg) holding W[co = 16mz + lq][ci = 16kc + 4lg + e][tap]
+    split as hi = fp16(w), lo = fp16(w - hi)."""
+    cout, cin, kh, kw = w.shape
+    mz, kc, t = -(-cout // 16), -(-cin // 16), kh * kw
+    wp = torch.zeros(mz * 16, kc * 16, t, dtype=torch.float32, device=w.device)
+    wp[:cout, :cin] = w.detach().reshape(cout, cin, t)
+    hi = wp.half()
+    lo = (wp - hi.float()).half()
+
+    def frag(x):
+        x = x.reshape(mz, 16, kc, 4, 4, t)             # [mz][lq][kc][lg][e][tap]
+        return x.permute(0, 2, 5, 3, 1, 4).reshape(mz, kc, t, 64, 4)
+    return torch.cat((frag(hi), frag(lo)), dim=-1).contiguous()
+
+
 def fold_parallel_1x1(w3: torch.Tensor, b3, w1: torch.Tensor, b1):
     """Parallel(conv3x3, conv1x1) (layers.py:346-356, Unet.py:233-234) == one 3x3 conv whose centre tap
     carries the 1x1 weights (exact in real arithmetic)."""

@@ -109,6 +109,76 @@ def test_conv_family(backend, case):
     check_stats(ost.cpu(), ref)
 
 
+MFMA_CASES = [
+    # B, C0, C1, Cout, H, W, gn, ss, res, tile_cfg
+    (2, 16, 0, 16, 16, 64, True, True, 'none', 3),
+    (1, 16, 16, 16, 24, 72, True, True, 'conv2', 3),        # ragged tile edges, concat input, 1x1 residual over a concat
+    (2, 8, 0, 8, 32, 32, True, False, 'id', 4),
+    (1, 16, 8, 16, 32, 32, True, True, 'conv', 4),
+    (1, 8, 0, 3, 16, 64, False, False, 'none', 3),           # final conv
+]
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("case", MFMA_CASES)
+def test_conv_matrix_core_path(backend, case):
+    """k3 s1 conv on v_mfma_f32_16x16x16_f16 with fp16x3 operand splits vs torch fp32 (same tolerance as the VALU path)"""
+    dev = setup(backend)
+    lib = L.lib()
+    B, C0, C1, Cout, H, W, gn, ss, res, cfg = case
+    g = torch.Generator().manual_seed(hash(case) & 0xffff)
+    rn = lambda *s_: torch.randn(*s_, generator=g)
+    x0 = rn(B, C0, H, W) * 1.5 + 0.3
+    x1 = rn(B, C1, H, W) if C1 else None
+    Cin = C0 + C1
+    w, bias = rn(Cout, Cin, 3, 3) * 0.2, rn(Cout)
+    gamma, beta = 1 + 0.2 * rn(Cin), 0.1 * rn(Cin)
+    sst = rn(B, 7 + 2 * Cin) * 0.3 if ss else None
+    sk = 2 ** -0.5
+    h = torch.cat((x0, x1 * sk), 1) if C1 else x0
+    if gn:
+        h = F.group_norm(h, 8, gamma, beta, 1e-5)
+        if ss:
+            h = h * (sst[:, 7:7 + Cin, None, None] + 1) + sst[:, 7 + Cin:7 + 2 * Cin, None, None]
+        h = F.silu(h)
+    ref = F.conv2d(h, w, bias, padding=1)
+    keep = {}
+    d = lambda name, t: keep.setdefault(name, t.to(dev).contiguous())
+    p = L.MiConvParams()
+    p.B, p.H, p.W = B, H, W
+    p.in0 = L.MiAct(d("x0", x0).data_ptr(), C0, d("s0", chan_stats(x0)).data_ptr(), 1, 1.0, 0)
+    if C1:
+        p.in1 = L.MiAct(d("x1", x1).data_ptr(), C1, d("s1", chan_stats(x1)).data_ptr(), 1, sk, 0)
+    p.Cout, p.ksize, p.stride, p.up2 = Cout, 3, 1, 0
+    p.w_f16, p.bias = d("wf", P.pack_conv_weight_f16frag(w)).data_ptr(), d("b", bias).data_ptr()
+    if gn:
+        p.gn_groups, p.gn_gamma, p.gn_beta, p.gn_eps = 8, d("g", gamma).data_ptr(), d("be", beta).data_ptr(), 1e-5
+        if ss:
+            p.scale_shift, p.ss_stride, p.ss_off = d("ss", sst).data_ptr(), sst.shape[1], 7
+    if res != 'none':
+        r0 = rn(B, Cout if res == 'id' else 5, H, W)
+        r1 = rn(B, 3, H, W) if res == 'conv2' else None
+        p.res0 = L.MiAct(d("r0", r0).data_ptr(), r0.shape[1], 0, 0, 1.0, 0)
+        if res == 'id':
+            ref = ref + r0
+        else:
+            rin = torch.cat((r0, r1 * sk), 1) if r1 is not None else r0
+            rw, rb = rn(Cout, rin.shape[1], 1, 1) * 0.3, rn(Cout)
+            ref = ref + F.conv2d(rin, rw, rb)
+            p.res_w = 1          # non-null marker: the residual is a 1x1 conv
+            p.res_w_f16 = d("rwf", P.pack_conv_weight_f16frag(rw)).data_ptr()
+            p.res_b = d("rb", rb).data_ptr()
+            if r1 is not None:
+                p.res1 = L.MiAct(d("r1", r1).data_ptr(), 3, 0, 0, sk, 0)
+    nt = tile_nt(lib, cfg, H, W)
+    out = torch.full((B, Cout, H, W), float('nan'), device=dev)
+    ost = torch.zeros(B, Cout, nt, 2, device=dev)
+    p.out, p.out_stats, p.tile_cfg = out.data_ptr(), ost.data_ptr(), cfg
+    L.check(lib.mi_conv_fwd(C.byref(p), L.current_stream()), "conv mfma")
+    assert (out.cpu() - ref).abs().max().item() < 2e-5
+    check_stats(ost.cpu(), ref)
+
+
 def test_conv_rejects_bad_arguments():
     setup("emu")
     lib = L.lib()
