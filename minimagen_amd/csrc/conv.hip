@@ -18,12 +18,16 @@ struct ConvCfg {
     static constexpr int TH = NT / TXN;           // output rows per tile (1 row per work-item)
     static constexpr int IH = TH * S + KS - S;    // staged input rows / cols (with halo)
     static constexpr int IW = TW * S + KS - S;
-    static constexpr int WIN4 = (TW_ + 8) / 4;    // vector path: aligned float4 window [ox0-4, ox0+TW+4) per staged row
-    static constexpr int IWP = VEC_ ? 4 * WIN4 : ((IW + 3) & ~3);   // LDS row pitch (16-byte aligned rows)
-    static constexpr int XOFF = VEC_ ? 3 : 0;     // LDS column of the tile's first halo pixel (gx = ox0-1)
+    // vector staging path: every staged row is the ALIGNED float4 window of SOURCE pixels that covers the tile's halo:
+    //   k3 s1: [ox0-4, ox0+TW+4)   k4 s2: [2ox0-4, 2ox0+2TW+4)   nearest-x2 + k3: source cols [ox0/2-4, ox0/2+TW/2+4)
+    static constexpr int SW = UP2_ ? TW_ / 2 + 8 : TW_ * S_ + 8;
+    static constexpr int WIN4 = SW / 4;
+    static constexpr int IHS = VEC_ ? (UP2_ ? TH / 2 + 2 : IH) : IH;          // staged rows
+    static constexpr int IWP = VEC_ ? SW : ((IW + 3) & ~3);                   // LDS row pitch (16-byte aligned rows)
+    static constexpr int XOFF = VEC_ ? 3 : 0;     // LDS column of the tile's first halo pixel
     static constexpr int CK = (S == 2) ? 2 : 4;   // input channels staged per round
     static constexpr int NIN = 4 * S + KS - S;    // input floats per row a work-item consumes
-    static constexpr int STAGE_FLOATS = CK * IH * IWP;
+    static constexpr int STAGE_FLOATS = CK * IHS * IWP;
     static constexpr int RED_FLOATS = 2 * COUT_T * (NT + 1);
     static constexpr int SMEM_FLOATS = STAGE_FLOATS > RED_FLOATS ? STAGE_FLOATS : RED_FLOATS;
 };
@@ -36,7 +40,7 @@ __global__ __launch_bounds__(CFG::NT) void conv_tile_kernel(const mi_conv_params
     constexpr int NT = CFG::NT, TW = CFG::TW, TH = CFG::TH, TXN = CFG::TXN, COUT_T = CFG::COUT_T;
     constexpr int KS = CFG::KS, S = CFG::S, IH = CFG::IH, IW = CFG::IW, IWP = CFG::IWP, CK = CFG::CK, NIN = CFG::NIN;
     constexpr bool UP2 = CFG::UP2, VEC = CFG::VEC;
-    constexpr int XOFF = CFG::XOFF;
+    constexpr int XOFF = CFG::XOFF, IHS = CFG::IHS;
 
     __shared__ __attribute__((aligned(16))) float smem[CFG::SMEM_FLOATS];
     __shared__ __attribute__((aligned(16))) float4 chP[MI_MAX_CIN + 1];   // {A, B, -log2(e)A, -log2(e)B}; last entry = zeros
@@ -72,7 +76,8 @@ __global__ __launch_bounds__(CFG::NT) void conv_tile_kernel(const mi_conv_params
     //   VEC  (k3 s1, W % 4 == 0): aligned float4 loads of the window [ox0-4, ox0+TW+4)
     //   !VEC (stride 2, nearest-upsample, ragged W): scalar loads, U at a time
     constexpr int WIN4 = CFG::WIN4;
-    constexpr int PER4 = (CK * IH * WIN4 + NT - 1) / NT;
+    constexpr int PER4 = (CK * IHS * WIN4 + NT - 1) / NT;
+    const int sy0 = UP2 ? oy0 / 2 - 1 : iy0, sx0 = UP2 ? ox0 / 2 - 4 : ox0 * S - 4;      // source coordinates of the staged window
     float4 xq4[VEC ? PER4 : 1];
     // per-work-item staging slots (tile geometry only -> identical for every channel round):
     //   msrc = element offset of the float4 inside one channel plane, or -1 when the slot is outside the image
@@ -83,11 +88,11 @@ __global__ __launch_bounds__(CFG::NT) void conv_tile_kernel(const mi_conv_params
         for (int u = 0; u < PER4; ++u) {
             const int q = tid + u * NT;
             const int rowid = q / WIN4, xq = q % WIN4;
-            const int ck = rowid / IH, iy = rowid % IH;
-            const int gy = iy0 + iy, gx0 = ox0 - 4 + 4 * xq;
-            const bool in = (ck < CK) && gy >= 0 && gy < Hv && gx0 >= 0 && gx0 < Wv;
+            const int ck = rowid / IHS, iy = rowid % IHS;
+            const int gy = sy0 + iy, gx0 = sx0 + 4 * xq;
+            const bool in = (ck < CK) && gy >= 0 && gy < Hin && gx0 >= 0 && gx0 < Win;
             msrc[u] = in ? gy * Win + gx0 : -1;
-            mdst[u] = (ck < CK) ? (ck * IH + iy) * IWP + 4 * xq : -1;
+            mdst[u] = (ck < CK) ? (ck * IHS + iy) * IWP + 4 * xq : -1;
             mck[u] = ck;
         }
     }
@@ -235,13 +240,27 @@ __global__ __launch_bounds__(CFG::NT) void conv_tile_kernel(const mi_conv_params
 #pragma unroll
             for (int ky = 0; ky < KS; ++ky) {
                 float in[NIN];
-                const float* row = &smem[(ck * IH + ty * S + ky) * IWP + tx * 4 * S + XOFF];
-                if constexpr (VEC) {
+                if constexpr (VEC && UP2) {
+                    // virtual column x0+j-1 is source column (x0+j-1)>>1: six taps share four source pixels
+                    const float* row = &smem[(ck * IHS + ((ty + ky - 1) >> 1) + 1) * IWP + 2 * tx + 3];
+                    const float s0 = row[0];
+                    const float2 s12 = *reinterpret_cast<const float2*>(row + 1);     // 8-byte aligned: column 2tx+4
+                    const float s3 = row[3];
+                    in[0] = s0; in[1] = s12.x; in[2] = s12.x; in[3] = s12.y; in[4] = s12.y; in[5] = s3;
+                } else if constexpr (VEC && S == 2) {
+                    const float* row = &smem[(ck * IHS + ty * 2 + ky) * IWP + 8 * tx + 3];
+                    in[0] = row[0];
+                    const float4 a4 = *reinterpret_cast<const float4*>(row + 1), b4 = *reinterpret_cast<const float4*>(row + 5);
+                    in[1] = a4.x; in[2] = a4.y; in[3] = a4.z; in[4] = a4.w; in[5] = b4.x; in[6] = b4.y; in[7] = b4.z; in[8] = b4.w;
+                    in[9] = row[9];
+                } else if constexpr (VEC) {
+                    const float* row = &smem[(ck * IHS + ty + ky) * IWP + tx * 4 + XOFF];
                     in[0] = row[0];
                     const float4 m4 = *reinterpret_cast<const float4*>(row + 1);      // 16-byte aligned: column 4tx+4
                     in[1] = m4.x; in[2] = m4.y; in[3] = m4.z; in[4] = m4.w;
                     in[5] = row[5];
                 } else {
+                    const float* row = &smem[(ck * IH + ty * S + ky) * IWP + tx * 4 * S];
 #pragma unroll
                     for (int j = 0; j < NIN; ++j) in[j] = row[j];
                 }
@@ -379,12 +398,13 @@ int launch_conv_v(const mi_conv_params& p, hipStream_t st) {
 
 template <int NT, int TW, int COUT_T, int KS, int S, bool UP2>
 int launch_conv(const mi_conv_params& p, hipStream_t st) {
-    if constexpr (KS == 3 && S == 1 && !UP2) {
-        const int Cin = p.in0.C + (p.in1.data ? p.in1.C : 0);
-        if ((p.W & 3) == 0 && (Cin & 3) == 0 && (p.in0.C & 3) == 0 &&
-            (size_t)p.B * (p.in0.C > p.in1.C ? p.in0.C : p.in1.C) * p.H * p.W < (1ull << 31))
-            return launch_conv_v<NT, TW, COUT_T, KS, S, UP2, true>(p, st);
-    }
+    // vector staging needs float4-aligned source rows and whole channel rounds; otherwise the scalar staging handles it
+    const int Cin = p.in0.C + (p.in1.data ? p.in1.C : 0);
+    const int Win = UP2 ? p.W / 2 : p.W * S;
+    constexpr int CKv = (S == 2) ? 2 : 4;
+    if ((Win & 3) == 0 && (Cin % CKv) == 0 && (p.in0.C % CKv) == 0 &&
+        (size_t)p.B * (p.in0.C > p.in1.C ? p.in0.C : p.in1.C) * p.H * p.W * S * S < (1ull << 31))
+        return launch_conv_v<NT, TW, COUT_T, KS, S, UP2, true>(p, st);
     return launch_conv_v<NT, TW, COUT_T, KS, S, UP2, false>(p, st);
 }
 

@@ -27,7 +27,7 @@ MAX_TEXT_LEN = 256
 # kernel-shape tuning knobs (A/B measurements; the defaults are what profiles/ was measured with)
 ATTN_VARIANT = int(os.environ.get("MINIMAGEN_ATTN_VARIANT", "6"))       # 6: fp16x3 MFMA (default); 0/1/3/4/5: exact-fp32 MFMA shapes
 CONV_SPLIT16 = int(os.environ.get("MINIMAGEN_CONV_SPLIT16", "1"))
-CONV_MFMA = int(os.environ.get("MINIMAGEN_CONV_MFMA", "0"))             # 1: k3 s1 convs on the matrix cores (fp16x3 split)
+CONV_MFMA = int(os.environ.get("MINIMAGEN_CONV_MFMA", "1"))             # 1: wide (>=16 in, >=16 out) k3 s1 convs on the matrix cores; 2: all k3 s1
 TILE64 = int(os.environ.get("MINIMAGEN_TILE64", "-1"))                  # force a conv tile shape at 64x64 / 128x128 (experiments)
 TILE128 = int(os.environ.get("MINIMAGEN_TILE128", "-1"))       # 1: 16-channel 3x3 outputs as two 8-channel workgroups
 JT = 17     # context tiles of 16 rows: 1 null + (2|4) time tokens + 256 text rows <= 272
@@ -229,7 +229,11 @@ class UnetEngine:
         ct = lib.mi_conv_cout_tile(Cout)
         cfg, nt = self._tile_cfg(Ho, Wo, batch, -(-Cout // ct))
         cin_tot = in0.C + (in1.C if in1 is not None else 0)
-        mfma = bool(CONV_MFMA) and ksize == 3 and stride == 1 and not up2 and Wo % 4 == 0 and id(wpack) in pk.conv_f16
+        # matrix-core path: measured faster only where the 16x16x16 tile is full (>= 16 input and 16 output channels) and the
+        # residual is not an identity add (profiles/): narrow layers stay on the VALU kernel
+        wide = cin_tot >= 16 and Cout >= 16 and not (res is not None and res[2] is None)
+        mfma = (CONV_MFMA == 2 or (CONV_MFMA == 1 and wide)) and ksize == 3 and stride == 1 and not up2 and Wo % 4 == 0 \
+            and id(wpack) in pk.conv_f16
         if mfma:
             cfg = 3 if Wo >= 64 else 4
             th, tw = (8, 64) if cfg == 3 else (16, 32)

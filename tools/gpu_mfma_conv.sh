@@ -1,9 +1,9 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 OUT=gpurun_out; mkdir -p $OUT
-timeout 600 python -m pytest tests/test_kernels.py -m gpu -q --timeout 300 -k "matrix_core or conv_family" 2>&1 | tail -3
+timeout 600 python -m pytest tests/test_kernels.py -m gpu -q --timeout 300 -k "conv" 2>&1 | tail -3
 MINIMAGEN_CONV_MFMA=1 timeout 600 python -m pytest tests/test_unet.py tests/test_sampler.py -m gpu -q --timeout 300 2>&1 | tail -3
-for CM in 0 1; do
+for CM in 1; do
   export MINIMAGEN_CONV_MFMA=$CM
   timeout 300 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --breakdown-out $OUT/bd_cm${CM}.json > $OUT/bench_cm${CM}.log 2>&1
   timeout 300 python bench.py --workload base64 --steps 1 --warmup 1 --no-cpu-baseline --no-breakdown > $OUT/bench_base_cm${CM}.log 2>&1
