@@ -253,14 +253,7 @@ __global__ __launch_bounds__(256, WPS) void cross_attn_folded_kernel(const mi_cr
 // lo*lo term is 2^-22 relative, so the result stays inside the fp32 parity tolerance.
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ void split_f16(const float (&x)[4], f16x4& hi, f16x4& lo) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const _Float16 h = (_Float16)x[e];
-        hi[e] = h;
-        lo[e] = (_Float16)(x[e] - (float)h);
-    }
-}
+__device__ __forceinline__ void split_f16(const float (&x)[4], f16x4& hi, f16x4& lo) { mi_split_f16(x, hi, lo); }
 
 template <int C, int JT, int WPS>
 __global__ __launch_bounds__(256, WPS) void cross_attn_f16x3_kernel(const mi_cross_attn_params p) {

@@ -18,6 +18,24 @@ __device__ __forceinline__ float mi_silu(float v) {
     return v * __builtin_amdgcn_rcpf(1.0f + expf(-v));
 }
 
+// fp16 hi/lo split of four fp32 values for the 3-term MFMA products: hi = x with the mantissa truncated to 10 bits (a bit
+// mask -> exactly representable in fp16 in the normal range, so the conversion is exact), lo = fp16(x - hi).  5 VALU ops
+// per pair instead of 10 for convert / convert back / subtract / convert / pack.
+typedef _Float16 mi_f16x4 __attribute__((ext_vector_type(4)));
+typedef __fp16 mi_h2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void mi_split_f16(const float (&x)[4], mi_f16x4& hi, mi_f16x4& lo) {
+    float h[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        h[e] = __uint_as_float(__float_as_uint(x[e]) & 0xFFFFE000u);
+        l[e] = x[e] - h[e];
+    }
+    const mi_h2 h01 = __builtin_amdgcn_cvt_pkrtz(h[0], h[1]), h23 = __builtin_amdgcn_cvt_pkrtz(h[2], h[3]);
+    const mi_h2 l01 = __builtin_amdgcn_cvt_pkrtz(l[0], l[1]), l23 = __builtin_amdgcn_cvt_pkrtz(l[2], l[3]);
+    hi[0] = (_Float16)h01[0]; hi[1] = (_Float16)h01[1]; hi[2] = (_Float16)h23[0]; hi[3] = (_Float16)h23[1];
+    lo[0] = (_Float16)l01[0]; lo[1] = (_Float16)l01[1]; lo[2] = (_Float16)l23[0]; lo[3] = (_Float16)l23[1];
+}
+
 __device__ __forceinline__ float mi_wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

@@ -122,6 +122,18 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const mi_conv_params 
     f32x4 acc[8];
 #pragma unroll
     for (int t = 0; t < 8; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // identity residual (layers.py:439 with res_conv = Identity): fetched now, consumed in the epilogue, so the loads fly
+    // under the whole MFMA loop instead of serialising behind it
+    const bool idres = p.res0.data && !rwf;
+    const int br0 = p.res0.bmod > 0 ? b % p.res0.bmod : b;
+    float resv[8][4];
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = co0 + 4 * lg + r, oy = oy0 + wave * RW + t / XT, ox = ox0 + 16 * (t % XT) + lq;
+            resv[t][r] = (idres && co < p.Cout && oy < H && ox < W) ? p.res0.data[((size_t)(br0 * p.res0.C + co) * H + oy) * W + ox] * p.res0.scale : 0.0f;
+        }
 
     // one round = 16 channels of either the convolution input (9 taps, activated) or the residual input (centre tap, raw)
     const int rounds = KC + RC;
@@ -180,12 +192,8 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const mi_conv_params 
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 f16x4 hi, lo;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const _Float16 h = (_Float16)v[j][e];
-                    hi[j] = h;
-                    lo[j] = (_Float16)(v[j][e] - (float)h);
-                }
+                const float ve[4] = {v[0][e], v[1][e], v[2][e], v[3][e]};
+                mi_split_f16(ve, hi, lo);
                 actH[dst + e] = hi;
                 actL[dst + e] = lo;
             }
@@ -210,7 +218,6 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const mi_conv_params 
 
     // ---------------- epilogue: this lane holds output channels co0 + 4lg + r of pixel lq of each of its 8 tiles
     float csum[4] = {0.f, 0.f, 0.f, 0.f}, csq[4] = {0.f, 0.f, 0.f, 0.f};
-    const int br0 = p.res0.bmod > 0 ? b % p.res0.bmod : b;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int co = co0 + 4 * lg + r;
@@ -221,8 +228,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const mi_conv_params 
         for (int t = 0; t < 8; ++t) {
             const int oy = oy0 + wave * RW + t / XT, ox = ox0 + 16 * (t % XT) + lq;
             if (oy < H && ox < W) {
-                float y = acc[t][r] + bv;
-                if (p.res0.data && !rwf) y += p.res0.data[((size_t)(br0 * p.res0.C + co) * H + oy) * W + ox] * p.res0.scale;   // identity residual
+                const float y = acc[t][r] + bv + resv[t][r];
                 p.out[((size_t)(b * p.Cout + co) * H + oy) * W + ox] = y;
                 csum[r] += y;
                 csq[r] = fmaf(y, y, csq[r]);

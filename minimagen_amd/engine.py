@@ -231,7 +231,7 @@ class UnetEngine:
         cin_tot = in0.C + (in1.C if in1 is not None else 0)
         # matrix-core path: measured faster only where the 16x16x16 tile is full (>= 16 input and 16 output channels) and the
         # residual is not an identity add (profiles/): narrow layers stay on the VALU kernel
-        wide = cin_tot >= 16 and Cout >= 16 and not (res is not None and res[2] is None)
+        wide = cin_tot >= 16 and Cout >= 16
         mfma = (CONV_MFMA == 2 or (CONV_MFMA == 1 and wide)) and ksize == 3 and stride == 1 and not up2 and Wo % 4 == 0 \
             and id(wpack) in pk.conv_f16
         if mfma:

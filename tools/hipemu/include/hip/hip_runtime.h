@@ -242,6 +242,16 @@ static inline hipemu_f32x4 hipemu_mfma_f32_16x16x16f16(hipemu_f16x4 a, hipemu_f1
 #define __builtin_amdgcn_mfma_f32_16x16x16f16 hipemu_mfma_f32_16x16x16f16
 #define __builtin_amdgcn_mfma_f32_16x16x4f32 hipemu_mfma_f32_16x16x4f32
 #define __builtin_amdgcn_mfma_f32_32x32x2f32 hipemu_mfma_f32_32x32x2f32
+typedef __fp16 hipemu_h2 __attribute__((ext_vector_type(2)));
+static inline _Float16 hipemu_f16_rtz(float f) {           // fp32 -> fp16, round toward zero (v_cvt_pkrtz_f16_f32)
+    _Float16 h = (_Float16)f;                             // RNE first, then step back if it rounded away from zero
+    if (std::isfinite(f) && std::fabs((float)h) > std::fabs(f)) {
+        unsigned short b; std::memcpy(&b, &h, 2); b -= 1; std::memcpy(&h, &b, 2);
+    }
+    return h;
+}
+static inline hipemu_h2 hipemu_cvt_pkrtz(float a, float b) { hipemu_h2 r; r[0] = (__fp16)hipemu_f16_rtz(a); r[1] = (__fp16)hipemu_f16_rtz(b); return r; }
+#define __builtin_amdgcn_cvt_pkrtz(a, b) hipemu_cvt_pkrtz((a), (b))
 #define __builtin_amdgcn_exp2f(x) exp2f(x)
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
 #define __builtin_amdgcn_rsqf(x) (1.0f / sqrtf(x))
