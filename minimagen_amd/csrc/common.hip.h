@@ -30,10 +30,13 @@ __device__ __forceinline__ void mi_split_f16(const float (&x)[4], mi_f16x4& hi, 
         h[e] = __uint_as_float(__float_as_uint(x[e]) & 0xFFFFE000u);
         l[e] = x[e] - h[e];
     }
+    typedef unsigned mi_u32x2 __attribute__((ext_vector_type(2)));
     const mi_h2 h01 = __builtin_amdgcn_cvt_pkrtz(h[0], h[1]), h23 = __builtin_amdgcn_cvt_pkrtz(h[2], h[3]);
     const mi_h2 l01 = __builtin_amdgcn_cvt_pkrtz(l[0], l[1]), l23 = __builtin_amdgcn_cvt_pkrtz(l[2], l[3]);
-    hi[0] = (_Float16)h01[0]; hi[1] = (_Float16)h01[1]; hi[2] = (_Float16)h23[0]; hi[3] = (_Float16)h23[1];
-    lo[0] = (_Float16)l01[0]; lo[1] = (_Float16)l01[1]; lo[2] = (_Float16)l23[0]; lo[3] = (_Float16)l23[1];
+    const mi_u32x2 hb = {__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23)};     // pure register moves
+    const mi_u32x2 lb = {__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23)};
+    hi = __builtin_bit_cast(mi_f16x4, hb);
+    lo = __builtin_bit_cast(mi_f16x4, lb);
 }
 
 __device__ __forceinline__ float mi_wave_sum(float v) {

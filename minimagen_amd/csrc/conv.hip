@@ -167,10 +167,6 @@ __global__ __launch_bounds__(CFG::NT) void conv_tile_kernel(const mi_conv_params
         }
     };
 
-    // identity residual (ResnetBlock with dim == dim_out): float4 per output channel, prefetched during the last round
-    const int oyq = oy0 + ty, oxq = ox0 + tx * 4;
-    const bool idres = VEC && p.res0.data && !p.res_w && (p.W & 3) == 0 && oxq + 3 < p.W;
-    float4 resq[VEC ? COUT_T : 1];
     stage_load(0);      // first round's loads fly under the statistics prologue
 
     // ---------------- prologue: per-channel affine for the fused GroupNorm / scale-shift
@@ -238,13 +234,6 @@ __global__ __launch_bounds__(CFG::NT) void conv_tile_kernel(const mi_conv_params
         stage_write(c0);
         __syncthreads();
         if (c0 + CK < Cin) stage_load(c0 + CK);       // in flight during the FMA loop below
-        else if (idres) {                             // last round: fetch the identity residual under the FMA loop
-#pragma unroll
-            for (int co = 0; co < COUT_T; ++co) {
-                const float* src = p.res0.data + ((size_t)(br0 * p.res0.C + (co0 + co < p.Cout ? co0 + co : 0)) * p.H + (oyq < p.H ? oyq : 0)) * p.W + oxq;
-                resq[co] = *reinterpret_cast<const float4*>(src);
-            }
-        }
         const int nck = (Cin - c0) < CK ? (Cin - c0) : CK;
         for (int ck = 0; ck < nck; ++ck) {
             const float* wc = wts + (size_t)(c0 + ck) * KS * KS * CoutPad + co0;
@@ -334,11 +323,7 @@ __global__ __launch_bounds__(CFG::NT) void conv_tile_kernel(const mi_conv_params
             for (int co = 0; co < COUT_T; ++co) {
                 if (co0 + co < p.Cout) {
                     const float* src = p.res0.data + ((size_t)(br0 * Cres0 + co0 + co) * p.H + oy) * p.W;
-                    if (idres) {
-                        const float4 t4 = resq[co];
-                        acc[0][co] += t4.x * p.res0.scale; acc[1][co] += t4.y * p.res0.scale;
-                        acc[2][co] += t4.z * p.res0.scale; acc[3][co] += t4.w * p.res0.scale;
-                    } else if (ox + 3 < p.W && (p.W & 3) == 0) {
+                    if (ox + 3 < p.W && (p.W & 3) == 0) {
                         const float4 t4 = *reinterpret_cast<const float4*>(src + ox);
                         acc[0][co] += t4.x * p.res0.scale; acc[1][co] += t4.y * p.res0.scale;
                         acc[2][co] += t4.z * p.res0.scale; acc[3][co] += t4.w * p.res0.scale;

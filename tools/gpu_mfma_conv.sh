@@ -1,7 +1,7 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 OUT=gpurun_out; mkdir -p $OUT
-timeout 600 python -m pytest tests/test_kernels.py -m gpu -q --timeout 300 -k "conv" 2>&1 | tail -3
+timeout 600 python -m pytest tests/test_kernels.py -m gpu -q --timeout 300 -k "conv or attention" 2>&1 | tail -3
 MINIMAGEN_CONV_MFMA=1 timeout 600 python -m pytest tests/test_unet.py tests/test_sampler.py -m gpu -q --timeout 300 2>&1 | tail -3
 for CM in 1; do
   export MINIMAGEN_CONV_MFMA=$CM
