@@ -249,6 +249,7 @@ typedef struct mi_posterior_params {
     const float* coef; const int* t_state;
     const float* noise;
     uint64_t seed; int sample0; int stream_base;
+    const uint64_t* seed_dev;     /* when non-NULL the seed is read from device memory (lets one captured graph serve every call) */
 } mi_posterior_params;
 int mi_posterior_fwd(const mi_posterior_params* p, void* stream);
 

@@ -91,8 +91,10 @@ class Imagen(nn.Module):
 
     # ------------------------------------------------------------------ sampling
     def _stage_state(self, ws, sched: GaussianDiffusion, B: int, n: int):
-        key = (id(ws), sched.num_timesteps)
-        st = self._sampler_state.get(key)
+        # the state (and the step graphs cached on it) lives on the workspace, so it dies with the buffers it points into
+        store = ws.__dict__.setdefault("sampler_state", {})
+        key = sched.num_timesteps
+        st = store.get(key)
         if st is None:
             dev = ws.dev
             st = type("StageState", (), {})()
@@ -102,7 +104,7 @@ class Imagen(nn.Module):
             st.hist = torch.zeros(3 * B * 2 * 2048, dtype=torch.int32, device=dev)
             st.s_q = torch.zeros(B, dtype=torch.float32, device=dev)
             st.v_q = torch.zeros(B, 2, dtype=torch.float32, device=dev)
-            self._sampler_state[key] = st
+            store[key] = st
         return st
 
     def _p_sample_loop(self, unet: Unet, shape, *, noise_scheduler: GaussianDiffusion, ws, cond_scale: float,
@@ -126,37 +128,55 @@ class Imagen(nn.Module):
             L.check(lib.mi_randn_fill(L.ptr(ws.x), B, n, seed, sample0, (stage << 20) | (1 << 19) | 1, stream), "mi_randn_fill")
         L.check(lib.mi_step_set(L.ptr(st.t_state), L.ptr(ws.times), B, T - 1, stream), "mi_step_set")
 
-        cp = L.MiCfgX0Params(B, n, L.ptr(ws.pred), 1 if two else 0, float(cond_scale), L.ptr(ws.x), L.ptr(st.coef), L.ptr(st.t_state), 0, L.ptr(st.x0))
         k_lo, k_hi, w = quantile_rank(n, self.dynamic_thresholding_percentile)
-        qp = L.MiQuantileParams(B, n, L.ptr(st.x0), k_lo, k_hi, w, L.ptr(st.hist), L.ptr(st.s_q), L.ptr(st.v_q))
-        pp = L.MiPosteriorParams(B, n, T, L.ptr(st.x0), L.ptr(st.s_q), L.ptr(ws.x), L.ptr(st.coef), L.ptr(st.t_state),
-                                 L.ptr(noise_dev), seed, sample0, stage << 20)
+        # the captured graph of one denoising step is cached per (workspace, guidance, threshold, noise mode, shard offset):
+        # the Philox seed lives in device memory, so replays of later sample() calls need no re-capture
+        gkey = (float(cond_scale), two, k_lo, k_hi, w, sample0, stage, T, noise_dev is None)
+        cached = getattr(st, "graphs", None)
+        if cached is None:
+            cached = st.graphs = {}
+        entry = cached.get(gkey) if (use_graph and noise_dev is None) else None
+        if noise_dev is None:
+            if not hasattr(st, "seed_dev"):
+                st.seed_dev = torch.zeros(1, dtype=torch.int64, device=ws.dev)
+            st.seed_dev.fill_(int(seed) & 0x7FFFFFFFFFFFFFFF)
+        if entry is None:
+            cp = L.MiCfgX0Params(B, n, L.ptr(ws.pred), 1 if two else 0, float(cond_scale), L.ptr(ws.x), L.ptr(st.coef), L.ptr(st.t_state), 0, L.ptr(st.x0))
+            qp = L.MiQuantileParams(B, n, L.ptr(st.x0), k_lo, k_hi, w, L.ptr(st.hist), L.ptr(st.s_q), L.ptr(st.v_q))
+            pp = L.MiPosteriorParams(B, n, T, L.ptr(st.x0), L.ptr(st.s_q), L.ptr(ws.x), L.ptr(st.coef), L.ptr(st.t_state),
+                                     L.ptr(noise_dev), int(seed) & 0x7FFFFFFFFFFFFFFF, sample0, stage << 20,
+                                     L.ptr(st.seed_dev) if noise_dev is None else 0)
 
-        def one_step():
-            eng.run(ws, stream)
-            L.check(lib.mi_cfg_x0_fwd(C.byref(cp), stream), "mi_cfg_x0_fwd")
-            L.check(lib.mi_quantile_fwd(C.byref(qp), stream), "mi_quantile_fwd")
-            L.check(lib.mi_posterior_fwd(C.byref(pp), stream), "mi_posterior_fwd")
-            L.check(lib.mi_step_advance(L.ptr(st.t_state), L.ptr(ws.times), B, stream), "mi_step_advance")
-
+            def one_step():
+                eng.run(ws, stream)
+                L.check(lib.mi_cfg_x0_fwd(C.byref(cp), stream), "mi_cfg_x0_fwd")
+                L.check(lib.mi_quantile_fwd(C.byref(qp), stream), "mi_quantile_fwd")
+                L.check(lib.mi_posterior_fwd(C.byref(pp), stream), "mi_posterior_fwd")
+                L.check(lib.mi_step_advance(L.ptr(st.t_state), L.ptr(ws.times), B, stream), "mi_step_advance")
+            entry = dict(step=one_step, graph=None, keep=(cp, qp, pp))
+            if use_graph:
+                L.check(lib.mi_graph_begin(stream), "mi_graph_begin")
+                try:
+                    one_step()
+                finally:
+                    g = C.c_void_p()
+                    rc = lib.mi_graph_end(stream, C.byref(g))
+                L.check(rc, "mi_graph_end")
+                entry["graph"] = g
+                if noise_dev is None:
+                    cached[gkey] = entry
         if use_graph:
-            L.check(lib.mi_graph_begin(stream), "mi_graph_begin")
-            try:
-                one_step()
-            finally:
-                g = C.c_void_p()
-                rc = lib.mi_graph_end(stream, C.byref(g))
-            L.check(rc, "mi_graph_end")
             try:
                 for _ in range(T):
-                    L.check(lib.mi_graph_launch(g, stream), "mi_graph_launch")
+                    L.check(lib.mi_graph_launch(entry["graph"], stream), "mi_graph_launch")
             finally:
-                if L.backend() == "hip-gfx950":
-                    torch.cuda.current_stream().synchronize()     # the exec must outlive its replays
-                lib.mi_graph_destroy(g)
+                if noise_dev is not None:          # one-off graph (injected noise buffer): the exec must outlive its replays
+                    if L.backend() == "hip-gfx950":
+                        torch.cuda.current_stream().synchronize()
+                    lib.mi_graph_destroy(entry["graph"])
         else:
             for _ in range(T):
-                one_step()
+                entry["step"]()
         img = torch.empty(shape, dtype=torch.float32, device=ws.dev)
         L.check(lib.mi_finalize_images(L.ptr(ws.x), L.ptr(img), B * n, 1 if self.auto_normalize_img else 0, stream), "mi_finalize_images")
         return img

@@ -113,7 +113,7 @@ class MiQuantileParams(C.Structure):
 class MiPosteriorParams(C.Structure):
     _fields_ = [("B", C.c_int), ("n", C.c_int), ("T", C.c_int), ("x0", C.c_void_p), ("s_q", C.c_void_p), ("x", C.c_void_p),
                 ("coef", C.c_void_p), ("t_state", C.c_void_p), ("noise", C.c_void_p),
-                ("seed", C.c_uint64), ("sample0", C.c_int), ("stream_base", C.c_int)]
+                ("seed", C.c_uint64), ("sample0", C.c_int), ("stream_base", C.c_int), ("seed_dev", C.c_void_p)]
 
 
 class MiResizeParams(C.Structure):

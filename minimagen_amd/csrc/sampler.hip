@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256) void posterior_kernel(const mi_posterior_param
 #pragma unroll
             for (int e = 0; e < 4; ++e) z[e] = (4 * qd + e < p.n) ? nz[4 * qd + e] : 0.0f;
         } else {
-            randn4(p.seed, (unsigned)(p.sample0 + b), (unsigned)(p.stream_base + k), (unsigned)qd, z);
+            randn4(p.seed_dev ? *p.seed_dev : p.seed, (unsigned)(p.sample0 + b), (unsigned)(p.stream_base + k), (unsigned)qd, z);
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
