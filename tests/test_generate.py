@@ -1,0 +1,76 @@
+"""the training-directory caller of Imagen.sample (minimagen/generate.py) -- parameter files,
+checkpoint selection (state_dicts first, tmp as fallback), output layout and the PIL conversion."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from minimagen_amd import Imagen as imagen_module
+from minimagen_amd import generate as G
+from oracle import restated as R
+from tests import _inputs as I
+from tests._backend import BACKENDS, setup
+
+IMAGEN_PARAMS = {"text_embed_dim": None, "channels": 3, "timesteps": 20, "cond_drop_prob": 0.15, "loss_type": "l2",
+                 "lowres_sample_noise_level": 0.2, "auto_normalize_img": True, "dynamic_thresholding_percentile": 0.9,
+                 "only_train_unet_number": None, "image_sizes": [64], "text_encoder_name": "t5_small"}
+
+
+def make_training_dir(root, where="state_dicts"):
+    for sub in ("parameters", "state_dicts", "tmp"):
+        os.makedirs(os.path.join(root, sub))
+    stamp = "20220816_165729"
+    json.dump(I.unet_params()["unet0"], open(os.path.join(root, "parameters", f"unet_0_params_{stamp}.json"), "w"))
+    json.dump(IMAGEN_PARAMS, open(os.path.join(root, "parameters", f"imagen_params_{stamp}.json"), "w"))
+    open(os.path.join(root, "parameters", f"training_parameters_{stamp}.txt"), "w").write("--BATCH_SIZE=2\n")
+    if where == "state_dicts":
+        torch.save(I.load("unet0_sd.pt"), os.path.join(root, "state_dicts", "unet_0_state_0_2_0.512.pth"))
+    elif where == "tmp":
+        torch.save(I.load("unet0_sd.pt"), os.path.join(root, "tmp", "unet_0_tmp.pth"))
+    return str(root)
+
+
+def test_load_params_and_checkpoint_selection(tmp_path):
+    setup("emu")
+    d = make_training_dir(tmp_path / "a")
+    unets, imagen = G.load_params(d)
+    assert unets == [I.unet_params()["unet0"]] and imagen == IMAGEN_PARAMS
+    m = G.load_minimagen(d)
+    sd = I.load("unet0_sd.pt")
+    assert all(torch.equal(v, sd[k]) for k, v in m.unets[0].state_dict().items())
+    assert m.noise_schedulers[0].num_timesteps == 20 and list(m.image_sizes) == [64]
+    m2 = G.load_minimagen(make_training_dir(tmp_path / "b", where="tmp"))           # generate.py:105-119
+    assert all(torch.equal(v, sd[k]) for k, v in m2.unets[0].state_dict().items())
+    with pytest.raises(ValueError):
+        G.load_minimagen(make_training_dir(tmp_path / "c", where="nowhere"))         # generate.py:110-111
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_sample_and_save_layout_and_pixels(backend, tmp_path, monkeypatch):
+    dev = setup(backend)
+    d = make_training_dir(tmp_path / "train")
+    captions = ["a happy dog", "a blue house"][:2 if backend == "gpu" else 1]      # the emulator is slow: one caption there
+    n = len(captions)
+    emb, mask = R.synthetic_text(n, length=8, seed=3)
+    monkeypatch.setattr(imagen_module, "t5_encode_text", lambda texts, name=None: (emb.clone(), mask.clone()))   # no T5 files offline
+    out = tmp_path / "out"
+    G.sample_and_save(captions, training_directory=d, save_directory=str(out), sample_args={"cond_scale": 1.})
+    assert open(out / "captions.txt").read() == "".join(c + "\n" for c in captions)
+    assert open(out / "imagen_training_directory.txt").read() == d
+    assert sorted(os.listdir(out / "generated_images")) == [f"image_{i}.png" for i in range(n)]
+    from PIL import Image
+    m = G.load_minimagen(d).to(dev)
+    ref = m.sample(text_embeds=emb.to(dev), text_masks=mask.to(dev), cond_scale=1.).cpu()
+    for i in range(n):
+        px = np.asarray(Image.open(out / "generated_images" / f"image_{i}.png"))
+        assert px.shape == (64, 64, 3) and px.dtype == np.uint8
+        want = ref[i].mul(255).to(torch.uint8).permute(1, 2, 0).numpy()              # ToPILImage: scale then truncate
+        assert np.array_equal(px, want)
+    with pytest.raises(FileExistsError):                                             # generate.py:21-22
+        G.sample_and_save(captions, minimagen=m, save_directory=str(out))
+    with pytest.raises(AssertionError):
+        G.sample_and_save(captions)
+    with pytest.raises(AssertionError):
+        G.sample_and_save(captions, minimagen=m, training_directory=d, save_directory=str(tmp_path / "z"))

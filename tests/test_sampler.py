@@ -12,11 +12,11 @@ from tests._backend import BACKENDS, GPU_ONLY, setup
 
 def make_imagen(sizes, T, dev, cond_drop_prob=0.15):
     p = I.unet_params()
-    unets = [Unet(**p["unet0"])] + ([Unet(**p["unet1"])] if len(sizes) > 1 else [])
+    unets = [Unet(**p["unet0"])] + [Unet(**p["unet1"]) for _ in sizes[1:]]      # every SR stage uses the unet_1 parameters
     im = Imagen(unets, text_encoder_name="t5_small", image_sizes=sizes, timesteps=T, cond_drop_prob=cond_drop_prob)
     im.unets[0].load_state_dict(I.load("unet0_sd.pt"))
-    if len(sizes) > 1:
-        im.unets[1].load_state_dict(I.load("unet1_sd.pt"))
+    for u in im.unets[1:]:
+        u.load_state_dict(I.load("unet1_sd.pt"))
     return im.to(dev)
 
 
@@ -93,6 +93,20 @@ def test_cascade_full_size_properties(backend):
     assert a.shape == (4, 3, 256, 256) and torch.isfinite(a).all() and a.min() >= 0 and a.max() <= 1
     e = im.sample(text_embeds=emb[2:].contiguous().to(dev), text_masks=mask[2:].contiguous().to(dev), cond_scale=3., _seed=5, _sample_offset=2)
     assert torch.equal(e, a[2:])
+
+
+@pytest.mark.parametrize("backend", GPU_ONLY)
+def test_three_stage_cascade_properties(backend):
+    """BASELINE config 5 shape (64 -> 256 -> 1024, third U-Net = unet_1 params, noise augmentation on both SR stages), B=2:
+    finite, in range, sharding-invariant"""
+    dev = setup(backend)
+    im = make_imagen([64, 256, 1024], 20, dev)
+    emb, mask = R.synthetic_text(2, length=64, seed=7)
+    a = im.sample(text_embeds=emb.to(dev), text_masks=mask.to(dev), cond_scale=3., lowres_sample_noise_level=0.2, _seed=5)
+    assert a.shape == (2, 3, 1024, 1024) and torch.isfinite(a).all() and a.min() >= 0 and a.max() <= 1
+    assert a.std() > 0.01
+    e = im.sample(text_embeds=emb[1:].contiguous().to(dev), text_masks=mask[1:].contiguous().to(dev), cond_scale=3., _seed=5, _sample_offset=1)
+    assert torch.equal(e, a[1:])
 
 
 def test_api_errors():
