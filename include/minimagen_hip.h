@@ -86,6 +86,7 @@ typedef struct mi_conv_params {
     const void* res_w_f16;
 } mi_conv_params;
 #define MI_CONV_SPLIT16 0x100
+#define MI_CONV_WAVES8  0x200   /* matrix-core path: 8 waves x 4 pixel-tiles per workgroup instead of 4 x 8 */
 
 /* tile_cfg -> output tile (th x tw) handled by one workgroup; out_nt = ceil(H/th)*ceil(W/tw) */
 int mi_conv_tile_shape(int tile_cfg, int* th, int* tw);

@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256, WPS) void cross_attn_folded_kernel(const mi_cr
         b = blockIdx.x / tiles;
         tile = blockIdx.x % tiles;
     }
-    const int bx = p.x.bmod > 0 ? b % p.x.bmod : b;
+    const int bx = mi_row_of(b, p.x.bmod);
     const int i0 = (tile * 4 + wave) * 16 * NQ;
     const float* xb = p.x.data + (size_t)bx * C * p.HW;
 
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256, WPS) void cross_attn_f16x3_kernel(const mi_cro
         b = blockIdx.x / tiles;
         tile = blockIdx.x % tiles;
     }
-    const int bx = p.x.bmod > 0 ? b % p.x.bmod : b;
+    const int bx = mi_row_of(b, p.x.bmod);
     const int i = (tile * 4 + wave) * 16 + lq;
     const bool ok = i < p.HW;
     const float* xb = p.x.data + (size_t)bx * C * p.HW;
@@ -488,7 +488,7 @@ namespace {
 
 __global__ __launch_bounds__(256) void ln_tokens_kernel(const mi_act x, int HW, const float* gamma, const float* beta, float* out) {
     const int b = blockIdx.y, C = x.C;
-    const int bx = x.bmod > 0 ? b % x.bmod : b;
+    const int bx = mi_row_of(b, x.bmod);
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= HW) return;
     const float* xb = x.data + (size_t)bx * C * HW + i;
@@ -511,7 +511,7 @@ __global__ __launch_bounds__(256) void self_attn_folded_kernel(const mi_self_att
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lq = lane & 15, lg = lane >> 4;
     const int tiles = (p.HW + 63) / 64;
     const int b = blockIdx.x / tiles, tile = blockIdx.x % tiles;
-    const int bx = p.x.bmod > 0 ? b % p.x.bmod : b;
+    const int bx = mi_row_of(b, p.x.bmod);
     const int i = (tile * 4 + wave) * 16 + lq;
     const bool ok = i < p.HW;
     const float* xb = p.x.data + (size_t)bx * C * p.HW;
@@ -662,7 +662,7 @@ __global__ __launch_bounds__(256) void chan_ff_kernel(const mi_chan_ff_params p,
                                                       const float* __restrict__ g1, const float* __restrict__ g2) {
     __shared__ float red[2 * C][4];
     const int b = blockIdx.y, tid = threadIdx.x;
-    const int bx = p.x.bmod > 0 ? b % p.x.bmod : b;
+    const int bx = mi_row_of(b, p.x.bmod);
     const int i = blockIdx.x * 256 + tid;
     const bool ok = i < p.HW;
     const float* xb = p.x.data + (size_t)bx * C * p.HW + (ok ? i : 0);

@@ -30,6 +30,68 @@ __device__ __forceinline__ void mi_split_f16(const float (&x)[4], mi_f16x4& hi, 
     }
 }
 
+// mi_act.bmod: row b of a tensor shared between the guidance halves lives at b % bmod.  The engine only ever shares between two
+// halves (B2 = 2 bmod), so the (wave-uniform but ~40-instruction) integer division is kept off the common path.
+__device__ __forceinline__ int mi_row_of(int b, int bmod) {
+    if (bmod <= 0 || b < bmod) return b;
+    return b < 2 * bmod ? b - bmod : b % bmod;
+}
+
+// GroupNorm statistics of a conv input (in0 ++ in1): the producers left per-tile partial (sum, sum of squares) per channel;
+// ONE wave (64 lanes, TPC lanes per channel) adds them up in a fixed order in fp64 -> chS / chQ.  Deterministic, and the
+// result does not depend on how the batch is sharded.  Called first thing in the kernel so that these short latency-bound
+// loads are in flight before the bulk input loads.
+__device__ __forceinline__ void mi_gn_channel_totals(const mi_act& in0, const mi_act& in1, int C0, int Cin, int b, int lane,
+                                                     double* chS, double* chQ) {
+    int TPC = 1;
+    while (TPC < 64 && TPC * 2 * Cin <= 64) TPC *= 2;
+    const int CPP = 64 / TPC;                       // channels per pass
+    for (int base = 0; base < Cin; base += CPP) {
+        const int c = base + lane / TPC, sub = lane % TPC;
+        double s = 0.0, q = 0.0;
+        if (c < Cin) {
+            const bool second = c >= C0;
+            const mi_act& a = second ? in1 : in0;
+            const int cc = second ? c - C0 : c;
+            const int ba = mi_row_of(b, a.bmod);
+            const float* st = a.stats + ((size_t)(ba * a.C + cc) * a.nt) * 2;
+            int t = sub;
+            for (; t + 3 * TPC < a.nt; t += 4 * TPC) {          // four independent loads in flight, added in tile order
+                const float2 v0 = *reinterpret_cast<const float2*>(st + 2 * t);
+                const float2 v1 = *reinterpret_cast<const float2*>(st + 2 * (t + TPC));
+                const float2 v2 = *reinterpret_cast<const float2*>(st + 2 * (t + 2 * TPC));
+                const float2 v3 = *reinterpret_cast<const float2*>(st + 2 * (t + 3 * TPC));
+                s += (double)v0.x; q += (double)v0.y;
+                s += (double)v1.x; q += (double)v1.y;
+                s += (double)v2.x; q += (double)v2.y;
+                s += (double)v3.x; q += (double)v3.y;
+            }
+            for (; t < a.nt; t += TPC) {
+                const float2 v = *reinterpret_cast<const float2*>(st + 2 * t);
+                s += (double)v.x;
+                q += (double)v.y;
+            }
+            s *= (double)a.scale;
+            q *= (double)a.scale * (double)a.scale;
+        }
+        for (int o = TPC >> 1; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
+        if (c < Cin && sub == 0) { chS[c] = s; chQ[c] = q; }
+    }
+}
+
+// mean and 1/std of one group from the channel totals: moments in fp64, the final rsqrt in fp32 like the reference
+__device__ __forceinline__ void mi_gn_group_moments(const double* chS, const double* chQ, int c_lo, int c_hi, double count, float eps,
+                                                    float& mean_out, float& rstd_out) {
+    double s = 0.0, q = 0.0;
+    for (int c = c_lo; c < c_hi; ++c) { s += chS[c]; q += chQ[c]; }
+    const double inv_n = 1.0 / count;
+    const double mean = s * inv_n;
+    double var = q * inv_n - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    mean_out = (float)mean;
+    rstd_out = 1.0f / sqrtf((float)(var + (double)eps));
+}
+
 __device__ __forceinline__ float mi_wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

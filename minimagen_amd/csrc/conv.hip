@@ -66,9 +66,13 @@ __global__ __launch_bounds__(CFG::NT) void conv_tile_kernel(const mi_conv_params
         for (int co = 0; co < COUT_T; ++co) acc[px][co] = 0.0f;
 
     const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;   // pad = 1 for every member of the family
-    const int b0 = p.in0.bmod > 0 ? b % p.in0.bmod : b, b1 = p.in1.bmod > 0 ? b % p.in1.bmod : b;
-    const int br0 = p.res0.bmod > 0 ? b % p.res0.bmod : b, br1 = p.res1.bmod > 0 ? b % p.res1.bmod : b;
+    const int b0 = mi_row_of(b, p.in0.bmod), b1 = mi_row_of(b, p.in1.bmod);
+    const int br0 = mi_row_of(b, p.res0.bmod), br1 = mi_row_of(b, p.res1.bmod);
     constexpr bool gn = CFG::GN;         // GroupNorm + SiLU prologue compiled in or out (no per-element branches)
+    // per-channel totals of the producer's per-tile partial sums: wave 0 only, first thing (see common.hip.h)
+    if constexpr (CFG::GN) {
+        if (tid < 64) mi_gn_channel_totals(p.in0, p.in1, C0, Cin, b, tid, chS, chQ);
+    }
 
     // Staging is split (T14): a round's global loads are issued back-to-back into registers with clamped
     // (always legal) addresses and no branches; the activation + LDS write happens after the barrier, and on
@@ -171,45 +175,10 @@ __global__ __launch_bounds__(CFG::NT) void conv_tile_kernel(const mi_conv_params
 
     // ---------------- prologue: per-channel affine for the fused GroupNorm / scale-shift
     if constexpr (CFG::GN) {
-        // per-channel totals of the producer's per-tile partial sums: done by wave 0 only (the other waves go straight
-        // to the barrier), TPC lanes per channel, fixed-order fp64 tree
-        if (tid < 64) {
-            int TPC = 1;
-            while (TPC < 64 && TPC * 2 * Cin <= 64) TPC *= 2;
-            const int CPP = 64 / TPC;                       // channels per pass
-            for (int base = 0; base < Cin; base += CPP) {
-                const int c = base + tid / TPC, sub = tid % TPC;
-                double s = 0.0, q = 0.0;
-                if (c < Cin) {
-                    const bool second = c >= C0;
-                    const mi_act& a = second ? p.in1 : p.in0;
-                    const int cc = second ? c - C0 : c;
-                    const int ba = a.bmod > 0 ? b % a.bmod : b;
-                    const float* st = a.stats + ((size_t)(ba * a.C + cc) * a.nt) * 2;
-                    for (int t = sub; t < a.nt; t += TPC) {
-                        const float2 v = *reinterpret_cast<const float2*>(st + 2 * t);
-                        s += (double)v.x;
-                        q += (double)v.y;
-                    }
-                    s *= (double)a.scale;
-                    q *= (double)a.scale * (double)a.scale;
-                }
-                for (int o = TPC >> 1; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
-                if (c < Cin && sub == 0) { chS[c] = s; chQ[c] = q; }
-            }
-        }
         __syncthreads();
         const int cpg = Cin / p.gn_groups;
-        for (int g = tid; g < p.gn_groups; g += NT) {
-            double s = 0.0, q = 0.0;
-            for (int c = g * cpg; c < (g + 1) * cpg; ++c) { s += chS[c]; q += chQ[c]; }
-            const double n = (double)cpg * (double)Hin * (double)Win;
-            const double mean = s / n;
-            double var = q / n - mean * mean;
-            var = var > 0.0 ? var : 0.0;
-            gMean[g] = (float)mean;
-            gRstd[g] = (float)(1.0 / sqrt(var + (double)p.gn_eps));
-        }
+        for (int g = tid; g < p.gn_groups; g += NT)
+            mi_gn_group_moments(chS, chQ, g * cpg, (g + 1) * cpg, (double)cpg * (double)Hin * (double)Win, p.gn_eps, gMean[g], gRstd[g]);
         __syncthreads();
         for (int c = tid; c < Cin; c += NT) {
             const int g = c / cpg;

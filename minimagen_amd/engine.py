@@ -27,6 +27,7 @@ MAX_TEXT_LEN = 256
 # kernel-shape tuning knobs (A/B measurements; the defaults are what profiles/ was measured with)
 ATTN_VARIANT = int(os.environ.get("MINIMAGEN_ATTN_VARIANT", "6"))       # 6: fp16x3 MFMA (default); 0/1/3/4/5: exact-fp32 MFMA shapes
 CONV_SPLIT16 = int(os.environ.get("MINIMAGEN_CONV_SPLIT16", "1"))
+CONV_WAVES8 = int(os.environ.get("MINIMAGEN_CONV_WAVES8", "1"))        # matrix-core conv: 8 waves x 4 pixel-tiles per workgroup
 CONV_MFMA = int(os.environ.get("MINIMAGEN_CONV_MFMA", "1"))             # 1: wide (>=16 in, >=16 out) k3 s1 convs on the matrix cores; 2: all k3 s1
 TILE64 = int(os.environ.get("MINIMAGEN_TILE64", "-1"))                  # force a conv tile shape at 64x64 / 128x128 (experiments)
 TILE128 = int(os.environ.get("MINIMAGEN_TILE128", "-1"))       # 1: 16-channel 3x3 outputs as two 8-channel workgroups
@@ -231,8 +232,8 @@ class UnetEngine:
         cin_tot = in0.C + (in1.C if in1 is not None else 0)
         # matrix-core path: measured faster only where the 16x16x16 tile is full (>= 16 input and 16 output channels) and the
         # residual is not an identity add (profiles/): narrow layers stay on the VALU kernel
-        wide = cin_tot >= 16 and Cout >= 16
-        mfma = (CONV_MFMA == 2 or (CONV_MFMA == 1 and wide)) and ksize == 3 and stride == 1 and not up2 and Wo % 4 == 0 \
+        wide = cin_tot >= 16 and Cout >= (8 if CONV_MFMA == 3 else 16)
+        mfma = (CONV_MFMA == 2 or (CONV_MFMA in (1, 3) and wide)) and ksize == 3 and stride == 1 and not up2 and Wo % 4 == 0 \
             and id(wpack) in pk.conv_f16
         if mfma:
             cfg = 3 if Wo >= 64 else 4
@@ -256,7 +257,7 @@ class UnetEngine:
             if r1 is not None:
                 p.res1 = r1.c(batch, skip_scale)
             p.res_w, p.res_b = L.ptr(rw), L.ptr(rb)
-        p.out, p.out_stats, p.tile_cfg = L.ptr(out.t), L.ptr(out.stats), cfg | (0x100 if CONV_SPLIT16 else 0)
+        p.out, p.out_stats, p.tile_cfg = L.ptr(out.t), L.ptr(out.stats), cfg | (0x100 if CONV_SPLIT16 else 0) | (0x200 if CONV_WAVES8 else 0)
         if mfma:
             p.w_f16 = L.ptr(pk.conv_f16[id(wpack)])
             if res is not None and res[2] is not None:
@@ -287,7 +288,7 @@ class UnetEngine:
         lib = L.lib()
         Cc, HW = h.C, h.H * h.W
         FR = lib.mi_attn_fragment_floats(Cc)
-        gv = torch.zeros(ws.B2, ca.heads, JT, 64, FR, dtype=torch.float32, device=ws.dev)
+        gv = torch.zeros(ws.B2, ca.heads, JT, 64, FR, dtype=torch.float32, device=ws.dev)      # zero-filled: padded context rows must read as finite
         ws.gv[id(ca)] = gv
         nt = -(-HW // (128 if ATTN_VARIANT in (0, 5) else 64))
         out = self._new_act(ws, ws.B2, Cc, h.H, h.W, nt)

@@ -72,7 +72,7 @@ struct Fiber {
 };
 
 struct Wave {
-    alignas(16) uint32_t buf[64][4];
+    alignas(16) uint32_t buf[64][8];
     bool part[64];
 };
 
@@ -240,6 +240,31 @@ static inline hipemu_f32x4 hipemu_mfma_f32_16x16x16f16(hipemu_f16x4 a, hipemu_f1
     return d;
 }
 #define __builtin_amdgcn_mfma_f32_16x16x16f16 hipemu_mfma_f32_16x16x16f16
+typedef _Float16 hipemu_f16x8 __attribute__((ext_vector_type(8)));
+// v_mfma_f32_16x16x32_f16 (gfx950): A[i = l&15][k = 8*(l>>4) + e], B[k = 8*(l>>4) + e][j = l&15], e = 0..7
+static inline hipemu_f32x4 hipemu_mfma_f32_16x16x32_f16(hipemu_f16x8 a, hipemu_f16x8 b, hipemu_f32x4 c, int, int, int) {
+    hipemu::Wave& w = hipemu::cur_wave();
+    int l = hipemu::g_cur->lane;
+    std::memcpy(&w.buf[l][0], &a, 16);
+    std::memcpy(&w.buf[l][4], &b, 16);
+    hipemu::wave_sync();
+    hipemu_f32x4 d = c;
+    int col = l & 15;
+    for (int r = 0; r < 4; ++r) {
+        int row = 4 * (l >> 4) + r;
+        float acc = c[r];
+        for (int k = 0; k < 32; ++k) {
+            hipemu_f16x8 av, bv;
+            std::memcpy(&av, &w.buf[row + 16 * (k >> 3)][0], 16);
+            std::memcpy(&bv, &w.buf[col + 16 * (k >> 3)][4], 16);
+            acc += (float)av[k & 7] * (float)bv[k & 7];
+        }
+        d[r] = acc;
+    }
+    hipemu::wave_sync();
+    return d;
+}
+#define __builtin_amdgcn_mfma_f32_16x16x32_f16 hipemu_mfma_f32_16x16x32_f16
 #define __builtin_amdgcn_mfma_f32_16x16x4f32 hipemu_mfma_f32_16x16x4f32
 #define __builtin_amdgcn_mfma_f32_32x32x2f32 hipemu_mfma_f32_32x32x2f32
 typedef __fp16 hipemu_h2 __attribute__((ext_vector_type(2)));

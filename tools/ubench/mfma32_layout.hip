@@ -1,0 +1,67 @@
+// Layout probe for v_mfma_f32_16x16x32_f16 on gfx950: checks D = A.B against the assumed operand layout
+//   A: lane (i = l & 15, g = l >> 4) holds A[i][k = 8g + e], e = 0..7;  B: lane (j = l & 15, g) holds B[k = 8g + e][j];
+//   D: lane holds D[4g + r][j = l & 15], r = 0..3.
+// hipcc --offload-arch=gfx950 -O2 -o mfma32_layout mfma32_layout.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cmath>
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__global__ void probe(const _Float16* A, const _Float16* B, float* D) {   // A [16][32], B [32][16], D [16][16]
+    const int l = threadIdx.x, q = l & 15, g = l >> 4;
+    f16x8 a, b;
+    for (int e = 0; e < 8; ++e) { a[e] = A[q * 32 + 8 * g + e]; b[e] = B[(8 * g + e) * 16 + q]; }
+    f32x4 c = {0.f, 0.f, 0.f, 0.f};
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    for (int r = 0; r < 4; ++r) D[(4 * g + r) * 16 + q] = c[r];
+}
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+template <int K32>
+__global__ __launch_bounds__(256) void rate(float* out, int iters) {
+    f16x8 a8, b8; f16x4 a4, b4;
+    for (int e = 0; e < 8; ++e) { a8[e] = (_Float16)(threadIdx.x * 0.001f + e); b8[e] = (_Float16)(0.5f + e); }
+    for (int e = 0; e < 4; ++e) { a4[e] = a8[e]; b4[e] = b8[e]; }
+    f32x4 c[8];
+    for (int t = 0; t < 8; ++t) c[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            if (K32) c[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a8, b8, c[t], 0, 0, 0);
+            else c[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(a4, b4, c[t], 0, 0, 0);
+        }
+    }
+    float s = 0.f;
+    for (int t = 0; t < 8; ++t) s += c[t][0] + c[t][1] + c[t][2] + c[t][3];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+template <int K32>
+static void time_rate(const char* name) {
+    float* out; hipMalloc(&out, 4096 * 256 * 4);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    const int iters = 2000, blocks = 2048;       // 2048 blocks x 4 waves = 8 waves per SIMD over 1024 SIMDs
+    hipLaunchKernelGGL(rate<K32>, dim3(blocks), dim3(256), 0, 0, out, 10);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(rate<K32>, dim3(blocks), dim3(256), 0, 0, out, iters);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const double n = (double)blocks * 4 * iters * 8;              // MFMA instructions
+    const double flop = n * 2.0 * 16 * 16 * (K32 ? 32 : 16);
+    printf("%s: %.3f ms, %.2f ns per MFMA per SIMD, %.0f TFLOP/s\n", name, ms, ms * 1e6 / (n / 1024.0), flop / (ms * 1e-3) / 1e12);
+}
+int main() {
+    time_rate<0>("v_mfma_f32_16x16x16_f16");
+    time_rate<1>("v_mfma_f32_16x16x32_f16");
+    _Float16 hA[16 * 32], hB[32 * 16];
+    float ref[256] = {0}, hD[256];
+    for (int i = 0; i < 512; ++i) { hA[i] = (_Float16)((float)((i * 37) % 23 - 11) * 0.125f); hB[i] = (_Float16)((float)((i * 53) % 19 - 9) * 0.25f); }
+    for (int i = 0; i < 16; ++i) for (int j = 0; j < 16; ++j) for (int k = 0; k < 32; ++k) ref[i * 16 + j] += (float)hA[i * 32 + k] * (float)hB[k * 16 + j];
+    _Float16 *dA, *dB; float* dD;
+    hipMalloc(&dA, sizeof(hA)); hipMalloc(&dB, sizeof(hB)); hipMalloc(&dD, sizeof(hD));
+    hipMemcpy(dA, hA, sizeof(hA), hipMemcpyHostToDevice); hipMemcpy(dB, hB, sizeof(hB), hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(probe, dim3(1), dim3(64), 0, 0, dA, dB, dD);
+    hipMemcpy(hD, dD, sizeof(hD), hipMemcpyDeviceToHost);
+    float err = 0.f;
+    for (int i = 0; i < 256; ++i) err = fmaxf(err, fabsf(hD[i] - ref[i]));
+    printf("v_mfma_f32_16x16x32_f16 assumed layout: max |err| = %g (%s)\n", err, err < 1e-3f ? "layout confirmed" : "LAYOUT MISMATCH");
+    return 0;
+}
