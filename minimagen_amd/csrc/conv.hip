@@ -8,6 +8,19 @@
 // emitted from the epilogue so no tensor is ever re-read for normalisation.
 #include "common.hip.h"
 
+#ifdef MI_TRACE
+// development aid (tools/trace_conv.py): accumulated shader-clock time per phase of the first workgroups of the last launch
+__device__ unsigned long long mi_trace_conv_buf[1024 * 8];
+extern "C" int mi_debug_read_trace_conv(void* dst, size_t bytes) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(mi_trace_conv_buf), bytes); }
+#define MI_TSTART() unsigned long long mi_t_last = clock64(), mi_t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define MI_TPHASE(k) do { const unsigned long long mi_t_now = clock64(); mi_t_acc[k] += mi_t_now - mi_t_last; mi_t_last = mi_t_now; } while (0)
+#define MI_TEND() do { if (threadIdx.x == 0) { const int wg = blockIdx.y * gridDim.x + blockIdx.x; if (wg < 1024) for (int k = 0; k < 8; ++k) mi_trace_conv_buf[wg * 8 + k] = mi_t_acc[k]; } } while (0)
+#else
+#define MI_TSTART() do { } while (0)
+#define MI_TPHASE(k) do { } while (0)
+#define MI_TEND() do { } while (0)
+#endif
+
 namespace {
 
 template <int NT_, int TW_, int COUT_T_, int KS_, int S_, bool UP2_, bool VEC_, bool GN_>
@@ -69,6 +82,7 @@ __global__ __launch_bounds__(CFG::NT) void conv_tile_kernel(const mi_conv_params
     const int b0 = mi_row_of(b, p.in0.bmod), b1 = mi_row_of(b, p.in1.bmod);
     const int br0 = mi_row_of(b, p.res0.bmod), br1 = mi_row_of(b, p.res1.bmod);
     constexpr bool gn = CFG::GN;         // GroupNorm + SiLU prologue compiled in or out (no per-element branches)
+    MI_TSTART();
     // per-channel totals of the producer's per-tile partial sums: wave 0 only, first thing (see common.hip.h)
     if constexpr (CFG::GN) {
         if (tid < 64) mi_gn_channel_totals(p.in0, p.in1, C0, Cin, b, tid, chS, chQ);
@@ -171,7 +185,9 @@ __global__ __launch_bounds__(CFG::NT) void conv_tile_kernel(const mi_conv_params
         }
     };
 
+    MI_TPHASE(0);       // stats totals (wave 0) + geometry
     stage_load(0);      // first round's loads fly under the statistics prologue
+    MI_TPHASE(1);
 
     // ---------------- prologue: per-channel affine for the fused GroupNorm / scale-shift
     if constexpr (CFG::GN) {
@@ -199,10 +215,15 @@ __global__ __launch_bounds__(CFG::NT) void conv_tile_kernel(const mi_conv_params
     if (tid == 0) chP[MI_MAX_CIN] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 
     for (int c0 = 0; c0 < Cin; c0 += CK) {
+        MI_TPHASE(c0 == 0 ? 2 : 5);     // rest of the prologue | previous round's FMA loop
         __syncthreads();   // previous round fully consumed (and chA/chB visible on the first round)
+        MI_TPHASE(3);
         stage_write(c0);
+        MI_TPHASE(4);
         __syncthreads();
+        MI_TPHASE(3);
         if (c0 + CK < Cin) stage_load(c0 + CK);       // in flight during the FMA loop below
+        MI_TPHASE(1);
         const int nck = (Cin - c0) < CK ? (Cin - c0) : CK;
         for (int ck = 0; ck < nck; ++ck) {
             const float* wc = wts + (size_t)(c0 + ck) * KS * KS * CoutPad + co0;
@@ -248,6 +269,7 @@ __global__ __launch_bounds__(CFG::NT) void conv_tile_kernel(const mi_conv_params
         }
     }
 
+    MI_TPHASE(5);       // last round's FMA loop
     // ---------------- epilogue: bias, residual, store, statistics of the output
     const int oy = oy0 + ty, ox = ox0 + tx * 4;
     const bool row_ok = oy < p.H;
@@ -344,6 +366,8 @@ __global__ __launch_bounds__(CFG::NT) void conv_tile_kernel(const mi_conv_params
             p.out_stats[((size_t)(b * p.Cout + co) * nt + tile) * 2 + (rrow & 1)] = a;
         }
     }
+    MI_TPHASE(6);
+    MI_TEND();
 }
 
 template <int NT, int TW, int COUT_T, int KS, int S, bool UP2, bool VEC, bool GN>

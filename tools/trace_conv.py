@@ -60,3 +60,38 @@ for i, n in enumerate(names):
 tot = t[:, 6] - t[:, 0]
 print(f"  workgroup total                    {np.median(tot):9.0f} {np.percentile(tot, 10):9.0f} {np.percentile(tot, 90):9.0f}")
 print(f"  first start -> last end            {t[:, 6].max() - t[:, 0].min():9.0f} cycles;  start spread {t[:, 0].max() - t[:, 0].min()}")
+
+# ---- the VALU conv (conv.hip): 8->8 GroupNorm conv of the 256x256 level, B=64 -> accumulated cycles per phase
+if hasattr(lib, "mi_debug_read_trace_conv"):
+    B, Cc, H, W = 64, 8, 256, 256
+    x = torch.randn(B, Cc, H, W, generator=g).to(dev)
+    nt_in = 64
+    stats = torch.zeros(B, Cc, nt_in, 2, device=dev)
+    stats[:, :, 0, 0] = x.sum((2, 3)); stats[:, :, 0, 1] = (x * x).sum((2, 3))
+    w = torch.randn(Cc, Cc, 3, 3, generator=g) * 0.2
+    wp = P.pack_conv_weight(w, 8).to(dev)
+    bias, gamma, beta = torch.zeros(Cc, device=dev), torch.ones(Cc, device=dev), torch.zeros(Cc, device=dev)
+    p = L.MiConvParams()
+    p.B, p.H, p.W = B, H, W
+    p.in0 = L.MiAct(x.data_ptr(), Cc, stats.data_ptr(), nt_in, 1.0, 0)
+    p.Cout, p.ksize, p.stride, p.up2 = Cc, 3, 1, 0
+    p.w, p.bias = wp.data_ptr(), bias.data_ptr()
+    p.gn_groups, p.gn_gamma, p.gn_beta, p.gn_eps = 8, gamma.data_ptr(), beta.data_ptr(), 1e-5
+    out = torch.empty(B, Cc, H, W, device=dev)
+    ost = torch.zeros(B, Cc, 64, 2, device=dev)
+    p.out, p.out_stats, p.tile_cfg = out.data_ptr(), ost.data_ptr(), 0 | 0x100
+    for _ in range(3):
+        L.check(lib.mi_conv_fwd(C.byref(p), st), "conv")
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(10):
+        L.check(lib.mi_conv_fwd(C.byref(p), st), "conv")
+    e1.record(); torch.cuda.synchronize()
+    print(f"VALU conv 8->8 @256 B64: avg launch {e0.elapsed_time(e1) / 10 * 1e3:.1f} us")
+    lib.mi_debug_read_trace_conv.argtypes = [C.c_void_p, C.c_size_t]
+    lib.mi_debug_read_trace_conv(buf.ctypes.data, buf.nbytes)
+    t = buf.reshape(1024, 8).astype(np.int64)
+    names = ["stats totals + geometry", "issue loads", "rest of prologue", "barrier waits", "activation + LDS write", "FMA loops", "epilogue", "-"]
+    for i, n in enumerate(names[:7]):
+        print(f"  {n:34s} {np.median(t[:, i]):9.0f} {np.percentile(t[:, i], 10):9.0f} {np.percentile(t[:, i], 90):9.0f}")
+    print(f"  total                              {np.median(t[:, :7].sum(1)):9.0f}")
