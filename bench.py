@@ -87,26 +87,32 @@ def entry_cost(name, p):
 
 
 def op_breakdown(im, stage, B, cond_scale, reps=20):
-    """Time every kernel launch of one U-Net evaluation of `stage` standalone with HIP events on the launch stream."""
+    """Time every kernel launch of one U-Net evaluation of `stage` with HIP events on the launch stream, IN PROGRAM ORDER (each
+    launch sees the cache state its predecessor leaves behind, as inside the captured graph), averaged over `reps` evaluations."""
     from minimagen_amd import _lib as L
     unet = im.unets[stage]
     S = im.image_sizes[stage]
     eng = unet.engine()
     ws = eng.workspace(B, 2 * B if cond_scale != 1 else B, S, S)
     stream = L.current_stream()
+    prog = [(fn, p, name) for fn, p, name in ws.prog if p is not None]
+    for _ in range(2):
+        eng.run(ws, stream)
+    acc = [0.0] * len(prog)
+    for _ in range(reps):
+        evs = []
+        for fn, p, name in prog:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn(C.byref(p), stream)
+            e1.record()
+            evs.append((e0, e1))
+        torch.cuda.synchronize()
+        for k, (e0, e1) in enumerate(evs):
+            acc[k] += e0.elapsed_time(e1)
     rows = []
-    for fn, p, name in ws.prog:
-        if p is None:
-            continue
-        for _ in range(3):
-            fn(C.byref(p), stream)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            fn(C.byref(p), stream)
-        e1.record()
-        e1.synchronize()
-        ms = e0.elapsed_time(e1) / reps
+    for k, (fn, p, name) in enumerate(prog):
+        ms = acc[k] / reps
         by, fl, bound = entry_cost(name, p)
         desc = name
         if name == "conv":
@@ -118,6 +124,23 @@ def op_breakdown(im, stage, B, cond_scale, reps=20):
             desc = f"crossembed {p.C0 + (p.C1 if p.in1 else 0)}->8 @{p.H}x{p.W} B{p.B}"
         rows.append(dict(op=desc, kernel=name, ms=ms, alg_bytes=by, alg_flops=fl, bound=bound))
     return rows
+
+
+def pmc_traffic(dom, rows, S):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes of THIS command (profiles/rNN_*_pmc_by_launch_shape.csv:
+    separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs, FETCH doubled per the gfx950 correction, see tools/summarize_profiles.py).
+    null when no committed profile matches the launch shape."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_cascade_T20_pmc_by_launch_shape.csv")))
+    if not files or dom["kernel"] != "cross_attn":
+        return {"traffic": None}
+    grid = rows * (-(-(S // 4) * (S // 4) // 64)) * 256          # bottleneck level = S/4; 64 tokens per 256-thread workgroup
+    for r in csv.DictReader(open(files[-1])):
+        if "cross_attn" in r["kernel"] and int(r["grid"]) == grid and r["fetch_MB_x2"] not in ("", "None") and r["write_MB"] not in ("", "None"):
+            return {"traffic": (float(r["fetch_MB_x2"]) + float(r["write_MB"])) * 1e6,
+                    "traffic_source": f"{os.path.basename(files[-1])}: FETCH_SIZE x2 + WRITE_SIZE per launch (bytes)"}
+    return {"traffic": None}
 
 
 def cpu_baseline():
@@ -239,6 +262,7 @@ def main():
             ex = dom["alg_flops"] * k / (dom["ms"] * 1e-3) / 1e12
             res["roofline"]["executed"] = {"achieved": ex, "frac": ex / peak,
                                            "note": f"MFMA flops actually issued = {k:g} x algorithmic (folded attention" + (", fp16x3 split; v_mfma_f32_16x16x16_f16" if attn_f16 else "; v_mfma_f32_16x16x4_f32") + ")"}
+        res["roofline"].update(pmc_traffic(dom, B * (2 if args.cond_scale != 1 else 1), sizes[stage]))
         alg_fwd_mb = {64: 28.82, 256: 124.97}.get(sizes[stage])
         nfwd = 2 if args.cond_scale != 1 else 1
         res["unet_eval"] = {"stage": stage, "sum_kernel_ms": total_ms, "launches": len(rows),

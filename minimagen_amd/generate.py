@@ -60,7 +60,9 @@ def load_minimagen(directory: str) -> Imagen:
     where = torch.device("cuda:0" if torch.cuda.is_available() else "cpu")
     for idx, path in enumerate(_checkpoint_files(directory)):
         model.unets[idx].load_state_dict(torch.load(path, map_location=where))
-    return model
+    # the reference leaves the module where it was built and samples there; this implementation has no CPU sampling path,
+    # so the loaded model goes to the device the checkpoints were mapped to
+    return model.to(where)
 
 
 def _prepare_output(save_directory: str) -> str:
