@@ -126,6 +126,32 @@ def op_breakdown(im, stage, B, cond_scale, reps=20):
     return rows
 
 
+def graph_step_ms(im, stage, B, cond_scale, T, reps=40):
+    """Per-step time of the stage's captured HIP graph (U-Net evaluation of both guidance halves + CFG/x0 + quantile + posterior draw),
+    replayed back to back exactly as sample() does -- the figure the end-to-end throughput is made of (no per-launch event overhead)."""
+    from minimagen_amd import _lib as L
+    lib = L.lib()
+    unet = im.unets[stage]
+    S = im.image_sizes[stage]
+    ws = unet.engine().workspace(B, 2 * B if cond_scale != 1 else B, S, S)
+    states = getattr(ws, "sampler_state", {})
+    entries = [(st, e) for st in states.values() for e in getattr(st, "graphs", {}).values() if e.get("graph")]
+    if not entries:
+        return None
+    st, entry = entries[-1]
+    stream = L.current_stream()
+    reps = min(reps, T - 2)
+    L.check(lib.mi_step_set(L.ptr(st.t_state), L.ptr(ws.times), B, T - 1, stream), "mi_step_set")
+    L.check(lib.mi_graph_launch(entry["graph"], stream), "mi_graph_launch")
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        L.check(lib.mi_graph_launch(entry["graph"], stream), "mi_graph_launch")
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
 def pmc_traffic(dom, rows, S):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes of THIS command (profiles/rNN_*_pmc_by_launch_shape.csv:
     separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs, FETCH doubled per the gfx950 correction, see tools/summarize_profiles.py).
@@ -175,6 +201,9 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
     ap.add_argument("--timesteps", type=int, default=100)
     ap.add_argument("--cond-scale", type=float, default=3.0)
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "half"],
+                    help="fp32 (default, the headline): every contraction fp32-grade; half: single-fp16-term matrix-core contractions "
+                         "(BASELINE's reduced-precision configurations; parity gate 3e-2) -- reported as a secondary line, never the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true")
     ap.add_argument("--breakdown-out", default="")
@@ -202,7 +231,7 @@ def main():
     emb, mask = emb.to(dev), mask.to(dev)
 
     def one_step(k):
-        out = im.sample(text_embeds=emb, text_masks=mask, cond_scale=args.cond_scale, _seed=1234 + k, _sample_offset=rank * B)
+        out = im.sample(text_embeds=emb, text_masks=mask, cond_scale=args.cond_scale, _seed=1234 + k, _sample_offset=rank * B, _precision=args.precision)
         if world > 1:
             pad = [torch.empty_like(out) for _ in range(world)]
             dist.all_gather(pad, out)
@@ -234,9 +263,9 @@ def main():
         "metric": "denoising-steps/sec (images/sec x T), base 64^2 + SR 64->256 cascade" if n_stages == 2 else "denoising-steps/sec (images/sec x T), base 64^2",
         "value": value, "unit": "denoising-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic (random-init weights seed 0, randn text embeddings seed 7 with ragged masks, Philox noise)",
+        "dtype": "f32" if args.precision == "fp32" else "f16 operands on the matrix cores, f32 accumulate/softmax/statistics/storage", "data": "synthetic (random-init weights seed 0, randn text embeddings seed 7 with ragged masks, Philox noise)",
         "config": {"workload": f"{args.workload}: unet_0 params @64x64" + (" + unet_1 params (lowres_cond) @256x256" if n_stages == 2 else "")
-                   + f", T={args.timesteps}/stage, cond_scale={args.cond_scale} (2 U-Net evals/step), dynamic thresholding 0.9, fp32",
+                   + f", T={args.timesteps}/stage, cond_scale={args.cond_scale} (2 U-Net evals/step), dynamic thresholding 0.9, " + ("fp32" if args.precision == "fp32" else "half-precision matrix-core contractions"),
                    "per_gpu_batch": B, "global_batch": gB, "timesteps": args.timesteps, "parallelism": f"dp{world}"},
         "images_per_s": gB * args.steps / dt,
     }
@@ -258,10 +287,10 @@ def main():
             # `achieved` prices the launch at the reference's ALGORITHMIC flops (q/k/v/out at 512 wide).  The folded
             # kernel needs 4x fewer multiply-adds (K = C = 16 instead of dim_head = 64); the fp16x3 variant issues each of them as
             # three f16 MFMAs (hi*hi + hi*lo + lo*hi, fp32 accumulate) to keep fp32-level accuracy -- report the issued rate too
-            k = 0.25 * (3.0 if attn_f16 else 1.0)
+            k = 0.25 * ((3.0 if args.precision == "fp32" else 1.0) if attn_f16 else 1.0)
             ex = dom["alg_flops"] * k / (dom["ms"] * 1e-3) / 1e12
             res["roofline"]["executed"] = {"achieved": ex, "frac": ex / peak,
-                                           "note": f"MFMA flops actually issued = {k:g} x algorithmic (folded attention" + (", fp16x3 split; v_mfma_f32_16x16x16_f16" if attn_f16 else "; v_mfma_f32_16x16x4_f32") + ")"}
+                                           "note": f"MFMA flops actually issued = {k:g} x algorithmic (folded attention" + ((", fp16x3 split" if args.precision == "fp32" else ", single fp16 term") + "; v_mfma_f32_16x16x16_f16" if attn_f16 else "; v_mfma_f32_16x16x4_f32") + ")"}
         res["roofline"].update(pmc_traffic(dom, B * (2 if args.cond_scale != 1 else 1), sizes[stage]))
         alg_fwd_mb = {64: 28.82, 256: 124.97}.get(sizes[stage])
         nfwd = 2 if args.cond_scale != 1 else 1
@@ -269,6 +298,15 @@ def main():
                             "alg_bytes_MB_per_image_forward": alg_fwd_mb,
                             "hbm_frac_whole_forward": (alg_fwd_mb * 1e6 * B * nfwd / (total_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if alg_fwd_mb else None,
                             "by_kernel_ms": {k: sum(r["ms"] for r in rows if r["kernel"] == k) for k in sorted({r["kernel"] for r in rows})}}
+        with torch.cuda.stream(im._stream):          # the stream sample() captured and replays on
+            gs = graph_step_ms(im, stage, B, args.cond_scale, args.timesteps)
+        torch.cuda.synchronize()
+        if gs is not None and alg_fwd_mb:
+            epi_mb = 6 * 3 * sizes[stage] ** 2 * 4 / 1e6                 # sampler epilogue bytes per image per step
+            res["unet_eval"]["graph_step_ms"] = gs
+            res["unet_eval"]["hbm_frac_graph_step"] = (alg_fwd_mb * nfwd + epi_mb) * 1e6 * B / (gs * 1e-3) / 1e9 / HBM_PEAK_GBS
+            res["unet_eval"]["note"] = ("sum_kernel_ms adds per-launch HIP-event intervals (program order, event overhead included); "
+                                        "graph_step_ms is one replay of the captured denoising step (U-Net x2 + CFG + quantile + posterior)")
         if args.breakdown_out:
             with open(args.breakdown_out, "w") as f:
                 json.dump(rows, f, indent=1)

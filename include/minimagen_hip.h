@@ -86,6 +86,7 @@ typedef struct mi_conv_params {
     const void* res_w_f16;
 } mi_conv_params;
 #define MI_CONV_SPLIT16 0x100
+#define MI_CONV_HALF    0x400   /* matrix-core path: single fp16 term per product (reduced-precision configuration; parity gate 3e-2) */
 #define MI_CONV_WAVES8  0x200   /* matrix-core path: 8 waves x 4 pixel-tiles per workgroup instead of 4 x 8 */
 
 /* tile_cfg -> output tile (th x tw) handled by one workgroup; out_nt = ceil(H/th)*ceil(W/tw) */
@@ -197,7 +198,8 @@ typedef struct mi_cross_attn_params {
     const float* n2_g; const float* n2_b;   /* to_out.1              gamma / beta */
     float* out; float* out_stats;   /* [B2][C][HW]; stats [B2][C][ceil(HW/tok)][2], tok = 128 (variant 0) or 64 (variant 1) */
     int variant;                    /* 0: 32 tokens per wave; 1,3,4: 16 tokens per wave (fp32 MFMA, exact); 6: 16 tokens per wave with the
-                                       contractions as 3-term fp16 splits on v_mfma_f32_16x16x16_f16 (hi*hi + hi*lo + lo*hi, ~2^-21) */
+                                       contractions as 3-term fp16 splits on v_mfma_f32_16x16x16_f16 (hi*hi + hi*lo + lo*hi, ~2^-21);
+                                       7: as 6 with a single fp16 term (reduced-precision configuration, same frag_f16 fragments) */
 } mi_cross_attn_params;
 int mi_cross_attn_fwd(const mi_cross_attn_params* p, void* stream);
 #define MI_ATTN_TOKENS_PER_WG 128

@@ -5,6 +5,8 @@ from __future__ import annotations
 import ctypes as C
 from typing import Callable, List, Literal, Tuple, Union
 
+import os
+
 import torch
 from torch import nn
 
@@ -217,10 +219,11 @@ class Imagen(nn.Module):
     def sample(self, texts: List[str] = None, text_masks: torch.Tensor = None, text_embeds: torch.Tensor = None,
                cond_scale: float = 1., lowres_sample_noise_level: float = None, return_pil_images: bool = False,
                device: torch.device = None, *, _noise: Callable = None, _seed: int = 1234, _sample_offset: int = 0,
-               _use_graph: bool = True):
+               _use_graph: bool = True, _precision: str = None):
         """minimagen/Imagen.py:424-510.  Private keyword-only extras (not in the reference): ``_noise(shape)`` injects a
         host noise stream in the reference's draw order (parity runs); otherwise noise is Philox keyed by
-        (``_seed``, ``_sample_offset`` + row, stage, step, element) so a sharded batch reproduces the unsharded one."""
+        (``_seed``, ``_sample_offset`` + row, stage, step, element) so a sharded batch reproduces the unsharded one;
+        ``_precision`` = "fp32" (default) or "half" (single-fp16-term matrix-core contractions, see engine.UnetEngine.precision)."""
         device = default(device, self.device)
         self._reset_unets_all_one_device(device=device)
         if exists(texts) and not exists(text_embeds):
@@ -256,6 +259,7 @@ class Imagen(nn.Module):
             for stage, (unet, channel, image_size, noise_scheduler) in enumerate(
                     zip(self.unets, self.sample_channels, self.image_sizes, self.noise_schedulers)):
                 eng = unet.engine()
+                eng.precision = _precision if _precision is not None else os.environ.get("MINIMAGEN_PRECISION", "fp32")
                 ws = eng.workspace(batch_size, B2, image_size, image_size)
                 eng.set_text(ws, text_embeds, text_masks, keep)
                 if unet.lowres_cond:

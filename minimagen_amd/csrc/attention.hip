@@ -255,7 +255,9 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void split_f16(const float (&x)[4], f16x4& hi, f16x4& lo) { mi_split_f16(x, hi, lo); }
 
-template <int C, int JT, int WPS>
+// HALF = true: the reduced-precision configuration (variant 7): single fp16 term per product (no lo halves), fp32 accumulate,
+// fp32 softmax -- the BASELINE 'half-precision with MFMA attention' configurations; parity gate 3e-2 / 3e-3 instead of fp32's 1e-4 / 1e-5
+template <int C, int JT, int WPS, bool HALF>
 __global__ __launch_bounds__(256, WPS) void cross_attn_f16x3_kernel(const mi_cross_attn_params p) {
     constexpr int KC = (C + 15) / 16, MT = (C + 15) / 16, FRH = 8 * KC + 8 * MT, TOK_WG = 64;
     __shared__ float red[4][2 * 16 * MT];
@@ -324,8 +326,10 @@ __global__ __launch_bounds__(256, WPS) void cross_attn_f16x3_kernel(const mi_cro
             for (int kc = 0; kc < KC; ++kc) {
                 const f16x4 ghi = *reinterpret_cast<const f16x4*>(gvh + (size_t)jt * 64 * FRH + 8 * kc);
                 const f16x4 glo = *reinterpret_cast<const f16x4*>(gvh + (size_t)jt * 64 * FRH + 8 * kc + 4);
-                acc = __builtin_amdgcn_mfma_f32_16x16x16f16(glo, xhi[kc], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x16f16(ghi, xlo[kc], acc, 0, 0, 0);
+                if constexpr (!HALF) {
+                    acc = __builtin_amdgcn_mfma_f32_16x16x16f16(glo, xhi[kc], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x16f16(ghi, xlo[kc], acc, 0, 0, 0);
+                }
                 acc = __builtin_amdgcn_mfma_f32_16x16x16f16(ghi, xhi[kc], acc, 0, 0, 0);
             }
             s[jt] = acc;
@@ -350,13 +354,20 @@ __global__ __launch_bounds__(256, WPS) void cross_attn_f16x3_kernel(const mi_cro
 #pragma unroll
             for (int r = 0; r < 4; ++r) { pe[r] = __builtin_amdgcn_exp2f(s[jt][r] - m); l += pe[r]; }
             f16x4 phi, plo;                       // B operand of PV: P[j = 16jt + 4lg + e][token lq] -- the C/D layout as it is
-            split_f16(pe, phi, plo);
+            if constexpr (HALF) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) phi[r] = (_Float16)pe[r];
+            } else {
+                split_f16(pe, phi, plo);
+            }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const f16x4 vhi = *reinterpret_cast<const f16x4*>(gvh + (size_t)jt * 64 * FRH + 8 * KC + 8 * mt);
                 const f16x4 vlo = *reinterpret_cast<const f16x4*>(gvh + (size_t)jt * 64 * FRH + 8 * KC + 8 * mt + 4);
-                oh[mt] = __builtin_amdgcn_mfma_f32_16x16x16f16(vlo, phi, oh[mt], 0, 0, 0);
-                oh[mt] = __builtin_amdgcn_mfma_f32_16x16x16f16(vhi, plo, oh[mt], 0, 0, 0);
+                if constexpr (!HALF) {
+                    oh[mt] = __builtin_amdgcn_mfma_f32_16x16x16f16(vlo, phi, oh[mt], 0, 0, 0);
+                    oh[mt] = __builtin_amdgcn_mfma_f32_16x16x16f16(vhi, plo, oh[mt], 0, 0, 0);
+                }
                 oh[mt] = __builtin_amdgcn_mfma_f32_16x16x16f16(vhi, phi, oh[mt], 0, 0, 0);
             }
         }
@@ -427,14 +438,18 @@ extern "C" int mi_cross_attn_fwd(const mi_cross_attn_params* pp, void* stream) {
     if (JT != 17) { mi_set_error("mi_cross_attn_fwd: context of %d rows (%d tiles) not instantiated (MinImagen: 1 + time tokens + 256)", p.J, JT); return MI_ERR_UNSUPPORTED; }
     if (p.B2 <= 0 || p.HW <= 0) { mi_set_error("mi_cross_attn_fwd: empty problem"); return MI_ERR_INVALID; }
     // out_stats tiles are MI_ATTN_TOKENS_PER_WG tokens (NQ = 2); p.variant = 1 selects NQ = 1 (64-token tiles)
-    if (p.variant == 6) {      // fp16x3 split on v_mfma_f32_16x16x16_f16 (fragments from mi_attn_fold_rows with frag_f16 = 1)
+    if (p.variant == 6 || p.variant == 7) {      // fp16 MFMA (fragments from mi_attn_fold_rows with frag_f16 = 1): 6 = 3-term split (fp32-grade), 7 = single term
         const dim3 g6(((p.HW + 63) / 64) * p.B2);
+#define MI_ATTN16_LAUNCH(CC) \
+        if (p.variant == 6) hipLaunchKernelGGL(HIP_KERNEL_NAME(cross_attn_f16x3_kernel<CC, 17, 3, false>), g6, dim3(256), 0, st, p); \
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(cross_attn_f16x3_kernel<CC, 17, 3, true>), g6, dim3(256), 0, st, p);
         switch (p.C) {
-            case 8: hipLaunchKernelGGL(HIP_KERNEL_NAME(cross_attn_f16x3_kernel<8, 17, 3>), g6, dim3(256), 0, st, p); break;
-            case 16: hipLaunchKernelGGL(HIP_KERNEL_NAME(cross_attn_f16x3_kernel<16, 17, 3>), g6, dim3(256), 0, st, p); break;
-            case 32: hipLaunchKernelGGL(HIP_KERNEL_NAME(cross_attn_f16x3_kernel<32, 17, 3>), g6, dim3(256), 0, st, p); break;
+            case 8: MI_ATTN16_LAUNCH(8) break;
+            case 16: MI_ATTN16_LAUNCH(16) break;
+            case 32: MI_ATTN16_LAUNCH(32) break;
             default: mi_set_error("mi_cross_attn_fwd: folded path instantiated for C in {8,16,32}, got %d", p.C); return MI_ERR_UNSUPPORTED;
         }
+#undef MI_ATTN16_LAUNCH
         return mi_check_launch("cross_attn_f16x3_kernel");
     }
     if (p.variant >= 3 && p.variant <= 5) {      // 16 / 32 tokens per wave with a register cap for 3, 4 / 2 waves per SIMD

@@ -25,10 +25,10 @@ extern "C" int mi_debug_read_trace(void* dst, size_t bytes) { return (int)hipMem
 
 namespace {
 
-template <int TW_, bool GN_, int NW_>
+template <int TW_, bool GN_, int NW_, bool HALF_>
 struct MfmaCfg {
     static constexpr int TW = TW_, TH = 512 / TW_;          // 8x64 or 16x32 output pixels per workgroup = 32 pixel-tiles of 16
-    static constexpr bool GN = GN_;
+    static constexpr bool GN = GN_, HALF = HALF_;          // HALF: single fp16 term per product (reduced-precision configuration)
     static constexpr int NW = NW_, NT = 64 * NW_;           // waves / work-items per workgroup
     static constexpr int TPW = 32 / NW_;                    // pixel-tiles per wave
     static constexpr int IH = TH + 2, WIN4 = (TW + 8) / 4, PW = 4 * WIN4;   // staged rows; float4 groups / pixels per staged row
@@ -43,8 +43,8 @@ template <class CFG>
 __global__ __launch_bounds__(CFG::NT, CFG::NW / 2) void conv3x3_mfma_kernel(const mi_conv_params p, const _Float16* __restrict__ wf, const _Float16* __restrict__ rwf) {
     constexpr int TW = CFG::TW, TH = CFG::TH, IH = CFG::IH, WIN4 = CFG::WIN4, PW = CFG::PW, XT = CFG::XT, PER = CFG::PER;
     constexpr int NT = CFG::NT, NW = CFG::NW, TPW = CFG::TPW;
-    constexpr bool GN = CFG::GN;
-    __shared__ __attribute__((aligned(16))) f16x4 actH[CFG::PLANE], actL[CFG::PLANE];
+    constexpr bool GN = CFG::GN, HALF = CFG::HALF;
+    __shared__ __attribute__((aligned(16))) f16x4 actH[CFG::PLANE], actL[HALF ? 1 : CFG::PLANE];
     __shared__ __attribute__((aligned(16))) f16x4 wl[5][64][4];         // this round's weight fragments: [tap pair][lane][hiA, hiB, loA, loB]
     __shared__ __attribute__((aligned(16))) float4 chP[MI_MAX_CIN + 1];
     __shared__ double chS[MI_MAX_CIN], chQ[MI_MAX_CIN];
@@ -210,9 +210,15 @@ __global__ __launch_bounds__(CFG::NT, CFG::NW / 2) void conv3x3_mfma_kernel(cons
             for (int e = 0; e < 4; ++e) {
                 f16x4 hi, lo;
                 const float ve[4] = {v[0][e], v[1][e], v[2][e], v[3][e]};
-                mi_split_f16(ve, hi, lo);
-                actH[dst + e] = hi;
-                actL[dst + e] = lo;
+                if constexpr (HALF) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) hi[k] = (_Float16)ve[k];
+                    actH[dst + e] = hi;
+                } else {
+                    mi_split_f16(ve, hi, lo);
+                    actH[dst + e] = hi;
+                    actL[dst + e] = lo;
+                }
             }
         }
         __syncthreads();
@@ -234,9 +240,11 @@ __global__ __launch_bounds__(CFG::NT, CFG::NW / 2) void conv3x3_mfma_kernel(cons
                 const int base = (lg * IH + gt / XT) * PW + 4 + 16 * (gt % XT) + lq - 1;
                 const int ia = base + (ta / 3) * PW + ta % 3, ib = base + (tb / 3) * PW + tb % 3;
                 const f16x8 ahi = __builtin_shufflevector(actH[ia], actH[ib], 0, 1, 2, 3, 4, 5, 6, 7);
-                const f16x8 alo = __builtin_shufflevector(actL[ia], actL[ib], 0, 1, 2, 3, 4, 5, 6, 7);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, whi, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, wlo, acc[t], 0, 0, 0);
+                if constexpr (!HALF) {
+                    const f16x8 alo = __builtin_shufflevector(actL[ia], actL[ib], 0, 1, 2, 3, 4, 5, 6, 7);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, whi, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, wlo, acc[t], 0, 0, 0);
+                }
                 acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, whi, acc[t], 0, 0, 0);
             }
         }
@@ -249,9 +257,12 @@ __global__ __launch_bounds__(CFG::NT, CFG::NW / 2) void conv3x3_mfma_kernel(cons
             for (int t = 0; t < TPW; ++t) {
                 const int gt = wave * TPW + t;
                 const int idx = (lg * IH + gt / XT + ky) * PW + 4 + 16 * (gt % XT) + lq + kx - 1;
-                const f16x4 ahi = actH[idx], alo = actL[idx];
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(alo, whi, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(ahi, wlo, acc[t], 0, 0, 0);
+                const f16x4 ahi = actH[idx];
+                if constexpr (!HALF) {
+                    const f16x4 alo = actL[idx];
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(alo, whi, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(ahi, wlo, acc[t], 0, 0, 0);
+                }
                 acc[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(ahi, whi, acc[t], 0, 0, 0);
             }
         }
@@ -294,9 +305,9 @@ __global__ __launch_bounds__(CFG::NT, CFG::NW / 2) void conv3x3_mfma_kernel(cons
     MI_STAMP(6);
 }
 
-template <int TW, bool GN, int NW>
+template <int TW, bool GN, int NW, bool HALF>
 int launch(const mi_conv_params& p, hipStream_t st) {
-    using CFG = MfmaCfg<TW, GN, NW>;
+    using CFG = MfmaCfg<TW, GN, NW, HALF>;
     const int tiles = ((p.H + CFG::TH - 1) / CFG::TH) * ((p.W + TW - 1) / TW);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_mfma_kernel<CFG>), dim3(tiles, p.B, (p.Cout + 15) / 16), dim3(CFG::NT), 0, st, p,
                        (const _Float16*)p.w_f16, (const _Float16*)p.res_w_f16);
@@ -306,7 +317,8 @@ int launch(const mi_conv_params& p, hipStream_t st) {
 template <int TW, bool GN>
 int launch_w(const mi_conv_params& p, hipStream_t st) {
     // MI_CONV_WAVES8: 8 waves x 4 pixel-tiles instead of 4 x 8 (same tile, same LDS; more waves in flight per CU)
-    return (p.tile_cfg & MI_CONV_WAVES8) ? launch<TW, GN, 8>(p, st) : launch<TW, GN, 4>(p, st);
+    if (p.tile_cfg & MI_CONV_HALF) return launch<TW, GN, 8, true>(p, st);       // reduced-precision configuration: single fp16 term
+    return (p.tile_cfg & MI_CONV_WAVES8) ? launch<TW, GN, 8, false>(p, st) : launch<TW, GN, 4, false>(p, st);
 }
 
 }  // namespace

@@ -62,6 +62,10 @@ class UnetEngine:
         self._pack = None
         self._pack_key = None
         self._ws = {}
+        # "fp32": every contraction fp32-grade (3-term fp16 splits on the matrix cores, fp32 VALU elsewhere);
+        # "half": the matrix-core contractions use a single fp16 term (fp32 accumulate / softmax / statistics / storage) --
+        #         the reduced-precision BASELINE configurations; parity gate 3e-2 / 3e-3 instead of 1e-4 / 1e-5
+        self.precision = os.environ.get("MINIMAGEN_PRECISION", "fp32")
 
     # ------------------------------------------------------------------ weights
     def _param_key(self):
@@ -170,13 +174,15 @@ class UnetEngine:
     def workspace(self, B: int, B2: int, H: int, W: int) -> Workspace:
         pk = self.pack()
         dev = next(self.unet.parameters()).device
-        key = (B, B2, H, W, str(dev))
+        assert self.precision in ("fp32", "half"), self.precision
+        key = (B, B2, H, W, str(dev), self.precision)
         ws = self._ws.get(key)
         if ws is not None:
             return ws
         u = self.unet
         ws = Workspace()
         ws.B, ws.B2, ws.H, ws.W, ws.dev = B, B2, H, W, dev
+        ws.half = self.precision == "half"
         f = lambda *shape: torch.zeros(*shape, dtype=torch.float32, device=dev)
         ws.x = f(B, u.channels, H, W)
         ws.lowres = f(B, u.channels, H, W) if u.lowres_cond else None
@@ -257,7 +263,7 @@ class UnetEngine:
             if r1 is not None:
                 p.res1 = r1.c(batch, skip_scale)
             p.res_w, p.res_b = L.ptr(rw), L.ptr(rb)
-        p.out, p.out_stats, p.tile_cfg = L.ptr(out.t), L.ptr(out.stats), cfg | (0x100 if CONV_SPLIT16 else 0) | (0x200 if CONV_WAVES8 else 0)
+        p.out, p.out_stats, p.tile_cfg = L.ptr(out.t), L.ptr(out.stats), cfg | (0x100 if CONV_SPLIT16 else 0) | (0x200 if CONV_WAVES8 else 0) | (0x400 if ws.half else 0)
         if mfma:
             p.w_f16 = L.ptr(pk.conv_f16[id(wpack)])
             if res is not None and res[2] is not None:
@@ -298,7 +304,7 @@ class UnetEngine:
         p.gv = L.ptr(gv)
         p.n1_g, p.n1_b = L.ptr(ca.norm.gamma), L.ptr(ca.norm.beta)
         p.n2_g, p.n2_b = L.ptr(ca.to_out[1].gamma), L.ptr(ca.to_out[1].beta)
-        p.out, p.out_stats, p.variant = L.ptr(out.t), L.ptr(out.stats), ATTN_VARIANT
+        p.out, p.out_stats, p.variant = L.ptr(out.t), L.ptr(out.stats), (7 if (ws.half and ATTN_VARIANT == 6) else ATTN_VARIANT)
         ws.prog.append((lib.mi_cross_attn_fwd, p, "cross_attn"))
         return out
 

@@ -37,6 +37,23 @@ def test_sample_matches_reference_golden(name, backend):
 
 
 @pytest.mark.parametrize("backend", GPU_ONLY)
+@pytest.mark.parametrize("name", ["sample_base_cs3.pt", "sample_cascade.pt"])
+def test_sample_half_precision_golden(name, backend):
+    """BASELINE's reduced-precision configurations (single fp16 term on the matrix cores; fp32 accumulate, softmax, statistics,
+    storage): SURVEY.md 8(c) half-precision gate max|d| <= 3e-2, mean|d| <= 3e-3 on [0,1] images vs the fp32 reference"""
+    dev = setup(backend)
+    g = I.load(name); m = g["meta"]
+    im = make_imagen(m["sizes"], m["T"], dev)
+    emb, mask = I.text(m)
+    out = im.sample(text_embeds=emb.to(dev), text_masks=mask.to(dev), cond_scale=m["cond_scale"], _noise=R.make_randn(m["noise_seed"]), _precision="half")
+    d = (out.cpu() - g["out"]).abs()
+    assert d.max() < 3e-2 and d.mean() < 3e-3, (d.max(), d.mean())
+    assert d.max() > 2e-6                                              # the reduced-precision kernels really ran
+    out32 = im.sample(text_embeds=emb.to(dev), text_masks=mask.to(dev), cond_scale=m["cond_scale"], _noise=R.make_randn(m["noise_seed"]))
+    assert (out32.cpu() - g["out"]).abs().max() < 1e-4                  # and the default stays fp32-grade
+
+
+@pytest.mark.parametrize("backend", GPU_ONLY)
 def test_step_golden(backend):
     """one _p_sample step through the kernels vs the reference (t=13 and t=0)"""
     import ctypes as C

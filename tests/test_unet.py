@@ -36,6 +36,27 @@ def test_forward_A_golden(backend):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
+def test_forward_A_half_precision(backend):
+    """the reduced-precision configuration (single fp16 term on the matrix cores, fp32 accumulate / softmax / statistics):
+    within the half-precision gate of SURVEY.md 8(c), and measurably different from the fp32-grade path (i.e. really active)"""
+    dev = setup(backend)
+    u0 = make_unet("unet0", dev)
+    g = I.load("fwdA.pt"); m = g["meta"]
+    emb, mask = I.text(m)
+    x = I.seeded((2, 3, 64, 64), m["x_seed"]).to(dev)
+    tm = torch.tensor(m["time"]).to(dev)
+    u0.engine().precision = "half"
+    oc = u0(x, tm, text_embeds=emb.to(dev), text_mask=mask.to(dev), cond_drop_prob=0.)
+    u0.engine().precision = "fp32"
+    of = u0(x, tm, text_embeds=emb.to(dev), text_mask=mask.to(dev), cond_drop_prob=0.)
+    d = (oc.cpu() - g["out_cond"]).abs()
+    scale = g["out_cond"].abs().max()
+    assert d.max() < 3e-2 * scale and d.mean() < 3e-3 * scale, (d.max(), d.mean(), scale)
+    assert d.max() > 10 * FWD_ATOL                                   # not the fp32-grade path
+    assert (of.cpu() - g["out_cond"]).abs().max() < FWD_ATOL         # switching back restores it
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
 def test_forward_B_golden_lowres(backend):
     dev = setup(backend)
     u1 = make_unet("unet1", dev)
