@@ -358,12 +358,11 @@ class UnetEngine:
         """one mi_attn_fold_rows launch covering every cross-attention block (they share C in practice; else one per C)"""
         lib = L.lib()
         calls = []
-        by_c = {}
-        for ca_id, gv in ws.gv.items():
-            by_c.setdefault(gv.shape[-1], []).append(ca_id)
         cas = {id(m): m for m in self.unet.modules() if isinstance(m, CrossAttention)}
-        by_c = {k: [i for i in v if i in cas] for k, v in by_c.items()}
-        by_c = {k: v for k, v in by_c.items() if v}
+        by_c = {}                       # one launch per channel count C (NOT per fragment size: C = 8 and C = 16 share FR = 8 floats)
+        for ca_id in ws.gv:
+            if ca_id in cas:
+                by_c.setdefault(cas[ca_id].to_q.in_features, []).append(ca_id)
         for _, ids in by_c.items():
             for i0 in range(0, len(ids), 8):
                 chunk = ids[i0:i0 + 8]

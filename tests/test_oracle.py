@@ -142,3 +142,26 @@ def test_against_reference_directly(sds):
         a = ua(xa, torch.tensor([3, 9]), text_embeds=emb[:2], text_mask=mask[:2])
     b = R.unet_forward(ua.state_dict(), xa, torch.tensor([3, 9]), text_embeds=emb[:2], text_mask=mask[:2])
     assert torch.allclose(a, b, atol=5e-6, rtol=1e-6)
+
+
+@pytest.mark.skipif(not ref_loader.reference_available(), reason="reference only exists in the build container")
+def test_sweep_configs_against_reference_directly():
+    """the constructor-argument sweep of tests/test_unet.py::test_config_sweep_vs_oracle: the oracle equals the unmodified reference"""
+    from tests.test_unet import SWEEP
+    ref = ref_loader.load_reference()
+    for case, (kw, S, extra) in sorted(SWEEP.items()):
+        torch.manual_seed(1)
+        ru = ref.Unet(**kw).eval()
+        sd = {k: v.clone() for k, v in ru.state_dict().items()}
+        E, ch = extra.get("E", 512), extra.get("ch", 3)
+        emb, mask = R.synthetic_text(2, length=10, seed=3)
+        if E != 512:
+            emb = torch.randn(2, 10, E, generator=torch.Generator().manual_seed(3)).masked_fill(~mask[:, :, None], 0.)
+        x, tm = I.seeded((2, ch, S, S), 6), torch.tensor([3, 9])
+        kwargs = dict(text_embeds=emb, text_mask=mask)
+        if extra.get("lowres"):
+            kwargs.update(lowres_cond_img=I.seeded((2, ch, S, S), 7), lowres_noise_times=torch.tensor([5, 5]))
+        with torch.no_grad():
+            a = ru(x, tm, **kwargs)
+        b = R.unet_forward(sd, x, tm, **kwargs)
+        assert torch.allclose(a, b, atol=5e-6, rtol=1e-6), case

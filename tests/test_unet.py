@@ -176,6 +176,45 @@ def test_attention_bearing_unet_vs_oracle(backend):
     assert (out.cpu() - ref).abs().max() < 4e-5
 
 
+_NARROW = dict(dim=8, dim_mults=(1, 2), num_resnet_blocks=1, layer_attns=False, layer_cross_attns=(False, True), memory_efficient=False)
+SWEEP = {
+    # non-memory-efficient levels run at dim_in: cross-attention at C = 8 AND C = 16 in one U-Net (they share a fragment size)
+    "ragged_48": (_NARROW, 48, {}),
+    "ragged_36": (_NARROW, 36, {}),
+    "three_levels": (dict(dim=8, dim_mults=(1, 2, 4), num_resnet_blocks=(1, 2, 1), layer_attns=False, layer_cross_attns=(False, True, True), memory_efficient=True), 64, {}),
+    "t5_base_width": ({**_NARROW, "text_embed_dim": 768}, 32, {"E": 768}),
+    "cond_dim_16": ({**_NARROW, "cond_dim": 16, "num_resnet_blocks": 2}, 32, {}),
+    "one_channel": ({**_NARROW, "channels": 1}, 32, {"ch": 1}),
+    "four_heads": ({**_NARROW, "attn_heads": 4}, 32, {}),
+    "dim16": ({**_NARROW, "dim": 16, "num_resnet_blocks": 2}, 32, {}),
+    "lowres_96": (dict(dim=8, dim_mults=(1, 2), num_resnet_blocks=(1, 2), layer_attns=False, layer_cross_attns=False, memory_efficient=True, lowres_cond=True), 96, {"lowres": True}),
+}
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("case", sorted(SWEEP))
+def test_config_sweep_vs_oracle(backend, case):
+    """constructor arguments away from the two BASELINE parameter files (ragged image sizes, three levels, other text /
+    conditioning widths, head counts, channel counts), each against the oracle (which equals the reference bit for bit on these)"""
+    dev = setup(backend)
+    kw, S, extra = SWEEP[case]
+    torch.manual_seed(1)
+    u = Unet(**kw)
+    sd = {k: v.clone() for k, v in u.state_dict().items()}
+    u = u.to(dev)
+    E, ch = extra.get("E", 512), extra.get("ch", 3)
+    emb, mask = R.synthetic_text(2, length=10, seed=3)
+    if E != 512:
+        emb = torch.randn(2, 10, E, generator=torch.Generator().manual_seed(3)).masked_fill(~mask[:, :, None], 0.)
+    x, tm = I.seeded((2, ch, S, S), 6), torch.tensor([3, 9])
+    kwargs = dict(text_embeds=emb, text_mask=mask)
+    if extra.get("lowres"):
+        kwargs.update(lowres_cond_img=I.seeded((2, ch, S, S), 7), lowres_noise_times=torch.tensor([5, 5]))
+    ref = R.unet_forward(sd, x, tm, **kwargs)
+    out = u(x.to(dev), tm.to(dev), **{k: v.to(dev) for k, v in kwargs.items()})
+    assert (out.cpu() - ref).abs().max() < FWD_ATOL
+
+
 @pytest.mark.parametrize("backend", GPU_ONLY)
 def test_self_attention_4096_tokens(backend):
     """K10 at full token count: layer_attns at the 64x64 level (4096 tokens + null row -> 17 context chunks of 256)"""
