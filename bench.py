@@ -158,7 +158,7 @@ def pmc_traffic(dom, rows, S):
     null when no committed profile matches the launch shape."""
     import csv
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_cascade_T20_pmc_by_launch_shape.csv")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_cascade_T25_pmc_by_launch_shape.csv")))
     if not files or dom["kernel"] != "cross_attn":
         return {"traffic": None}
     grid = rows * (-(-(S // 4) * (S // 4) // 64)) * 256          # bottleneck level = S/4; 64 tokens per 256-thread workgroup

@@ -33,11 +33,14 @@ __global__ __launch_bounds__(256) void text_cond_kernel(const mi_text_cond_param
     float* crow = p.c_text + (size_t)bb * p.max_len * p.cd;
     // 1. projected / null tokens (pre-norm) -> c_text
     for (int j = tid; j < p.max_len; j += NT) {
-        const bool valid = keep && j < p.L && (p.text_mask == nullptr || p.text_mask[(size_t)b * p.L + j] != 0);
-        const float* e = p.text_embeds + ((size_t)b * p.L + j) * p.E;
+        // Unet.py:581-603: rows past the caption are zero-PADDED after the projection (no bias); the padded mask is False there, so
+        // with a mask they become null embeddings -- but WITHOUT a mask every row of a kept sample stays, the padding as exact zeros
+        const bool in_caption = j < p.L;
+        const bool valid = keep && (p.text_mask == nullptr || (in_caption && p.text_mask[(size_t)b * p.L + j] != 0));
+        const float* e = p.text_embeds + ((size_t)b * p.L + (in_caption ? j : 0)) * p.E;
         for (int o = 0; o < p.cd; ++o) {
             float v;
-            if (valid) v = dot_row(p.text_to_cond.w + (size_t)o * p.E, e, p.E) + (p.text_to_cond.b ? p.text_to_cond.b[o] : 0.0f);
+            if (valid) v = in_caption ? dot_row(p.text_to_cond.w + (size_t)o * p.E, e, p.E) + (p.text_to_cond.b ? p.text_to_cond.b[o] : 0.0f) : 0.0f;
             else v = p.null_text_embed[(size_t)j * p.cd + o];
             crow[(size_t)j * p.cd + o] = v;
         }

@@ -13,7 +13,7 @@ from oracle import restated as R
 from tests import _inputs as I
 from tests._backend import BACKENDS, setup
 
-IMAGEN_PARAMS = {"text_embed_dim": None, "channels": 3, "timesteps": 20, "cond_drop_prob": 0.15, "loss_type": "l2",
+IMAGEN_PARAMS = {"text_embed_dim": None, "channels": 3, "timesteps": 25, "cond_drop_prob": 0.15, "loss_type": "l2",
                  "lowres_sample_noise_level": 0.2, "auto_normalize_img": True, "dynamic_thresholding_percentile": 0.9,
                  "only_train_unet_number": None, "image_sizes": [64], "text_encoder_name": "t5_small"}
 
@@ -40,7 +40,7 @@ def test_load_params_and_checkpoint_selection(tmp_path):
     m = G.load_minimagen(d)
     sd = I.load("unet0_sd.pt")
     assert all(torch.equal(v, sd[k]) for k, v in m.unets[0].state_dict().items())
-    assert m.noise_schedulers[0].num_timesteps == 20 and list(m.image_sizes) == [64]
+    assert m.noise_schedulers[0].num_timesteps == 25 and list(m.image_sizes) == [64]
     m2 = G.load_minimagen(make_training_dir(tmp_path / "b", where="tmp"))           # generate.py:105-119
     assert all(torch.equal(v, sd[k]) for k, v in m2.unets[0].state_dict().items())
     with pytest.raises(ValueError):

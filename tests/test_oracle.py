@@ -158,7 +158,7 @@ def test_sweep_configs_against_reference_directly():
         if E != 512:
             emb = torch.randn(2, 10, E, generator=torch.Generator().manual_seed(3)).masked_fill(~mask[:, :, None], 0.)
         x, tm = I.seeded((2, ch, S, S), 6), torch.tensor([3, 9])
-        kwargs = dict(text_embeds=emb, text_mask=mask)
+        kwargs = dict(text_embeds=emb, text_mask=None if extra.get("nomask") else mask)
         if extra.get("lowres"):
             kwargs.update(lowres_cond_img=I.seeded((2, ch, S, S), 7), lowres_noise_times=torch.tensor([5, 5]))
         with torch.no_grad():

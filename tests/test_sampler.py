@@ -80,7 +80,7 @@ def test_step_golden(backend):
 def test_determinism_graph_and_sharding(backend):
     dev = setup(backend)
     gpu = backend == "gpu"
-    T, B, cs = (20, 4, 3.) if gpu else (20, 2, 1.)                     # the emulator runs the same launches ~1e4x slower: fewer rows, no CFG
+    T, B, cs = (25, 4, 3.) if gpu else (21, 2, 1.)                     # the emulator runs the same launches ~1e4x slower: fewer rows, no CFG
     im = make_imagen([64], T, dev)
     emb, mask = R.synthetic_text(B, length=16, seed=7)
     emb, mask = emb.to(dev), mask.to(dev)
@@ -104,7 +104,7 @@ def test_determinism_graph_and_sharding(backend):
 def test_cascade_full_size_properties(backend):
     """BASELINE sizes (64 -> 256, B=4): finite, in range, deterministic, sharding-invariant with on-device noise"""
     dev = setup(backend)
-    im = make_imagen([64, 256], 20, dev)
+    im = make_imagen([64, 256], 25, dev)
     emb, mask = R.synthetic_text(4, length=64, seed=7)
     a = im.sample(text_embeds=emb.to(dev), text_masks=mask.to(dev), cond_scale=3., _seed=5)
     assert a.shape == (4, 3, 256, 256) and torch.isfinite(a).all() and a.min() >= 0 and a.max() <= 1
@@ -117,7 +117,7 @@ def test_three_stage_cascade_properties(backend):
     """BASELINE config 5 shape (64 -> 256 -> 1024, third U-Net = unet_1 params, noise augmentation on both SR stages), B=2:
     finite, in range, sharding-invariant"""
     dev = setup(backend)
-    im = make_imagen([64, 256, 1024], 20, dev)
+    im = make_imagen([64, 256, 1024], 25, dev)
     emb, mask = R.synthetic_text(2, length=64, seed=7)
     a = im.sample(text_embeds=emb.to(dev), text_masks=mask.to(dev), cond_scale=3., lowres_sample_noise_level=0.2, _seed=5)
     assert a.shape == (2, 3, 1024, 1024) and torch.isfinite(a).all() and a.min() >= 0 and a.max() <= 1
@@ -126,9 +126,44 @@ def test_three_stage_cascade_properties(backend):
     assert torch.equal(e, a[1:])
 
 
+_BASE = dict(dim=8, dim_mults=(1, 2), num_resnet_blocks=1, layer_attns=False, layer_cross_attns=False, memory_efficient=False)
+_SR = dict(dim=8, dim_mults=(1, 2), num_resnet_blocks=(1, 2), layer_attns=False, layer_cross_attns=False, memory_efficient=True)
+ARG_SWEEP = {   # Imagen kwargs, sample kwargs, image sizes, batch, caption length
+    "percentile_095": (dict(dynamic_thresholding_percentile=0.95), dict(cond_scale=2.), [32], 3, 10),
+    "lowres_noise_05": (dict(lowres_sample_noise_level=0.5), dict(cond_scale=1.), [32, 64], 2, 10),
+    "no_text_mask": (dict(), dict(cond_scale=2., nomask=True), [32], 2, 10),
+    "caption_longer_than_256": (dict(), dict(cond_scale=2.), [32], 2, 300),
+    "one_channel": (dict(channels=1), dict(cond_scale=2.), [32], 2, 10),
+    "odd_batch_no_guidance": (dict(), dict(cond_scale=1.), [32], 5, 10),
+}
+
+
+@pytest.mark.parametrize("backend", GPU_ONLY)
+@pytest.mark.parametrize("case", sorted(ARG_SWEEP))
+def test_sampler_argument_sweep_vs_oracle(backend, case):
+    """Imagen / sample() arguments away from the BASELINE parameter files, full sample() against the oracle (same injected noise)"""
+    dev = setup(backend)
+    ikw, skw, sizes, B, Ltxt = ARG_SWEEP[case]
+    skw = dict(skw)
+    torch.manual_seed(2)
+    ch = ikw.get("channels", 3)
+    unets = [Unet(**{**_BASE, "channels": ch})] + [Unet(**{**_SR, "channels": ch, "lowres_cond": True}) for _ in sizes[1:]]
+    im = Imagen(unets, text_encoder_name="t5_small", image_sizes=sizes, timesteps=25, cond_drop_prob=0.15, **ikw)
+    sds = [{k: v.clone() for k, v in u.state_dict().items()} for u in im.unets]
+    im = im.to(dev)
+    emb, mask = R.synthetic_text(B, length=Ltxt, seed=3)
+    if skw.pop("nomask", False):
+        mask = None
+    out = im.sample(text_embeds=emb.to(dev), text_masks=None if mask is None else mask.to(dev), _noise=R.make_randn(5), **skw)
+    ref = R.sample(sds, sizes, 25, text_embeds=emb, text_masks=mask, cond_scale=skw.get("cond_scale", 1.), randn=R.make_randn(5),
+                   lowres_sample_noise_level=ikw.get("lowres_sample_noise_level", 0.2), percentile=ikw.get("dynamic_thresholding_percentile", 0.9), channels=ch)
+    d = (out.cpu() - ref).abs()
+    assert d.max() < 1e-4 and d.mean() < 1e-5, (d.max(), d.mean())
+
+
 def test_api_errors():
     setup("emu")
-    im = make_imagen([64], 20, "cpu", cond_drop_prob=0.)
+    im = make_imagen([64], 25, "cpu", cond_drop_prob=0.)
     emb, mask = R.synthetic_text(1, length=8, seed=1)
     with pytest.raises(AssertionError):
         im.sample(text_embeds=emb, text_masks=mask, cond_scale=3.)      # Imagen.py:291-295: no CFG without cond dropout

@@ -186,6 +186,7 @@ SWEEP = {
     "cond_dim_16": ({**_NARROW, "cond_dim": 16, "num_resnet_blocks": 2}, 32, {}),
     "one_channel": ({**_NARROW, "channels": 1}, 32, {"ch": 1}),
     "four_heads": ({**_NARROW, "attn_heads": 4}, 32, {}),
+    "no_text_mask": (_NARROW, 32, {"nomask": True}),            # Unet.py:581-603: the zero padding after the projection stays zero
     "dim16": ({**_NARROW, "dim": 16, "num_resnet_blocks": 2}, 32, {}),
     "lowres_96": (dict(dim=8, dim_mults=(1, 2), num_resnet_blocks=(1, 2), layer_attns=False, layer_cross_attns=False, memory_efficient=True, lowres_cond=True), 96, {"lowres": True}),
 }
@@ -207,11 +208,11 @@ def test_config_sweep_vs_oracle(backend, case):
     if E != 512:
         emb = torch.randn(2, 10, E, generator=torch.Generator().manual_seed(3)).masked_fill(~mask[:, :, None], 0.)
     x, tm = I.seeded((2, ch, S, S), 6), torch.tensor([3, 9])
-    kwargs = dict(text_embeds=emb, text_mask=mask)
+    kwargs = dict(text_embeds=emb, text_mask=None if extra.get("nomask") else mask)
     if extra.get("lowres"):
         kwargs.update(lowres_cond_img=I.seeded((2, ch, S, S), 7), lowres_noise_times=torch.tensor([5, 5]))
     ref = R.unet_forward(sd, x, tm, **kwargs)
-    out = u(x.to(dev), tm.to(dev), **{k: v.to(dev) for k, v in kwargs.items()})
+    out = u(x.to(dev), tm.to(dev), **{k: (v.to(dev) if v is not None else None) for k, v in kwargs.items()})
     assert (out.cpu() - ref).abs().max() < FWD_ATOL
 
 

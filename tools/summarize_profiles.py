@@ -30,7 +30,7 @@ def load(path):
     return d
 
 
-shutil.copy(f"{G}/prof_trace/cascade_kernel_stats.csv", f"profiles/{tag}_cascade_T20_kernel_stats.csv")
+shutil.copy(f"{G}/prof_trace/cascade_kernel_stats.csv", f"profiles/{tag}_cascade_T25_kernel_stats.csv")
 a, b = load(f"{G}/prof_sq/cascade_counter_collection.csv"), load(f"{G}/prof_sq2/cascade_counter_collection.csv")
 f, w = load(f"{G}/prof_fetch/cascade_counter_collection.csv"), load(f"{G}/prof_write/cascade_counter_collection.csv")
 rows = []
@@ -52,7 +52,7 @@ for key, c in a.items():
         fetch_MB_x2=round(2 * st.mean(f[key]["FETCH_SIZE"]) / 1024, 1) if key in f and "FETCH_SIZE" in f[key] else None,
         write_MB=round(st.mean(w[key]["WRITE_SIZE"]) / 1024, 1) if key in w and "WRITE_SIZE" in w[key] else None))
 rows.sort(key=lambda r: -r["total_ms"])
-with open(f"profiles/{tag}_cascade_T20_pmc_by_launch_shape.csv", "w", newline="") as fh:
+with open(f"profiles/{tag}_cascade_T25_pmc_by_launch_shape.csv", "w", newline="") as fh:
     wr = csv.DictWriter(fh, fieldnames=list(rows[0].keys()))
     wr.writeheader()
     wr.writerows(rows)
