@@ -315,6 +315,7 @@ def main():
     if rank == 0:
         print(json.dumps(res))
     if world > 1:
+        dist.barrier()               # rank 0 did the (untimed) per-kernel breakdown: leave together
         dist.destroy_process_group()
 
 
