@@ -38,14 +38,14 @@ __device__ __forceinline__ int mi_row_of(int b, int bmod) {
 }
 
 // GroupNorm statistics of a conv input (in0 ++ in1): the producers left per-tile partial (sum, sum of squares) per channel;
-// ONE wave (64 lanes, TPC lanes per channel) adds them up in a fixed order in fp64 -> chS / chQ.  Deterministic, and the
-// result does not depend on how the batch is sharded.  Called first thing in the kernel so that these short latency-bound
-// loads are in flight before the bulk input loads.
-__device__ __forceinline__ void mi_gn_channel_totals(const mi_act& in0, const mi_act& in1, int C0, int Cin, int b, int lane,
+// the first `nlanes` work-items (a multiple of 64; TPC <= 64 lanes per channel, never straddling a wave) add them up in a fixed
+// order in fp64 -> chS / chQ.  Deterministic, and the result does not depend on how the batch is sharded.  Called first thing in
+// the kernel so that these short latency-bound loads are in flight before the bulk input loads.
+__device__ __forceinline__ void mi_gn_channel_totals(const mi_act& in0, const mi_act& in1, int C0, int Cin, int b, int lane, int nlanes,
                                                      double* chS, double* chQ) {
     int TPC = 1;
-    while (TPC < 64 && TPC * 2 * Cin <= 64) TPC *= 2;
-    const int CPP = 64 / TPC;                       // channels per pass
+    while (TPC < 64 && TPC * 2 * Cin <= nlanes) TPC *= 2;
+    const int CPP = nlanes / TPC;                   // channels per pass
     for (int base = 0; base < Cin; base += CPP) {
         const int c = base + lane / TPC, sub = lane % TPC;
         double s = 0.0, q = 0.0;

@@ -85,7 +85,7 @@ __global__ __launch_bounds__(CFG::NT) void conv_tile_kernel(const mi_conv_params
     MI_TSTART();
     // per-channel totals of the producer's per-tile partial sums: wave 0 only, first thing (see common.hip.h)
     if constexpr (CFG::GN) {
-        if (tid < 64) mi_gn_channel_totals(p.in0, p.in1, C0, Cin, b, tid, chS, chQ);
+        mi_gn_channel_totals(p.in0, p.in1, C0, Cin, b, tid, NT, chS, chQ);       // all waves: one round trip instead of nt / TPC
     }
 
     // Staging is split (T14): a round's global loads are issued back-to-back into registers with clamped
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(CFG::NT) void conv_tile_kernel(const mi_conv_params
     const int sy0 = UP2 ? oy0 / 2 - 1 : iy0, sx0 = UP2 ? ox0 / 2 - 4 : ox0 * S - 4;      // source coordinates of the staged window
     float4 xq4[VEC ? PER4 : 1];
     // per-work-item staging slots (tile geometry only -> identical for every channel round):
-    //   msrc = element offset of the float4 inside one channel plane, or -1 when the slot is outside the image
+    //   msrc = element offset of the float4 from the first channel plane of a round, or -1 when the slot is outside the image
     //   mdst = LDS index of the float4 (16-byte aligned), or -1 for an unused slot; mck = channel within the round
     int msrc[VEC ? PER4 : 1], mdst[VEC ? PER4 : 1], mck[VEC ? PER4 : 1];
     if constexpr (VEC) {
@@ -109,21 +109,20 @@ __global__ __launch_bounds__(CFG::NT) void conv_tile_kernel(const mi_conv_params
             const int ck = rowid / IHS, iy = rowid % IHS;
             const int gy = sy0 + iy, gx0 = sx0 + 4 * xq;
             const bool in = (ck < CK) && gy >= 0 && gy < Hin && gx0 >= 0 && gx0 < Win;
-            msrc[u] = in ? gy * Win + gx0 : -1;
+            msrc[u] = in ? ck * Hin * Win + gy * Win + gx0 : -1;       // relative to the round's first channel plane
             mdst[u] = (ck < CK) ? (ck * IHS + iy) * IWP + 4 * xq : -1;
             mck[u] = ck;
         }
     }
     auto stage_load = [&](int c0) {
         if constexpr (VEC) {
+            // the vector path requires Cin % CK == 0 and C0 % CK == 0: a round never straddles the two concatenated inputs, so
+            // its base pointer is wave-uniform (SGPR) and every load is base + a per-slot offset computed once per tile
+            const bool second = c0 >= C0;
+            const float* base = second ? p.in1.data + (size_t)(b1 * C1 + (c0 - C0)) * Hin * Win : p.in0.data + (size_t)(b0 * C0 + c0) * Hin * Win;
 #pragma unroll
             for (int u = 0; u < PER4; ++u) {
-                const int c = c0 + mck[u];            // the vector path requires Cin % CK == 0, so c < Cin
-                const bool inimg = msrc[u] >= 0;
-                const bool second = inimg && c >= C0;
-                const float* base = second ? p.in1.data : p.in0.data;
-                const int cc = second ? (b1 * C1 + (c - C0)) : (b0 * C0 + c);
-                const unsigned off = inimg ? (unsigned)(cc * Hin * Win + msrc[u]) : 0u;   // unused slots read element 0 (legal, ignored)
+                const unsigned off = msrc[u] >= 0 ? (unsigned)msrc[u] : 0u;     // unused / outside slots read element 0 (legal, ignored)
                 xq4[u] = *reinterpret_cast<const float4*>(base + off);
             }
         }

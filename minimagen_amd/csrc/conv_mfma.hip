@@ -67,7 +67,7 @@ __global__ __launch_bounds__(CFG::NT, CFG::NW / 2) void conv3x3_mfma_kernel(cons
     // ---------------- GroupNorm statistics of the input: wave 0 reduces the producers' per-tile partial sums (fp64) FIRST, so its
     // (short, latency-bound) loads are already in flight while every wave computes its staging geometry and issues round 0's loads
     if constexpr (GN) {
-        if (tid < 64) mi_gn_channel_totals(p.in0, p.in1, C0, Cin, b, tid, chS, chQ);
+        mi_gn_channel_totals(p.in0, p.in1, C0, Cin, b, tid, NT, chS, chQ);
     }
     // ---------------- staging slots (geometry only): unit = (channel quad, staged row, float4 group)
     int msrc[PER], mdst[PER];
