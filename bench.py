@@ -187,9 +187,18 @@ def cpu_baseline():
         if time.time() - t0 > 20.0:
             break
     dt = time.time() - t0
+    # plus one SR U-Net forward (unet_1 params, lowres conditioning, 256x256) at B=4 on the same host threads
+    sd1 = torch.load(os.path.join(ROOT, "tests", "golden", "unet1_sd.pt"), weights_only=False)
+    x1, lr1 = randn((4, 3, 256, 256)), randn((4, 3, 256, 256))
+    tm, lt = torch.full((4,), 50), torch.full((4,), 20)
+    R.unet_forward(sd1, x1, tm, lowres_cond_img=lr1, lowres_noise_times=lt, text_embeds=emb, text_mask=mask)          # warm-up
+    t1 = time.time()
+    R.unet_forward(sd1, x1, tm, lowres_cond_img=lr1, lowres_noise_times=lt, text_embeds=emb, text_mask=mask)
+    sr_ms = (time.time() - t1) * 1e3
     return dict(value=B * done / dt, unit="denoising-steps/s", cores=ncores, kind="port",
                 sample=f"oracle/restated.py p_sample loop: base U-Net (unet_0 params) 64x64, B=4, cond_scale=3 (BASELINE config 1), "
-                       f"{done} of {T} timesteps in {dt:.1f}s on {ncores} host threads")
+                       f"{done} of {T} timesteps in {dt:.1f}s on {ncores} host threads",
+                sr_unet_forward_B4_ms=sr_ms)
 
 
 def main():
