@@ -86,6 +86,7 @@ typedef struct mi_conv_params {
     const void* res_w_f16;
 } mi_conv_params;
 #define MI_CONV_SPLIT16 0x100
+#define MI_CONV_SPLIT8  0x800   /* 8-channel outputs as two 4-channel workgroups (small, latency-bound launches) */
 #define MI_CONV_HALF    0x400   /* matrix-core path: single fp16 term per product (reduced-precision configuration; parity gate 3e-2) */
 #define MI_CONV_WAVES8  0x200   /* matrix-core path: 8 waves x 4 pixel-tiles per workgroup instead of 4 x 8 */
 

@@ -440,9 +440,12 @@ extern "C" int mi_cross_attn_fwd(const mi_cross_attn_params* pp, void* stream) {
     // out_stats tiles are MI_ATTN_TOKENS_PER_WG tokens (NQ = 2); p.variant = 1 selects NQ = 1 (64-token tiles)
     if (p.variant == 6 || p.variant == 7) {      // fp16 MFMA (fragments from mi_attn_fold_rows with frag_f16 = 1): 6 = 3-term split (fp32-grade), 7 = single term
         const dim3 g6(((p.HW + 63) / 64) * p.B2);
+#ifndef MI_ATTN_WPS
+#define MI_ATTN_WPS 3            /* waves per SIMD the register budget is set for (C <= 16; C = 32 needs the 3-wave budget) */
+#endif
 #define MI_ATTN16_LAUNCH(CC) \
-        if (p.variant == 6) hipLaunchKernelGGL(HIP_KERNEL_NAME(cross_attn_f16x3_kernel<CC, 17, 3, false>), g6, dim3(256), 0, st, p); \
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(cross_attn_f16x3_kernel<CC, 17, 3, true>), g6, dim3(256), 0, st, p);
+        if (p.variant == 6) hipLaunchKernelGGL(HIP_KERNEL_NAME(cross_attn_f16x3_kernel<CC, 17, (CC <= 16 ? MI_ATTN_WPS : 3), false>), g6, dim3(256), 0, st, p); \
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(cross_attn_f16x3_kernel<CC, 17, (CC <= 16 ? MI_ATTN_WPS : 3), true>), g6, dim3(256), 0, st, p);
         switch (p.C) {
             case 8: MI_ATTN16_LAUNCH(8) break;
             case 16: MI_ATTN16_LAUNCH(16) break;

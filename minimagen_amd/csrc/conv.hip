@@ -438,19 +438,21 @@ extern "C" int mi_conv_fwd(const mi_conv_params* pp, void* stream) {
     if (p.up2 && ((p.H | p.W) & 1)) { mi_set_error("mi_conv_fwd: up2 needs even output size"); return MI_ERR_INVALID; }
     if (p.w_f16) return mi_conv_mfma_launch(p, st);
     const int ct = mi_conv_cout_tile(p.Cout);
+    // MI_CONV_SPLIT8: 8 output channels as two 4-channel workgroups -- twice the waves for the small (latency-bound) launches
+    const bool split8 = (p.tile_cfg & MI_CONV_SPLIT8) && ct == 8 && p.Cout == 8;
     if (p.ksize == 3 && p.stride == 1 && !p.up2) {
-        if (ct == 4) return dispatch_tile<4, 3, 1, false>(p, st);
+        if (ct == 4 || split8) return dispatch_tile<4, 3, 1, false>(p, st);
         if (ct == 8 || (p.tile_cfg & MI_CONV_SPLIT16)) return dispatch_tile<8, 3, 1, false>(p, st);
         return dispatch_tile<16, 3, 1, false>(p, st);
     }
     if (p.ksize == 3 && p.stride == 1 && p.up2) {
         if (ct == 16) return dispatch_tile<16, 3, 1, true>(p, st);
-        if (ct == 8) return dispatch_tile<8, 3, 1, true>(p, st);
+        if (ct == 8 && !split8) return dispatch_tile<8, 3, 1, true>(p, st);
         return dispatch_tile<4, 3, 1, true>(p, st);
     }
     if (p.ksize == 4 && p.stride == 2 && !p.up2) {
         if (ct == 16) return dispatch_tile<8, 4, 2, false>(p, st);     // 16 taps x 16 channels would not fit the SGPR file: 2 channel tiles
-        if (ct == 8) return dispatch_tile<8, 4, 2, false>(p, st);
+        if (ct == 8 && !split8) return dispatch_tile<8, 4, 2, false>(p, st);
         return dispatch_tile<4, 4, 2, false>(p, st);
     }
     mi_set_error("mi_conv_fwd: unsupported conv k%d s%d up%d", p.ksize, p.stride, p.up2);

@@ -27,6 +27,7 @@ MAX_TEXT_LEN = 256
 # kernel-shape tuning knobs (A/B measurements; the defaults are what profiles/ was measured with)
 ATTN_VARIANT = int(os.environ.get("MINIMAGEN_ATTN_VARIANT", "6"))       # 6: fp16x3 MFMA (default); 0/1/3/4/5: exact-fp32 MFMA shapes
 CONV_SPLIT16 = int(os.environ.get("MINIMAGEN_CONV_SPLIT16", "1"))
+CONV_SPLIT8 = int(os.environ.get("MINIMAGEN_CONV_SPLIT8", "64"))        # 8-channel outputs of images up to SPLIT8^2 pixels as two 4-channel workgroups (0 = off)
 CONV_WAVES8 = int(os.environ.get("MINIMAGEN_CONV_WAVES8", "1"))        # matrix-core conv: 8 waves x 4 pixel-tiles per workgroup
 CONV_MFMA = int(os.environ.get("MINIMAGEN_CONV_MFMA", "1"))             # 1: wide (>=16 in, >=16 out) k3 s1 convs on the matrix cores; 2: all k3 s1
 TILE64 = int(os.environ.get("MINIMAGEN_TILE64", "-1"))                  # force a conv tile shape at 64x64 / 128x128 (experiments)
@@ -263,7 +264,7 @@ class UnetEngine:
             if r1 is not None:
                 p.res1 = r1.c(batch, skip_scale)
             p.res_w, p.res_b = L.ptr(rw), L.ptr(rb)
-        p.out, p.out_stats, p.tile_cfg = L.ptr(out.t), L.ptr(out.stats), cfg | (0x100 if CONV_SPLIT16 else 0) | (0x200 if CONV_WAVES8 else 0) | (0x400 if ws.half else 0)
+        p.out, p.out_stats, p.tile_cfg = L.ptr(out.t), L.ptr(out.stats), cfg | (0x100 if CONV_SPLIT16 else 0) | (0x200 if CONV_WAVES8 else 0) | (0x400 if ws.half else 0) | (0x800 if (CONV_SPLIT8 and Ho * Wo <= CONV_SPLIT8 * CONV_SPLIT8) else 0)
         if mfma:
             p.w_f16 = L.ptr(pk.conv_f16[id(wpack)])
             if res is not None and res[2] is not None:
