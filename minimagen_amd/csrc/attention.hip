@@ -252,6 +252,7 @@ __global__ __launch_bounds__(256, WPS) void cross_attn_folded_kernel(const mi_cr
 // hides 2-3 VALU instructions.  x = hi + lo with hi = fp16(x), lo = fp16(x - hi) keeps 22 mantissa bits; the dropped
 // lo*lo term is 2^-22 relative, so the result stays inside the fp32 parity tolerance.
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ void split_f16(const float (&x)[4], f16x4& hi, f16x4& lo) { mi_split_f16(x, hi, lo); }
 
@@ -260,7 +261,13 @@ __device__ __forceinline__ void split_f16(const float (&x)[4], f16x4& hi, f16x4&
 template <int C, int JT, int WPS, bool HALF>
 __global__ __launch_bounds__(256, WPS) void cross_attn_f16x3_kernel(const mi_cross_attn_params p) {
     constexpr int KC = (C + 15) / 16, MT = (C + 15) / 16, FRH = 8 * KC + 8 * MT, TOK_WG = 64;
+    constexpr int JP = (JT + 1) / 2;
     __shared__ float red[4][2 * 16 * MT];
+    // One head's context fragments, staged once per workgroup (the four waves share them; measured: per-wave global loads of the
+    // fragments cost 16-50 % of the kernel).  G as loaded: [tile][kc][lane]{4 hi, 4 lo}; V re-paired for the K = 32 instruction:
+    // [tile pair][mt][lane]{4 hi(t0), 4 hi(t1)} and the same for lo.
+    __shared__ __attribute__((aligned(16))) uint4 fG[JT * KC * 64];
+    __shared__ __attribute__((aligned(16))) f16x4 fVh[JP * MT * 64 * 2], fVl[JP * MT * 64 * 2];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lq = lane & 15, lg = lane >> 4;
     const int tiles = (p.HW + TOK_WG - 1) / TOK_WG;
     int b, tile;
@@ -313,24 +320,50 @@ __global__ __launch_bounds__(256, WPS) void cross_attn_f16x3_kernel(const mi_cro
     f32x4 oacc[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) oacc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const _Float16* gvb = reinterpret_cast<const _Float16*>(p.gv) + (size_t)b * p.heads * JT * 64 * FRH + (size_t)lane * FRH;
+    const _Float16* gvb = reinterpret_cast<const _Float16*>(p.gv) + (size_t)b * p.heads * JT * 64 * FRH;
     const int jlast = p.J - 1;
+    if (JT & 1) {       // the odd last tile has no partner: its slot multiplies P = 0 and must hold finite numbers
+        for (int i = tid; i < MT * 64; i += 256) {
+            const int mt = i / 64, ln = i % 64;
+            fVh[(((JP - 1) * MT + mt) * 64 + ln) * 2 + 1] = (f16x4){0, 0, 0, 0};
+            fVl[(((JP - 1) * MT + mt) * 64 + ln) * 2 + 1] = (f16x4){0, 0, 0, 0};
+        }
+    }
 
     for (int h = 0; h < p.heads; ++h) {
         const _Float16* gvh = gvb + (size_t)h * JT * 64 * FRH;
+        __syncthreads();                                  // the previous head's fragments are no longer read
+        for (int i = tid; i < JT * 64 * (KC + MT); i += 256) {       // 16-byte chunks, consecutive work-items -> consecutive chunks
+            const int q = i % (KC + MT), r = i / (KC + MT), ln = r % 64, jt = r / 64;
+            union { uint4 u; f16x4 h2[2]; } v;
+            v.u = *reinterpret_cast<const uint4*>(gvh + (size_t)r * FRH + 8 * q);
+            if (q < KC) {
+                fG[(jt * KC + q) * 64 + ln] = v.u;
+            } else {
+                const int o = (((jt >> 1) * MT + (q - KC)) * 64 + ln) * 2 + (jt & 1);
+                fVh[o] = v.h2[0];
+                fVl[o] = v.h2[1];
+            }
+        }
+        __syncthreads();
         f32x4 s[JT];
 #pragma unroll
         for (int jt = 0; jt < JT; ++jt) {
             f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kc = 0; kc < KC; ++kc) {
-                const f16x4 ghi = *reinterpret_cast<const f16x4*>(gvh + (size_t)jt * 64 * FRH + 8 * kc);
-                const f16x4 glo = *reinterpret_cast<const f16x4*>(gvh + (size_t)jt * 64 * FRH + 8 * kc + 4);
+                union { uint4 u; f16x4 h2[2]; } g;
+                g.u = fG[(jt * KC + kc) * 64 + lane];
+                const f16x4 ghi = g.h2[0];
                 if constexpr (!HALF) {
-                    acc = __builtin_amdgcn_mfma_f32_16x16x16f16(glo, xhi[kc], acc, 0, 0, 0);
+                    // (the K = 32 form {G hi|G lo}.{x hi|x hi} + K = 16 G hi.x lo saves one instruction per tile but returned wrong
+                    //  results on the device -- a K = 16 MFMA feeding a dependent K = 32 one -- and only 3.6 % of the kernel; not used)
+                    acc = __builtin_amdgcn_mfma_f32_16x16x16f16(g.h2[1], xhi[kc], acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_16x16x16f16(ghi, xlo[kc], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x16f16(ghi, xhi[kc], acc, 0, 0, 0);
+                } else {
+                    acc = __builtin_amdgcn_mfma_f32_16x16x16f16(ghi, xhi[kc], acc, 0, 0, 0);
                 }
-                acc = __builtin_amdgcn_mfma_f32_16x16x16f16(ghi, xhi[kc], acc, 0, 0, 0);
             }
             s[jt] = acc;
         }
@@ -348,27 +381,37 @@ __global__ __launch_bounds__(256, WPS) void cross_attn_f16x3_kernel(const mi_cro
         f32x4 oh[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) oh[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // PV on the K = 32 instruction, context tiles in pairs (t0, t1): {V hi(t0)|V hi(t1)} . {P hi(t0)|P hi(t1)} + {V hi}.{P lo} + {V lo}.{P hi}.
+        // The B operand is the C/D layout of the two score tiles as it is: P[j = 16t + 4lg + e][token lq].
 #pragma unroll
-        for (int jt = 0; jt < JT; ++jt) {
-            float pe[4];
+        for (int jp = 0; jp < JP; ++jp) {
+            f16x4 ph[2], pl[2];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { pe[r] = __builtin_amdgcn_exp2f(s[jt][r] - m); l += pe[r]; }
-            f16x4 phi, plo;                       // B operand of PV: P[j = 16jt + 4lg + e][token lq] -- the C/D layout as it is
-            if constexpr (HALF) {
+            for (int ts = 0; ts < 2; ++ts) {
+                const int jt = 2 * jp + ts;
+                float pe[4] = {0.f, 0.f, 0.f, 0.f};
+                if (jt < JT) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) phi[r] = (_Float16)pe[r];
-            } else {
-                split_f16(pe, phi, plo);
+                    for (int r = 0; r < 4; ++r) { pe[r] = __builtin_amdgcn_exp2f(s[jt < JT ? jt : 0][r] - m); l += pe[r]; }
+                }
+                if constexpr (HALF) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ph[ts][r] = (_Float16)pe[r];
+                } else {
+                    split_f16(pe, ph[ts], pl[ts]);
+                }
             }
+            const f16x8 phi = __builtin_shufflevector(ph[0], ph[1], 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                const f16x4 vhi = *reinterpret_cast<const f16x4*>(gvh + (size_t)jt * 64 * FRH + 8 * KC + 8 * mt);
-                const f16x4 vlo = *reinterpret_cast<const f16x4*>(gvh + (size_t)jt * 64 * FRH + 8 * KC + 8 * mt + 4);
+                const f16x8 vhi = *reinterpret_cast<const f16x8*>(&fVh[((jp * MT + mt) * 64 + lane) * 2]);
                 if constexpr (!HALF) {
-                    oh[mt] = __builtin_amdgcn_mfma_f32_16x16x16f16(vlo, phi, oh[mt], 0, 0, 0);
-                    oh[mt] = __builtin_amdgcn_mfma_f32_16x16x16f16(vhi, plo, oh[mt], 0, 0, 0);
+                    const f16x8 plo = __builtin_shufflevector(pl[0], pl[1], 0, 1, 2, 3, 4, 5, 6, 7);
+                    const f16x8 vlo = *reinterpret_cast<const f16x8*>(&fVl[((jp * MT + mt) * 64 + lane) * 2]);
+                    oh[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vlo, phi, oh[mt], 0, 0, 0);
+                    oh[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vhi, plo, oh[mt], 0, 0, 0);
                 }
-                oh[mt] = __builtin_amdgcn_mfma_f32_16x16x16f16(vhi, phi, oh[mt], 0, 0, 0);
+                oh[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vhi, phi, oh[mt], 0, 0, 0);
             }
         }
         l += __shfl_xor(l, 16);

@@ -4,7 +4,7 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"
 OUT=gpurun_out; mkdir -p $OUT
 for V in "$@"; do
   export MINIMAGEN_HIP_LIB=$(pwd)/minimagen_amd/libminimagen_hip$V.so
-  timeout 300 python -m pytest tests/test_kernels.py -m gpu -q --timeout 300 -k "cross_attention" 2>&1 | tail -1
+  timeout 300 python -m pytest tests/test_kernels.py tests/test_unet.py -m gpu -q --timeout 300 -k "cross_attention or golden or half" 2>&1 | tail -1
   timeout 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/ab_c$V.log 2>&1
   timeout 300 python bench.py --workload base64 --steps 2 --warmup 1 --no-cpu-baseline > $OUT/ab_b$V.log 2>&1
   python - <<PY

@@ -48,7 +48,83 @@ static void time_rate(const char* name) {
     const double flop = n * 2.0 * 16 * 16 * (K32 ? 32 : 16);
     printf("%s: %.3f ms, %.2f ns per MFMA per SIMD, %.0f TFLOP/s\n", name, ms, ms * 1e6 / (n / 1024.0), flop / (ms * 1e-3) / 1e12);
 }
+// dependent chains (one accumulator) with NV independent VALU FMAs between consecutive MFMAs: what a softmax-then-PV loop looks like
+template <int K32, int NV>
+__global__ __launch_bounds__(256) void chain(float* out, int iters) {
+    f16x8 a8, b8; f16x4 a4, b4;
+    for (int e = 0; e < 8; ++e) { a8[e] = (_Float16)(threadIdx.x * 0.001f + e); b8[e] = (_Float16)(0.5f + e); }
+    for (int e = 0; e < 4; ++e) { a4[e] = a8[e]; b4[e] = b8[e]; }
+    f32x4 c = {0.f, 0.f, 0.f, 0.f};
+    float v[8];
+    for (int k = 0; k < 8; ++k) v[k] = threadIdx.x * 0.01f + k;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            if (K32) c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a8, b8, c, 0, 0, 0);
+            else c = __builtin_amdgcn_mfma_f32_16x16x16f16(a4, b4, c, 0, 0, 0);
+#pragma unroll
+            for (int k = 0; k < NV; ++k) v[k & 7] = __builtin_fmaf(v[k & 7], 1.0001f, 0.5f);
+        }
+    }
+    float s = c[0] + c[1] + c[2] + c[3];
+    for (int k = 0; k < 8; ++k) s += v[k];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+// same, with NV v_exp_f32 (transcendental unit) between consecutive MFMAs
+template <int K32, int NV>
+__global__ __launch_bounds__(256) void chain_exp(float* out, int iters) {
+    f16x8 a8, b8; f16x4 a4, b4;
+    for (int e = 0; e < 8; ++e) { a8[e] = (_Float16)(threadIdx.x * 0.001f + e); b8[e] = (_Float16)(0.5f + e); }
+    for (int e = 0; e < 4; ++e) { a4[e] = a8[e]; b4[e] = b8[e]; }
+    f32x4 c = {0.f, 0.f, 0.f, 0.f};
+    float v[8];
+    for (int k = 0; k < 8; ++k) v[k] = -(threadIdx.x * 0.01f + k);
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            if (K32) c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a8, b8, c, 0, 0, 0);
+            else c = __builtin_amdgcn_mfma_f32_16x16x16f16(a4, b4, c, 0, 0, 0);
+#pragma unroll
+            for (int k = 0; k < NV; ++k) v[k & 7] = __builtin_amdgcn_exp2f(v[k & 7]);
+        }
+    }
+    float s = c[0] + c[1] + c[2] + c[3];
+    for (int k = 0; k < 8; ++k) s += v[k];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+template <int K32, int NV>
+static void time_chain_exp(const char* name, int wps) {
+    float* out; hipMalloc(&out, 4096 * 256 * 4);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    const int iters = 2000, blocks = 256 * wps;
+    hipLaunchKernelGGL((chain_exp<K32, NV>), dim3(blocks), dim3(256), 0, 0, out, 10);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((chain_exp<K32, NV>), dim3(blocks), dim3(256), 0, 0, out, iters);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    printf("%s, %d v_exp_f32 between, %d waves/SIMD: %.1f ns per group per wave, %.1f ns per SIMD slot\n", name, NV, wps, ms * 1e6 / (iters * 8.0), ms * 1e6 / (iters * 8.0 * wps));
+}
+template <int K32, int NV>
+static void time_chain(const char* name, int wps) {
+    float* out; hipMalloc(&out, 4096 * 256 * 4);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    const int iters = 2000, blocks = 256 * wps;                   // wps waves per SIMD (256 CUs x 4 SIMDs, 4 waves per block)
+    hipLaunchKernelGGL((chain<K32, NV>), dim3(blocks), dim3(256), 0, 0, out, 10);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((chain<K32, NV>), dim3(blocks), dim3(256), 0, 0, out, iters);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    printf("%s, %d VALU between, %d waves/SIMD: %.1f ns per (MFMA + VALU group) per wave, %.1f ns per SIMD slot\n", name, NV, wps, ms * 1e6 / (iters * 8.0), ms * 1e6 / (iters * 8.0 * wps));
+}
 int main() {
+    for (int wps = 1; wps <= 3; wps += 2) {
+        time_chain_exp<0, 0>("dependent 16x16x16", wps); time_chain_exp<0, 1>("dependent 16x16x16", wps);
+        time_chain_exp<0, 2>("dependent 16x16x16", wps); time_chain_exp<0, 4>("dependent 16x16x16", wps);
+        time_chain<0, 0>("dependent 16x16x16", wps); time_chain<1, 0>("dependent 16x16x32", wps);
+        time_chain<0, 4>("dependent 16x16x16", wps); time_chain<1, 4>("dependent 16x16x32", wps);
+        time_chain<0, 8>("dependent 16x16x16", wps); time_chain<1, 8>("dependent 16x16x32", wps);
+        time_chain<0, 16>("dependent 16x16x16", wps); time_chain<1, 16>("dependent 16x16x32", wps);
+    }
     time_rate<0>("v_mfma_f32_16x16x16_f16");
     time_rate<1>("v_mfma_f32_16x16x32_f16");
     _Float16 hA[16 * 32], hB[32 * 16];
