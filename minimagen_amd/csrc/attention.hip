@@ -333,7 +333,10 @@ __global__ __launch_bounds__(256, WPS) void cross_attn_f16x3_kernel(const mi_cro
     for (int h = 0; h < p.heads; ++h) {
         const _Float16* gvh = gvb + (size_t)h * JT * 64 * FRH;
         __syncthreads();                                  // the previous head's fragments are no longer read
-        for (int i = tid; i < JT * 64 * (KC + MT); i += 256) {       // 16-byte chunks, consecutive work-items -> consecutive chunks
+        // 16-byte chunks, consecutive work-items -> consecutive chunks.  Deliberately a rolled loop: unrolled (or prefetched a head ahead
+        // in registers) the kernel needs 164 instead of 124 registers, drops from 4 to 3 waves per SIMD and is 19 % slower (measured)
+#pragma unroll 1
+        for (int i = tid; i < JT * 64 * (KC + MT); i += 256) {
             const int q = i % (KC + MT), r = i / (KC + MT), ln = r % 64, jt = r / 64;
             union { uint4 u; f16x4 h2[2]; } v;
             v.u = *reinterpret_cast<const uint4*>(gvh + (size_t)r * FRH + 8 * q);
