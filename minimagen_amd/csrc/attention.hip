@@ -258,11 +258,13 @@ __device__ __forceinline__ void split_f16(const float (&x)[4], f16x4& hi, f16x4&
 
 // HALF = true: the reduced-precision configuration (variant 7): single fp16 term per product (no lo halves), fp32 accumulate,
 // fp32 softmax -- the BASELINE 'half-precision with MFMA attention' configurations; parity gate 3e-2 / 3e-3 instead of fp32's 1e-4 / 1e-5
-template <int C, int JT, int WPS, bool HALF>
-__global__ __launch_bounds__(256, WPS) void cross_attn_f16x3_kernel(const mi_cross_attn_params p) {
-    constexpr int KC = (C + 15) / 16, MT = (C + 15) / 16, FRH = 8 * KC + 8 * MT, TOK_WG = 64;
+// NWV waves of 16 tokens per workgroup: every workgroup copies the whole head's fragments, so larger workgroups divide that
+// L2 -> LDS traffic (1.1 GB per SR launch at 4 waves); statistics stay per 64-token tile (4 waves)
+template <int C, int JT, int WPS, bool HALF, int NWV>
+__global__ __launch_bounds__(64 * NWV, WPS) void cross_attn_f16x3_kernel(const mi_cross_attn_params p) {
+    constexpr int KC = (C + 15) / 16, MT = (C + 15) / 16, FRH = 8 * KC + 8 * MT, TOK_WG = 16 * NWV, NT = 64 * NWV;
     constexpr int JP = (JT + 1) / 2;
-    __shared__ float red[4][2 * 16 * MT];
+    __shared__ float red[NWV][2 * 16 * MT];
     // One head's context fragments, staged once per workgroup (the four waves share them; measured: per-wave global loads of the
     // fragments cost 16-50 % of the kernel).  G as loaded: [tile][kc][lane]{4 hi, 4 lo}; V re-paired for the K = 32 instruction:
     // [tile pair][mt][lane]{4 hi(t0), 4 hi(t1)} and the same for lo.
@@ -280,7 +282,7 @@ __global__ __launch_bounds__(256, WPS) void cross_attn_f16x3_kernel(const mi_cro
         tile = blockIdx.x % tiles;
     }
     const int bx = mi_row_of(b, p.x.bmod);
-    const int i = (tile * 4 + wave) * 16 + lq;
+    const int i = (tile * NWV + wave) * 16 + lq;
     const bool ok = i < p.HW;
     const float* xb = p.x.data + (size_t)bx * C * p.HW;
 
@@ -323,7 +325,7 @@ __global__ __launch_bounds__(256, WPS) void cross_attn_f16x3_kernel(const mi_cro
     const _Float16* gvb = reinterpret_cast<const _Float16*>(p.gv) + (size_t)b * p.heads * JT * 64 * FRH;
     const int jlast = p.J - 1;
     if (JT & 1) {       // the odd last tile has no partner: its slot multiplies P = 0 and must hold finite numbers
-        for (int i = tid; i < MT * 64; i += 256) {
+        for (int i = tid; i < MT * 64; i += NT) {
             const int mt = i / 64, ln = i % 64;
             fVh[(((JP - 1) * MT + mt) * 64 + ln) * 2 + 1] = (f16x4){0, 0, 0, 0};
             fVl[(((JP - 1) * MT + mt) * 64 + ln) * 2 + 1] = (f16x4){0, 0, 0, 0};
@@ -336,7 +338,7 @@ __global__ __launch_bounds__(256, WPS) void cross_attn_f16x3_kernel(const mi_cro
         // 16-byte chunks, consecutive work-items -> consecutive chunks.  Deliberately a rolled loop: unrolled (or prefetched a head ahead
         // in registers) the kernel needs 164 instead of 124 registers, drops from 4 to 3 waves per SIMD and is 19 % slower (measured)
 #pragma unroll 1
-        for (int i = tid; i < JT * 64 * (KC + MT); i += 256) {
+        for (int i = tid; i < JT * 64 * (KC + MT); i += NT) {
             const int q = i % (KC + MT), r = i / (KC + MT), ln = r % 64, jt = r / 64;
             union { uint4 u; f16x4 h2[2]; } v;
             v.u = *reinterpret_cast<const uint4*>(gvh + (size_t)r * FRH + 8 * q);
@@ -471,7 +473,13 @@ __global__ __launch_bounds__(256, WPS) void cross_attn_f16x3_kernel(const mi_cro
                 for (int r = 0; r < 4; ++r) { const int a = 16 * mt + 4 * lg + r; red[wave][2 * a] = csum[4 * mt + r]; red[wave][2 * a + 1] = csq[4 * mt + r]; }
         }
         __syncthreads();
-        if (tid < 2 * C) p.out_stats[((size_t)(b * C + (tid >> 1)) * tiles + tile) * 2 + (tid & 1)] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+        const int nt64 = (p.HW + 63) / 64;               // statistics tiles are 64 tokens = 4 waves, whatever the workgroup size
+        for (int sub = 0; sub < NWV / 4; ++sub) {
+            const int st = tile * (NWV / 4) + sub;
+            if (tid < 2 * C && st < nt64)
+                p.out_stats[((size_t)(b * C + (tid >> 1)) * nt64 + st) * 2 + (tid & 1)] =
+                    red[4 * sub][tid] + red[4 * sub + 1][tid] + red[4 * sub + 2][tid] + red[4 * sub + 3][tid];
+        }
     }
 }
 
@@ -485,13 +493,15 @@ extern "C" int mi_cross_attn_fwd(const mi_cross_attn_params* pp, void* stream) {
     if (p.B2 <= 0 || p.HW <= 0) { mi_set_error("mi_cross_attn_fwd: empty problem"); return MI_ERR_INVALID; }
     // out_stats tiles are MI_ATTN_TOKENS_PER_WG tokens (NQ = 2); p.variant = 1 selects NQ = 1 (64-token tiles)
     if (p.variant == 6 || p.variant == 7) {      // fp16 MFMA (fragments from mi_attn_fold_rows with frag_f16 = 1): 6 = 3-term split (fp32-grade), 7 = single term
-        const dim3 g6(((p.HW + 63) / 64) * p.B2);
-#ifndef MI_ATTN_WPS
-#define MI_ATTN_WPS 3            /* waves per SIMD the register budget is set for (C <= 16; C = 32 needs the 3-wave budget) */
-#endif
+        // waves per workgroup (measured on MI355X): 8 for the SR bottleneck (4096 tokens: 0.53 -> 0.47 ms per pair of launches),
+        // 16 for up to 1024 tokens (base U-Net)
+        const int nwv = p.HW <= 1024 ? 16 : 8;
+        const dim3 g6(((p.HW + 16 * nwv - 1) / (16 * nwv)) * p.B2);
 #define MI_ATTN16_LAUNCH(CC) \
-        if (p.variant == 6) hipLaunchKernelGGL(HIP_KERNEL_NAME(cross_attn_f16x3_kernel<CC, 17, (CC <= 16 ? MI_ATTN_WPS : 3), false>), g6, dim3(256), 0, st, p); \
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(cross_attn_f16x3_kernel<CC, 17, (CC <= 16 ? MI_ATTN_WPS : 3), true>), g6, dim3(256), 0, st, p);
+        if (p.variant == 6 && nwv == 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(cross_attn_f16x3_kernel<CC, 17, 4, false, 8>), g6, dim3(512), 0, st, p); \
+        else if (p.variant == 6) hipLaunchKernelGGL(HIP_KERNEL_NAME(cross_attn_f16x3_kernel<CC, 17, 4, false, 16>), g6, dim3(1024), 0, st, p); \
+        else if (nwv == 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(cross_attn_f16x3_kernel<CC, 17, 4, true, 8>), g6, dim3(512), 0, st, p); \
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(cross_attn_f16x3_kernel<CC, 17, 4, true, 16>), g6, dim3(1024), 0, st, p);
         switch (p.C) {
             case 8: MI_ATTN16_LAUNCH(8) break;
             case 16: MI_ATTN16_LAUNCH(16) break;
