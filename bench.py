@@ -152,6 +152,27 @@ def graph_step_ms(im, stage, B, cond_scale, T, reps=40):
     return e0.elapsed_time(e1) / reps
 
 
+def t5_leg(dev, B, Lq=64, reps=10):
+    """SURVEY.md 8(d) T5 leg: T5EncoderModel(T5Config()) (= t5-small shape) with random-init weights seed 0, random ids, ragged masks,
+    encoded by the HIP kernels of csrc/t5.hip (once per sample() when captions are given as text)."""
+    from transformers import T5Config, T5EncoderModel
+    from minimagen_amd.t5 import T5EncoderHIP
+    torch.manual_seed(0)
+    enc = T5EncoderHIP.from_hf(T5EncoderModel(T5Config()).eval(), device=dev)
+    ids = torch.randint(0, 32128, (B, Lq), generator=torch.Generator().manual_seed(1))
+    _, mask = synthetic_text(B, length=Lq)
+    enc.encode(ids.to(dev), mask.to(dev))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        enc.encode(ids.to(dev), mask.to(dev))
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / reps * 1e3
+    flops = B * Lq * 37.7e6 + 6 * B * 4 * 8 * Lq * Lq * 64           # SURVEY 8(a) a16
+    return {"ms": ms, "tokens_per_s": B * Lq / (ms * 1e-3), "tflops_fp32": flops / (ms * 1e-3) / 1e12,
+            "config": f"t5-small shape (d_model 512, 6 layers, 8 heads, d_ff 2048), B={B}, L={Lq}, fp32 MFMA GEMMs"}
+
+
 def pmc_traffic(dom, rows, S):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes of THIS command (profiles/rNN_*_pmc_by_launch_shape.csv:
     separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs, FETCH doubled per the gfx950 correction, see tools/summarize_profiles.py).
@@ -213,6 +234,7 @@ def main():
     ap.add_argument("--precision", default="fp32", choices=["fp32", "half"],
                     help="fp32 (default, the headline): every contraction fp32-grade; half: single-fp16-term matrix-core contractions "
                          "(BASELINE's reduced-precision configurations; parity gate 3e-2) -- reported as a secondary line, never the headline")
+    ap.add_argument("--t5", action="store_true", help="also time the T5 text-embedding pass (K16) for the batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true")
     ap.add_argument("--breakdown-out", default="")
@@ -319,6 +341,8 @@ def main():
         if args.breakdown_out:
             with open(args.breakdown_out, "w") as f:
                 json.dump(rows, f, indent=1)
+    if rank == 0 and args.t5:
+        res["t5_encode"] = t5_leg(dev, B)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline()
     if rank == 0:
