@@ -224,6 +224,8 @@ typedef struct mi_cfg_x0_params {
     const float* coef; const int* t_state;
     float* pred_out;              /* [B][n] guided prediction or NULL */
     float* x0;                    /* [B][n] or NULL */
+    unsigned* hist0;              /* optional: pass-0 slice [B][2][MI_Q_BINS] of the quantile histograms (zero on entry): the radix
+                                     select's first pass over |x0| is accumulated here while x0 is produced (see mi_quantile_params.pass0_done) */
 } mi_cfg_x0_params;
 int mi_cfg_x0_fwd(const mi_cfg_x0_params* p, void* stream);
 
@@ -236,9 +238,11 @@ typedef struct mi_quantile_params {
     int B, n;
     const float* x0;              /* [B][n] */
     int k_lo, k_hi; float w;
-    unsigned* hist;               /* [3][B][2][MI_Q_BINS], zeroed by mi_quantile_fwd itself */
+    unsigned* hist;               /* [3][B][2][MI_Q_BINS], zeroed by mi_quantile_fwd itself unless self_cleaning */
     float* s_out;                 /* [B]  lerp(v_lo, v_hi, w) -- NOT yet clamped to >= 1 */
     float* v_out;                 /* [B][2] the two selected order statistics, or NULL */
+    int pass0_done;               /* 1: mi_cfg_x0_fwd already accumulated pass 0 into hist (its hist0 field); skips that pass */
+    int self_cleaning;            /* 1: hist is zero on entry (caller's guarantee) and is left zeroed on exit: no memset launch */
 } mi_quantile_params;
 int mi_quantile_fwd(const mi_quantile_params* p, void* stream);
 

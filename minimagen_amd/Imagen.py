@@ -143,8 +143,11 @@ class Imagen(nn.Module):
                 st.seed_dev = torch.zeros(1, dtype=torch.int64, device=ws.dev)
             st.seed_dev.fill_(int(seed) & 0x7FFFFFFFFFFFFFFF)
         if entry is None:
-            cp = L.MiCfgX0Params(B, n, L.ptr(ws.pred), 1 if two else 0, float(cond_scale), L.ptr(ws.x), L.ptr(st.coef), L.ptr(st.t_state), 0, L.ptr(st.x0))
-            qp = L.MiQuantileParams(B, n, L.ptr(st.x0), k_lo, k_hi, w, L.ptr(st.hist), L.ptr(st.s_q), L.ptr(st.v_q))
+            # the radix select's first pass rides on the kernel that produces x0, and the histograms clean themselves: st.hist is
+            # zero on allocation and every mi_quantile_fwd leaves it zeroed again
+            cp = L.MiCfgX0Params(B, n, L.ptr(ws.pred), 1 if two else 0, float(cond_scale), L.ptr(ws.x), L.ptr(st.coef), L.ptr(st.t_state), 0, L.ptr(st.x0),
+                                 L.ptr(st.hist))
+            qp = L.MiQuantileParams(B, n, L.ptr(st.x0), k_lo, k_hi, w, L.ptr(st.hist), L.ptr(st.s_q), L.ptr(st.v_q), 1, 1)
             pp = L.MiPosteriorParams(B, n, T, L.ptr(st.x0), L.ptr(st.s_q), L.ptr(ws.x), L.ptr(st.coef), L.ptr(st.t_state),
                                      L.ptr(noise_dev), int(seed) & 0x7FFFFFFFFFFFFFFF, sample0, stage << 20,
                                      L.ptr(st.seed_dev) if noise_dev is None else 0)

@@ -102,12 +102,13 @@ class MiChanFFParams(C.Structure):
 
 class MiCfgX0Params(C.Structure):
     _fields_ = [("B", C.c_int), ("n", C.c_int), ("pred2", C.c_void_p), ("two", C.c_int), ("cond_scale", C.c_float),
-                ("x_t", C.c_void_p), ("coef", C.c_void_p), ("t_state", C.c_void_p), ("pred_out", C.c_void_p), ("x0", C.c_void_p)]
+                ("x_t", C.c_void_p), ("coef", C.c_void_p), ("t_state", C.c_void_p), ("pred_out", C.c_void_p), ("x0", C.c_void_p),
+                ("hist0", C.c_void_p)]
 
 
 class MiQuantileParams(C.Structure):
     _fields_ = [("B", C.c_int), ("n", C.c_int), ("x0", C.c_void_p), ("k_lo", C.c_int), ("k_hi", C.c_int), ("w", C.c_float),
-                ("hist", C.c_void_p), ("s_out", C.c_void_p), ("v_out", C.c_void_p)]
+                ("hist", C.c_void_p), ("s_out", C.c_void_p), ("v_out", C.c_void_p), ("pass0_done", C.c_int), ("self_cleaning", C.c_int)]
 
 
 class MiPosteriorParams(C.Structure):

@@ -12,10 +12,16 @@
 namespace {
 
 // ------------------------------------------------------------------ K11 epilogue
+template <bool HIST>
 __global__ __launch_bounds__(256) void cfg_x0_kernel(const mi_cfg_x0_params p) {
+    __shared__ unsigned lh[HIST ? MI_Q_BINS : 1];      // pass 0 of the radix select (bits 30..20 of |x0|), fused into the producer of x0
     const int b = blockIdx.y;
     const int t = p.t_state ? *p.t_state : 0;
     const float ca = p.coef ? p.coef[t * 8 + 0] : 0.0f, cb = p.coef ? p.coef[t * 8 + 1] : 0.0f;
+    if constexpr (HIST) {
+        for (int i = threadIdx.x; i < MI_Q_BINS; i += 256) lh[i] = 0u;
+        __syncthreads();
+    }
     for (int i = blockIdx.x * 256 + threadIdx.x; i < p.n; i += gridDim.x * 256) {
         const float c = p.pred2[(size_t)b * p.n + i];
         float pred = c;
@@ -26,7 +32,18 @@ __global__ __launch_bounds__(256) void cfg_x0_kernel(const mi_cfg_x0_params p) {
         if (p.pred_out) p.pred_out[(size_t)b * p.n + i] = pred;
         if (p.x0) {
             const float xt = p.x_t[(size_t)b * p.n + i];
-            p.x0[(size_t)b * p.n + i] = __fsub_rn(__fmul_rn(ca, xt), __fmul_rn(cb, pred));   // diffusion_model.py:159-162
+            const float x0 = __fsub_rn(__fmul_rn(ca, xt), __fmul_rn(cb, pred));   // diffusion_model.py:159-162
+            p.x0[(size_t)b * p.n + i] = x0;
+            if constexpr (HIST) atomicAdd(&lh[__float_as_uint(fabsf(x0)) >> 20], 1u);
+        }
+    }
+    if constexpr (HIST) {
+        __syncthreads();
+        // both order statistics share the pass-0 histogram (no prefix yet): the same counts go to the two selector slots
+        unsigned* gh = p.hist0 + ((size_t)b * 2) * MI_Q_BINS;
+        for (int i = threadIdx.x; i < MI_Q_BINS; i += 256) {
+            const unsigned v = lh[i];
+            if (v) { atomicAdd(&gh[i], v); atomicAdd(&gh[MI_Q_BINS + i], v); }
         }
     }
 }
@@ -126,6 +143,13 @@ __global__ __launch_bounds__(256) void quantile_finish_kernel(const mi_quantile_
         const float s = (fabsf(p.w) < 0.5f) ? fmaf(p.w, d, a) : fmaf(__fsub_rn(p.w, 1.0f), d, bb);
         p.s_out[b] = s;
         if (p.v_out) { p.v_out[2 * b] = a; p.v_out[2 * b + 1] = bb; }
+    }
+    if (p.self_cleaning) {       // leave this image's counters zeroed for the next denoising step (no memset launch)
+        __syncthreads();
+        for (int ps = 0; ps < 3; ++ps) {
+            unsigned* gh = p.hist + (((size_t)ps * p.B + b) * 2) * MI_Q_BINS;
+            for (int i = threadIdx.x; i < 2 * MI_Q_BINS; i += 256) gh[i] = 0u;
+        }
     }
 }
 
@@ -256,16 +280,19 @@ inline int grid_for(long long n, int cap = 2048) {
 extern "C" int mi_cfg_x0_fwd(const mi_cfg_x0_params* p, void* stream) {
     if (p->B <= 0 || p->n <= 0) { mi_set_error("mi_cfg_x0_fwd: empty"); return MI_ERR_INVALID; }
     if (p->x0 && (!p->x_t || !p->coef || !p->t_state)) { mi_set_error("mi_cfg_x0_fwd: x0 needs x_t, coef, t_state"); return MI_ERR_INVALID; }
-    hipLaunchKernelGGL(cfg_x0_kernel, dim3(grid_for(p->n, 256), p->B), dim3(256), 0, (hipStream_t)stream, *p);
+    if (p->hist0 && !p->x0) { mi_set_error("mi_cfg_x0_fwd: hist0 needs x0"); return MI_ERR_INVALID; }
+    if (p->hist0) hipLaunchKernelGGL(HIP_KERNEL_NAME(cfg_x0_kernel<true>), dim3(grid_for(p->n, 128), p->B), dim3(256), 0, (hipStream_t)stream, *p);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(cfg_x0_kernel<false>), dim3(grid_for(p->n, 256), p->B), dim3(256), 0, (hipStream_t)stream, *p);
     return mi_check_launch("cfg_x0_kernel");
 }
 
 extern "C" int mi_quantile_fwd(const mi_quantile_params* p, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (p->B <= 0 || p->n <= 0 || p->k_lo < 0 || p->k_hi >= p->n || p->k_lo > p->k_hi) { mi_set_error("mi_quantile_fwd: bad ranks"); return MI_ERR_INVALID; }
-    if (hipMemsetAsync(p->hist, 0, (size_t)3 * p->B * 2 * MI_Q_BINS * sizeof(unsigned), st) != hipSuccess) { mi_set_error("mi_quantile_fwd: memset failed"); return MI_ERR_LAUNCH; }
+    if (p->pass0_done && !p->self_cleaning) { mi_set_error("mi_quantile_fwd: pass0_done needs self_cleaning (the memset would erase pass 0)"); return MI_ERR_INVALID; }
+    if (!p->self_cleaning && hipMemsetAsync(p->hist, 0, (size_t)3 * p->B * 2 * MI_Q_BINS * sizeof(unsigned), st) != hipSuccess) { mi_set_error("mi_quantile_fwd: memset failed"); return MI_ERR_LAUNCH; }
     const dim3 grid(grid_for((p->n + 15) / 16, 64), p->B);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(quantile_hist_kernel<0>), grid, dim3(256), 0, st, *p);
+    if (!p->pass0_done) hipLaunchKernelGGL(HIP_KERNEL_NAME(quantile_hist_kernel<0>), grid, dim3(256), 0, st, *p);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(quantile_hist_kernel<1>), grid, dim3(256), 0, st, *p);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(quantile_hist_kernel<2>), grid, dim3(256), 0, st, *p);
     hipLaunchKernelGGL(quantile_finish_kernel, dim3(p->B), dim3(256), 0, st, *p);

@@ -332,6 +332,17 @@ def test_sampler_elementwise_bit_exact(backend):
         s = torch.zeros(B, device=dev)
         qp = L.MiQuantileParams(B, n, x0.data_ptr(), k_lo, k_hi, w, hist.data_ptr(), s.data_ptr(), None)
         L.check(lib.mi_quantile_fwd(C.byref(qp), L.current_stream()))
+        # the fused form the sampler uses: pass 0 of the radix select rides on the kernel that writes x0, and the histograms
+        # (zero on entry) are left zeroed -> same threshold bits, twice in a row without a memset
+        hist2 = torch.zeros_like(hist)
+        s2, x0b = torch.zeros(B, device=dev), torch.zeros(B, n, device=dev)
+        for _ in range(2):
+            pf = L.MiCfgX0Params(B, n, pred2d.data_ptr(), 1, 3.0, xtd.data_ptr(), coef.data_ptr(), tstate.data_ptr(), 0, x0b.data_ptr(), hist2.data_ptr())
+            L.check(lib.mi_cfg_x0_fwd(C.byref(pf), L.current_stream()))
+            s2.zero_()
+            qf = L.MiQuantileParams(B, n, x0b.data_ptr(), k_lo, k_hi, w, hist2.data_ptr(), s2.data_ptr(), None, 1, 1)
+            L.check(lib.mi_quantile_fwd(C.byref(qf), L.current_stream()))
+            assert torch.equal(x0b, x0) and torch.equal(s2, s) and int(hist2.abs().sum()) == 0
         x = xtd.clone()
         pp = L.MiPosteriorParams(B, n, T, x0.data_ptr(), s.data_ptr(), x.data_ptr(), coef.data_ptr(), tstate.data_ptr(), noised.data_ptr(), 0, 0, 0)
         L.check(lib.mi_posterior_fwd(C.byref(pp), L.current_stream()))
