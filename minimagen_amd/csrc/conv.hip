@@ -34,9 +34,14 @@ struct ConvCfg {
     // vector staging path: every staged row is the ALIGNED float4 window of SOURCE pixels that covers the tile's halo:
     //   k3 s1: [ox0-4, ox0+TW+4)   k4 s2: [2ox0-4, 2ox0+2TW+4)   nearest-x2 + k3: source cols [ox0/2-4, ox0/2+TW/2+4)
     static constexpr int SW = UP2_ ? TW_ / 2 + 8 : TW_ * S_ + 8;
+    static constexpr int SW_HALF_PAD() { return ((SW / 2 + 3) + 3) & ~3; }
     static constexpr int WIN4 = SW / 4;
     static constexpr int IHS = VEC_ ? (UP2_ ? TH / 2 + 2 : IH) : IH;          // staged rows
-    static constexpr int IWP = VEC_ ? SW : ((IW + 3) & ~3);                   // LDS row pitch (16-byte aligned rows)
+    // stride 2 (vector path): a staged row is DE-INTERLEAVED into an even-column and an odd-column plane of PE floats each, so a
+    // work-item's ten taps are two aligned float4 + two scalars at a 16-byte lane stride (interleaved, the 32-byte lane stride made
+    // the four SIMDs of a CU queue on 8-way LDS bank conflicts: measured 4x the FMA time)
+    static constexpr int PE = (SW_HALF_PAD());
+    static constexpr int IWP = VEC_ ? (S_ == 2 ? 2 * PE : SW) : ((IW + 3) & ~3);   // LDS row pitch (16-byte aligned rows)
     static constexpr int XOFF = VEC_ ? 3 : 0;     // LDS column of the tile's first halo pixel
     static constexpr int CK = (S == 2) ? 2 : 4;   // input channels staged per round
     static constexpr int NIN = 4 * S + KS - S;    // input floats per row a work-item consumes
@@ -110,7 +115,7 @@ __global__ __launch_bounds__(CFG::NT) void conv_tile_kernel(const mi_conv_params
             const int gy = sy0 + iy, gx0 = sx0 + 4 * xq;
             const bool in = (ck < CK) && gy >= 0 && gy < Hin && gx0 >= 0 && gx0 < Win;
             msrc[u] = in ? ck * Hin * Win + gy * Win + gx0 : -1;       // relative to the round's first channel plane
-            mdst[u] = (ck < CK) ? (ck * IHS + iy) * IWP + 4 * xq : -1;
+            mdst[u] = (ck < CK) ? (ck * IHS + iy) * IWP + (S == 2 ? 2 : 4) * xq : -1;      // stride 2: index into the even plane
             mck[u] = ck;
         }
     }
@@ -146,7 +151,15 @@ __global__ __launch_bounds__(CFG::NT) void conv_tile_kernel(const mi_conv_params
                         o[e] = xe[e] * P.x;
                     }
                 }
-                if (mdst[u] >= 0) *reinterpret_cast<float4*>(&smem[mdst[u]]) = make_float4(o[0], o[1], o[2], o[3]);
+                if constexpr (S == 2) {
+                    if (mdst[u] >= 0) {      // staged column c = 4xq + e: even e -> even plane at c/2 + 2, odd e -> odd plane at (c-1)/2 + 3
+                        *reinterpret_cast<float2*>(&smem[mdst[u] + 2]) = make_float2(o[0], o[2]);
+                        smem[mdst[u] + CFG::PE + 3] = o[1];
+                        smem[mdst[u] + CFG::PE + 4] = o[3];
+                    }
+                } else {
+                    if (mdst[u] >= 0) *reinterpret_cast<float4*>(&smem[mdst[u]]) = make_float4(o[0], o[1], o[2], o[3]);
+                }
             }
         } else {
             constexpr int TOT = CK * IH * IW, U = 8;
@@ -237,11 +250,13 @@ __global__ __launch_bounds__(CFG::NT) void conv_tile_kernel(const mi_conv_params
                     const float s3 = row[3];
                     in[0] = s0; in[1] = s12.x; in[2] = s12.x; in[3] = s12.y; in[4] = s12.y; in[5] = s3;
                 } else if constexpr (VEC && S == 2) {
-                    const float* row = &smem[(ck * IHS + ty * 2 + ky) * IWP + 8 * tx + 3];
-                    in[0] = row[0];
-                    const float4 a4 = *reinterpret_cast<const float4*>(row + 1), b4 = *reinterpret_cast<const float4*>(row + 5);
-                    in[1] = a4.x; in[2] = a4.y; in[3] = a4.z; in[4] = a4.w; in[5] = b4.x; in[6] = b4.y; in[7] = b4.z; in[8] = b4.w;
-                    in[9] = row[9];
+                    // taps 2x0-1 .. 2x0+8 of the four outputs x0 .. x0+3: odd columns O[4tx+1..4tx+5], even columns E[4tx+2..4tx+6]
+                    const float* rowE = &smem[(ck * IHS + ty * 2 + ky) * IWP + 4 * tx + 4];
+                    const float* rowO = rowE + CFG::PE;
+                    const float4 e4 = *reinterpret_cast<const float4*>(rowE), o4 = *reinterpret_cast<const float4*>(rowO);
+                    in[0] = o4.x; in[1] = e4.x; in[2] = o4.y; in[3] = e4.y; in[4] = o4.z; in[5] = e4.z; in[6] = o4.w; in[7] = e4.w;
+                    in[8] = rowO[4];
+                    in[9] = rowE[4];
                 } else if constexpr (VEC) {
                     const float* row = &smem[(ck * IHS + ty + ky) * IWP + tx * 4 + XOFF];
                     in[0] = row[0];

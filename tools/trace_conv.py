@@ -95,3 +95,31 @@ if hasattr(lib, "mi_debug_read_trace_conv"):
     for i, n in enumerate(names[:7]):
         print(f"  {n:34s} {np.median(t[:, i]):9.0f} {np.percentile(t[:, i], 10):9.0f} {np.percentile(t[:, i], 90):9.0f}")
     print(f"  total                              {np.median(t[:, :7].sum(1)):9.0f}")
+
+# ---- the stride-2 Downsample conv (k4 s2 p1): 8->8, input 256x256 -> output 128x128, B=32 (shared between the guidance halves)
+if hasattr(lib, "mi_debug_read_trace_conv"):
+    B, Cc, H, W = 32, 8, 128, 128
+    x = torch.randn(B, Cc, 2 * H, 2 * W, generator=g).to(dev)
+    w = torch.randn(Cc, Cc, 4, 4, generator=g) * 0.2
+    wp = P.pack_conv_weight(w, 8).to(dev)
+    p = L.MiConvParams()
+    p.B, p.H, p.W = B, H, W
+    p.in0 = L.MiAct(x.data_ptr(), Cc, 0, 0, 1.0, 0)
+    p.Cout, p.ksize, p.stride, p.up2 = Cc, 4, 2, 0
+    p.w, p.bias = wp.data_ptr(), bias.data_ptr()
+    out = torch.empty(B, Cc, H, W, device=dev)
+    ost = torch.zeros(B, Cc, 16, 2, device=dev)
+    p.out, p.out_stats, p.tile_cfg = out.data_ptr(), ost.data_ptr(), 0 | 0x100
+    for _ in range(3):
+        L.check(lib.mi_conv_fwd(C.byref(p), st), "conv")
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(10):
+        L.check(lib.mi_conv_fwd(C.byref(p), st), "conv")
+    e1.record(); torch.cuda.synchronize()
+    print(f"VALU conv k4s2 8->8 @128 B32: avg launch {e0.elapsed_time(e1) / 10 * 1e3:.1f} us")
+    lib.mi_debug_read_trace_conv(buf.ctypes.data, buf.nbytes)
+    t = buf.reshape(1024, 8).astype(np.int64)[:512]
+    for i, n in enumerate(names[:7]):
+        print(f"  {n:34s} {np.median(t[:, i]):9.0f} {np.percentile(t[:, i], 10):9.0f} {np.percentile(t[:, i], 90):9.0f}")
+    print(f"  total                              {np.median(t[:, :7].sum(1)):9.0f}")
