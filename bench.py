@@ -140,7 +140,8 @@ def graph_step_ms(im, stage, B, cond_scale, T, reps=40):
         return None
     st, entry = entries[-1]
     stream = L.current_stream()
-    reps = min(reps, T - 2)
+    per = entry.get("per", 1)                      # denoising steps captured per graph
+    reps = max(1, min(reps, T - 2 * per) // per)
     L.check(lib.mi_step_set(L.ptr(st.t_state), L.ptr(ws.times), B, T - 1, stream), "mi_step_set")
     L.check(lib.mi_graph_launch(entry["graph"], stream), "mi_graph_launch")
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -149,7 +150,7 @@ def graph_step_ms(im, stage, B, cond_scale, T, reps=40):
         L.check(lib.mi_graph_launch(entry["graph"], stream), "mi_graph_launch")
     e1.record()
     e1.synchronize()
-    return e0.elapsed_time(e1) / reps
+    return e0.elapsed_time(e1) / (reps * per)
 
 
 def t5_leg(dev, B, Lq=64, reps=10):
