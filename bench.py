@@ -246,12 +246,20 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", 0))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (there is no CPU path)"
+    # MINIMAGEN_BENCH_ONE_GPU=1 is a control-flow smoke test only (no valid number): every rank on cuda:0, collectives through gloo on
+    # host copies -- lets the N > 1 path run on a single-GPU box (RCCL refuses two ranks on one device)
+    one_gpu = os.environ.get("MINIMAGEN_BENCH_ONE_GPU", "0") == "1"
+    if one_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from minimagen_amd import _lib as L
     from minimagen_amd.distributed import gather_samples
@@ -264,9 +272,14 @@ def main():
 
     def one_step(k):
         out = im.sample(text_embeds=emb, text_masks=mask, cond_scale=args.cond_scale, _seed=1234 + k, _sample_offset=rank * B, _precision=args.precision)
-        if world > 1:
+        if world > 1 and one_gpu:
+            host = out.cpu()
+            pad = [torch.empty_like(host) for _ in range(world)]
+            dist.all_gather(pad, host)
+            out = torch.cat(pad, 0).to(dev)
+        elif world > 1:
             pad = [torch.empty_like(out) for _ in range(world)]
-            dist.all_gather(pad, out)
+            dist.all_gather(pad, out)                      # RCCL over xGMI: the only collective of the path
             out = torch.cat(pad, 0)
         return out
 
@@ -283,7 +296,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tt = torch.tensor([dt], device="cpu" if one_gpu else dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     assert torch.isfinite(out).all() and out.shape[0] == gB
