@@ -19,15 +19,32 @@ __device__ __forceinline__ float mi_silu(float v) {
 }
 
 // fp16 hi/lo split of four fp32 values for the 3-term MFMA products: hi = fp16(x), lo = fp16(x - hi) (22 mantissa bits kept).
-// (A mask + v_cvt_pkrtz formulation was measured 16 % slower on MI355X than these plain conversions.)
+// (A mask + v_cvt_pkrtz formulation was measured 16 % slower on MI355X than plain conversions; the v_fma_mix_f32 form below 4 % faster
+//  on the attention kernel.  -DMI_SPLIT_PLAIN builds the plain form on the device too.)
 typedef _Float16 mi_f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 mi_f16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void mi_split_f16(const float (&x)[4], mi_f16x4& hi, mi_f16x4& lo) {
+#if !defined(MI_SPLIT_PLAIN) && !defined(HIPEMU)
+    // x - float(hi) straight from the packed halves with v_fma_mix_f32 (fma(f16 -> f32, -1, x); exact, Sterbenz): no separate
+    // v_cvt_f32_f16 per element.  The emulator build takes the plain form below, which computes the same bits.
+#pragma unroll
+    for (int e = 0; e < 4; e += 2) {
+        const mi_f16x2 h2 = {(_Float16)x[e], (_Float16)x[e + 1]};
+        const unsigned hb = __builtin_bit_cast(unsigned, h2);
+        float l0, l1;
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(hb), "v"(x[e]));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(hb), "v"(x[e + 1]));
+        hi[e] = h2[0]; hi[e + 1] = h2[1];
+        lo[e] = (_Float16)l0; lo[e + 1] = (_Float16)l1;
+    }
+#else
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const _Float16 h = (_Float16)x[e];
         hi[e] = h;
         lo[e] = (_Float16)(x[e] - (float)h);
     }
+#endif
 }
 
 // mi_act.bmod: row b of a tensor shared between the guidance halves lives at b % bmod.  The engine only ever shares between two
