@@ -335,7 +335,7 @@ def main():
             k = 0.25 * ((3.0 if args.precision == "fp32" else 1.0) if attn_f16 else 1.0)
             ex = dom["alg_flops"] * k / (dom["ms"] * 1e-3) / 1e12
             res["roofline"]["executed"] = {"achieved": ex, "frac": ex / peak,
-                                           "note": f"MFMA flops actually issued = {k:g} x algorithmic (folded attention" + ((", fp16x3 split" if args.precision == "fp32" else ", single fp16 term") + "; v_mfma_f32_16x16x16_f16" if attn_f16 else "; v_mfma_f32_16x16x4_f32") + ")"}
+                                           "note": f"MFMA flops actually issued = {k:g} x algorithmic (folded attention" + ((", fp16x3 split" if args.precision == "fp32" else ", single fp16 term") + "; v_mfma_f32_16x16x16_f16 (QK^T) and 16x16x32_f16 (PV)" if attn_f16 else "; v_mfma_f32_16x16x4_f32") + ")"}
         res["roofline"].update(pmc_traffic(dom, B * (2 if args.cond_scale != 1 else 1), sizes[stage]))
         alg_fwd_mb = {64: 28.82, 256: 124.97}.get(sizes[stage])
         nfwd = 2 if args.cond_scale != 1 else 1
