@@ -5,8 +5,10 @@ reference's requirements.txt line 31) for the only way MinImagen calls it:
 
 TEST INFRASTRUCTURE ONLY.  The package is neither installed nor vendored under
 /root/reference, so this follows its published algorithm.
-PARITY UNPINNED: there is no reference implementation or golden vector in the
-container to check this file against.
+PARITY UNPINNED on the package itself: there is no resize-right implementation or golden
+vector in the container.  Independent evidence: away from the (reflect-padded) border the
+result agrees with Pillow's BICUBIC -- the same Keys a = -1/2 kernel and pixel-centre
+convention -- to fp32 rounding (tests/test_oracle.py::test_cubic_resize_interior_matches_pillow_bicubic).
 
 Algorithm (per resized dim, dims processed in order of increasing scale factor,
 ties in dim order => H then W for a (B,C,H,W) tensor and a scalar factor):

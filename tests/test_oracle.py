@@ -165,3 +165,18 @@ def test_sweep_configs_against_reference_directly():
             a = ru(x, tm, **kwargs)
         b = R.unet_forward(sd, x, tm, **kwargs)
         assert torch.allclose(a, b, atol=5e-6, rtol=1e-6), case
+
+
+def test_cubic_resize_interior_matches_pillow_bicubic():
+    """resize-right is neither installed nor vendored, so its restatement cannot be pinned on the package itself.  Pillow's
+    BICUBIC is an independent implementation of the same Keys (a = -1/2) kernel with the same pixel-centre convention: away
+    from the border (where Pillow renormalises the taps and resize-right reflect-pads) the two must agree to fp32 rounding."""
+    from PIL import Image
+    from oracle import resize_restated as RR
+    g = torch.Generator().manual_seed(0)
+    for shape, f, border in (((64, 64), 4.0, 12), ((32, 48), 2.0, 6)):
+        x = torch.randn(1, 1, *shape, generator=g)
+        up = RR.resize(x, scale_factors=f, pad_mode='reflect')[0, 0].numpy()
+        pil = np.asarray(Image.fromarray(x[0, 0].numpy(), mode='F').resize((int(shape[1] * f), int(shape[0] * f)), resample=Image.BICUBIC))
+        assert up.shape == pil.shape
+        assert np.abs(up - pil)[border:-border, border:-border].max() < 5e-6
