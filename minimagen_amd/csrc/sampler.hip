@@ -137,7 +137,13 @@ __global__ __launch_bounds__(256) void quantile_finish_kernel(const mi_quantile_
         }
     }
     if (threadIdx.x == 0) {
-        const float a = __uint_as_float(prefix[0]), bb = __uint_as_float(prefix[1]);
+        // torch.quantile returns NaN for a row that contains a NaN (not the order statistic): NaN bit patterns sit above infinity,
+        // i.e. in the top bins of pass 0 (0x7F9.. are NaN only; arithmetic produces the canonical 0x7FC00000)
+        const unsigned* h0 = p.hist + ((size_t)b * 2) * MI_Q_BINS;
+        unsigned nan_count = 0;
+        for (int k = 0x7F9; k < MI_Q_BINS; ++k) nan_count += h0[k];
+        float a = __uint_as_float(prefix[0]), bb = __uint_as_float(prefix[1]);
+        if (nan_count) a = bb = __uint_as_float(0x7FC00000u);
         const float d = __fsub_rn(bb, a);
         // ATen lerp: weight < 0.5 ? a + w*d : b - d*(1-w), multiply-add fused
         const float s = (fabsf(p.w) < 0.5f) ? fmaf(p.w, d, a) : fmaf(__fsub_rn(p.w, 1.0f), d, bb);
@@ -200,7 +206,8 @@ __global__ __launch_bounds__(256) void posterior_kernel(const mi_posterior_param
     const int b = blockIdx.y;
     const int t = *p.t_state;
     const float c1 = p.coef[t * 8 + 2], c2 = p.coef[t * 8 + 3], sigma = p.coef[t * 8 + 4];
-    const float s = fmaxf(p.s_q[b], 1.0f);                                       // Imagen.py:320
+    const float sq = p.s_q[b];
+    const float s = (sq < 1.0f) ? 1.0f : sq;                                     // Imagen.py:320 clamp_(min=1.): a NaN threshold stays NaN, as in torch
     const int k = (p.T - 1) - t;
     const float* nz = p.noise ? p.noise + ((size_t)k * p.B + b) * p.n : nullptr;
     const int nq = (p.n + 3) / 4;
@@ -218,7 +225,7 @@ __global__ __launch_bounds__(256) void posterior_kernel(const mi_posterior_param
             if (i < p.n) {
                 const size_t o = (size_t)b * p.n + i;
                 float x0 = p.x0[o];
-                x0 = __fdiv_rn(fminf(fmaxf(x0, -s), s), s);                       // Imagen.py:323
+                x0 = __fdiv_rn(x0 != x0 ? x0 : fminf(fmaxf(x0, -s), s), s);       // Imagen.py:323 (torch.clamp propagates NaN)
                 const float mean = __fadd_rn(__fmul_rn(c1, x0), __fmul_rn(c2, p.x[o]));   // diffusion_model.py:118-121
                 p.x[o] = __fadd_rn(mean, __fmul_rn(sigma, z[e]));               // Imagen.py:370
             }
@@ -235,7 +242,7 @@ __global__ void step_advance_kernel(int* t_state, long long* times, int B, int s
 
 __global__ __launch_bounds__(256) void finalize_kernel(const float* x, float* out, long long total, int unnormalize) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const float v = fminf(fmaxf(x[i], -1.0f), 1.0f);
+        const float v = x[i] != x[i] ? x[i] : fminf(fmaxf(x[i], -1.0f), 1.0f);      // torch.clamp propagates NaN
         out[i] = unnormalize ? __fmul_rn(__fadd_rn(v, 1.0f), 0.5f) : v;
     }
 }

@@ -161,6 +161,22 @@ def test_sampler_argument_sweep_vs_oracle(backend, case):
     assert d.max() < 1e-4 and d.mean() < 1e-5, (d.max(), d.mean())
 
 
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_degenerate_T20_schedule_is_all_nan_like_the_reference(backend):
+    """timesteps=20 passes the reference's assert (diffusion_model.py:24) but gives beta_T = 1: sqrt_recip_alphas_cumprod[T-1] is
+    inf, x0 becomes inf - inf, torch.quantile / clamp propagate the NaN and the reference returns an all-NaN image.  Same here."""
+    dev = setup(backend)
+    torch.manual_seed(2)
+    u = Unet(dim=8, dim_mults=(1, 2), num_resnet_blocks=1, layer_attns=False, layer_cross_attns=False, memory_efficient=True)
+    im = Imagen([u], text_encoder_name="t5_small", image_sizes=[32], timesteps=20, cond_drop_prob=0.15)
+    sd = {k: v.clone() for k, v in im.unets[0].state_dict().items()}
+    im = im.to(dev)
+    emb, mask = R.synthetic_text(2, length=10, seed=3)
+    out = im.sample(text_embeds=emb.to(dev), text_masks=mask.to(dev), cond_scale=2., _noise=R.make_randn(5))
+    ref = R.sample([sd], [32], 20, text_embeds=emb, text_masks=mask, cond_scale=2., randn=R.make_randn(5))
+    assert torch.isnan(ref).all() and torch.isnan(out).all()
+
+
 def test_api_errors():
     setup("emu")
     im = make_imagen([64], 25, "cpu", cond_drop_prob=0.)
