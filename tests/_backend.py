@@ -15,14 +15,19 @@ BACKENDS = [pytest.param("gpu", marks=pytest.mark.gpu), pytest.param("emu", mark
 GPU_ONLY = [pytest.param("gpu", marks=pytest.mark.gpu)]
 
 
+_EMU_BUILT = False
+
+
 def setup(kind: str) -> torch.device:
     if kind == "gpu":
         assert torch.cuda.is_available(), "-m gpu tests need the MI355X"
         L.use_library(L.DEFAULT_LIB)
         assert L.backend() == "hip-gfx950"
         return torch.device("cuda:0")
-    if not os.path.exists(EMU_LIB):
-        subprocess.run(["make", "-j8", "-C", os.path.join(ROOT, "tools", "hipemu")], check=True)
+    global _EMU_BUILT
+    if not _EMU_BUILT:            # once per test process: a no-op when up to date, a rebuild when a kernel source changed
+        subprocess.run(["make", "-j8", "-C", os.path.join(ROOT, "tools", "hipemu")], check=True, stdout=subprocess.DEVNULL)
+        _EMU_BUILT = True
     L.use_library(EMU_LIB)
     assert L.backend() == "hipemu"
     return torch.device("cpu")
