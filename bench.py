@@ -47,6 +47,8 @@ def build_imagen(workload, timesteps, dev):
     torch.manual_seed(0)
     if workload == "base64":
         unets, sizes = [Unet(**p["unet0"])], (64,)
+    elif workload == "cascade64_256_1024":      # BASELINE config 5's shape: the third stage reuses the unet_1 parameters (no 1024^2 config ships)
+        unets, sizes = [Unet(**p["unet0"]), Unet(**p["unet1"]), Unet(**p["unet1"])], (64, 256, 1024)
     else:
         unets, sizes = [Unet(**p["unet0"]), Unet(**p["unet1"])], (64, 256)
     im = Imagen(unets, text_encoder_name="t5_small", image_sizes=sizes, timesteps=timesteps, cond_drop_prob=0.15)
@@ -228,7 +230,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="cascade64_256", choices=["cascade64_256", "base64"])
+    ap.add_argument("--workload", default="cascade64_256", choices=["cascade64_256", "base64", "cascade64_256_1024"])
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
     ap.add_argument("--timesteps", type=int, default=100)
     ap.add_argument("--cond-scale", type=float, default=3.0)
@@ -305,11 +307,12 @@ def main():
     steps_per_sample = args.timesteps * n_stages
     value = gB * steps_per_sample * args.steps / dt
     res = {
-        "metric": "denoising-steps/sec (images/sec x T), base 64^2 + SR 64->256 cascade" if n_stages == 2 else "denoising-steps/sec (images/sec x T), base 64^2",
+        "metric": {1: "denoising-steps/sec (images/sec x T), base 64^2", 2: "denoising-steps/sec (images/sec x T), base 64^2 + SR 64->256 cascade",
+                   3: "denoising-steps/sec (images/sec x T), base 64^2 + SR 64->256 + SR 256->1024 cascade"}[n_stages],
         "value": value, "unit": "denoising-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32" if args.precision == "fp32" else "f16 operands on the matrix cores, f32 accumulate/softmax/statistics/storage", "data": "synthetic (random-init weights seed 0, randn text embeddings seed 7 with ragged masks, Philox noise)",
-        "config": {"workload": f"{args.workload}: unet_0 params @64x64" + (" + unet_1 params (lowres_cond) @256x256" if n_stages == 2 else "")
+        "config": {"workload": f"{args.workload}: unet_0 params @64x64" + (" + unet_1 params (lowres_cond) @256x256" if n_stages >= 2 else "") + (" + unet_1 params (lowres_cond) @1024x1024" if n_stages == 3 else "")
                    + f", T={args.timesteps}/stage, cond_scale={args.cond_scale} (2 U-Net evals/step), dynamic thresholding 0.9, " + ("fp32" if args.precision == "fp32" else "half-precision matrix-core contractions"),
                    "per_gpu_batch": B, "global_batch": gB, "timesteps": args.timesteps, "parallelism": f"dp{world}"},
         "images_per_s": gB * args.steps / dt,
@@ -337,7 +340,7 @@ def main():
             res["roofline"]["executed"] = {"achieved": ex, "frac": ex / peak,
                                            "note": f"MFMA flops actually issued = {k:g} x algorithmic (folded attention" + ((", fp16x3 split" if args.precision == "fp32" else ", single fp16 term") + "; v_mfma_f32_16x16x16_f16 (QK^T) and 16x16x32_f16 (PV)" if attn_f16 else "; v_mfma_f32_16x16x4_f32") + ")"}
         res["roofline"].update(pmc_traffic(dom, B * (2 if args.cond_scale != 1 else 1), sizes[stage]))
-        alg_fwd_mb = {64: 28.82, 256: 124.97}.get(sizes[stage])
+        alg_fwd_mb = {64: 28.82, 256: 124.97, 1024: 124.97 * 16}.get(sizes[stage])
         nfwd = 2 if args.cond_scale != 1 else 1
         res["unet_eval"] = {"stage": stage, "sum_kernel_ms": total_ms, "launches": len(rows),
                             "alg_bytes_MB_per_image_forward": alg_fwd_mb,
