@@ -126,3 +126,21 @@ def test_sample_distributed_world_size_2_gloo(tmp_path):
     procs = [subprocess.Popen([sys.executable, str(script), ROOT, port, str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
     outs = [p.communicate(timeout=600)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
+
+
+def test_bench_contract_helpers():
+    """bench.py pieces that need no GPU: the CLI parses, the synthetic text follows SURVEY.md 8(d) (ragged masks, masked rows zeroed,
+    rows keyed by the global index), and the roofline's PMC traffic is found in the committed profile of the dominant launch shape"""
+    import importlib
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True)
+    assert out.returncode == 0 and "--gpus" in out.stdout and "--steps" in out.stdout and "--warmup" in out.stdout
+    emb, mask = bench.synthetic_text(30, length=64)
+    assert emb.shape == (30, 64, 512) and mask.dtype == torch.bool
+    assert [int(m.sum()) for m in mask[:3]] == [64, 63, 62] and int(mask[24].sum()) == 64           # L - (r mod 24)
+    assert float(emb[1, 63].abs().max()) == 0.0 and float(emb[1, 62].abs().max()) > 0.0
+    emb2, mask2 = bench.synthetic_text(4, length=64, row0=26)                                      # rank offset = global rows 26..29
+    assert torch.equal(emb2, emb[26:30]) and torch.equal(mask2, mask[26:30])
+    t = bench.pmc_traffic({"kernel": "cross_attn"}, 64, 256)
+    assert t["traffic"] is None or 3e7 < t["traffic"] < 1e8
