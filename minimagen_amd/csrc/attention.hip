@@ -362,7 +362,8 @@ __global__ __launch_bounds__(64 * NWV, WPS) void cross_attn_f16x3_kernel(const m
                 const f16x4 ghi = g.h2[0];
                 if constexpr (!HALF) {
                     // (the K = 32 form {G hi|G lo}.{x hi|x hi} + K = 16 G hi.x lo saves one instruction per tile but returned wrong
-                    //  results on the device -- a K = 16 MFMA feeding a dependent K = 32 one -- and only 3.6 % of the kernel; not used)
+                    //  results on the device in this kernel in every ordering tried, although the same pair of instructions is correct in
+                    //  isolation (tools/ubench/mfma32_layout.hip) -- unresolved; it is worth only 3.6 % of the kernel and is not used)
                     acc = __builtin_amdgcn_mfma_f32_16x16x16f16(g.h2[1], xhi[kc], acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_16x16x16f16(ghi, xlo[kc], acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_16x16x16f16(ghi, xhi[kc], acc, 0, 0, 0);

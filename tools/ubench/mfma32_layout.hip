@@ -16,6 +16,18 @@ __global__ void probe(const _Float16* A, const _Float16* B, float* D) {   // A [
     for (int r = 0; r < 4; ++r) D[(4 * g + r) * 16 + q] = c[r];
 }
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+// hazard probe: a K = 16 MFMA feeding a dependent K = 32 one on the same accumulator (and the reverse order)
+template <int ORDER>
+__global__ void mixed(const _Float16* A, const _Float16* B, const _Float16* A4, const _Float16* B4, float* D) {
+    const int l = threadIdx.x, q = l & 15, g = l >> 4;
+    f16x8 a, b; f16x4 a4, b4;
+    for (int e = 0; e < 8; ++e) { a[e] = A[q * 32 + 8 * g + e]; b[e] = B[(8 * g + e) * 16 + q]; }
+    for (int e = 0; e < 4; ++e) { a4[e] = A4[q * 16 + 4 * g + e]; b4[e] = B4[(4 * g + e) * 16 + q]; }
+    f32x4 c = {0.f, 0.f, 0.f, 0.f};
+    if (ORDER == 0) { c = __builtin_amdgcn_mfma_f32_16x16x16f16(a4, b4, c, 0, 0, 0); c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+    else { c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); c = __builtin_amdgcn_mfma_f32_16x16x16f16(a4, b4, c, 0, 0, 0); }
+    for (int r = 0; r < 4; ++r) D[(4 * g + r) * 16 + q] = c[r];
+}
 template <int K32>
 __global__ __launch_bounds__(256) void rate(float* out, int iters) {
     f16x8 a8, b8; f16x4 a4, b4;
@@ -139,5 +151,21 @@ int main() {
     float err = 0.f;
     for (int i = 0; i < 256; ++i) err = fmaxf(err, fabsf(hD[i] - ref[i]));
     printf("v_mfma_f32_16x16x32_f16 assumed layout: max |err| = %g (%s)\n", err, err < 1e-3f ? "layout confirmed" : "LAYOUT MISMATCH");
+    {   // K = 16 then dependent K = 32 (and the reverse) on one accumulator
+        _Float16 hA4[16 * 16], hB4[16 * 16];
+        for (int i = 0; i < 256; ++i) { hA4[i] = (_Float16)((float)((i * 29) % 17 - 8) * 0.25f); hB4[i] = (_Float16)((float)((i * 31) % 13 - 6) * 0.5f); }
+        float ref2[256];
+        for (int i = 0; i < 16; ++i) for (int j = 0; j < 16; ++j) { float s = ref[i * 16 + j]; for (int k = 0; k < 16; ++k) s += (float)hA4[i * 16 + k] * (float)hB4[k * 16 + j]; ref2[i * 16 + j] = s; }
+        _Float16 *dA4, *dB4; hipMalloc(&dA4, sizeof(hA4)); hipMalloc(&dB4, sizeof(hB4));
+        hipMemcpy(dA4, hA4, sizeof(hA4), hipMemcpyHostToDevice); hipMemcpy(dB4, hB4, sizeof(hB4), hipMemcpyHostToDevice);
+        for (int order = 0; order < 2; ++order) {
+            if (order == 0) hipLaunchKernelGGL(mixed<0>, dim3(1), dim3(64), 0, 0, dA, dB, dA4, dB4, dD);
+            else hipLaunchKernelGGL(mixed<1>, dim3(1), dim3(64), 0, 0, dA, dB, dA4, dB4, dD);
+            hipMemcpy(hD, dD, sizeof(hD), hipMemcpyDeviceToHost);
+            float e2 = 0.f;
+            for (int i = 0; i < 256; ++i) e2 = fmaxf(e2, fabsf(hD[i] - ref2[i]));
+            printf("%s on one accumulator: max |err| = %g\n", order == 0 ? "K=16 then dependent K=32" : "K=32 then dependent K=16", e2);
+        }
+    }
     return 0;
 }
