@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MI_ABI_VERSION 1
+#define MI_ABI_VERSION 2
 
 enum mi_status {
     MI_OK = 0,
@@ -84,11 +84,19 @@ typedef struct mi_conv_params {
        [ceil(Cout/16)][ceil(Cin/16)][9 taps][64 lanes][4 hi | 4 lo halves]; res_w_f16 likewise with 1 tap over the residual channels */
     const void* w_f16;
     const void* res_w_f16;
+    /* row-paired matrix-core path (conv_rp.hip; tile_cfg 5..7): B-operand fragments of v_mfma_f32_16x16x32_f16 with
+       N = (output row parity dy, 8 output channels), K = (4 input rows, 8 input channels) per horizontal tap:
+       [ceil(Cin/8)][steps][ceil(Cout/8)][64 lanes][8 hi | 8 lo halves] of w * 2^w_rp_exp (power-of-two pre-scaling keeps the
+       fp16 hi/lo split in the normal range whatever the magnitude of the weights); res_w_rp likewise for the 1x1 residual */
+    const void* w_rp;
+    const void* res_w_rp;
+    int w_rp_exp, res_w_rp_exp;
 } mi_conv_params;
 #define MI_CONV_SPLIT16 0x100
 #define MI_CONV_SPLIT8  0x800   /* 8-channel outputs as two 4-channel workgroups (small, latency-bound launches) */
 #define MI_CONV_HALF    0x400   /* matrix-core path: single fp16 term per product (reduced-precision configuration; parity gate 3e-2) */
 #define MI_CONV_WAVES8  0x200   /* matrix-core path: 8 waves x 4 pixel-tiles per workgroup instead of 4 x 8 */
+#define MI_CONV_RP_FIRST 5      /* tile_cfg 5: 16x64, 6: 8x64, 7: 8x32 output tiles of the row-paired matrix-core path */
 
 /* tile_cfg -> output tile (th x tw) handled by one workgroup; out_nt = ceil(H/th)*ceil(W/tw) */
 int mi_conv_tile_shape(int tile_cfg, int* th, int* tw);

@@ -33,6 +33,7 @@ class MiConvParams(C.Structure):
         ("res0", MiAct), ("res1", MiAct), ("res_w", C.c_void_p), ("res_b", C.c_void_p),
         ("out", C.c_void_p), ("out_stats", C.c_void_p), ("tile_cfg", C.c_int),
         ("w_f16", C.c_void_p), ("res_w_f16", C.c_void_p),
+        ("w_rp", C.c_void_p), ("res_w_rp", C.c_void_p), ("w_rp_exp", C.c_int), ("res_w_rp_exp", C.c_int),
     ]
 
 

@@ -1,9 +1,21 @@
 // Shared device helpers for the MinImagen gfx950 kernels.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstring>
 #include "minimagen_hip.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Pointers that reach a kernel inside a by-value parameter struct and then go through a select (in0 / in1, res0 / res1) lose their
+// address space: the compiler emits FLAT loads, which count on vmcnt AND lgkmcnt -- every LDS wait then also waits for the global
+// loads in flight and software prefetch is dead.  mi_global() pins the global address space (identity on the emulator).
+#if defined(HIPEMU)
+template <class T> using mi_gptr = T*;
+template <class T> static inline T* mi_global(T* p) { return p; }
+#else
+template <class T> using mi_gptr = T __attribute__((address_space(1)))*;
+template <class T> __device__ __forceinline__ mi_gptr<T> mi_global(T* p) { return (mi_gptr<T>)p; }
+#endif
 
 #define MI_MAX_CIN 256      // direct-conv family: input channels (after concat) per launch
 #define MI_MAX_GROUPS 32
@@ -96,6 +108,70 @@ __device__ __forceinline__ void mi_gn_channel_totals(const mi_act& in0, const mi
     }
 }
 
+// Buffer-addressed global memory: a wave-uniform base (resource descriptor in SGPRs) + a 32-bit per-lane byte offset + a scalar byte
+// offset -- no 64-bit address arithmetic on the VALU per access, and the accesses stay ordinary counted vector-memory operations.
+#if defined(HIPEMU)
+struct mi_buf { char* base; };
+static inline mi_buf mi_make_buf(const void* base) { return {(char*)base}; }
+static inline float mi_buf_load_f32(const mi_buf& r, unsigned voff, unsigned soff) { float v; memcpy(&v, r.base + voff + soff, 4); return v; }
+static inline f32x4 mi_buf_load_f32x4(const mi_buf& r, unsigned voff, unsigned soff) { f32x4 v; memcpy(&v, r.base + voff + soff, 16); return v; }
+static inline void mi_buf_store_f32x4(const mi_buf& r, unsigned voff, unsigned soff, f32x4 v) { memcpy(r.base + voff + soff, &v, 16); }
+#else
+typedef __amdgpu_buffer_rsrc_t mi_buf;
+typedef unsigned mi_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ mi_buf mi_make_buf(const void* base) { return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000); }
+__device__ __forceinline__ float mi_buf_load_f32(const mi_buf& r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ f32x4 mi_buf_load_f32x4(const mi_buf& r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ void mi_buf_store_f32x4(const mi_buf& r, unsigned voff, unsigned soff, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(mi_u32x4, v), r, (int)voff, (int)soff, 0);
+}
+#endif
+
+// Split form of mi_gn_channel_totals for kernels that software-pipeline their loads: mi_gn_totals_issue() puts up to MI_STATS_K
+// partial (sum, sumsq) pairs per lane into registers with unconditional loads (clamped addresses), so the kernel can issue its bulk
+// loads right behind them and consume the statistics while those are still in flight (vmcnt is in order); mi_gn_totals_finish() adds
+// them up in fp64 in a fixed order.  Returns false (nothing issued) when the problem does not fit the fast path -- the caller then
+// uses mi_gn_channel_totals.
+#define MI_STATS_K 8
+struct mi_stats_regs { float2 v[MI_STATS_K]; int c, tpc; float scale; };
+__device__ __forceinline__ bool mi_gn_totals_issue(const mi_act& in0, const mi_act& in1, int C0, int Cin, int b, int lane, int nlanes, mi_stats_regs& r) {
+    int TPC = 1;
+    while (TPC < 64 && TPC * 2 * Cin <= nlanes) TPC *= 2;
+    const int nt_max = (Cin > C0 && in1.nt > in0.nt) ? in1.nt : in0.nt;
+    if (TPC * Cin > nlanes || nt_max > MI_STATS_K * TPC) return false;
+    const int c = lane / TPC, sub = lane % TPC;
+    const bool live = c < Cin;
+    const bool second = live && c >= C0;
+    const mi_act& a = second ? in1 : in0;
+    const int cc = live ? (second ? c - C0 : c) : 0;
+    const int ba = mi_row_of(b, a.bmod);
+    const mi_gptr<const float> st = mi_global(a.stats) + ((size_t)(ba * a.C + cc) * a.nt) * 2;
+#pragma unroll
+    for (int k = 0; k < MI_STATS_K; ++k) {
+        const int t = sub + k * TPC;
+        const bool ok = live && t < a.nt;
+        const float x = st[2 * (ok ? t : 0)], y = st[2 * (ok ? t : 0) + 1];
+        r.v[k] = make_float2(ok ? x : 0.0f, ok ? y : 0.0f);
+    }
+    r.c = live ? c : -1;
+    r.tpc = TPC;
+    r.scale = a.scale;
+    return true;
+}
+__device__ __forceinline__ void mi_gn_totals_finish(const mi_stats_regs& r, int lane, double* chS, double* chQ) {
+    double s = 0.0, q = 0.0;
+#pragma unroll
+    for (int k = 0; k < MI_STATS_K; ++k) { s += (double)r.v[k].x; q += (double)r.v[k].y; }
+    s *= (double)r.scale;
+    q *= (double)r.scale * (double)r.scale;
+    for (int o = r.tpc >> 1; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
+    if (r.c >= 0 && (lane % r.tpc) == 0) { chS[r.c] = s; chQ[r.c] = q; }
+}
+
 // mean and 1/std of one group from the channel totals: moments in fp64, the final rsqrt in fp32 like the reference
 __device__ __forceinline__ void mi_gn_group_moments(const double* chS, const double* chQ, int c_lo, int c_hi, double count, float eps,
                                                     float& mean_out, float& rstd_out) {
@@ -121,6 +197,7 @@ __device__ __forceinline__ float mi_wave_max(float v) {
 }
 
 int mi_conv_mfma_launch(const mi_conv_params& p, hipStream_t st);   // conv_mfma.hip
+int mi_conv_rp_launch(const mi_conv_params& p, hipStream_t st);     // conv_rp.hip
 
 // host-side error plumbing (capi.hip)
 void mi_set_error(const char* fmt, ...);

@@ -430,6 +430,9 @@ int dispatch_tile(const mi_conv_params& p, hipStream_t st) {
 
 extern "C" int mi_conv_tile_shape(int tile_cfg, int* th, int* tw) {
     switch (tile_cfg & 0xff) {
+        case 5: *th = 16; *tw = 64; return MI_OK;     // row-paired matrix-core path (conv_rp.hip)
+        case 6: *th = 8; *tw = 64; return MI_OK;
+        case 7: *th = 8; *tw = 32; return MI_OK;
         case 3: *th = 8; *tw = 64; return MI_OK;      // matrix-core path (conv_mfma.hip)
         case 4: *th = 16; *tw = 32; return MI_OK;
         case 0: *th = 16; *tw = 64; return MI_OK;
@@ -451,6 +454,7 @@ extern "C" int mi_conv_fwd(const mi_conv_params* pp, void* stream) {
     if (p.res0.data && !p.res_w && p.res0.C != p.Cout) { mi_set_error("mi_conv_fwd: identity residual needs Cres == Cout"); return MI_ERR_INVALID; }
     if (p.B <= 0 || p.H <= 0 || p.W <= 0 || p.Cout <= 0) { mi_set_error("mi_conv_fwd: empty problem"); return MI_ERR_INVALID; }
     if (p.up2 && ((p.H | p.W) & 1)) { mi_set_error("mi_conv_fwd: up2 needs even output size"); return MI_ERR_INVALID; }
+    if (p.w_rp) return mi_conv_rp_launch(p, st);
     if (p.w_f16) return mi_conv_mfma_launch(p, st);
     const int ct = mi_conv_cout_tile(p.Cout);
     // MI_CONV_SPLIT8: 8 output channels as two 4-channel workgroups -- twice the waves for the small (latency-bound) launches

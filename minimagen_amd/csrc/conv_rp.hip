@@ -1,0 +1,604 @@
+// Row-paired matrix-core convolution for the NARROW layers of MinImagen's U-Nets (8..32 channels): the 3x3 stride-1 convs
+// of Block / ResnetBlock (layers.py:131-145, 415-439) incl. the fused GroupNorm -> scale/shift -> SiLU prologue, the identity or
+// 1x1-conv residual and the next GroupNorm's partial statistics; with MODE the nearest-x2 Upsample conv (layers.py:512-515) and
+// the k4 s2 Downsample conv (layers.py:319).
+//
+// Why: with 8 channels the plain implicit GEMM leaves the matrix cores half empty (K = 8 of 16/32, N = 8 of 16), so round 1 ran
+// these layers as fp32 VALU direct convolutions and measured them VALU-issue-bound at ~2.5 TB/s of algorithmic traffic.
+// How: one v_mfma_f32_16x16x32_f16 computes D[16 pixels along x][N = (dy, co)] for TWO output rows at once:
+//   N = 16 = output-row parity dy (2) x 8 output channels,
+//   K = 32 = 4 input rows r (the rows the two output rows touch) x 8 input channels, for ONE horizontal tap kx,
+//   B[(r, ci)][(dy, co)] = W[co][ci][ky = r - dy][kx]   (zero where r - dy is not a tap: 6 of the 8 (r, dy) pairs are live),
+// so N is full and K is 75 % full whatever the channel count; wider layers loop over channel octets (rounds) and N tiles.
+// A lane's A operand is ONE aligned 16-byte LDS read: activations are staged pixel-major, channel-interleaved, [row][x][8 halves]
+// (hi plane, lo plane), with lane group lg <-> input row via the permutation (0, 2, 1, 3) so that the two rows a 16-lane
+// ds_read_b128 group touches are 2 * PW chunks apart = 0 mod 16 chunks: conflict-free with an unpadded pitch.
+// fp32 parity: every operand is split x = hi + lo (fp16 each) and multiplied as hi*hi + lo*hi + hi*lo (fp32 accumulate).  Both
+// operands are brought into the fp16 normal range by exact power-of-two scalings -- the weights once at pack time
+// (2^w_rp_exp), the activations per launch from the GroupNorm affine / the producer's statistics -- undone in the epilogue,
+// so the split keeps ~22 bits whatever the magnitude of the checkpoint's weights.
+#include "common.hip.h"
+#include <type_traits>
+
+typedef _Float16 rp_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 rp_f16x2 __attribute__((ext_vector_type(2)));
+typedef float rp_f32x2 __attribute__((ext_vector_type(2)));
+
+#ifdef MI_TRACE
+// development aid (tools/bench_conv.py): accumulated shader-clock time per phase of the first workgroups of the last launch
+__device__ unsigned long long mi_trace_rp_buf[1024 * 8];
+extern "C" int mi_debug_read_trace_rp(void* dst, size_t bytes) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(mi_trace_rp_buf), bytes); }
+#define RP_TSTART() unsigned long long rp_t_last = clock64(), rp_t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define RP_TPHASE(k) do { const unsigned long long rp_t_now = clock64(); rp_t_acc[k] += rp_t_now - rp_t_last; rp_t_last = rp_t_now; } while (0)
+#define RP_TEND() do { if (threadIdx.x == 0 && blockIdx.x < 1024) for (int k = 0; k < 8; ++k) mi_trace_rp_buf[blockIdx.x * 8 + k] = rp_t_acc[k]; } while (0)
+#else
+#define RP_TSTART() do { } while (0)
+#define RP_TPHASE(k) do { } while (0)
+#define RP_TEND() do { } while (0)
+#endif
+
+#ifndef RP_SCHED_BARRIER
+#define RP_SCHED_BARRIER 1
+#endif
+#ifndef RP_BUF
+#define RP_BUF 0          // 1: buffer-addressed loads / stores (32-bit offsets, no address VALU; measured: more registers, slower)
+#endif
+
+namespace {
+
+constexpr int RP_MAXC = 64;          // input channels (after concat) per launch on this path
+
+// 8 fp32 values -> 8 fp16 hi + 8 fp16 lo (lo = fp16(x - hi), both round-to-nearest: v_cvt_pk_f16_f32 on gfx950)
+__device__ __forceinline__ void rp_split8(const float (&y)[8], uint4& hi, uint4& lo) {
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const rp_f32x2 v = {y[2 * i], y[2 * i + 1]};
+        const rp_f16x2 h2 = __builtin_convertvector(v, rp_f16x2);
+        h[i] = __builtin_bit_cast(unsigned, h2);
+        float l0, l1;
+#if !defined(HIPEMU)
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(h[i]), "v"(y[2 * i]));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(h[i]), "v"(y[2 * i + 1]));
+#else
+        l0 = y[2 * i] - (float)h2[0];
+        l1 = y[2 * i + 1] - (float)h2[1];
+#endif
+        const rp_f32x2 lv = {l0, l1};
+        l[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(lv, rp_f16x2));
+    }
+    hi = make_uint4(h[0], h[1], h[2], h[3]);
+    lo = make_uint4(l[0], l[1], l[2], l[3]);
+}
+__device__ __forceinline__ uint4 rp_hi8(const float (&y)[8]) {
+    unsigned h[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const rp_f32x2 v = {y[2 * i], y[2 * i + 1]};
+        h[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, rp_f16x2));
+    }
+    return make_uint4(h[0], h[1], h[2], h[3]);
+}
+
+// exponent e with |m| in [2^(e-1), 2^e); 0 for zero / non-finite input (-> no scaling)
+__device__ __forceinline__ int rp_exponent(float m) {
+    const unsigned u = __float_as_uint(m) & 0x7fffffffu;
+    const int be = (int)(u >> 23);
+    if (be == 0 || be == 255) return 0;
+    return be - 126;
+}
+__device__ __forceinline__ int rp_clamp_exp(int k) { return k < -60 ? -60 : (k > 60 ? 60 : k); }
+
+// MODE 0: 3x3 stride 1.  MODE 1: nearest x2 up-sampling followed by 3x3 stride 1 (the low-resolution tile is staged; the taps
+// address it through (v >> 1)).  MODE 2: 4x4 stride 2 (N = 16 output channels of ONE output row, K = 4 input rows x 8 channels
+// per horizontal tap: full K).
+// KO_ / RO_: channel octets of the conv input / of the 1x1-residual input when known at compile time (the layer shapes of the
+// BASELINE U-Nets), -1 = read from the parameters: with the round structure static the whole tile loop is straight-line code, which
+// is what lets the compiler keep the next tile's loads in flight across the MFMA loop and the epilogue (with run-time rounds it
+// falls back to s_waitcnt vmcnt(0) at every join).
+template <int TH_, int TW_, int NJ_, bool GN_, bool HALF_, int MODE_, int KO_ = -1, int RO_ = -1>
+struct RpCfg {
+    static constexpr int TH = TH_, TW = TW_, NJ = NJ_, MODE = MODE_, KO_T = KO_, RO_T = RO_;
+    static constexpr bool GN = GN_, HALF = HALF_;
+    // staged source window (rows x units) and LDS pitch in 16-byte chunks
+    static constexpr int IH = MODE_ == 0 ? TH_ + 2 : (MODE_ == 1 ? TH_ / 2 + 2 : 2 * TH_ + 2);
+    static constexpr int UW = MODE_ == 0 ? TW_ + 2 : (MODE_ == 1 ? TW_ / 2 + 2 : 2 * TW_ + 2);
+    static constexpr int PW = MODE_ == 0 ? TW_ + 8 : (MODE_ == 1 ? TW_ / 2 + 8 : TW_ + 4);      // MODE 2: pitch of ONE column-parity plane
+    static constexpr int PLANE = MODE_ == 2 ? 2 * IH * PW : IH * PW;
+    static constexpr int NU = IH * UW, PER = (NU + 255) / 256;
+    static constexpr int GX = TW_ / 16, GY = MODE_ == 2 ? TH_ : TH_ / 2, NG = GX * GY, GPW = NG / 4;
+    static constexpr int NSTEP = MODE_ == 2 ? 4 : 3;
+    // waves per SIMD the register allocation leaves room for: 4 where that needs no spills (a spill is a counted memory operation:
+    // its s_waitcnt also waits for the prefetch), else 3
+    static constexpr int WPS = (NJ_ == 1 && TH_ * TW_ <= 512 && (KO_ + RO_ == 1 || TH_ * TW_ <= 256)) ? 4 : 3;
+};
+
+template <class CFG>
+__global__ __launch_bounds__(256, CFG::WPS) void conv_rp_kernel(const mi_conv_params p, const uint4* __restrict__ wrp, const uint4* __restrict__ rwrp,
+                                                                const int ntile) {
+    constexpr int TH = CFG::TH, TW = CFG::TW, NJ = CFG::NJ, IH = CFG::IH, UW = CFG::UW, PW = CFG::PW, MODE = CFG::MODE;
+    constexpr int NU = CFG::NU, PER = CFG::PER, GX = CFG::GX, GPW = CFG::GPW, NSTEP = CFG::NSTEP;
+    constexpr bool GN = CFG::GN, HALF = CFG::HALF;
+    __shared__ __attribute__((aligned(16))) uint4 actH[CFG::PLANE];
+    __shared__ __attribute__((aligned(16))) uint4 actL[HALF ? 1 : CFG::PLANE];
+    __shared__ __attribute__((aligned(16))) float4 chP[RP_MAXC];
+    __shared__ double chS[RP_MAXC], chQ[RP_MAXC], chS2[RP_MAXC], chQ2[RP_MAXC];
+    __shared__ float gMean[MI_MAX_GROUPS], gRstd[MI_MAX_GROUPS];
+    __shared__ float red[4][NJ * 16];
+    __shared__ int sExp[4];
+    __shared__ __attribute__((aligned(16))) uint4 wl[NSTEP * NJ * 64 * 2];      // this round's B fragments: [step][jt][lane][hi, lo]
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lq = lane & 15, lg = lane >> 4;
+    const int H = p.H, W = p.W;
+    const int tiles_x = (W + TW - 1) / TW, tiles = tiles_x * ((H + TH - 1) / TH);
+    const int strips = (tiles + ntile - 1) / ntile;
+    // One workgroup = one strip of `ntile` consecutive tiles of ONE image: the statistics / affine prologue is paid once per strip and
+    // the next tile's loads fly under the current tile's MFMA loop and epilogue.
+    // XCD-aware placement (speed only): workgroup L runs on XCD L % 8; give each XCD whole images so that halo re-reads and the
+    // producer -> consumer hand-over of an image stay in one L2
+    int b, strip;
+    if ((p.B & 7) == 0) {
+        const int L = blockIdx.x, k = L >> 3;
+        b = (L & 7) + 8 * (k / strips);
+        strip = k % strips;
+    } else {
+        b = blockIdx.x / strips;
+        strip = blockIdx.x % strips;
+    }
+    const int tile_lo = strip * ntile, tile_hi = (tile_lo + ntile < tiles) ? tile_lo + ntile : tiles;
+    const int C0 = p.in0.C, C1 = p.in1.data ? p.in1.C : 0, Cin = C0 + C1;
+    const int Cr0 = (p.res0.data && rwrp) ? p.res0.C : 0, Cr1 = (Cr0 && p.res1.data) ? p.res1.C : 0, Cres = Cr0 + Cr1;
+    constexpr bool STATIC_ROUNDS = CFG::KO_T >= 0;
+    const int KO = STATIC_ROUNDS ? CFG::KO_T : (Cin >> 3), RO = STATIC_ROUNDS ? CFG::RO_T : (Cres >> 3), rounds = KO + RO;
+    constexpr bool ONE_ROUND = STATIC_ROUNDS && CFG::KO_T + CFG::RO_T == 1;
+    // source image extent
+    const int Hs = MODE == 0 ? H : (MODE == 1 ? H / 2 : 2 * H), Ws = MODE == 0 ? W : (MODE == 1 ? W / 2 : 2 * W);
+    const int HWs = Hs * Ws;
+
+    RP_TSTART();
+    // ---------------- staging geometry: one unit = one source pixel (all 8 channels of the round); everything but the tile origin is
+    // the same for every tile of the strip
+    int ldst[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int q = tid + u * 256;
+        const int iy = q / UW, c = q - iy * UW;
+        const bool valid = q < NU;
+        if (MODE == 2) ldst[u] = valid ? ((c & 1) * IH + iy) * PW + (c >> 1) : -1;       // de-interleaved column parities
+        else ldst[u] = valid ? iy * PW + c : -1;
+    }
+    float raw[PER][8];
+    unsigned inmask = 0;              // bit u: unit u of the tile whose loads are in `raw` lies inside the image
+    auto load_raw = [&](int tile, int rnd) {
+        const int oy0 = (tile / tiles_x) * TH, ox0 = (tile % tiles_x) * TW;
+        const int sy0 = MODE == 0 ? oy0 - 1 : (MODE == 1 ? oy0 / 2 - 1 : 2 * oy0 - 1);
+        const int sx0 = MODE == 0 ? ox0 - 1 : (MODE == 1 ? ox0 / 2 - 1 : 2 * ox0 - 1);
+        const bool isres = rnd >= KO;
+        const int c0 = 8 * (isres ? rnd - KO : rnd);
+        const mi_act& t0 = isres ? p.res0 : p.in0;
+        const mi_act& t1 = isres ? p.res1 : p.in1;
+        const int Ca = isres ? Cr0 : C0, Cb = isres ? Cr1 : C1;
+        const bool second = c0 >= Ca;
+        const int bb = mi_row_of(b, second ? t1.bmod : t0.bmod);
+        const float* basep = second ? t1.data + ((size_t)bb * Cb + (c0 - Ca)) * HWs : t0.data + ((size_t)bb * Ca + c0) * HWs;
+#if RP_BUF
+        const mi_buf base = mi_make_buf(basep);
+#else
+        const mi_gptr<const float> base = mi_global(basep);
+#endif
+        unsigned off[PER];
+        inmask = 0;
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int q = tid + u * 256;
+            const int iy = q / UW, c = q - iy * UW;
+            const int gy = sy0 + iy, gx = sx0 + c;
+            const bool in = ldst[u] >= 0 && gy >= 0 && gy < Hs && gx >= 0 && gx < Ws;
+            inmask |= in ? (1u << u) : 0u;
+            off[u] = in ? (unsigned)(gy * Ws + gx) * 4u : 0u;  // byte offset; outside / unused slots read element 0 (legal, masked below)
+        }
+        // channel planes through the scalar offset of a buffer load: one address register per unit, no VALU work per load
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int u = 0; u < PER; ++u) {
+#if RP_BUF
+                raw[u][j] = mi_buf_load_f32(base, off[u], (unsigned)(j * HWs) * 4u);
+#else
+                raw[u][j] = *reinterpret_cast<mi_gptr<const float>>(reinterpret_cast<mi_gptr<const char>>(base + (size_t)j * HWs) + off[u]);
+#endif
+            }
+    };
+    // ---------------- the small loads first (statistics of the inputs: GroupNorm moments / magnitude for the fp16 scaling; the
+    // per-channel affine parameters), the first tile's bulk loads right behind them: ONE memory round trip for the whole prologue, and
+    // the statistics are reduced while the bulk loads are still in flight (vmcnt is in order)
+    const bool have_stats = GN || p.in0.stats != nullptr;
+    const bool res_stats = RO > 0 && p.res0.stats != nullptr && (Cr1 == 0 || p.res1.stats != nullptr);
+    mi_stats_regs sr, sr2;
+    const bool fast = have_stats && mi_gn_totals_issue(p.in0, p.in1, C0, Cin, b, tid, 256, sr);
+    const bool fast2 = res_stats && mi_gn_totals_issue(p.res0, p.res1, Cr0, Cres, b, tid, 256, sr2);
+    float pg = 0.f, pb = 0.f, psc = 1.f, psh = 0.f;        // lane c < Cin: gamma, beta, scale + 1, shift of channel c
+    if constexpr (GN) {
+        const int c = lane < Cin ? lane : 0;
+        pg = p.gn_gamma[c];
+        pb = p.gn_beta[c];
+        if (p.scale_shift) {
+            const float* ss = p.scale_shift + (size_t)b * p.ss_stride + p.ss_off;
+            psc = ss[c] + 1.0f;
+            psh = ss[Cin + c];
+        }
+    }
+    load_raw(tile_lo, 0);
+    RP_TPHASE(0);       // geometry + the prologue's and the first tile's loads issued
+    if (fast) mi_gn_totals_finish(sr, tid, chS, chQ);
+    else if (have_stats) mi_gn_channel_totals(p.in0, p.in1, C0, Cin, b, tid, 256, chS, chQ);
+    if (fast2) mi_gn_totals_finish(sr2, tid, chS2, chQ2);
+    else if (res_stats) mi_gn_channel_totals(p.res0, p.res1, Cr0, Cres, b, tid, 256, chS2, chQ2);
+
+    // ---------------- per-channel affine of the fused GroupNorm / scale-shift, and the power-of-two operand scalings
+    if (have_stats || res_stats) __syncthreads();
+    if constexpr (GN) {
+        const int cpg = Cin / p.gn_groups;
+        for (int g = tid; g < p.gn_groups; g += 256)
+            mi_gn_group_moments(chS, chQ, g * cpg, (g + 1) * cpg, (double)cpg * (double)HWs, p.gn_eps, gMean[g], gRstd[g]);
+        __syncthreads();
+    }
+    if (wave == 0) {
+        const int c = lane;
+        float A = 0.f, Bc = 0.f, m = 0.f;
+        if constexpr (GN) {
+            if (c < Cin) {
+                const int cpg = Cin / p.gn_groups, g = c / cpg;
+                float An = pg, Bn = pb;         // the affine in the normalised domain: magnitude of the activation
+                A = gRstd[g] * pg;
+                Bc = pb - gMean[g] * A;
+                if (p.scale_shift) {
+                    A *= psc;
+                    Bc = Bc * psc + psh;
+                    An *= psc;
+                    Bn = Bn * psc + psh;
+                }
+                A *= (c >= C0) ? p.in1.scale : p.in0.scale;
+                m = 4.0f * fabsf(An) + fabsf(Bn);                    // |SiLU(a)| <= |a|; 4 sigma of the normalised input
+            }
+            m = mi_wave_max(m);
+        } else if (have_stats) {
+            double q = (c < Cin) ? chQ[c] : 0.0;                    // rms of the raw input (the tensors' scales are already applied)
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+            m = 4.0f * sqrtf((float)(q / ((double)Cin * (double)HWs)));
+        }
+        int ka = (m > 0.f) ? rp_clamp_exp(4 - rp_exponent(m)) : 0;            // scaled magnitudes land in [8, 16)
+        int E = ka + p.w_rp_exp, kr = 0;
+        if (RO > 0) {
+            float mr = 4.0f;
+            if (res_stats) {
+                double q = (c < Cres) ? chQ2[c] : 0.0;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+                mr = 4.0f * sqrtf((float)(q / ((double)Cres * (double)HWs)));
+            }
+            const int kr_max = (mr > 0.f) ? rp_clamp_exp(4 - rp_exponent(mr)) : 0;
+            const int Er = kr_max + p.res_w_rp_exp;
+            if (Er < E) E = Er;                                      // one accumulator: both products carry 2^E; lowering a scale is always safe
+            ka = E - p.w_rp_exp;
+            kr = E - p.res_w_rp_exp;
+        }
+        if (c < Cin) {
+            if constexpr (GN) {
+                chP[c] = make_float4(ldexpf(A, ka), ldexpf(Bc, ka), A * -1.44269504088896340736f, Bc * -1.44269504088896340736f);
+            } else {
+                chP[c] = make_float4(ldexpf((c >= C0) ? p.in1.scale : p.in0.scale, ka), 0.f, 0.f, 0.f);
+            }
+        }
+        if (lane == 0) { sExp[0] = ka; sExp[1] = kr; sExp[2] = E; }
+    }
+    RP_TPHASE(1);       // statistics round trip + affine / exponent prologue
+
+    const int perm = ((lg & 1) << 1) | (lg >> 1);         // lane group -> input row (0, 2, 1, 3)
+    const bool idres = p.res0.data && !rwrp;
+#if RP_BUF
+    const mi_buf obuf = mi_make_buf(p.out + (size_t)b * p.Cout * H * W);
+    const mi_buf rbuf = mi_make_buf(idres ? p.res0.data + (size_t)mi_row_of(b, p.res0.bmod) * p.res0.C * H * W : p.out);
+#else
+    const mi_gptr<float> obuf = mi_global(p.out + (size_t)b * p.Cout * H * W);
+    const mi_gptr<const float> rbuf = mi_global(idres ? p.res0.data + (size_t)mi_row_of(b, p.res0.bmod) * p.res0.C * H * W : p.out);
+#endif
+    constexpr bool idres_any = !(CFG::RO_T > 0);          // a 1x1 residual conv excludes the identity residual
+
+    // B fragments (weights), global [round][step][jt][lane][8 hi | 8 lo]: each round's set is staged through LDS and shared by the four
+    // waves (registers: 24 NJ per lane if kept per wave); a single-round layer stages it once for the whole strip
+    constexpr int WCH = NSTEP * NJ * 128, WPER = (WCH + 255) / 256;      // 16-byte chunks per round, per work-item
+    uint4 wreg[WPER];
+    auto load_b = [&](int rnd) {
+        const bool isres = rnd >= KO;
+        const int k8 = isres ? rnd - KO : rnd;
+        const uint4* src = isres ? rwrp + (size_t)k8 * NJ * 128 : wrp + (size_t)k8 * WCH;
+        const int n = isres ? NJ * 128 : WCH;
+#pragma unroll
+        for (int i = 0; i < WPER; ++i) {
+            const int k = tid + i * 256;
+            if (k < n) wreg[i] = src[k];
+        }
+    };
+    auto store_b = [&](int rnd) {
+        const int n = rnd >= KO ? NJ * 128 : WCH;
+#pragma unroll
+        for (int i = 0; i < WPER; ++i) {
+            const int k = tid + i * 256;
+            if (k < n) wl[k] = wreg[i];
+        }
+    };
+    if (ONE_ROUND) { load_b(0); store_b(0); }
+    // bias per N tile (this lane's output channel), once per strip: a load inside the tile loop would have to wait for the prefetch
+    float bvv[NJ];
+#pragma unroll
+    for (int jt = 0; jt < NJ; ++jt) {
+        const int co = MODE == 2 ? 16 * jt + lq : 8 * jt + (lq & 7);
+        bvv[jt] = (p.bias && co < p.Cout) ? p.bias[co] : 0.0f;
+        if (Cres && p.res_b && co < p.Cout) bvv[jt] += p.res_b[co];
+    }
+
+    // the last tile of the strip is peeled (HAS_NEXT = false): a CONDITIONAL prefetch would merge two wait-count states at the join
+    // and force the conservative one (wait for everything) on every tile
+    auto do_tile = [&](const int tile, auto has_next_tag) {
+        constexpr bool HAS_NEXT = decltype(has_next_tag)::value;
+        const int oy0 = (tile / tiles_x) * TH, ox0 = (tile % tiles_x) * TW;
+        f32x4 acc[GPW][NJ];
+#pragma unroll
+        for (int g = 0; g < GPW; ++g)
+#pragma unroll
+            for (int jt = 0; jt < NJ; ++jt) acc[g][jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        float4 rv[idres_any ? GPW : 1][idres_any ? NJ : 1];
+        auto one_round = [&](const int rnd) {
+            const bool isres = rnd >= KO;
+            const int k8 = isres ? rnd - KO : rnd;
+            if (!ONE_ROUND) load_b(rnd);
+            RP_TPHASE(6);
+            __syncthreads();          // previous round's / tile's LDS fully consumed; chP / sExp visible before the first transform
+            RP_TPHASE(2);
+            // ---- activations: GroupNorm-apply + scale/shift + SiLU (or the raw scaled input), fp16 split, one 16-byte chunk per pixel
+            {
+                float rsc = 0.f;
+                if (isres) rsc = ldexpf((8 * k8 >= Cr0) ? p.res1.scale : p.res0.scale, sExp[1]);
+#pragma unroll
+                for (int u = 0; u < PER; ++u) {
+                    if (ldst[u] < 0) continue;
+                    float y[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float x = raw[u][j];
+                        if (isres) {
+                            y[j] = x * rsc;
+                        } else {
+                            const float4 P = chP[8 * k8 + j];
+                            if constexpr (GN) {
+                                const float a = fmaf(x, P.x, P.y);
+                                const float ex = __builtin_amdgcn_exp2f(fmaf(x, P.z, P.w));       // exp(-a)
+                                y[j] = a * __builtin_amdgcn_rcpf(1.0f + ex);
+                            } else {
+                                y[j] = x * P.x;
+                            }
+                        }
+                    }
+                    uint4 hv, lv = make_uint4(0u, 0u, 0u, 0u);
+                    if constexpr (HALF) hv = rp_hi8(y); else rp_split8(y, hv, lv);
+                    if (!((inmask >> u) & 1u)) { hv = make_uint4(0u, 0u, 0u, 0u); lv = hv; }      // zero padding follows the activation (as in the reference)
+                    actH[ldst[u]] = hv;
+                    if constexpr (!HALF) actL[ldst[u]] = lv;
+                }
+            }
+            if (!ONE_ROUND) store_b(rnd);
+            RP_TPHASE(3);       // wait for the raw loads + transform + LDS write
+            __syncthreads();
+            RP_TPHASE(2);
+            // the next loads (this tile's next round, or the next tile's first) fly under the MFMA loop and the epilogue
+            if (rnd + 1 < rounds) {
+                load_raw(tile, rnd + 1);
+            } else {
+                // identity residual of THIS tile first (consumed in the epilogue with the next tile's loads still in flight: vmcnt is in order)
+                if (idres) {
+#pragma unroll
+                    for (int jt = 0; jt < NJ; ++jt) {
+                        const int co = MODE == 2 ? 16 * jt + lq : 8 * jt + (lq & 7);
+                        const int dy = MODE == 2 ? 0 : lq >> 3;
+#pragma unroll
+                        for (int g = 0; g < GPW; ++g) {
+                            const int G = wave * GPW + g, gyy = G / GX, gxx = G % GX;
+                            const int oy = oy0 + (MODE == 2 ? gyy : 2 * gyy + dy), ox = ox0 + 16 * gxx + 4 * lg;
+                            // unconditional load from a clamped (always legal) address: no exec-masked block, so the waits stay counted
+                            const bool ok = co < p.Cout && oy < H && ox < W;
+                            const unsigned o = ok ? (unsigned)((co * H + oy) * W + ox) * 4u : 0u;
+#if RP_BUF
+                            const f32x4 r4 = mi_buf_load_f32x4(rbuf, o, 0u);
+#else
+                            const f32x4 r4 = *reinterpret_cast<mi_gptr<const f32x4>>(reinterpret_cast<mi_gptr<const char>>(rbuf) + o);
+#endif
+                            rv[g][jt] = make_float4(r4[0], r4[1], r4[2], r4[3]);
+                        }
+                    }
+                }
+                if constexpr (HAS_NEXT) load_raw(tile + 1, 0);
+            }
+#if RP_SCHED_BARRIER
+            __builtin_amdgcn_sched_barrier(0);      // keep the loads AHEAD of the MFMA loop (the scheduler otherwise spreads them over it)
+#endif
+            // ---- D[px 16][(dy, co)] += act[px][(r, ci)] . B[(r, ci)][(dy, co)], one instruction triple per horizontal tap
+#pragma unroll
+            for (int s = 0; s < NSTEP; ++s) {
+                if (isres && s > 0) continue;
+                const int sx = isres ? 1 : s;                // the 1x1 residual conv is the centre tap
+                rp_f16x8 bh[NJ], bl[NJ];
+#pragma unroll
+                for (int jt = 0; jt < NJ; ++jt) {
+                    bh[jt] = __builtin_bit_cast(rp_f16x8, wl[((s * NJ + jt) * 64 + lane) * 2]);
+                    if constexpr (!HALF) bl[jt] = __builtin_bit_cast(rp_f16x8, wl[((s * NJ + jt) * 64 + lane) * 2 + 1]);
+                }
+#pragma unroll
+                for (int g = 0; g < GPW; ++g) {
+                    const int G = wave * GPW + g, gyy = G / GX, gxx = G % GX;
+                    int idx;
+                    if (MODE == 0) idx = (2 * gyy + perm) * PW + 16 * gxx + lq + sx;
+                    else if (MODE == 1) idx = (((2 * gyy + perm - 1) >> 1) + 1) * PW + ((16 * gxx + lq + sx - 1) >> 1) + 1;
+                    else idx = ((sx & 1) * IH + 2 * gyy + lg) * PW + 16 * gxx + lq + (sx >> 1);   // MODE 2: lane group = vertical tap; column 2x + kx -> parity plane
+                    const rp_f16x8 ah = __builtin_bit_cast(rp_f16x8, actH[idx]);
+                    if constexpr (!HALF) {
+                        const rp_f16x8 al = __builtin_bit_cast(rp_f16x8, actL[idx]);
+#pragma unroll
+                        for (int jt = 0; jt < NJ; ++jt) {
+                            acc[g][jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[jt], acc[g][jt], 0, 0, 0);
+                            acc[g][jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[jt], acc[g][jt], 0, 0, 0);
+                        }
+                    }
+#pragma unroll
+                    for (int jt = 0; jt < NJ; ++jt)
+                        acc[g][jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[jt], acc[g][jt], 0, 0, 0);
+                }
+            }
+            RP_TPHASE(4);       // MFMA loop (+ the next load issue)
+        };
+        if constexpr (STATIC_ROUNDS) {
+#pragma unroll
+            for (int rnd = 0; rnd < CFG::KO_T + CFG::RO_T; ++rnd) one_round(rnd);
+        } else {
+            for (int rnd = 0; rnd < rounds; ++rnd) one_round(rnd);
+        }
+
+        // ---------------- epilogue: lane (lq, lg) holds pixels 4lg .. 4lg+3 of column j = lq of every group
+        const float unscale = ldexpf(1.0f, -sExp[2]);
+        float csum[NJ], csq[NJ];
+#pragma unroll
+        for (int jt = 0; jt < NJ; ++jt) {
+            csum[jt] = 0.f; csq[jt] = 0.f;
+            const int co = MODE == 2 ? 16 * jt + lq : 8 * jt + (lq & 7);
+            const int dy = MODE == 2 ? 0 : lq >> 3;
+            const float bv = bvv[jt];
+            const float rs = idres ? p.res0.scale : 0.0f;
+            float4 yv[GPW];
+#pragma unroll
+            for (int g = 0; g < GPW; ++g) {          // all arithmetic first, unconditionally (one counted wait for the residual loads) ...
+                float4 y;
+                y.x = fmaf(acc[g][jt][0], unscale, bv); y.y = fmaf(acc[g][jt][1], unscale, bv);
+                y.z = fmaf(acc[g][jt][2], unscale, bv); y.w = fmaf(acc[g][jt][3], unscale, bv);
+                if constexpr (idres_any) {
+                    if (idres) { const float4 r = rv[g][jt]; y.x = fmaf(r.x, rs, y.x); y.y = fmaf(r.y, rs, y.y); y.z = fmaf(r.z, rs, y.z); y.w = fmaf(r.w, rs, y.w); }
+                }
+                yv[g] = y;
+            }
+#pragma unroll
+            for (int g = 0; g < GPW; ++g) {          // ... then the (edge-masked) stores, which need no wait
+                const int G = wave * GPW + g, gyy = G / GX, gxx = G % GX;
+                const int oy = oy0 + (MODE == 2 ? gyy : 2 * gyy + dy), ox = ox0 + 16 * gxx + 4 * lg;
+                const bool ok = co < p.Cout && oy < H && ox < W;
+                const float4 y = yv[g];
+#if RP_BUF
+                if (ok) mi_buf_store_f32x4(obuf, (unsigned)((co * H + oy) * W + ox) * 4u, 0u, (f32x4){y.x, y.y, y.z, y.w});
+#else
+                if (ok) *reinterpret_cast<mi_gptr<f32x4>>(reinterpret_cast<mi_gptr<char>>(obuf) + (unsigned)((co * H + oy) * W + ox) * 4u) = (f32x4){y.x, y.y, y.z, y.w};
+#endif
+                csum[jt] += ok ? (y.x + y.y) + (y.z + y.w) : 0.0f;
+                csq[jt] += ok ? fmaf(y.x, y.x, fmaf(y.y, y.y, fmaf(y.z, y.z, y.w * y.w))) : 0.0f;
+            }
+        }
+        if (p.out_stats) {
+            constexpr int CPT = MODE == 2 ? 16 : 8;               // channels per N tile
+#pragma unroll
+            for (int jt = 0; jt < NJ; ++jt) {
+                if (MODE != 2) { csum[jt] += __shfl_xor(csum[jt], 8); csq[jt] += __shfl_xor(csq[jt], 8); }
+                csum[jt] += __shfl_xor(csum[jt], 16); csq[jt] += __shfl_xor(csq[jt], 16);
+                csum[jt] += __shfl_xor(csum[jt], 32); csq[jt] += __shfl_xor(csq[jt], 32);
+                if (lane < CPT) { red[wave][2 * (CPT * jt + lane)] = csum[jt]; red[wave][2 * (CPT * jt + lane) + 1] = csq[jt]; }
+            }
+            __syncthreads();
+            if (tid < 2 * CPT * NJ && (tid >> 1) < p.Cout)
+                p.out_stats[((size_t)(b * p.Cout + (tid >> 1)) * tiles + tile) * 2 + (tid & 1)] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+        }
+        RP_TPHASE(5);       // epilogue
+    };
+    for (int tile = tile_lo; tile + 1 < tile_hi; ++tile) do_tile(tile, std::true_type{});
+    do_tile(tile_hi - 1, std::false_type{});
+    RP_TEND();
+}
+
+template <int TH, int TW, int NJ, bool GN, bool HALF, int MODE, int KO, int RO>
+int launch_rp(const mi_conv_params& p, hipStream_t st) {
+    using CFG = RpCfg<TH, TW, NJ, GN, HALF, MODE, KO, RO>;
+    const int tiles = ((p.H + TH - 1) / TH) * ((p.W + TW - 1) / TW);
+    // tiles per workgroup (speed only; the per-tile statistics do not depend on it): tile_cfg bits 12..15, default such that the chip
+    // still gets >= ~8 workgroups per CU
+    int ntile = (p.tile_cfg >> 12) & 0xf;
+    if (ntile == 0) { ntile = 1; while (ntile < 8 && (size_t)p.B * (tiles / (2 * ntile)) >= 2048) ntile *= 2; }
+    const int strips = (tiles + ntile - 1) / ntile;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_rp_kernel<CFG>), dim3(strips * p.B), dim3(256), 0, st, p, (const uint4*)p.w_rp, (const uint4*)p.res_w_rp, ntile);
+    return mi_check_launch("conv_rp_kernel");
+}
+
+template <int TH, int TW, int NJ, int MODE, int KO, int RO>
+int launch_rp_v(const mi_conv_params& p, hipStream_t st) {
+    const bool half = (p.tile_cfg & MI_CONV_HALF) != 0;
+    if constexpr (MODE == 0) {
+        if (p.gn_groups > 0) return half ? launch_rp<TH, TW, NJ, true, true, MODE, KO, RO>(p, st) : launch_rp<TH, TW, NJ, true, false, MODE, KO, RO>(p, st);
+    }
+    if constexpr (KO <= 1 && RO <= 0)        // without GroupNorm: the final conv (8 channels in) and the generic fall-back only
+        return half ? launch_rp<TH, TW, NJ, false, true, MODE, KO, RO>(p, st) : launch_rp<TH, TW, NJ, false, false, MODE, KO, RO>(p, st);
+    return launch_rp_v<TH, TW, NJ, MODE, -1, -1>(p, st);
+}
+
+// the layer shapes of the BASELINE U-Nets get a kernel with a compile-time round structure; everything else the generic one
+template <int TH, int TW, int NJ, int MODE>
+int launch_rp_kr(const mi_conv_params& p, hipStream_t st) {
+    const int ko = (p.in0.C + (p.in1.data ? p.in1.C : 0)) >> 3;
+    const int ro = (p.res0.data && p.res_w_rp) ? (p.res0.C + (p.res1.data ? p.res1.C : 0)) >> 3 : 0;
+    if constexpr (MODE == 0 && NJ == 1) {
+        if (ko == 1 && ro == 0) return launch_rp_v<TH, TW, NJ, MODE, 1, 0>(p, st);
+        if (ko == 2 && ro == 0) return launch_rp_v<TH, TW, NJ, MODE, 2, 0>(p, st);
+        if (ko == 1 && ro == 2) return launch_rp_v<TH, TW, NJ, MODE, 1, 2>(p, st);
+    }
+    if constexpr (MODE == 0 && NJ == 2) {
+        if (ko == 1 && ro == 0) return launch_rp_v<TH, TW, NJ, MODE, 1, 0>(p, st);
+        if (ko == 2 && ro == 0) return launch_rp_v<TH, TW, NJ, MODE, 2, 0>(p, st);
+        if (ko == 4 && ro == 0) return launch_rp_v<TH, TW, NJ, MODE, 4, 0>(p, st);
+        if (ko == 2 && ro == 4) return launch_rp_v<TH, TW, NJ, MODE, 2, 4>(p, st);
+    }
+    return launch_rp_v<TH, TW, NJ, MODE, -1, -1>(p, st);
+}
+
+template <int TH, int TW, int MODE>
+int launch_rp_nj(const mi_conv_params& p, hipStream_t st) {
+    const int nj = MODE == 2 ? (p.Cout + 15) / 16 : (p.Cout + 7) / 8;
+    switch (nj) {
+        case 1: return launch_rp_kr<TH, TW, 1, MODE>(p, st);
+        case 2:
+            if constexpr (TH * TW <= 512) return launch_rp_kr<TH, TW, 2, MODE>(p, st);
+            break;
+        case 3: case 4:
+            if constexpr (MODE == 0 && TH * TW <= 256) return launch_rp_kr<TH, TW, 4, MODE>(p, st);
+            break;
+    }
+    mi_set_error("mi_conv_fwd: row-paired path: %d output channels not instantiated for this tile", p.Cout);
+    return MI_ERR_UNSUPPORTED;
+}
+
+}  // namespace
+
+int mi_conv_rp_launch(const mi_conv_params& p, hipStream_t st) {
+    const int C0 = p.in0.C, C1 = p.in1.data ? p.in1.C : 0, Cin = C0 + C1;
+    const int mode = p.up2 ? 1 : (p.stride == 2 ? 2 : 0);
+    if (!((p.ksize == 3 && p.stride == 1) || (p.ksize == 4 && p.stride == 2 && !p.up2))) { mi_set_error("mi_conv_fwd: row-paired path is k3 s1 (optionally nearest x2) or k4 s2"); return MI_ERR_UNSUPPORTED; }
+    if (mode != 0) { mi_set_error("mi_conv_fwd: row-paired path: mode %d not built yet", mode); return MI_ERR_UNSUPPORTED; }
+    if ((p.W & 3) || (C0 & 7) || (C1 & 7) || Cin > RP_MAXC) { mi_set_error("mi_conv_fwd: row-paired path needs W %% 4 == 0 and channel counts in multiples of 8 up to %d", RP_MAXC); return MI_ERR_UNSUPPORTED; }
+    if (mode != 0 && p.gn_groups > 0) { mi_set_error("mi_conv_fwd: GroupNorm prologue is only built for the k3 s1 family"); return MI_ERR_UNSUPPORTED; }
+    if (p.res0.data && p.res_w) {
+        const int Cres = p.res0.C + (p.res1.data ? p.res1.C : 0);
+        if (!p.res_w_rp || (p.res0.C & 7) || (p.res1.data && (p.res1.C & 7)) || Cres > RP_MAXC) { mi_set_error("mi_conv_fwd: row-paired path needs res_w_rp and residual channels in multiples of 8"); return MI_ERR_INVALID; }
+    }
+    const size_t biggest = (size_t)(C0 > C1 ? C0 : C1) * p.H * p.W * (mode == 2 ? 4 : 1);
+    if (biggest >= (1ull << 31)) { mi_set_error("mi_conv_fwd: row-paired path indexes one image with 32-bit offsets"); return MI_ERR_UNSUPPORTED; }
+    switch (p.tile_cfg & 0xff) {
+        case 5: return launch_rp_nj<16, 64, 0>(p, st);
+        case 6: return launch_rp_nj<8, 64, 0>(p, st);
+        case 7: return launch_rp_nj<8, 32, 0>(p, st);
+    }
+    mi_set_error("mi_conv_fwd: row-paired path uses tile_cfg 5 (16x64), 6 (8x64) or 7 (8x32)");
+    return MI_ERR_INVALID;
+}

@@ -30,6 +30,11 @@ CONV_SPLIT16 = int(os.environ.get("MINIMAGEN_CONV_SPLIT16", "1"))
 CONV_SPLIT8 = int(os.environ.get("MINIMAGEN_CONV_SPLIT8", "64"))        # 8-channel outputs of images up to SPLIT8^2 pixels as two 4-channel workgroups (0 = off)
 CONV_WAVES8 = int(os.environ.get("MINIMAGEN_CONV_WAVES8", "1"))        # matrix-core conv: 8 waves x 4 pixel-tiles per workgroup
 CONV_MFMA = int(os.environ.get("MINIMAGEN_CONV_MFMA", "1"))             # 1: wide (>=16 in, >=16 out) k3 s1 convs on the matrix cores; 2: all k3 s1
+CONV_RP = int(os.environ.get("MINIMAGEN_CONV_RP", "1"))                 # 1: narrow k3 s1 convs (channels in multiples of 8, <= 64 in) on the row-paired matrix-core kernel
+RP_TILE = {k: int(os.environ.get("MINIMAGEN_RP_TILE_" + k, d)) for k, d in (("L", "6"), ("M", "6"), ("S", "7"))}   # tile_cfg for images > 128^2 / > 64^2 / smaller
+RP_MIN_HW = int(os.environ.get("MINIMAGEN_RP_MIN_HW", str(64 * 64 + 1)))  # ... for images of at least this many pixels (measured: the 64x64 levels are
+                                                                         # latency-bound per workgroup and faster on the 16-channel MFMA kernel)
+RP_NTILE = int(os.environ.get("MINIMAGEN_RP_NTILE", "0"))               # tiles per workgroup of the row-paired kernel (0 = the library's choice)
 TILE64 = int(os.environ.get("MINIMAGEN_TILE64", "-1"))                  # force a conv tile shape at 64x64 / 128x128 (experiments)
 TILE128 = int(os.environ.get("MINIMAGEN_TILE128", "-1"))       # 1: 16-channel 3x3 outputs as two 8-channel workgroups
 JT = 17     # context tiles of 16 rows: 1 null + (2|4) time tokens + 256 text rows <= 272
@@ -96,6 +101,7 @@ class UnetEngine:
         pk.freq = P.sinusoid_freq(u.dim, dev)
         pk.conv = {}
         pk.conv_f16 = {}
+        pk.conv_rp = {}
         pk.attn = {}
 
         def conv_pack(mod: nn.Conv2d, w=None, b=None):
@@ -105,6 +111,8 @@ class UnetEngine:
             pk.keep.append(wp)
             if w.shape[-1] in (1, 3):
                 pk.conv_f16[id(wp)] = P.pack_conv_weight_f16frag(w.to(dev))
+            if w.shape[-1] == 3 and w.shape[1] % 8 == 0 and w.shape[1] <= 64 and w.shape[0] <= 32:
+                pk.conv_rp[id(wp)] = P.pack_conv_weight_rp(w.to(dev))
             return wp
 
         resblocks: List[ResnetBlock] = [m for m in u.modules() if isinstance(m, ResnetBlock)]
@@ -129,6 +137,8 @@ class UnetEngine:
                 rw = P.pack_conv_weight(rb.res_conv.weight, ct).reshape(rb.res_conv.weight.shape[1], -1).contiguous()
                 pk.keep.append(rw)
                 pk.conv_f16[id(rw)] = P.pack_conv_weight_f16frag(rb.res_conv.weight)
+                if rb.res_conv.weight.shape[1] % 8 == 0 and rb.res_conv.weight.shape[1] <= 64:
+                    pk.conv_rp[id(rw)] = P.pack_conv_weight_rp(rb.res_conv.weight)
                 pk.conv[id(rb.res_conv)] = rw
             if rb.cross_attn is not None:
                 ca: CrossAttention = rb.cross_attn.fn
@@ -242,7 +252,18 @@ class UnetEngine:
         wide = cin_tot >= 16 and Cout >= (8 if CONV_MFMA == 3 else 16)
         mfma = (CONV_MFMA == 2 or (CONV_MFMA in (1, 3) and wide)) and ksize == 3 and stride == 1 and not up2 and Wo % 4 == 0 \
             and id(wpack) in pk.conv_f16
-        if mfma:
+        # row-paired matrix-core path (conv_rp.hip): every narrow k3 s1 conv whose channel counts come in octets
+        rp = bool(CONV_RP) and ksize == 3 and stride == 1 and not up2 and Wo % 4 == 0 and id(wpack) in pk.conv_rp and Ho * Wo >= RP_MIN_HW \
+            and in0.C % 8 == 0 and (in1 is None or in1.C % 8 == 0) \
+            and (res is None or res[2] is None or (id(res[2]) in pk.conv_rp and res[0].C % 8 == 0 and (res[1] is None or res[1].C % 8 == 0)))
+        if rp:
+            mfma = False
+            cfg = RP_TILE["L"] if Ho * Wo > 128 * 128 else (RP_TILE["M"] if Ho * Wo > 64 * 64 else RP_TILE["S"])
+            if Cout > 16 and cfg == 5:
+                cfg = 6
+            th, tw = {5: (16, 64), 6: (8, 64), 7: (8, 32)}[cfg]
+            nt = -(-Ho // th) * -(-Wo // tw)
+        elif mfma:
             cfg = 3 if Wo >= 64 else 4
             th, tw = (8, 64) if cfg == 3 else (16, 32)
             nt = -(-Ho // th) * -(-Wo // tw)
@@ -265,7 +286,14 @@ class UnetEngine:
                 p.res1 = r1.c(batch, skip_scale)
             p.res_w, p.res_b = L.ptr(rw), L.ptr(rb)
         p.out, p.out_stats, p.tile_cfg = L.ptr(out.t), L.ptr(out.stats), cfg | (0x100 if CONV_SPLIT16 else 0) | (0x200 if CONV_WAVES8 else 0) | (0x400 if ws.half else 0) | (0x800 if (CONV_SPLIT8 and Ho * Wo <= CONV_SPLIT8 * CONV_SPLIT8) else 0)
-        if mfma:
+        if rp:
+            p.tile_cfg |= (RP_NTILE & 0xf) << 12
+            frag, p.w_rp_exp = pk.conv_rp[id(wpack)]
+            p.w_rp = L.ptr(frag)
+            if res is not None and res[2] is not None:
+                rfrag, p.res_w_rp_exp = pk.conv_rp[id(res[2])]
+                p.res_w_rp = L.ptr(rfrag)
+        elif mfma:
             p.w_f16 = L.ptr(pk.conv_f16[id(wpack)])
             if res is not None and res[2] is not None:
                 p.res_w_f16 = L.ptr(pk.conv_f16[id(res[2])])

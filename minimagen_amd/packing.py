@@ -76,3 +76,45 @@ def sinusoid_freq(dim: int, device) -> torch.Tensor:
     half = dim // 2
     k = math.log(10000) / (half - 1)
     return torch.exp(torch.arange(half) * -k).float().contiguous().to(device)
+
+
+RP_PERM = (0, 2, 1, 3)      # lane group -> input row of the row-paired matrix-core conv (csrc/conv_rp.hip)
+
+
+def pack_conv_weight_rp(w: torch.Tensor):
+    """[Cout][Cin][3][3] (or [Cout][Cres][1][1]) fp32 -> (fragments, exponent) for csrc/conv_rp.hip.
+
+    B operand of v_mfma_f32_16x16x32_f16 with N = (output-row parity dy, 8 output channels), K = (4 input rows, 8 input channels)
+    per horizontal tap kx: [ceil(Cin/8)][steps][ceil(Cout/8)][64 lanes][8 hi | 8 lo] fp16, lane (lq, lg) holding
+    W[co = 8jt + (lq & 7)][ci = 8k + e][ky = RP_PERM[lg] - (lq >> 3)][kx = step] (zero where ky is not a tap; a 1x1 residual conv
+    is the centre tap).  The weights are pre-scaled by 2^exponent so that max|w| lands in [128, 256): the fp16 split hi = fp16(w'),
+    lo = fp16(w' - hi) then keeps ~22 bits whatever the magnitude of the checkpoint's weights; the kernel undoes the scale."""
+    cout, cin, kh, kw = w.shape
+    assert (kh, kw) in ((3, 3), (1, 1))
+    wd = w.detach().double().cpu()
+    mx = float(wd.abs().max())
+    exp = 0 if (mx == 0.0 or not math.isfinite(mx)) else 7 - math.floor(math.log2(mx))
+    exp = max(-100, min(100, exp))
+    ws = wd * (2.0 ** exp)
+    nj, ko, steps = -(-cout // 8), -(-cin // 8), kw
+    wp = torch.zeros(nj * 8, ko * 8, 3, kw, dtype=torch.float64)
+    if kh == 3:
+        wp[:cout, :cin] = ws
+    else:
+        wp[:cout, :cin, 1, :] = ws[:, :, 0, :]          # centre row; its single "step" is the centre column
+    lane = torch.arange(64)
+    lq, lg = lane & 15, lane >> 4
+    r = torch.tensor(RP_PERM)[lg]
+    ky = r - (lq >> 3)
+    live = ((ky >= 0) & (ky <= 2)).double()
+    kyc = ky.clamp(0, 2)
+    out = torch.zeros(ko, steps, nj, 64, 8, dtype=torch.float64)
+    for k in range(ko):
+        for s in range(steps):
+            for jt in range(nj):
+                co = 8 * jt + (lq & 7)
+                vals = wp[co, 8 * k:8 * k + 8, :, s]                   # [64 lanes][8 ci][3 ky]
+                out[k, s, jt] = vals[lane, :, kyc] * live[:, None]
+    hi = out.float().half()
+    lo = (out - hi.double()).float().half()
+    return torch.cat((hi, lo), dim=-1).contiguous().to(w.device), exp

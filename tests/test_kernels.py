@@ -179,6 +179,93 @@ def test_conv_matrix_core_path(backend, case):
     check_stats(ost.cpu(), ref)
 
 
+RP_CASES = [
+    # B, C0, C1, Cout, H, W, gn, ss, res, tile_cfg, xscale, wscale
+    (2, 8, 0, 8, 16, 64, True, True, 'id', 5, 1.0, 1.0),
+    (1, 8, 8, 8, 24, 72, True, True, 'conv2', 5, 1.0, 1.0),          # ragged tile edges, concat input, 1x1 residual over a concat
+    (8, 16, 0, 16, 16, 32, True, True, 'id', 7, 1.0, 1.0),           # B % 8 == 0: the XCD-aware workgroup -> image map
+    (1, 16, 16, 16, 20, 64, True, False, 'conv', 6, 1.0, 1.0),
+    (1, 8, 0, 3, 16, 64, False, False, 'none', 5, 1.0, 1.0),          # final conv (Cout 3 -> one padded N tile)
+    (1, 32, 0, 32, 8, 32, True, True, 'none', 7, 1.0, 1.0),           # four N tiles
+    (1, 8, 0, 8, 16, 64, True, True, 'id', 6, 256.0, 256.0),          # range safety of the fp16 split: large / small operands
+    (1, 8, 8, 8, 16, 32, True, False, 'conv', 7, 1.0 / 256, 1.0 / 256),
+    (1, 8, 0, 8, 16, 32, False, False, 'none', 7, 1.0 / 256, 300.0),
+    (1, 8, 0, 8, 16, 32, False, False, 'id', 7, 4096.0, 1.0 / 300),
+    (2, 8, 0, 8, 40, 128, True, True, 'id', 6 | (3 << 12), 1.0, 1.0),        # strips of 3 tiles per workgroup (ragged last strip)
+    (1, 16, 16, 16, 24, 64, True, True, 'conv2', 7 | (4 << 12), 1.0, 1.0),   # strips x several rounds (concat input + 1x1 residual)
+]
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("case", RP_CASES)
+def test_conv_row_paired_path(backend, case):
+    """k3 s1 conv on v_mfma_f32_16x16x32_f16 with N = (row parity, 8 channels) and power-of-two scaled fp16x3 operand splits vs torch
+    fp32: same tolerance as the VALU path, relative to the magnitude of the output for the scaled cases"""
+    dev = setup(backend)
+    lib = L.lib()
+    B, C0, C1, Cout, H, W, gn, ss, res, cfg, xs, wsc = case
+    g = torch.Generator().manual_seed(hash(case) & 0xffff)
+    rn = lambda *s_: torch.randn(*s_, generator=g)
+    x0 = (rn(B, C0, H, W) * 1.5 + 0.3) * xs
+    x1 = rn(B, C1, H, W) * xs if C1 else None
+    Cin = C0 + C1
+    w, bias = rn(Cout, Cin, 3, 3) * 0.2 * wsc, rn(Cout) * wsc * (1.0 if gn else xs)
+    gamma, beta = 1 + 0.2 * rn(Cin), 0.1 * rn(Cin)
+    sst = rn(B, 7 + 2 * Cin) * 0.3 if ss else None
+    if ss and xs != 1.0:
+        sst[:, 7] = 50.0                    # a large scale and shift on some channels (layers.py:141-143)
+        sst[:, 7 + Cin + 1] = -50.0
+    sk = 2 ** -0.5
+    h = torch.cat((x0, x1 * sk), 1) if C1 else x0
+    if gn:
+        h = F.group_norm(h, 8, gamma, beta, 1e-5)
+        if ss:
+            h = h * (sst[:, 7:7 + Cin, None, None] + 1) + sst[:, 7 + Cin:7 + 2 * Cin, None, None]
+        h = F.silu(h)
+    ref = F.conv2d(h.double(), w.double(), bias.double(), padding=1)
+    keep = {}
+    d = lambda name, t: keep.setdefault(name, t.to(dev).contiguous())
+    p = L.MiConvParams()
+    p.B, p.H, p.W = B, H, W
+    p.in0 = L.MiAct(d("x0", x0).data_ptr(), C0, d("s0", chan_stats(x0)).data_ptr(), 1, 1.0, 0)
+    if C1:
+        p.in1 = L.MiAct(d("x1", x1).data_ptr(), C1, d("s1", chan_stats(x1)).data_ptr(), 1, sk, 0)
+    p.Cout, p.ksize, p.stride, p.up2 = Cout, 3, 1, 0
+    wf, wexp = P.pack_conv_weight_rp(w)
+    p.w_rp, p.w_rp_exp, p.bias = d("wf", wf).data_ptr(), wexp, d("b", bias).data_ptr()
+    if gn:
+        p.gn_groups, p.gn_gamma, p.gn_beta, p.gn_eps = 8, d("g", gamma).data_ptr(), d("be", beta).data_ptr(), 1e-5
+        if ss:
+            p.scale_shift, p.ss_stride, p.ss_off = d("ss", sst).data_ptr(), sst.shape[1], 7
+    if res != 'none':
+        rsc = xs if not gn else 1.0
+        r0 = rn(B, Cout if res == 'id' else 8, H, W) * rsc
+        r1 = rn(B, 16, H, W) * rsc if res == 'conv2' else None
+        p.res0 = L.MiAct(d("r0", r0).data_ptr(), r0.shape[1], d("rs0", chan_stats(r0)).data_ptr(), 1, 1.0, 0)
+        if res == 'id':
+            ref = ref + r0
+        else:
+            rin = torch.cat((r0, r1 * sk), 1) if r1 is not None else r0
+            rw, rb = rn(Cout, rin.shape[1], 1, 1) * 0.3, rn(Cout)
+            ref = ref + F.conv2d(rin.double(), rw.double(), rb.double())
+            p.res_w = 1          # non-null marker: the residual is a 1x1 conv
+            rwf, rwexp = P.pack_conv_weight_rp(rw)
+            p.res_w_rp, p.res_w_rp_exp = d("rwf", rwf).data_ptr(), rwexp
+            p.res_b = d("rb", rb).data_ptr()
+            if r1 is not None:
+                p.res1 = L.MiAct(d("r1", r1).data_ptr(), 16, d("rs1", chan_stats(r1)).data_ptr(), 1, sk, 0)
+    nt = tile_nt(lib, cfg, H, W)
+    out = torch.full((B, Cout, H, W), float('nan'), device=dev)
+    ost = torch.zeros(B, Cout, nt, 2, device=dev)
+    p.out, p.out_stats, p.tile_cfg = out.data_ptr(), ost.data_ptr(), cfg
+    L.check(lib.mi_conv_fwd(C.byref(p), L.current_stream()), "conv rp")
+    scale = max(1.0, ref.abs().max().item() / 8.0)          # unit-scale cases: outputs of magnitude ~8
+    err = (out.cpu().double() - ref).abs().max().item()
+    print(f"rp conv {case}: max|d| = {err:.2e} (gate {2e-5 * scale:.2e}, |ref|max {ref.abs().max().item():.3g})")
+    assert err < 2e-5 * scale
+    check_stats(ost.cpu(), ref.float())
+
+
 def test_conv_rejects_bad_arguments():
     setup("emu")
     lib = L.lib()

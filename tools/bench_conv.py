@@ -1,0 +1,116 @@
+"""Development aid: time ONE conv launch shape of the SR / base U-Net in isolation on the GPU (HIP events, back to back) and, with the
+-DMI_TRACE build of the library (MINIMAGEN_HIP_LIB=.../libminimagen_hip_trace.so), print the per-phase shader-clock breakdown of
+conv_rp.hip.   python tools/bench_conv.py B Cin Cout H W gn res(none|id|conv) path(rp5|rp6|rp7|old) [C1]"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from minimagen_amd import _lib as L
+from minimagen_amd import packing as P
+
+lib = L.lib()
+dev = torch.device("cuda:0")
+
+
+def run(B, C0, Cout, H, W, gn, res, path, C1=0, reps=20, nt_in=None):
+    g = torch.Generator().manual_seed(1)
+    Cin = C0 + C1
+    x0 = torch.randn(B, C0, H, W, generator=g).to(dev)
+    x1 = torch.randn(B, C1, H, W, generator=g).to(dev) if C1 else None
+    nt_in = nt_in or max(1, (H // 16) * (W // 64))
+
+    def stats(x):
+        st = torch.zeros(x.shape[0], x.shape[1], nt_in, 2, device=dev)
+        st[:, :, 0, 0] = x.sum((2, 3)); st[:, :, 0, 1] = (x * x).sum((2, 3))
+        return st
+    s0, s1 = stats(x0), (stats(x1) if C1 else None)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.2
+    bias, gamma, beta = torch.zeros(Cout, device=dev), torch.ones(Cin, device=dev), torch.zeros(Cin, device=dev)
+    p = L.MiConvParams()
+    p.B, p.H, p.W = B, H, W
+    p.in0 = L.MiAct(x0.data_ptr(), C0, s0.data_ptr(), nt_in, 1.0, 0)
+    if C1:
+        p.in1 = L.MiAct(x1.data_ptr(), C1, s1.data_ptr(), nt_in, 0.7071, 0)
+    p.Cout, p.ksize, p.stride, p.up2 = Cout, 3, 1, 0
+    keep = []
+    if path.startswith("rp"):
+        wf, p.w_rp_exp = P.pack_conv_weight_rp(w)
+        wf = wf.to(dev); keep.append(wf)
+        p.w_rp = wf.data_ptr()
+        cfg = int(path[2:3]) | (int(os.environ.get("NTILE", "0")) << 12)
+    elif path == "mfma":
+        wf = P.pack_conv_weight_f16frag(w).to(dev); keep.append(wf)
+        p.w_f16 = wf.data_ptr()
+        cfg = (3 if W >= 64 else 4) | 0x200
+    else:
+        ct = lib.mi_conv_cout_tile(Cout)
+        wp = P.pack_conv_weight(w, ct).to(dev); keep.append(wp)
+        p.w = wp.data_ptr()
+        cfg = (0 if (W >= 64 and H * W > 64 * 64) else 2) | 0x100 | (0x800 if H * W <= 64 * 64 else 0)
+    p.bias = bias.data_ptr()
+    if gn:
+        p.gn_groups, p.gn_gamma, p.gn_beta, p.gn_eps = 8, gamma.data_ptr(), beta.data_ptr(), 1e-5
+    if res == "id":
+        r = torch.randn(B, Cout, H, W, generator=g).to(dev); keep.append(r)
+        p.res0 = L.MiAct(r.data_ptr(), Cout, 0, 0, 1.0, 0)
+    elif res == "conv":
+        r = torch.randn(B, Cin, H, W, generator=g).to(dev); keep.append(r)
+        rs = stats(r); keep.append(rs)
+        p.res0 = L.MiAct(r.data_ptr(), Cin, rs.data_ptr(), nt_in, 1.0, 0)
+        rw = torch.randn(Cout, Cin, 1, 1, generator=g) * 0.3
+        p.res_w = 1
+        if path.startswith("rp"):
+            rwf, p.res_w_rp_exp = P.pack_conv_weight_rp(rw); rwf = rwf.to(dev); keep.append(rwf); p.res_w_rp = rwf.data_ptr()
+        elif path == "mfma":
+            rwf = P.pack_conv_weight_f16frag(rw).to(dev); keep.append(rwf); p.res_w_f16 = rwf.data_ptr()
+        else:
+            rwp = P.pack_conv_weight(rw, lib.mi_conv_cout_tile(Cout)).reshape(Cin, -1).contiguous().to(dev); keep.append(rwp); p.res_w = rwp.data_ptr()
+    th, tw = C.c_int(), C.c_int()
+    lib.mi_conv_tile_shape(cfg & 0xff, C.byref(th), C.byref(tw))
+    nt = -(-H // th.value) * -(-W // tw.value)
+    out = torch.empty(B, Cout, H, W, device=dev)
+    ost = torch.zeros(B, Cout, nt, 2, device=dev)
+    p.out, p.out_stats, p.tile_cfg = out.data_ptr(), ost.data_ptr(), cfg
+    st = L.current_stream()
+    for _ in range(3):
+        L.check(lib.mi_conv_fwd(C.byref(p), st), "conv")
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        L.check(lib.mi_conv_fwd(C.byref(p), st), "conv")
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / reps * 1e3
+    mb = (B * (Cin + Cout + (Cout if res == "id" else (Cin if res == "conv" else 0))) * H * W * 4) / 1e6
+    print(f"{path:5s} B{B} {Cin}->{Cout} @{H}x{W} gn={int(gn)} res={res}: {us:7.1f} us  ({mb:.0f} MB -> {mb / us * 1e-3 * 1e3:.2f} TB/s)".replace("TB/s", "GB/ms"))
+    if path.startswith("rp") and hasattr(lib, "mi_debug_read_trace_rp"):
+        buf = np.zeros(1024 * 8, dtype=np.uint64)
+        lib.mi_debug_read_trace_rp.argtypes = [C.c_void_p, C.c_size_t]
+        lib.mi_debug_read_trace_rp(buf.ctypes.data, buf.nbytes)
+        t = buf.reshape(1024, 8).astype(np.int64)
+        names = ["stats+geometry+issue loads", "affine prologue", "barrier waits", "wait raw + transform + LDS write", "MFMA loop", "epilogue", "B-frag issue"]
+        for i, n in enumerate(names):
+            print(f"      {n:34s} {np.median(t[:, i]):9.0f} {np.percentile(t[:, i], 10):9.0f} {np.percentile(t[:, i], 90):9.0f}")
+        print(f"      total                              {np.median(t[:, :7].sum(1)):9.0f}")
+    return us
+
+
+if __name__ == "__main__":
+    a = sys.argv[1:]
+    if a:
+        run(int(a[0]), int(a[1]), int(a[2]), int(a[3]), int(a[4]), a[5] == "1", a[6], a[7], int(a[8]) if len(a) > 8 else 0)
+    else:
+        for nt in (1, 2, 4, 8):
+            os.environ["NTILE"] = str(nt)
+            print("NTILE", nt)
+            for path in ("rp5", "rp6"):
+                run(64, 8, 8, 256, 256, True, "id", path)
+            run(64, 8, 3, 256, 256, False, "none", "rp6")
+            for path in ("rp6", "rp7"):
+                run(64, 8, 8, 128, 128, True, "id", path)
+            for path in ("rp6", "rp7"):
+                run(64, 16, 16, 64, 64, True, "id", path)
