@@ -108,6 +108,19 @@ __device__ __forceinline__ void mi_gn_channel_totals(const mi_act& in0, const mi
     }
 }
 
+// global-memory accessors with the address space pinned (see mi_global)
+__device__ __forceinline__ float mi_ldg(const float* p) { return *mi_global(p); }
+__device__ __forceinline__ float4 mi_ldg4(const float* p) {
+    const f32x4 v = *reinterpret_cast<mi_gptr<const f32x4>>(mi_global(p));
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ uint4 mi_ldg4u(const void* p) {
+    const f32x4 v = *reinterpret_cast<mi_gptr<const f32x4>>(mi_global(reinterpret_cast<const float*>(p)));
+    return make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3]));
+}
+__device__ __forceinline__ void mi_stg(float* p, float v) { *mi_global(p) = v; }
+__device__ __forceinline__ void mi_stg4(float* p, float4 v) { *reinterpret_cast<mi_gptr<f32x4>>(mi_global(p)) = (f32x4){v.x, v.y, v.z, v.w}; }
+
 // Buffer-addressed global memory: a wave-uniform base (resource descriptor in SGPRs) + a 32-bit per-lane byte offset + a scalar byte
 // offset -- no 64-bit address arithmetic on the VALU per access, and the accesses stay ordinary counted vector-memory operations.
 #if defined(HIPEMU)

@@ -128,7 +128,7 @@ __global__ __launch_bounds__(CFG::NT) void conv_tile_kernel(const mi_conv_params
 #pragma unroll
             for (int u = 0; u < PER4; ++u) {
                 const unsigned off = msrc[u] >= 0 ? (unsigned)msrc[u] : 0u;     // unused / outside slots read element 0 (legal, ignored)
-                xq4[u] = *reinterpret_cast<const float4*>(base + off);
+                xq4[u] = mi_ldg4(base + off);
             }
         }
     };
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(CFG::NT) void conv_tile_kernel(const mi_conv_params
                     const float* base = second ? p.in1.data : p.in0.data;
                     const int cc = second ? (b1 * C1 + (c - C0)) : (b0 * C0 + c);
                     const unsigned off = inimg ? (unsigned)((cc * Hin + sy) * Win + sx) : 0u;
-                    xs[u] = base[off];
+                    xs[u] = mi_ldg(base + off);
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
@@ -303,11 +303,11 @@ __global__ __launch_bounds__(CFG::NT) void conv_tile_kernel(const mi_conv_params
                 const float sc = second ? p.res1.scale : p.res0.scale;
                 float rv[4];
                 if (ox + 3 < p.W && (p.W & 3) == 0) {
-                    const float4 t4 = *reinterpret_cast<const float4*>(src + ox);
+                    const float4 t4 = mi_ldg4(src + ox);
                     rv[0] = t4.x * sc; rv[1] = t4.y * sc; rv[2] = t4.z * sc; rv[3] = t4.w * sc;
                 } else {
 #pragma unroll
-                    for (int px = 0; px < 4; ++px) rv[px] = (ox + px < p.W) ? src[ox + px] * sc : 0.0f;
+                    for (int px = 0; px < 4; ++px) rv[px] = (ox + px < p.W) ? mi_ldg(src + ox + px) * sc : 0.0f;
                 }
                 const float* wr = res_wts + (size_t)cr * CoutPad + co0;
 #pragma unroll
@@ -329,13 +329,13 @@ __global__ __launch_bounds__(CFG::NT) void conv_tile_kernel(const mi_conv_params
                 if (co0 + co < p.Cout) {
                     const float* src = p.res0.data + ((size_t)(br0 * Cres0 + co0 + co) * p.H + oy) * p.W;
                     if (ox + 3 < p.W && (p.W & 3) == 0) {
-                        const float4 t4 = *reinterpret_cast<const float4*>(src + ox);
+                        const float4 t4 = mi_ldg4(src + ox);
                         acc[0][co] += t4.x * p.res0.scale; acc[1][co] += t4.y * p.res0.scale;
                         acc[2][co] += t4.z * p.res0.scale; acc[3][co] += t4.w * p.res0.scale;
                     } else {
 #pragma unroll
                         for (int px = 0; px < 4; ++px)
-                            if (ox + px < p.W) acc[px][co] += src[ox + px] * p.res0.scale;
+                            if (ox + px < p.W) acc[px][co] += mi_ldg(src + ox + px) * p.res0.scale;
                     }
                 }
             }
@@ -348,13 +348,13 @@ __global__ __launch_bounds__(CFG::NT) void conv_tile_kernel(const mi_conv_params
         if (row_ok && (co0 + co) < p.Cout) {
             float* dst = p.out + ((size_t)(b * p.Cout + co0 + co) * p.H + oy) * p.W + ox;
             if (ox + 3 < p.W && (p.W & 3) == 0) {
-                *reinterpret_cast<float4*>(dst) = make_float4(acc[0][co], acc[1][co], acc[2][co], acc[3][co]);
+                mi_stg4(dst, make_float4(acc[0][co], acc[1][co], acc[2][co], acc[3][co]));
 #pragma unroll
                 for (int px = 0; px < 4; ++px) { s += acc[px][co]; q = fmaf(acc[px][co], acc[px][co], q); }
             } else {
 #pragma unroll
                 for (int px = 0; px < 4; ++px)
-                    if (ox + px < p.W) { dst[px] = acc[px][co]; s += acc[px][co]; q = fmaf(acc[px][co], acc[px][co], q); }
+                    if (ox + px < p.W) { mi_stg(dst + px, acc[px][co]); s += acc[px][co]; q = fmaf(acc[px][co], acc[px][co], q); }
             }
         }
         ssum[co] = s;

@@ -105,7 +105,7 @@ __global__ __launch_bounds__(CFG::NT, CFG::NW / 2) void conv3x3_mfma_kernel(cons
                 float4 x4 = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (mdst[u] >= 0 && msrc[u] >= 0 && c < Ct) {
                     const float* src = c >= Ca ? base1 + (c - Ca) * HW : base0 + c * HW;
-                    x4 = *reinterpret_cast<const float4*>(src + msrc[u]);
+                    x4 = mi_ldg4(src + msrc[u]);
                 }
                 raw[u][j] = x4;
             }
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(CFG::NT, CFG::NW / 2) void conv3x3_mfma_kernel(cons
         const int gt = wave * TPW + t, oy = oy0 + gt / XT, ox = ox0 + 16 * (gt % XT) + 4 * lg;
         resv[t] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (idres && co < p.Cout && oy < H && ox < W)
-            resv[t] = *reinterpret_cast<const float4*>(p.res0.data + ((size_t)(br0 * p.res0.C + co) * H + oy) * W + ox);
+            resv[t] = mi_ldg4(p.res0.data + ((size_t)(br0 * p.res0.C + co) * H + oy) * W + ox);
     }
 
     MI_STAMP(1);
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(CFG::NT, CFG::NW / 2) void conv3x3_mfma_kernel(cons
             const _Float16* src = isres ? rwf + ((size_t)(mz * RC + kc)) * 64 * 8 : wf + ((size_t)(mz * KC + kc) * 9) * 64 * 8;
             for (int i = tid; i < ntap * 64; i += NT) {
                 union { uint4 u; f16x4 h[2]; } v;
-                v.u = *reinterpret_cast<const uint4*>(src + (size_t)i * 8);
+                v.u = mi_ldg4u(src + (size_t)i * 8);
                 const int tap = isres ? 8 : i >> 6, ln = i & 63;
                 wl[tap >> 1][ln][tap & 1] = v.h[0];
                 wl[tap >> 1][ln][2 + (tap & 1)] = v.h[1];
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(CFG::NT, CFG::NW / 2) void conv3x3_mfma_kernel(cons
                 y.y = acc[t][1] + bv + resv[t].y * rs;
                 y.z = acc[t][2] + bv + resv[t].z * rs;
                 y.w = acc[t][3] + bv + resv[t].w * rs;
-                *reinterpret_cast<float4*>(p.out + ((size_t)(b * p.Cout + co) * H + oy) * W + ox) = y;
+                mi_stg4(p.out + ((size_t)(b * p.Cout + co) * H + oy) * W + ox, y);
                 csum += (y.x + y.y) + (y.z + y.w);
                 csq = fmaf(y.x, y.x, fmaf(y.y, y.y, fmaf(y.z, y.z, fmaf(y.w, y.w, csq))));
             }

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(NT) void crossembed_422_kernel(const mi_crossembed_
         const float* src = plane(c);
         if (vec) {
 #pragma unroll
-            for (int u = 0; u < PER4; ++u) xq4[u] = *reinterpret_cast<const float4*>(src + (msrc[u] >= 0 ? msrc[u] : 0));
+            for (int u = 0; u < PER4; ++u) xq4[u] = mi_ldg4(src + (msrc[u] >= 0 ? msrc[u] : 0));
         }
     };
     auto stage_write = [&](int c) {
