@@ -19,6 +19,7 @@
 // so the split keeps ~22 bits whatever the magnitude of the checkpoint's weights.
 #include "common.hip.h"
 #include <type_traits>
+#include <utility>
 
 typedef _Float16 rp_f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 rp_f16x2 __attribute__((ext_vector_type(2)));
@@ -80,6 +81,9 @@ __device__ __forceinline__ uint4 rp_hi8(const float (&y)[8]) {
     return make_uint4(h[0], h[1], h[2], h[3]);
 }
 
+template <class F, int... I>
+__device__ __forceinline__ void rp_for_rounds(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
+
 // exponent e with |m| in [2^(e-1), 2^e); 0 for zero / non-finite input (-> no scaling)
 __device__ __forceinline__ int rp_exponent(float m) {
     const unsigned u = __float_as_uint(m) & 0x7fffffffu;
@@ -126,7 +130,10 @@ __global__ __launch_bounds__(256, CFG::WPS) void conv_rp_kernel(const mi_conv_pa
     __shared__ float gMean[MI_MAX_GROUPS], gRstd[MI_MAX_GROUPS];
     __shared__ float red[4][NJ * 16];
     __shared__ int sExp[4];
-    __shared__ __attribute__((aligned(16))) uint4 wl[NSTEP * NJ * 64 * 2];      // this round's B fragments: [step][jt][lane][hi, lo]
+    // B fragments [step][jt][lane][hi, lo]: every round's set when the round structure is static (staged once per strip), else one round's
+    constexpr int WCH = NSTEP * NJ * 128;                                        // 16-byte chunks of one conv round
+    constexpr int WTOT = CFG::KO_T >= 0 ? CFG::KO_T * WCH + CFG::RO_T * NJ * 128 : WCH;
+    __shared__ __attribute__((aligned(16))) uint4 wl[WTOT];
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lq = lane & 15, lg = lane >> 4;
     const int H = p.H, W = p.W;
@@ -150,7 +157,9 @@ __global__ __launch_bounds__(256, CFG::WPS) void conv_rp_kernel(const mi_conv_pa
     const int Cr0 = (p.res0.data && rwrp) ? p.res0.C : 0, Cr1 = (Cr0 && p.res1.data) ? p.res1.C : 0, Cres = Cr0 + Cr1;
     constexpr bool STATIC_ROUNDS = CFG::KO_T >= 0;
     const int KO = STATIC_ROUNDS ? CFG::KO_T : (Cin >> 3), RO = STATIC_ROUNDS ? CFG::RO_T : (Cres >> 3), rounds = KO + RO;
-    constexpr bool ONE_ROUND = STATIC_ROUNDS && CFG::KO_T + CFG::RO_T == 1;
+    constexpr int RT = STATIC_ROUNDS ? CFG::KO_T + CFG::RO_T : 1;         // static round count (1 slot in the generic kernel)
+    constexpr int NSLOT = RT;                                             // raw-load register slots (one per round; <= PFD + 1 are live at a time)
+    constexpr int PFD = RT >= 2 ? 2 : 1;                                  // prefetch distance in rounds
     // source image extent
     const int Hs = MODE == 0 ? H : (MODE == 1 ? H / 2 : 2 * H), Ws = MODE == 0 ? W : (MODE == 1 ? W / 2 : 2 * W);
     const int HWs = Hs * Ws;
@@ -167,9 +176,10 @@ __global__ __launch_bounds__(256, CFG::WPS) void conv_rp_kernel(const mi_conv_pa
         if (MODE == 2) ldst[u] = valid ? ((c & 1) * IH + iy) * PW + (c >> 1) : -1;       // de-interleaved column parities
         else ldst[u] = valid ? iy * PW + c : -1;
     }
-    float raw[PER][8];
-    unsigned inmask = 0;              // bit u: unit u of the tile whose loads are in `raw` lies inside the image
-    auto load_raw = [&](int tile, int rnd) {
+    float raw[NSLOT][PER][8];
+    unsigned inmask[NSLOT];           // bit u: unit u of the tile whose loads are in the slot lies inside the image
+    auto load_raw = [&](int tile, int rnd, auto slot_tag) {
+        constexpr int slot = decltype(slot_tag)::value;
         const int oy0 = (tile / tiles_x) * TH, ox0 = (tile % tiles_x) * TW;
         const int sy0 = MODE == 0 ? oy0 - 1 : (MODE == 1 ? oy0 / 2 - 1 : 2 * oy0 - 1);
         const int sx0 = MODE == 0 ? ox0 - 1 : (MODE == 1 ? ox0 / 2 - 1 : 2 * ox0 - 1);
@@ -187,14 +197,14 @@ __global__ __launch_bounds__(256, CFG::WPS) void conv_rp_kernel(const mi_conv_pa
         const mi_gptr<const float> base = mi_global(basep);
 #endif
         unsigned off[PER];
-        inmask = 0;
+        unsigned im = 0;
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
             const int q = tid + u * 256;
             const int iy = q / UW, c = q - iy * UW;
             const int gy = sy0 + iy, gx = sx0 + c;
             const bool in = ldst[u] >= 0 && gy >= 0 && gy < Hs && gx >= 0 && gx < Ws;
-            inmask |= in ? (1u << u) : 0u;
+            im |= in ? (1u << u) : 0u;
             off[u] = in ? (unsigned)(gy * Ws + gx) * 4u : 0u;  // byte offset; outside / unused slots read element 0 (legal, masked below)
         }
         // channel planes through the scalar offset of a buffer load: one address register per unit, no VALU work per load
@@ -203,17 +213,29 @@ __global__ __launch_bounds__(256, CFG::WPS) void conv_rp_kernel(const mi_conv_pa
 #pragma unroll
             for (int u = 0; u < PER; ++u) {
 #if RP_BUF
-                raw[u][j] = mi_buf_load_f32(base, off[u], (unsigned)(j * HWs) * 4u);
+                raw[slot][u][j] = mi_buf_load_f32(base, off[u], (unsigned)(j * HWs) * 4u);
 #else
-                raw[u][j] = *reinterpret_cast<mi_gptr<const float>>(reinterpret_cast<mi_gptr<const char>>(base + (size_t)j * HWs) + off[u]);
+                raw[slot][u][j] = *reinterpret_cast<mi_gptr<const float>>(reinterpret_cast<mi_gptr<const char>>(base + (size_t)j * HWs) + off[u]);
 #endif
             }
+        inmask[slot] = im;
     };
     // ---------------- the small loads first (statistics of the inputs: GroupNorm moments / magnitude for the fp16 scaling; the
     // per-channel affine parameters), the first tile's bulk loads right behind them: ONE memory round trip for the whole prologue, and
     // the statistics are reduced while the bulk loads are still in flight (vmcnt is in order)
     const bool have_stats = GN || p.in0.stats != nullptr;
     const bool res_stats = RO > 0 && p.res0.stats != nullptr && (Cr1 == 0 || p.res1.stats != nullptr);
+    constexpr int WPER = (WTOT + 255) / 256;           // 16-byte weight chunks per work-item
+    uint4 wreg[WPER];
+    if constexpr (STATIC_ROUNDS) {                     // every round's weight fragments: two linear copies (conv rounds, residual rounds)
+        constexpr int WC = CFG::KO_T * WCH;
+#pragma unroll
+        for (int i = 0; i < WPER; ++i) {
+            const int k = tid + i * 256;
+            const int kc = k < WTOT ? k : 0;
+            wreg[i] = (CFG::RO_T > 0 && kc >= WC) ? mi_ldg4u(rwrp + (kc - WC)) : mi_ldg4u(wrp + kc);
+        }
+    }
     mi_stats_regs sr, sr2;
     const bool fast = have_stats && mi_gn_totals_issue(p.in0, p.in1, C0, Cin, b, tid, 256, sr);
     const bool fast2 = res_stats && mi_gn_totals_issue(p.res0, p.res1, Cr0, Cres, b, tid, 256, sr2);
@@ -228,8 +250,16 @@ __global__ __launch_bounds__(256, CFG::WPS) void conv_rp_kernel(const mi_conv_pa
             psh = ss[Cin + c];
         }
     }
-    load_raw(tile_lo, 0);
+    load_raw(tile_lo, 0, std::integral_constant<int, 0>{});
+    if constexpr (PFD >= 2) load_raw(tile_lo, 1, std::integral_constant<int, 1>{});
     RP_TPHASE(0);       // geometry + the prologue's and the first tile's loads issued
+    if constexpr (STATIC_ROUNDS) {
+#pragma unroll
+        for (int i = 0; i < WPER; ++i) {
+            const int k = tid + i * 256;
+            if (k < WTOT) wl[k] = wreg[i];
+        }
+    }
     if (fast) mi_gn_totals_finish(sr, tid, chS, chQ);
     else if (have_stats) mi_gn_channel_totals(p.in0, p.in1, C0, Cin, b, tid, 256, chS, chQ);
     if (fast2) mi_gn_totals_finish(sr2, tid, chS2, chQ2);
@@ -306,10 +336,7 @@ __global__ __launch_bounds__(256, CFG::WPS) void conv_rp_kernel(const mi_conv_pa
 #endif
     constexpr bool idres_any = !(CFG::RO_T > 0);          // a 1x1 residual conv excludes the identity residual
 
-    // B fragments (weights), global [round][step][jt][lane][8 hi | 8 lo]: each round's set is staged through LDS and shared by the four
-    // waves (registers: 24 NJ per lane if kept per wave); a single-round layer stages it once for the whole strip
-    constexpr int WCH = NSTEP * NJ * 128, WPER = (WCH + 255) / 256;      // 16-byte chunks per round, per work-item
-    uint4 wreg[WPER];
+    // generic kernel: one round's B fragments at a time through LDS
     auto load_b = [&](int rnd) {
         const bool isres = rnd >= KO;
         const int k8 = isres ? rnd - KO : rnd;
@@ -318,7 +345,7 @@ __global__ __launch_bounds__(256, CFG::WPS) void conv_rp_kernel(const mi_conv_pa
 #pragma unroll
         for (int i = 0; i < WPER; ++i) {
             const int k = tid + i * 256;
-            if (k < n) wreg[i] = src[k];
+            wreg[i] = mi_ldg4u(src + (k < n ? k : 0));
         }
     };
     auto store_b = [&](int rnd) {
@@ -329,7 +356,6 @@ __global__ __launch_bounds__(256, CFG::WPS) void conv_rp_kernel(const mi_conv_pa
             if (k < n) wl[k] = wreg[i];
         }
     };
-    if (ONE_ROUND) { load_b(0); store_b(0); }
     // bias per N tile (this lane's output channel), once per strip: a load inside the tile loop would have to wait for the prefetch
     float bvv[NJ];
 #pragma unroll
@@ -350,10 +376,14 @@ __global__ __launch_bounds__(256, CFG::WPS) void conv_rp_kernel(const mi_conv_pa
 #pragma unroll
             for (int jt = 0; jt < NJ; ++jt) acc[g][jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         float4 rv[idres_any ? GPW : 1][idres_any ? NJ : 1];
-        auto one_round = [&](const int rnd) {
+        auto one_round = [&](auto rnd_tag) {
+            using RTag = decltype(rnd_tag);
+            constexpr bool RC = !std::is_same<RTag, int>::value;           // compile-time round index
+            constexpr int slot = [] { if constexpr (RC) return (int)RTag::value; else return 0; }();
+            const int rnd = rnd_tag;
             const bool isres = rnd >= KO;
             const int k8 = isres ? rnd - KO : rnd;
-            if (!ONE_ROUND) load_b(rnd);
+            if constexpr (!STATIC_ROUNDS) load_b(rnd);
             RP_TPHASE(6);
             __syncthreads();          // previous round's / tile's LDS fully consumed; chP / sExp visible before the first transform
             RP_TPHASE(2);
@@ -367,7 +397,7 @@ __global__ __launch_bounds__(256, CFG::WPS) void conv_rp_kernel(const mi_conv_pa
                     float y[8];
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        const float x = raw[u][j];
+                        const float x = raw[slot][u][j];
                         if (isres) {
                             y[j] = x * rsc;
                         } else {
@@ -383,42 +413,46 @@ __global__ __launch_bounds__(256, CFG::WPS) void conv_rp_kernel(const mi_conv_pa
                     }
                     uint4 hv, lv = make_uint4(0u, 0u, 0u, 0u);
                     if constexpr (HALF) hv = rp_hi8(y); else rp_split8(y, hv, lv);
-                    if (!((inmask >> u) & 1u)) { hv = make_uint4(0u, 0u, 0u, 0u); lv = hv; }      // zero padding follows the activation (as in the reference)
+                    if (!((inmask[slot] >> u) & 1u)) { hv = make_uint4(0u, 0u, 0u, 0u); lv = hv; }      // zero padding follows the activation (as in the reference)
                     actH[ldst[u]] = hv;
                     if constexpr (!HALF) actL[ldst[u]] = lv;
                 }
             }
-            if (!ONE_ROUND) store_b(rnd);
+            if constexpr (!STATIC_ROUNDS) store_b(rnd);
             RP_TPHASE(3);       // wait for the raw loads + transform + LDS write
             __syncthreads();
             RP_TPHASE(2);
             // the next loads (this tile's next round, or the next tile's first) fly under the MFMA loop and the epilogue
-            if (rnd + 1 < rounds) {
-                load_raw(tile, rnd + 1);
-            } else {
-                // identity residual of THIS tile first (consumed in the epilogue with the next tile's loads still in flight: vmcnt is in order)
-                if (idres) {
+            // identity residual of THIS tile first, in the last round (consumed in the epilogue with the later loads still in flight: vmcnt is in order)
+            if (rnd + 1 == rounds && idres) {
 #pragma unroll
-                    for (int jt = 0; jt < NJ; ++jt) {
-                        const int co = MODE == 2 ? 16 * jt + lq : 8 * jt + (lq & 7);
-                        const int dy = MODE == 2 ? 0 : lq >> 3;
+                for (int jt = 0; jt < NJ; ++jt) {
+                    const int co = MODE == 2 ? 16 * jt + lq : 8 * jt + (lq & 7);
+                    const int dy = MODE == 2 ? 0 : lq >> 3;
 #pragma unroll
-                        for (int g = 0; g < GPW; ++g) {
-                            const int G = wave * GPW + g, gyy = G / GX, gxx = G % GX;
-                            const int oy = oy0 + (MODE == 2 ? gyy : 2 * gyy + dy), ox = ox0 + 16 * gxx + 4 * lg;
-                            // unconditional load from a clamped (always legal) address: no exec-masked block, so the waits stay counted
-                            const bool ok = co < p.Cout && oy < H && ox < W;
-                            const unsigned o = ok ? (unsigned)((co * H + oy) * W + ox) * 4u : 0u;
+                    for (int g = 0; g < GPW; ++g) {
+                        const int G = wave * GPW + g, gyy = G / GX, gxx = G % GX;
+                        const int oy = oy0 + (MODE == 2 ? gyy : 2 * gyy + dy), ox = ox0 + 16 * gxx + 4 * lg;
+                        // unconditional load from a clamped (always legal) address: no exec-masked block, so the waits stay counted
+                        const bool ok = co < p.Cout && oy < H && ox < W;
+                        const unsigned o = ok ? (unsigned)((co * H + oy) * W + ox) * 4u : 0u;
 #if RP_BUF
-                            const f32x4 r4 = mi_buf_load_f32x4(rbuf, o, 0u);
+                        const f32x4 r4 = mi_buf_load_f32x4(rbuf, o, 0u);
 #else
-                            const f32x4 r4 = *reinterpret_cast<mi_gptr<const f32x4>>(reinterpret_cast<mi_gptr<const char>>(rbuf) + o);
+                        const f32x4 r4 = *reinterpret_cast<mi_gptr<const f32x4>>(reinterpret_cast<mi_gptr<const char>>(rbuf) + o);
 #endif
-                            rv[g][jt] = make_float4(r4[0], r4[1], r4[2], r4[3]);
-                        }
+                        rv[g][jt] = make_float4(r4[0], r4[1], r4[2], r4[3]);
                     }
                 }
-                if constexpr (HAS_NEXT) load_raw(tile + 1, 0);
+            }
+            // the loads PFD rounds ahead (this tile's, or the next tile's) fly under the MFMA loops and the epilogue
+            if constexpr (RC) {
+                constexpr int tgt = (int)RTag::value + PFD;
+                if constexpr (tgt < RT) load_raw(tile, tgt, std::integral_constant<int, tgt>{});
+                else if constexpr (HAS_NEXT) load_raw(tile + 1, tgt - RT, std::integral_constant<int, tgt - RT>{});
+            } else {
+                if (rnd + 1 < rounds) load_raw(tile, rnd + 1, std::integral_constant<int, 0>{});
+                else if constexpr (HAS_NEXT) load_raw(tile + 1, 0, std::integral_constant<int, 0>{});
             }
 #if RP_SCHED_BARRIER
             __builtin_amdgcn_sched_barrier(0);      // keep the loads AHEAD of the MFMA loop (the scheduler otherwise spreads them over it)
@@ -431,8 +465,9 @@ __global__ __launch_bounds__(256, CFG::WPS) void conv_rp_kernel(const mi_conv_pa
                 rp_f16x8 bh[NJ], bl[NJ];
 #pragma unroll
                 for (int jt = 0; jt < NJ; ++jt) {
-                    bh[jt] = __builtin_bit_cast(rp_f16x8, wl[((s * NJ + jt) * 64 + lane) * 2]);
-                    if constexpr (!HALF) bl[jt] = __builtin_bit_cast(rp_f16x8, wl[((s * NJ + jt) * 64 + lane) * 2 + 1]);
+                    const int wo = STATIC_ROUNDS ? (isres ? CFG::KO_T * WCH + k8 * NJ * 128 : k8 * WCH) : 0;
+                    bh[jt] = __builtin_bit_cast(rp_f16x8, wl[wo + ((s * NJ + jt) * 64 + lane) * 2]);
+                    if constexpr (!HALF) bl[jt] = __builtin_bit_cast(rp_f16x8, wl[wo + ((s * NJ + jt) * 64 + lane) * 2 + 1]);
                 }
 #pragma unroll
                 for (int g = 0; g < GPW; ++g) {
@@ -458,8 +493,7 @@ __global__ __launch_bounds__(256, CFG::WPS) void conv_rp_kernel(const mi_conv_pa
             RP_TPHASE(4);       // MFMA loop (+ the next load issue)
         };
         if constexpr (STATIC_ROUNDS) {
-#pragma unroll
-            for (int rnd = 0; rnd < CFG::KO_T + CFG::RO_T; ++rnd) one_round(rnd);
+            rp_for_rounds(std::make_integer_sequence<int, RT>{}, one_round);
         } else {
             for (int rnd = 0; rnd < rounds; ++rnd) one_round(rnd);
         }

@@ -31,9 +31,8 @@ CONV_SPLIT8 = int(os.environ.get("MINIMAGEN_CONV_SPLIT8", "64"))        # 8-chan
 CONV_WAVES8 = int(os.environ.get("MINIMAGEN_CONV_WAVES8", "1"))        # matrix-core conv: 8 waves x 4 pixel-tiles per workgroup
 CONV_MFMA = int(os.environ.get("MINIMAGEN_CONV_MFMA", "1"))             # 1: wide (>=16 in, >=16 out) k3 s1 convs on the matrix cores; 2: all k3 s1
 CONV_RP = int(os.environ.get("MINIMAGEN_CONV_RP", "1"))                 # 1: narrow k3 s1 convs (channels in multiples of 8, <= 64 in) on the row-paired matrix-core kernel
-RP_TILE = {k: int(os.environ.get("MINIMAGEN_RP_TILE_" + k, d)) for k, d in (("L", "6"), ("M", "6"), ("S", "7"))}   # tile_cfg for images > 128^2 / > 64^2 / smaller
-RP_MIN_HW = int(os.environ.get("MINIMAGEN_RP_MIN_HW", str(64 * 64 + 1)))  # ... for images of at least this many pixels (measured: the 64x64 levels are
-                                                                         # latency-bound per workgroup and faster on the 16-channel MFMA kernel)
+RP_TILE = {k: int(os.environ.get("MINIMAGEN_RP_TILE_" + k, d)) for k, d in (("L", "6"), ("M", "6"), ("S", "6"))}   # tile_cfg for images > 128^2 / > 64^2 / smaller
+RP_MIN_HW = int(os.environ.get("MINIMAGEN_RP_MIN_HW", "0"))             # ... for images of at least this many pixels
 RP_NTILE = int(os.environ.get("MINIMAGEN_RP_NTILE", "0"))               # tiles per workgroup of the row-paired kernel (0 = the library's choice)
 TILE64 = int(os.environ.get("MINIMAGEN_TILE64", "-1"))                  # force a conv tile shape at 64x64 / 128x128 (experiments)
 TILE128 = int(os.environ.get("MINIMAGEN_TILE128", "-1"))       # 1: 16-channel 3x3 outputs as two 8-channel workgroups
@@ -259,8 +258,10 @@ class UnetEngine:
         if rp:
             mfma = False
             cfg = RP_TILE["L"] if Ho * Wo > 128 * 128 else (RP_TILE["M"] if Ho * Wo > 64 * 64 else RP_TILE["S"])
-            if Cout > 16 and cfg == 5:
+            if Cout > 8 and cfg == 5:
                 cfg = 6
+            if Cout > 16:
+                cfg = 7                  # four N tiles are only instantiated for the 8x32 tile
             th, tw = {5: (16, 64), 6: (8, 64), 7: (8, 32)}[cfg]
             nt = -(-Ho // th) * -(-Wo // tw)
         elif mfma:
