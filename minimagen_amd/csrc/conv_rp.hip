@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256, CFG::WPS) void conv_rp_kernel(const mi_conv_pa
     __shared__ __attribute__((aligned(16))) float4 chP[RP_MAXC];
     __shared__ double chS[RP_MAXC], chQ[RP_MAXC], chS2[RP_MAXC], chQ2[RP_MAXC];
     __shared__ float gMean[MI_MAX_GROUPS], gRstd[MI_MAX_GROUPS];
-    __shared__ float red[4][NJ * 16];
+    __shared__ float red[4][NJ * (MODE == 2 ? 32 : 16)];
     __shared__ int sExp[4];
     // B fragments [step][jt][lane][hi, lo]: every round's set when the round structure is static (staged once per strip), else one round's
     constexpr int WCH = NSTEP * NJ * 128;                                        // 16-byte chunks of one conv round
@@ -573,7 +573,7 @@ int launch_rp_v(const mi_conv_params& p, hipStream_t st) {
     if constexpr (MODE == 0) {
         if (p.gn_groups > 0) return half ? launch_rp<TH, TW, NJ, true, true, MODE, KO, RO>(p, st) : launch_rp<TH, TW, NJ, true, false, MODE, KO, RO>(p, st);
     }
-    if constexpr (KO <= 1 && RO <= 0)        // without GroupNorm: the final conv (8 channels in) and the generic fall-back only
+    if constexpr ((KO <= 1 && RO <= 0) || MODE != 0)        // without GroupNorm: the final conv (8 channels in), the up / down-sampling convs and the generic fall-back only
         return half ? launch_rp<TH, TW, NJ, false, true, MODE, KO, RO>(p, st) : launch_rp<TH, TW, NJ, false, false, MODE, KO, RO>(p, st);
     return launch_rp_v<TH, TW, NJ, MODE, -1, -1>(p, st);
 }
@@ -583,6 +583,10 @@ template <int TH, int TW, int NJ, int MODE>
 int launch_rp_kr(const mi_conv_params& p, hipStream_t st) {
     const int ko = (p.in0.C + (p.in1.data ? p.in1.C : 0)) >> 3;
     const int ro = (p.res0.data && p.res_w_rp) ? (p.res0.C + (p.res1.data ? p.res1.C : 0)) >> 3 : 0;
+    if constexpr (MODE != 0 && NJ == 1) {
+        if (ko == 1 && ro == 0) return launch_rp_v<TH, TW, NJ, MODE, 1, 0>(p, st);
+        if (ko == 2 && ro == 0 && MODE == 1) return launch_rp_v<TH, TW, NJ, MODE, 2, 0>(p, st);
+    }
     if constexpr (MODE == 0 && NJ == 1) {
         if (ko == 1 && ro == 0) return launch_rp_v<TH, TW, NJ, MODE, 1, 0>(p, st);
         if (ko == 2 && ro == 0) return launch_rp_v<TH, TW, NJ, MODE, 2, 0>(p, st);
@@ -603,7 +607,7 @@ int launch_rp_nj(const mi_conv_params& p, hipStream_t st) {
     switch (nj) {
         case 1: return launch_rp_kr<TH, TW, 1, MODE>(p, st);
         case 2:
-            if constexpr (TH * TW <= 512) return launch_rp_kr<TH, TW, 2, MODE>(p, st);
+            if constexpr (TH * TW <= 512 && MODE == 0) return launch_rp_kr<TH, TW, 2, MODE>(p, st);
             break;
         case 3: case 4:
             if constexpr (MODE == 0 && TH * TW <= 256) return launch_rp_kr<TH, TW, 4, MODE>(p, st);
@@ -619,7 +623,8 @@ int mi_conv_rp_launch(const mi_conv_params& p, hipStream_t st) {
     const int C0 = p.in0.C, C1 = p.in1.data ? p.in1.C : 0, Cin = C0 + C1;
     const int mode = p.up2 ? 1 : (p.stride == 2 ? 2 : 0);
     if (!((p.ksize == 3 && p.stride == 1) || (p.ksize == 4 && p.stride == 2 && !p.up2))) { mi_set_error("mi_conv_fwd: row-paired path is k3 s1 (optionally nearest x2) or k4 s2"); return MI_ERR_UNSUPPORTED; }
-    if (mode != 0) { mi_set_error("mi_conv_fwd: row-paired path: mode %d not built yet", mode); return MI_ERR_UNSUPPORTED; }
+    if (mode != 0 && p.res0.data) { mi_set_error("mi_conv_fwd: row-paired path: no residual on the up / down-sampling convs"); return MI_ERR_UNSUPPORTED; }
+    if (mode == 1 && ((p.H | p.W) & 1)) { mi_set_error("mi_conv_fwd: up2 needs even output size"); return MI_ERR_INVALID; }
     if ((p.W & 3) || (C0 & 7) || (C1 & 7) || Cin > RP_MAXC) { mi_set_error("mi_conv_fwd: row-paired path needs W %% 4 == 0 and channel counts in multiples of 8 up to %d", RP_MAXC); return MI_ERR_UNSUPPORTED; }
     if (mode != 0 && p.gn_groups > 0) { mi_set_error("mi_conv_fwd: GroupNorm prologue is only built for the k3 s1 family"); return MI_ERR_UNSUPPORTED; }
     if (p.res0.data && p.res_w) {
@@ -628,6 +633,16 @@ int mi_conv_rp_launch(const mi_conv_params& p, hipStream_t st) {
     }
     const size_t biggest = (size_t)(C0 > C1 ? C0 : C1) * p.H * p.W * (mode == 2 ? 4 : 1);
     if (biggest >= (1ull << 31)) { mi_set_error("mi_conv_fwd: row-paired path indexes one image with 32-bit offsets"); return MI_ERR_UNSUPPORTED; }
+    if (mode == 1) {
+        if ((p.tile_cfg & 0xff) == 6) return launch_rp_nj<8, 64, 1>(p, st);
+        mi_set_error("mi_conv_fwd: row-paired up-sampling conv uses tile_cfg 6 (8x64)");
+        return MI_ERR_INVALID;
+    }
+    if (mode == 2) {
+        if ((p.tile_cfg & 0xff) == 7) return launch_rp_nj<8, 32, 2>(p, st);
+        mi_set_error("mi_conv_fwd: row-paired stride-2 conv uses tile_cfg 7 (8x32)");
+        return MI_ERR_INVALID;
+    }
     switch (p.tile_cfg & 0xff) {
         case 5: return launch_rp_nj<16, 64, 0>(p, st);
         case 6: return launch_rp_nj<8, 64, 0>(p, st);

@@ -30,7 +30,7 @@ CONV_SPLIT16 = int(os.environ.get("MINIMAGEN_CONV_SPLIT16", "1"))
 CONV_SPLIT8 = int(os.environ.get("MINIMAGEN_CONV_SPLIT8", "64"))        # 8-channel outputs of images up to SPLIT8^2 pixels as two 4-channel workgroups (0 = off)
 CONV_WAVES8 = int(os.environ.get("MINIMAGEN_CONV_WAVES8", "1"))        # matrix-core conv: 8 waves x 4 pixel-tiles per workgroup
 CONV_MFMA = int(os.environ.get("MINIMAGEN_CONV_MFMA", "1"))             # 1: wide (>=16 in, >=16 out) k3 s1 convs on the matrix cores; 2: all k3 s1
-CONV_RP = int(os.environ.get("MINIMAGEN_CONV_RP", "1"))                 # 1: narrow k3 s1 convs (channels in multiples of 8, <= 64 in) on the row-paired matrix-core kernel
+CONV_RP = int(os.environ.get("MINIMAGEN_CONV_RP", "2"))                 # 1: narrow k3 s1 convs (channels in multiples of 8, <= 64 in) on the row-paired matrix-core kernel; 2: also nearest-x2 + k3 and k4 s2
 RP_TILE = {k: int(os.environ.get("MINIMAGEN_RP_TILE_" + k, d)) for k, d in (("L", "6"), ("M", "6"), ("S", "6"))}   # tile_cfg for images > 128^2 / > 64^2 / smaller
 RP_MIN_HW = int(os.environ.get("MINIMAGEN_RP_MIN_HW", "0"))             # ... for images of at least this many pixels
 RP_NTILE = int(os.environ.get("MINIMAGEN_RP_NTILE", "0"))               # tiles per workgroup of the row-paired kernel (0 = the library's choice)
@@ -110,7 +110,7 @@ class UnetEngine:
             pk.keep.append(wp)
             if w.shape[-1] in (1, 3):
                 pk.conv_f16[id(wp)] = P.pack_conv_weight_f16frag(w.to(dev))
-            if w.shape[-1] == 3 and w.shape[1] % 8 == 0 and w.shape[1] <= 64 and w.shape[0] <= 32:
+            if w.shape[-1] in (3, 4) and w.shape[1] % 8 == 0 and w.shape[1] <= 64 and w.shape[0] <= (32 if w.shape[-1] == 3 else 16):
                 pk.conv_rp[id(wp)] = P.pack_conv_weight_rp(w.to(dev))
             return wp
 
@@ -252,7 +252,8 @@ class UnetEngine:
         mfma = (CONV_MFMA == 2 or (CONV_MFMA in (1, 3) and wide)) and ksize == 3 and stride == 1 and not up2 and Wo % 4 == 0 \
             and id(wpack) in pk.conv_f16
         # row-paired matrix-core path (conv_rp.hip): every narrow k3 s1 conv whose channel counts come in octets
-        rp = bool(CONV_RP) and ksize == 3 and stride == 1 and not up2 and Wo % 4 == 0 and id(wpack) in pk.conv_rp and Ho * Wo >= RP_MIN_HW \
+        rp = bool(CONV_RP) and ((ksize == 3 and stride == 1) or (ksize == 4 and stride == 2 and not up2 and CONV_RP >= 2)) \
+            and (not up2 or (CONV_RP >= 2 and Cout <= 8)) and Wo % 4 == 0 and id(wpack) in pk.conv_rp and Ho * Wo >= RP_MIN_HW \
             and in0.C % 8 == 0 and (in1 is None or in1.C % 8 == 0) \
             and (res is None or res[2] is None or (id(res[2]) in pk.conv_rp and res[0].C % 8 == 0 and (res[1] is None or res[1].C % 8 == 0)))
         if rp:
@@ -262,6 +263,10 @@ class UnetEngine:
                 cfg = 6
             if Cout > 16:
                 cfg = 7                  # four N tiles are only instantiated for the 8x32 tile
+            if up2:
+                cfg = 6                  # the up- / down-sampling members have one tile shape each
+            if stride == 2:
+                cfg = 7
             th, tw = {5: (16, 64), 6: (8, 64), 7: (8, 32)}[cfg]
             nt = -(-Ho // th) * -(-Wo // tw)
         elif mfma:

@@ -90,12 +90,28 @@ def pack_conv_weight_rp(w: torch.Tensor):
     is the centre tap).  The weights are pre-scaled by 2^exponent so that max|w| lands in [128, 256): the fp16 split hi = fp16(w'),
     lo = fp16(w' - hi) then keeps ~22 bits whatever the magnitude of the checkpoint's weights; the kernel undoes the scale."""
     cout, cin, kh, kw = w.shape
-    assert (kh, kw) in ((3, 3), (1, 1))
+    assert (kh, kw) in ((3, 3), (1, 1), (4, 4))
     wd = w.detach().double().cpu()
     mx = float(wd.abs().max())
     exp = 0 if (mx == 0.0 or not math.isfinite(mx)) else 7 - math.floor(math.log2(mx))
     exp = max(-100, min(100, exp))
     ws = wd * (2.0 ** exp)
+    if kh == 4:
+        # k4 s2 (Downsample): N = 16 output channels of ONE output row, K = (4 vertical taps <-> lane group, 8 input channels), one
+        # step per horizontal tap: lane (lq, lg) holds W[co = 16jt + lq][ci = 8k + e][ky = lg][kx = step]
+        nj, ko = -(-cout // 16), -(-cin // 8)
+        wp = torch.zeros(nj * 16, ko * 8, 4, 4, dtype=torch.float64)
+        wp[:cout, :cin] = ws
+        lane = torch.arange(64)
+        lq, lg = lane & 15, lane >> 4
+        out = torch.zeros(ko, 4, nj, 64, 8, dtype=torch.float64)
+        for k in range(ko):
+            for s in range(4):
+                for jt in range(nj):
+                    out[k, s, jt] = wp[16 * jt + lq, 8 * k:8 * k + 8, :, s][lane, :, lg]
+        hi = out.float().half()
+        lo = (out - hi.double()).float().half()
+        return torch.cat((hi, lo), dim=-1).contiguous().to(w.device), exp
     nj, ko, steps = -(-cout // 8), -(-cin // 8), kw
     wp = torch.zeros(nj * 8, ko * 8, 3, kw, dtype=torch.float64)
     if kh == 3:

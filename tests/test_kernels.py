@@ -266,6 +266,50 @@ def test_conv_row_paired_path(backend, case):
     check_stats(ost.cpu(), ref.float())
 
 
+RP_MODE_CASES = [
+    # B, Cin, Cout, H, W (OUTPUT), ksize, stride, up2, tile_cfg, xscale
+    (2, 16, 8, 32, 64, 3, 1, 1, 6, 1.0),            # nearest x2 + conv (Upsample, layers.py:512-515)
+    (8, 8, 8, 16, 128, 3, 1, 1, 6 | (2 << 12), 1.0),
+    (1, 8, 8, 24, 72, 3, 1, 1, 6, 1.0 / 256),        # ragged tile edges
+    (2, 8, 16, 16, 32, 4, 2, 0, 7, 1.0),            # Downsample k4 s2 (layers.py:319)
+    (1, 8, 8, 20, 40, 4, 2, 0, 7 | (2 << 12), 300.0),
+]
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("case", RP_MODE_CASES)
+def test_conv_row_paired_resampling(backend, case):
+    """the nearest-x2 + k3 and the k4 s2 members of the row-paired matrix-core kernel vs torch fp32"""
+    dev = setup(backend)
+    lib = L.lib()
+    B, Cin, Cout, H, W, ks, stride, up2, cfg, xs = case
+    g = torch.Generator().manual_seed(sum(int(v * 7) for v in case) & 0xffff)
+    rn = lambda *s_: torch.randn(*s_, generator=g)
+    Hin, Win = (H // 2, W // 2) if up2 else (H * stride, W * stride)
+    x0 = (rn(B, Cin, Hin, Win) * 1.5 + 0.3) * xs
+    w, bias = rn(Cout, Cin, ks, ks) * 0.2, rn(Cout) * xs
+    h = F.interpolate(x0, scale_factor=2, mode='nearest') if up2 else x0
+    ref = F.conv2d(h.double(), w.double(), bias.double(), stride=stride, padding=1)
+    keep = {}
+    d = lambda name, t: keep.setdefault(name, t.to(dev).contiguous())
+    p = L.MiConvParams()
+    p.B, p.H, p.W = B, H, W
+    p.in0 = L.MiAct(d("x0", x0).data_ptr(), Cin, d("s0", chan_stats(x0)).data_ptr(), 1, 1.0, 0)
+    p.Cout, p.ksize, p.stride, p.up2 = Cout, ks, stride, up2
+    wf, wexp = P.pack_conv_weight_rp(w)
+    p.w_rp, p.w_rp_exp, p.bias = d("wf", wf).data_ptr(), wexp, d("b", bias).data_ptr()
+    nt = tile_nt(lib, cfg, H, W)
+    out = torch.full((B, Cout, H, W), float('nan'), device=dev)
+    ost = torch.zeros(B, Cout, nt, 2, device=dev)
+    p.out, p.out_stats, p.tile_cfg = out.data_ptr(), ost.data_ptr(), cfg
+    L.check(lib.mi_conv_fwd(C.byref(p), L.current_stream()), "conv rp")
+    scale = max(1.0, ref.abs().max().item() / 8.0)
+    err = (out.cpu().double() - ref).abs().max().item()
+    print(f"rp resampling conv {case}: max|d| = {err:.2e} (gate {2e-5 * scale:.2e})")
+    assert err < 2e-5 * scale
+    check_stats(ost.cpu(), ref.float())
+
+
 def test_conv_rejects_bad_arguments():
     setup("emu")
     lib = L.lib()
