@@ -253,6 +253,12 @@ __global__ __launch_bounds__(256, WPS) void cross_attn_folded_kernel(const mi_cr
 // lo*lo term is 2^-22 relative, so the result stays inside the fp32 parity tolerance.
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+// ATTN_QK32=1: QK^T as {G hi | G lo}.{x hi | x hi} (K = 32) + G hi . x lo (K = 16).  Correct on the SIMT emulator, WRONG on the MI355X
+// (round 1 and round 2, every ordering; the same pair is correct in isolation, tools/ubench/mfma32_layout.hip) and worth only 2 % of the
+// kernel (measured 0.413 vs 0.421 ms per pair of launches): off.
+#ifndef ATTN_QK32
+#define ATTN_QK32 0
+#endif
 
 __device__ __forceinline__ void split_f16(const float (&x)[4], f16x4& hi, f16x4& lo) { mi_split_f16(x, hi, lo); }
 
@@ -268,8 +274,12 @@ __global__ __launch_bounds__(64 * NWV, WPS) void cross_attn_f16x3_kernel(const m
     // One head's context fragments, staged once per workgroup (the four waves share them; measured: per-wave global loads of the
     // fragments cost 16-50 % of the kernel).  G as loaded: [tile][kc][lane]{4 hi, 4 lo}; V re-paired for the K = 32 instruction:
     // [tile pair][mt][lane]{4 hi(t0), 4 hi(t1)} and the same for lo.
-    __shared__ __attribute__((aligned(16))) uint4 fG[JT * KC * 64];
-    __shared__ __attribute__((aligned(16))) f16x4 fVh[JP * MT * 64 * 2], fVl[JP * MT * 64 * 2];
+    // One head's context fragments as they lie in global memory, [tile][chunk q][lane] 16 bytes (q < KC: G {4 hi | 4 lo}, else V {4 hi | 4 lo}),
+    // DOUBLE-buffered and filled by LDS-DMA (global_load_lds_dwordx4: no registers, asynchronous): head h + 1 streams in under head h's
+    // MFMA / softmax work, one barrier per head.  (Round 1 staged them with a synchronous barrier - copy - barrier per head: measured
+    // 19 % of the kernel.)  Tile JT is an all-zero tile: the partner of the odd last tile in the K = 32 PV instruction.
+    constexpr int QC = KC + MT, ROWS = JT * QC;
+    __shared__ __attribute__((aligned(16))) uint4 frag[2][(ROWS + QC) * 64];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lq = lane & 15, lg = lane >> 4;
     const int tiles = (p.HW + TOK_WG - 1) / TOK_WG;
     int b, tile;
@@ -324,33 +334,29 @@ __global__ __launch_bounds__(64 * NWV, WPS) void cross_attn_f16x3_kernel(const m
     for (int mt = 0; mt < MT; ++mt) oacc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const _Float16* gvb = reinterpret_cast<const _Float16*>(p.gv) + (size_t)b * p.heads * JT * 64 * FRH;
     const int jlast = p.J - 1;
-    if (JT & 1) {       // the odd last tile has no partner: its slot multiplies P = 0 and must hold finite numbers
-        for (int i = tid; i < MT * 64; i += NT) {
-            const int mt = i / 64, ln = i % 64;
-            fVh[(((JP - 1) * MT + mt) * 64 + ln) * 2 + 1] = (f16x4){0, 0, 0, 0};
-            fVl[(((JP - 1) * MT + mt) * 64 + ln) * 2 + 1] = (f16x4){0, 0, 0, 0};
+    for (int i = tid; i < 2 * QC * 64; i += NT) frag[i / (QC * 64)][ROWS * 64 + i % (QC * 64)] = make_uint4(0u, 0u, 0u, 0u);
+    auto issue_head = [&](int h, int buf) {
+        const _Float16* gvh = gvb + (size_t)h * JT * 64 * FRH;
+        for (int r = wave; r < ROWS; r += NWV) {             // one 1 KB row (64 lanes x 16 bytes) per instruction
+            const int jt = r / QC, q = r % QC;
+            const _Float16* src = gvh + ((size_t)(jt * 64 + lane) * QC + q) * 8;
+#if defined(HIPEMU)
+            frag[buf][r * 64 + lane] = *reinterpret_cast<const uint4*>(src);
+#else
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)&frag[buf][r * 64], 16, 0, 0);
+#endif
         }
-    }
+    };
+    issue_head(0, 0);
 
     for (int h = 0; h < p.heads; ++h) {
-        const _Float16* gvh = gvb + (size_t)h * JT * 64 * FRH;
-        __syncthreads();                                  // the previous head's fragments are no longer read
-        // 16-byte chunks, consecutive work-items -> consecutive chunks.  Deliberately a rolled loop: unrolled (or prefetched a head ahead
-        // in registers) the kernel needs 164 instead of 124 registers, drops from 4 to 3 waves per SIMD and is 19 % slower (measured)
-#pragma unroll 1
-        for (int i = tid; i < JT * 64 * (KC + MT); i += NT) {
-            const int q = i % (KC + MT), r = i / (KC + MT), ln = r % 64, jt = r / 64;
-            union { uint4 u; f16x4 h2[2]; } v;
-            v.u = *reinterpret_cast<const uint4*>(gvh + (size_t)r * FRH + 8 * q);
-            if (q < KC) {
-                fG[(jt * KC + q) * 64 + ln] = v.u;
-            } else {
-                const int o = (((jt >> 1) * MT + (q - KC)) * 64 + ln) * 2 + (jt & 1);
-                fVh[o] = v.h2[0];
-                fVl[o] = v.h2[1];
-            }
-        }
-        __syncthreads();
+        const int hb = h & 1;
+#if !defined(HIPEMU)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of head h has landed in LDS ...
+#endif
+        __syncthreads();                                  // ... everybody's has, and nobody reads head h - 1's buffer any more
+        if (h + 1 < p.heads) issue_head(h + 1, hb ^ 1);
         f32x4 s[JT];
 #pragma unroll
         for (int jt = 0; jt < JT; ++jt) {
@@ -358,15 +364,20 @@ __global__ __launch_bounds__(64 * NWV, WPS) void cross_attn_f16x3_kernel(const m
 #pragma unroll
             for (int kc = 0; kc < KC; ++kc) {
                 union { uint4 u; f16x4 h2[2]; } g;
-                g.u = fG[(jt * KC + kc) * 64 + lane];
+                g.u = frag[hb][(jt * QC + kc) * 64 + lane];
                 const f16x4 ghi = g.h2[0];
                 if constexpr (!HALF) {
-                    // (the K = 32 form {G hi|G lo}.{x hi|x hi} + K = 16 G hi.x lo saves one instruction per tile but returned wrong
-                    //  results on the device in this kernel in every ordering tried, although the same pair of instructions is correct in
-                    //  isolation (tools/ubench/mfma32_layout.hip) -- unresolved; it is worth only 3.6 % of the kernel and is not used)
+#if ATTN_QK32
+                    // {G hi | G lo} . {x hi | x hi} on the K = 32 instruction (the LDS chunk IS that A operand) + G hi . x lo on the K = 16 one:
+                    // two instructions per tile instead of three
+                    const f16x8 xhh = __builtin_shufflevector(xhi[kc], xhi[kc], 0, 1, 2, 3, 4, 5, 6, 7);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x16f16(ghi, xlo[kc], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, g.u), xhh, acc, 0, 0, 0);
+#else
                     acc = __builtin_amdgcn_mfma_f32_16x16x16f16(g.h2[1], xhi[kc], acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_16x16x16f16(ghi, xlo[kc], acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_16x16x16f16(ghi, xhi[kc], acc, 0, 0, 0);
+#endif
                 } else {
                     acc = __builtin_amdgcn_mfma_f32_16x16x16f16(ghi, xhi[kc], acc, 0, 0, 0);
                 }
@@ -410,10 +421,14 @@ __global__ __launch_bounds__(64 * NWV, WPS) void cross_attn_f16x3_kernel(const m
             const f16x8 phi = __builtin_shufflevector(ph[0], ph[1], 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                const f16x8 vhi = *reinterpret_cast<const f16x8*>(&fVh[((jp * MT + mt) * 64 + lane) * 2]);
+                const uint2* f2 = reinterpret_cast<const uint2*>(&frag[hb][0]);
+                const int i0 = ((2 * jp) * QC + KC + mt) * 64 + lane, i1 = ((2 * jp + 1) * QC + KC + mt) * 64 + lane;
+                const uint2 a0 = f2[2 * i0], a1 = f2[2 * i1];
+                const f16x8 vhi = __builtin_bit_cast(f16x8, make_uint4(a0.x, a0.y, a1.x, a1.y));
                 if constexpr (!HALF) {
                     const f16x8 plo = __builtin_shufflevector(pl[0], pl[1], 0, 1, 2, 3, 4, 5, 6, 7);
-                    const f16x8 vlo = *reinterpret_cast<const f16x8*>(&fVl[((jp * MT + mt) * 64 + lane) * 2]);
+                    const uint2 b0 = f2[2 * i0 + 1], b1 = f2[2 * i1 + 1];
+                    const f16x8 vlo = __builtin_bit_cast(f16x8, make_uint4(b0.x, b0.y, b1.x, b1.y));
                     oh[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vlo, phi, oh[mt], 0, 0, 0);
                     oh[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vhi, plo, oh[mt], 0, 0, 0);
                 }
