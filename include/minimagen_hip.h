@@ -194,7 +194,17 @@ typedef struct mi_attn_fold_params {
         const float* g0;            /* [heads][C]      log2(e) * scale * Wq_h^T null_k */
         const float* v0;            /* [heads][C]      Wo_h null_v */
         float* gv;
+        float* table;               /* mode 1 / 2: compact folded rows [steps * B2][nrows][heads][C][2] = (g, vw) */
     } blk[MI_ATTN_MAX_BLOCKS];
+    /* The timestep sequence of a sampling loop is known in advance (T-1 .. 0, the same for every sample), so everything that depends
+       only on (timestep, text) is computed ONCE per sample() for all T steps and the per-step work shrinks to a scatter:
+         mode 0: fold c_rows and write the fragments (one step; Unet.forward)
+         mode 1: fold c_rows of B2 = steps * rows virtual batch rows into blk[].table (no fragments written)
+         mode 2: scatter the rows of step *t_state from blk[].table into the fragments of the B2 real batch rows, and copy that
+                 step's ss_n scale/shift values per row from ss_all to ss (the ResnetBlocks' time_mlp outputs) */
+    int mode;
+    const int* t_state;
+    const float* ss_all; float* ss; int ss_n;
 } mi_attn_fold_params;
 int mi_attn_fold_rows(const mi_attn_fold_params* p, void* stream);
 int mi_attn_fragment_floats(int C);     /* FR */

@@ -129,6 +129,7 @@ class Imagen(nn.Module):
         else:
             L.check(lib.mi_randn_fill(L.ptr(ws.x), B, n, seed, sample0, (stage << 20) | (1 << 19) | 1, stream), "mi_randn_fill")
         L.check(lib.mi_step_set(L.ptr(st.t_state), L.ptr(ws.times), B, T - 1, stream), "mi_step_set")
+        eng.prepare_step_tables(ws, T, st.t_state, stream)       # (timestep, text)-only conditioning of all T steps, once
 
         k_lo, k_hi, w = quantile_rank(n, self.dynamic_thresholding_percentile)
         # the captured graph of one denoising step is cached per (workspace, guidance, threshold, noise mode, shard offset):
@@ -153,7 +154,7 @@ class Imagen(nn.Module):
                                      L.ptr(st.seed_dev) if noise_dev is None else 0)
 
             def one_step():
-                eng.run(ws, stream)
+                eng.run_step(ws, stream)
                 L.check(lib.mi_cfg_x0_fwd(C.byref(cp), stream), "mi_cfg_x0_fwd")
                 L.check(lib.mi_quantile_fwd(C.byref(qp), stream), "mi_quantile_fwd")
                 L.check(lib.mi_posterior_fwd(C.byref(pp), stream), "mi_posterior_fwd")

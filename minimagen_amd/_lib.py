@@ -72,7 +72,7 @@ class MiCondStepParams(C.Structure):
 
 
 class MiAttnFoldBlk(C.Structure):
-    _fields_ = [("mg", C.c_void_p), ("mv", C.c_void_p), ("g0", C.c_void_p), ("v0", C.c_void_p), ("gv", C.c_void_p)]
+    _fields_ = [("mg", C.c_void_p), ("mv", C.c_void_p), ("g0", C.c_void_p), ("v0", C.c_void_p), ("gv", C.c_void_p), ("table", C.c_void_p)]
 
 
 class MiAttnFoldParams(C.Structure):
@@ -80,6 +80,7 @@ class MiAttnFoldParams(C.Structure):
         ("B2", C.c_int), ("C", C.c_int), ("cd", C.c_int), ("heads", C.c_int), ("JT", C.c_int),
         ("c_rows", C.c_void_p), ("c_stride_b", C.c_int), ("row0", C.c_int), ("nrows", C.c_int), ("write_null", C.c_int), ("frag_f16", C.c_int),
         ("n_blocks", C.c_int), ("blk", MiAttnFoldBlk * 8),
+        ("mode", C.c_int), ("t_state", C.c_void_p), ("ss_all", C.c_void_p), ("ss", C.c_void_p), ("ss_n", C.c_int),
     ]
 
 

@@ -363,8 +363,9 @@ __global__ __launch_bounds__(64 * NWV, WPS) void cross_attn_f16x3_kernel(const m
             f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kc = 0; kc < KC; ++kc) {
-                union { uint4 u; f16x4 h2[2]; } g;
-                g.u = frag[hb][(jt * QC + kc) * 64 + lane];
+                union { uint4 u; f16x4 h2[2]; uint2 u2; } g;
+                if constexpr (HALF) g.u2 = reinterpret_cast<const uint2*>(&frag[hb][0])[2 * ((jt * QC + kc) * 64 + lane)];    // hi halves only
+                else g.u = frag[hb][(jt * QC + kc) * 64 + lane];
                 const f16x4 ghi = g.h2[0];
                 if constexpr (!HALF) {
 #if ATTN_QK32
@@ -383,6 +384,8 @@ __global__ __launch_bounds__(64 * NWV, WPS) void cross_attn_f16x3_kernel(const m
                 }
             }
             s[jt] = acc;
+            // single-term variant: one MFMA per tile leaves the scheduler free to hoist every tile's LDS read (spills at 128 registers)
+            if constexpr (HALF) { if ((jt & 3) == 3) __builtin_amdgcn_sched_barrier(0); }
         }
         float m = -INFINITY;
 #pragma unroll

@@ -144,15 +144,22 @@ __global__ __launch_bounds__(256) void cond_step_kernel(const mi_cond_step_param
         p.ss[(size_t)bb * p.time_mlps.out + r] = dot_row(p.time_mlps.w + (size_t)r * p.tcd, hid, p.tcd) + p.time_mlps.b[r];
 }
 
-// context rows -> MFMA A-operand fragments of the folded cross-attention (see minimagen_hip.h)
+// context rows -> MFMA A-operand fragments of the folded cross-attention (see minimagen_hip.h).  Modes 1 / 2 split the work into
+// "fold every step's rows once per sample()" (table of (g, vw) pairs) and "scatter one step's rows" (per denoising step).
 __global__ __launch_bounds__(256) void attn_fold_rows_kernel(const mi_attn_fold_params p) {
     const int bb = blockIdx.x, blk = blockIdx.y;
+    if (blk == p.n_blocks) {          // mode 2 only: this step's scale/shift rows
+        const float* src = p.ss_all + ((size_t)(*p.t_state) * gridDim.x + bb) * p.ss_n;
+        for (int i = threadIdx.x; i < p.ss_n; i += 256) p.ss[(size_t)bb * p.ss_n + i] = src[i];
+        return;
+    }
     const int C = p.C, NGP = (C / 4) < 4 ? 4 : (C / 4), MT = (C + 15) / 16, FR = NGP + 4 * MT;
     const float* mg = p.blk[blk].mg;
     const float* mv = p.blk[blk].mv;
     float* gv = p.blk[blk].gv + (size_t)bb * p.heads * p.JT * 64 * FR;
     const int first = p.write_null ? -1 : 0;
     const int total = (p.nrows - first) * p.heads * C;
+    const size_t trow = p.mode == 2 ? (size_t)(*p.t_state) * gridDim.x + bb : (size_t)bb;      // row of the compact table
     for (int idx = threadIdx.x; idx < total; idx += 256) {
         const int a = idx % C, h = (idx / C) % p.heads, r = idx / (C * p.heads) + first;
         float g, v;
@@ -163,9 +170,16 @@ __global__ __launch_bounds__(256) void attn_fold_rows_kernel(const mi_attn_fold_
             v = p.blk[blk].v0[h * C + a];
         } else {
             j = p.row0 + r;
-            const float* c = p.c_rows + (size_t)bb * p.c_stride_b + (size_t)r * p.cd;
-            g = dot_row(mg + ((size_t)h * C + a) * p.cd, c, p.cd);
-            v = dot_row(mv + ((size_t)h * C + a) * p.cd, c, p.cd);
+            float* tab = p.mode ? p.blk[blk].table + (((trow * p.nrows + r) * p.heads + h) * C + a) * 2 : nullptr;
+            if (p.mode == 2) {
+                g = tab[0];
+                v = tab[1];
+            } else {
+                const float* c = p.c_rows + (size_t)bb * p.c_stride_b + (size_t)r * p.cd;
+                g = dot_row(mg + ((size_t)h * C + a) * p.cd, c, p.cd);
+                v = dot_row(mv + ((size_t)h * C + a) * p.cd, c, p.cd);
+                if (p.mode == 1) { tab[0] = g; tab[1] = v; continue; }
+            }
         }
         const int jt = j >> 4, jm = j & 15;
         if (p.frag_f16) {
@@ -206,8 +220,11 @@ extern "C" int mi_cond_step_fwd(const mi_cond_step_params* p, void* stream) {
 }
 
 extern "C" int mi_attn_fold_rows(const mi_attn_fold_params* p, void* stream) {
-    if (p->n_blocks < 1 || p->n_blocks > MI_ATTN_MAX_BLOCKS || (p->C % 4) != 0 || p->B2 <= 0) { mi_set_error("mi_attn_fold_rows: bad n_blocks / C"); return MI_ERR_INVALID; }
-    if (p->row0 + p->nrows > p->JT * 16) { mi_set_error("mi_attn_fold_rows: rows beyond the padded context"); return MI_ERR_INVALID; }
-    hipLaunchKernelGGL(attn_fold_rows_kernel, dim3(p->B2, p->n_blocks), dim3(256), 0, (hipStream_t)stream, *p);
+    const bool stage = p->mode == 2;
+    if (p->n_blocks < (stage ? 0 : 1) || p->n_blocks > MI_ATTN_MAX_BLOCKS || (p->n_blocks && (p->C % 4) != 0) || p->B2 <= 0) { mi_set_error("mi_attn_fold_rows: bad n_blocks / C"); return MI_ERR_INVALID; }
+    if (p->n_blocks && p->mode != 1 && p->row0 + p->nrows > p->JT * 16) { mi_set_error("mi_attn_fold_rows: rows beyond the padded context"); return MI_ERR_INVALID; }
+    if (p->mode < 0 || p->mode > 2 || (p->mode && p->write_null) || (stage && (!p->t_state || (p->ss_n > 0 && (!p->ss_all || !p->ss))))) { mi_set_error("mi_attn_fold_rows: bad mode / table arguments"); return MI_ERR_INVALID; }
+    for (int k = 0; k < p->n_blocks; ++k) if (p->mode && !p->blk[k].table) { mi_set_error("mi_attn_fold_rows: mode %d needs blk[].table", p->mode); return MI_ERR_INVALID; }
+    hipLaunchKernelGGL(attn_fold_rows_kernel, dim3(p->B2, p->n_blocks + ((stage && p->ss_n > 0) ? 1 : 0)), dim3(256), 0, (hipStream_t)stream, *p);
     return mi_check_launch("attn_fold_rows_kernel");
 }

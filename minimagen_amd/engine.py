@@ -429,8 +429,10 @@ class UnetEngine:
         cp.norm_w, cp.norm_b = L.ptr(u.norm_cond.weight), L.ptr(u.norm_cond.bias)
         cp.time_mlps = L.MiLinear(L.ptr(pk.tm_w), L.ptr(pk.tm_b), u.time_cond_dim, pk.R)
         cp.ss, cp.c_time, cp.t_out = L.ptr(ws.ss), L.ptr(ws.c_time), L.ptr(ws.t_out)
-        ws.prog.append((lib.mi_cond_step_fwd, cp, "cond_step"))
-        fold_slot = len(ws.prog)        # the time-row fold is inserted here once the attention blocks are known
+        # everything that depends only on (timestep, text): one step at a time for Unet.forward (ws.prog_cond), all T steps at once for
+        # the sampling loop (prepare_step_tables / ws.prog_stage)
+        ws.cond_params = cp
+        ws.prog_cond = [(lib.mi_cond_step_fwd, cp, "cond_step")]
 
         # ---- K3: init conv.  For super-resolution U-Nets the low-res conditioning image is constant over the T steps and
         # the convolution is linear, so conv(cat(x, lr)) = conv_x(x) + conv_lr(lr): the lr half runs once per sample()
@@ -501,7 +503,7 @@ class UnetEngine:
             raise L.MinImagenHipError(f"U-Net output is {out.H}x{out.W} for a {H}x{W} input (image size must be divisible by the down-sampling factor)")
         # time-token rows of the folded context, every step
         if ws.gv:
-            ws.prog[fold_slot:fold_slot] = self._fold_params(ws, pk, ws.c_time, ws.ntot * u.cond_dim, 1, ws.ntot, 0)
+            ws.prog_cond += self._fold_params(ws, pk, ws.c_time, ws.ntot * u.cond_dim, 1, ws.ntot, 0)
 
     # ------------------------------------------------------------------ execution
     def set_text(self, ws, text_embeds: torch.Tensor, text_mask: Optional[torch.Tensor], keep: torch.Tensor):
@@ -537,11 +539,74 @@ class UnetEngine:
         for fn, p, name in ws.prog_pre:
             L.check(fn(C.byref(p), st), name)
 
+    def prepare_step_tables(self, ws, T: int, t_state: torch.Tensor, stream=None):
+        """Once per ``sample()`` stage: the per-step conditioning (every ResnetBlock's scale/shift, the folded time-token rows of the
+        cross-attention context) for ALL T timesteps -- the sequence T-1 .. 0 is known in advance and identical for every sample -- so
+        that the denoising step only scatters row ``t`` of the tables (one small launch instead of cond_step + fold).  Same kernels,
+        same arithmetic, same bits as the step-at-a-time path."""
+        u, pk, lib = self.unet, self.pack(), L.lib()
+        st = L.current_stream() if stream is None else stream
+        B2, dev = ws.B2, ws.dev
+        key = (T, t_state.data_ptr())
+        tb = ws.__dict__.setdefault("step_tables", {}).get(key)
+        if tb is None:
+            tb = Workspace()
+            n = T * B2
+            tb.times = torch.arange(T, dtype=torch.int64, device=dev).repeat_interleave(B2).contiguous()
+            tb.lowres_times = torch.zeros(n, dtype=torch.int64, device=dev) if u.lowres_cond else None
+            tb.text_hiddens = torch.empty(n, u.time_cond_dim, dtype=torch.float32, device=dev)
+            tb.ss = torch.empty(n, max(pk.R, 1), dtype=torch.float32, device=dev)
+            tb.c_time = torch.empty(n, ws.ntot, u.cond_dim, dtype=torch.float32, device=dev)
+            cp = L.MiCondStepParams.from_buffer_copy(ws.cond_params)
+            cp.B2 = cp.B = n
+            cp.time, cp.lowres_time = L.ptr(tb.times), L.ptr(tb.lowres_times)
+            cp.text_hiddens, cp.ss, cp.c_time, cp.t_out = L.ptr(tb.text_hiddens), L.ptr(tb.ss), L.ptr(tb.c_time), 0
+            tb.cond = cp
+            tb.fold, tb.tables = [], []
+            stage_blocks = []
+            for fn, fp, name in self._fold_params(ws, pk, tb.c_time, ws.ntot * u.cond_dim, 1, ws.ntot, 0):
+                f1 = L.MiAttnFoldParams.from_buffer_copy(fp)
+                f1.B2, f1.mode = n, 1
+                for k in range(fp.n_blocks):
+                    t = torch.empty(n, ws.ntot, fp.heads, fp.C, 2, dtype=torch.float32, device=dev)
+                    tb.tables.append(t)
+                    f1.blk[k].table = L.ptr(t)
+                tb.fold.append(f1)
+                f2 = L.MiAttnFoldParams.from_buffer_copy(f1)            # per-step scatter of the same blocks
+                f2.B2, f2.mode, f2.t_state = B2, 2, L.ptr(t_state)
+                stage_blocks.append(f2)
+            if not stage_blocks:                                       # no cross-attention anywhere: the scale/shift rows only
+                f2 = L.MiAttnFoldParams()
+                f2.B2, f2.mode, f2.t_state, f2.n_blocks = B2, 2, L.ptr(t_state), 0
+                stage_blocks.append(f2)
+            stage_blocks[0].ss_all, stage_blocks[0].ss, stage_blocks[0].ss_n = L.ptr(tb.ss), L.ptr(ws.ss), ws.ss.shape[1]
+            tb.stage = [(lib.mi_attn_fold_rows, f2, "stage_step") for f2 in stage_blocks]
+            tb.keep = t_state
+            ws.step_tables[key] = tb
+        tb.text_hiddens.view(T, B2, -1).copy_(ws.text_hiddens.unsqueeze(0).expand(T, -1, -1))
+        if u.lowres_cond:
+            tb.lowres_times.view(T, B2)[:, :ws.B].copy_(ws.lowres_times.unsqueeze(0).expand(T, -1))
+            if B2 != ws.B:
+                tb.lowres_times.view(T, B2)[:, ws.B:].copy_(ws.lowres_times.unsqueeze(0).expand(T, -1))
+        L.check(lib.mi_cond_step_fwd(C.byref(tb.cond), st), "mi_cond_step_fwd (all steps)")
+        for f1 in tb.fold:
+            L.check(lib.mi_attn_fold_rows(C.byref(f1), st), "mi_attn_fold_rows (all steps)")
+        ws.prog_stage = tb.stage
+
+    def run_step(self, ws, stream=None):
+        """One denoising step's U-Net evaluation inside the sampling loop: scatter the current step's conditioning (see
+        prepare_step_tables), then the image kernels."""
+        st = L.current_stream() if stream is None else stream
+        for fn, p, name in ws.prog_stage + ws.prog:
+            rc = fn(C.byref(p), st)
+            if rc != 0:
+                L.check(rc, name)
+
     def run(self, ws, stream=None):
         """Enqueue one U-Net evaluation (all conditioning rows) on the current stream: ws.x / ws.times /
         ws.lowres / ws.lowres_times -> ws.pred."""
         st = L.current_stream() if stream is None else stream
-        for fn, p, name in ws.prog:
+        for fn, p, name in ws.prog_cond + ws.prog:
             rc = fn(C.byref(p), st) if p is not None else fn(None, st)
             if rc != 0:
                 L.check(rc, name)
