@@ -174,6 +174,9 @@ class Imagen(nn.Module):
                 L.check(rc, "mi_graph_end")
                 entry["graph"] = g
                 if noise_dev is None:
+                    while len(cached) >= 8:                      # bounded: one exec per (guidance, threshold, shard offset) combination
+                        old = cached.pop(next(iter(cached)))
+                        lib.mi_graph_destroy(old["graph"])
                     cached[gkey] = entry
         if use_graph:
             try:
@@ -267,8 +270,9 @@ class Imagen(nn.Module):
             for stage, (unet, channel, image_size, noise_scheduler) in enumerate(
                     zip(self.unets, self.sample_channels, self.image_sizes, self.noise_schedulers)):
                 eng = unet.engine()
-                eng.precision = _precision if _precision is not None else os.environ.get("MINIMAGEN_PRECISION", "fp32")
-                ws = eng.workspace(batch_size, B2, image_size, image_size)
+                # per call, never sticky engine state: a later Unet.forward stays on the engine's default precision
+                ws = eng.workspace(batch_size, B2, image_size, image_size,
+                                   precision=_precision if _precision is not None else os.environ.get("MINIMAGEN_PRECISION", "fp32"))
                 eng.set_text(ws, text_embeds, text_masks, keep)
                 if unet.lowres_cond:
                     self._lowres_conditioning(img, image_size, ws, lowres_sample_noise_level, _noise, _seed, _sample_offset, stage)

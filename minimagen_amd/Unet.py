@@ -2,7 +2,8 @@
 state-dict layout (minimagen/Unet.py), executed by hand-written HIP kernels on MI355X."""
 from __future__ import annotations
 
-from typing import Union
+from dataclasses import dataclass
+from typing import List, Union
 
 import torch
 from torch import nn
@@ -19,6 +20,41 @@ class _Rearrange(nn.Module):
     def __init__(self, r):
         super().__init__()
         self.r = r
+
+
+ATTN_DIM_HEAD = 64      # Unet.py:86
+NUM_TIME_TOKENS = 2     # Unet.py:87
+RESNET_GROUPS = 8       # Unet.py:88
+MAX_TEXT_LEN = 256      # Unet.py:145
+CROSS_EMBED_KERNELS = (3, 7, 15)
+
+
+@dataclass(frozen=True)
+class LevelSpec:
+    """One resolution level of the U-Net, the unit both halves of the trunk are generated from."""
+    index: int
+    width_in: int           # channels entering the level on the way down (= leaving it on the way up)
+    width_out: int          # channels handed to the next deeper level
+    res_blocks: int         # ResnetBlocks after the level's first one
+    groups: int
+    self_attention: bool    # TransformerBlock after the ResnetBlocks
+    cross_attention: bool   # the level's first ResnetBlock attends to the conditioning tokens
+    deepest: bool
+
+    def trunk_width(self, memory_efficient: bool) -> int:
+        """channels the level's ResnetBlocks run at on the way down: the down-sampling conv comes first when memory_efficient"""
+        return self.width_out if memory_efficient else self.width_in
+
+
+def level_plan(dim: int, dim_mults, num_resnet_blocks, layer_attns, layer_cross_attns) -> List[LevelSpec]:
+    """The per-level table behind Unet.py:170-330: widths dim * (1, *dim_mults) chained level to level, the per-level knobs broadcast
+    from scalars."""
+    widths = [dim] + [dim * m for m in dim_mults]
+    n = len(dim_mults)
+    per_level = [cast_tuple(v, n) for v in (num_resnet_blocks, RESNET_GROUPS, layer_attns, layer_cross_attns)]
+    assert all(len(v) == n for v in per_level), "per-level settings must have one entry per resolution"
+    return [LevelSpec(i, widths[i], widths[i + 1], per_level[0][i], per_level[1][i], bool(per_level[2][i]), bool(per_level[3][i]), i == n - 1)
+            for i in range(n)]
 
 
 class Unet(nn.Module):
@@ -45,116 +81,93 @@ class Unet(nn.Module):
     ):
         super().__init__()
         # constructor kwargs, for _cast_model_parameters (Unet.py:81-83)
-        self._locals = dict(dim=dim, dim_mults=dim_mults, channels=channels, channels_out=channels_out, cond_dim=cond_dim,
-                            text_embed_dim=text_embed_dim, num_resnet_blocks=num_resnet_blocks, layer_attns=layer_attns,
-                            layer_cross_attns=layer_cross_attns, attn_heads=attn_heads, lowres_cond=lowres_cond,
-                            memory_efficient=memory_efficient, attend_at_middle=attend_at_middle)
-
-        ATTN_DIM_HEAD = 64      # Unet.py:86
-        NUM_TIME_TOKENS = 2     # Unet.py:87
-        RESNET_GROUPS = 8       # Unet.py:88
-        self.num_time_tokens = NUM_TIME_TOKENS
-        self.attn_dim_head = ATTN_DIM_HEAD
-        self.attn_heads = attn_heads
-        self.dim = dim
-
-        cond_dim = default(cond_dim, dim)
-        self.cond_dim = cond_dim
-        time_cond_dim = dim * 4 * (2 if lowres_cond else 1)
-        self.time_cond_dim = time_cond_dim
-
-        self.to_time_hiddens = nn.Sequential(SinusoidalPosEmb(dim), nn.Linear(dim, time_cond_dim), nn.SiLU())
-        self.to_time_cond = nn.Sequential(nn.Linear(time_cond_dim, time_cond_dim))
-        self.to_time_tokens = nn.Sequential(nn.Linear(time_cond_dim, cond_dim * NUM_TIME_TOKENS), _Rearrange(NUM_TIME_TOKENS))
-
-        self.lowres_cond = lowres_cond
-        if lowres_cond:
-            self.to_lowres_time_hiddens = nn.Sequential(SinusoidalPosEmb(dim), nn.Linear(dim, time_cond_dim), nn.SiLU())
-            self.to_lowres_time_cond = nn.Sequential(nn.Linear(time_cond_dim, time_cond_dim))
-            self.to_lowres_time_tokens = nn.Sequential(nn.Linear(time_cond_dim, cond_dim * NUM_TIME_TOKENS), _Rearrange(NUM_TIME_TOKENS))
-
-        self.norm_cond = nn.LayerNorm(cond_dim)
-        self.text_embed_dim = text_embed_dim
-        self.text_to_cond = nn.Linear(self.text_embed_dim, cond_dim)
-        max_text_len = 256
-        self.max_text_len = max_text_len
-        self.null_text_embed = nn.Parameter(torch.randn(1, max_text_len, cond_dim))
-        self.null_text_hidden = nn.Parameter(torch.randn(1, time_cond_dim))
-        self.to_text_non_attn_cond = nn.Sequential(
-            nn.LayerNorm(cond_dim),
-            nn.Linear(cond_dim, time_cond_dim),
-            nn.SiLU(),
-            nn.Linear(time_cond_dim, time_cond_dim)
-        )
-
-        self.channels = channels
-        self.channels_out = default(channels_out, channels)
-        self.init_conv = CrossEmbedLayer(channels if not lowres_cond else channels * 2, dim_out=dim, kernel_sizes=(3, 7, 15), stride=1)
-
-        dims = [dim, *map(lambda m: dim * m, dim_mults)]
-        in_out = list(zip(dims[:-1], dims[1:]))
-        num_resolutions = len(in_out)
-        num_resnet_blocks = cast_tuple(num_resnet_blocks, num_resolutions)
-        resnet_groups = cast_tuple(RESNET_GROUPS, num_resolutions)
-        layer_attns = cast_tuple(layer_attns, num_resolutions)
-        layer_cross_attns = cast_tuple(layer_cross_attns, num_resolutions)
-        assert all([layers == num_resolutions for layers in list(map(len, (resnet_groups, layer_attns, layer_cross_attns)))])
-
-        self.skip_connect_scale = 2 ** -0.5
-        self.downs = nn.ModuleList([])
-        self.ups = nn.ModuleList([])
-        layer_params = [num_resnet_blocks, resnet_groups, layer_attns, layer_cross_attns]
-        reversed_layer_params = list(map(reversed, layer_params))
-        skip_connect_dims = []
-
-        for ind, ((dim_in, dim_out), layer_num_resnet_blocks, groups, layer_attn, layer_cross_attn) in enumerate(zip(in_out, *layer_params)):
-            is_last = ind == (num_resolutions - 1)
-            layer_cond_dim = cond_dim if layer_cross_attn else None
-            transformer_block_klass = TransformerBlock if layer_attn else Identity
-            current_dim = dim_in
-            pre_downsample = None
-            if memory_efficient:
-                pre_downsample = Downsample(dim_in, dim_out)
-                current_dim = dim_out
-            skip_connect_dims.append(current_dim)
-            post_downsample = None
-            if not memory_efficient:
-                post_downsample = Downsample(current_dim, dim_out) if not is_last else Parallel(
-                    nn.Conv2d(dim_in, dim_out, 3, padding=1), nn.Conv2d(dim_in, dim_out, 1))
-            self.downs.append(nn.ModuleList([
-                pre_downsample,
-                ResnetBlock(current_dim, current_dim, cond_dim=layer_cond_dim, time_cond_dim=time_cond_dim, groups=groups),
-                nn.ModuleList([ResnetBlock(current_dim, current_dim, time_cond_dim=time_cond_dim, groups=groups)
-                               for _ in range(layer_num_resnet_blocks)]),
-                transformer_block_klass(dim=current_dim, heads=attn_heads, dim_head=ATTN_DIM_HEAD),
-                post_downsample,
-            ]))
-
-        mid_dim = dims[-1]
-        self.mid_block1 = ResnetBlock(mid_dim, mid_dim, cond_dim=cond_dim, time_cond_dim=time_cond_dim, groups=resnet_groups[-1])
-        self.mid_attn = EinopsToAndFrom('b c h w', 'b (h w) c',
-                                        Residual(Attention(mid_dim, heads=attn_heads, dim_head=ATTN_DIM_HEAD))) if attend_at_middle else None
-        self.mid_block2 = ResnetBlock(mid_dim, mid_dim, cond_dim=cond_dim, time_cond_dim=time_cond_dim, groups=resnet_groups[-1])
-
-        for ind, ((dim_in, dim_out), layer_num_resnet_blocks, groups, layer_attn, layer_cross_attn) in enumerate(
-                zip(reversed(in_out), *reversed_layer_params)):
-            is_last = ind == (num_resolutions - 1)
-            layer_cond_dim = cond_dim if layer_cross_attn else None
-            transformer_block_klass = TransformerBlock if layer_attn else Identity
-            skip_connect_dim = skip_connect_dims.pop()
-            self.ups.append(nn.ModuleList([
-                ResnetBlock(dim_out + skip_connect_dim, dim_out, cond_dim=layer_cond_dim, time_cond_dim=time_cond_dim, groups=groups),
-                nn.ModuleList([ResnetBlock(dim_out + skip_connect_dim, dim_out, time_cond_dim=time_cond_dim, groups=groups)
-                               for _ in range(layer_num_resnet_blocks)]),
-                transformer_block_klass(dim=dim_out, heads=attn_heads, dim_head=ATTN_DIM_HEAD),
-                Upsample(dim_out, dim_in) if not is_last or memory_efficient else Identity()
-            ]))
-
-        self.init_conv_to_final_conv_residual = False       # Unet.py:91
-        self.final_res_block = ResnetBlock(dim, dim, time_cond_dim=time_cond_dim, groups=resnet_groups[0])
-        self.final_conv = nn.Conv2d(dim, self.channels_out, 3, padding=3 // 2)
-
+        self._locals = {k: v for k, v in locals().items() if k not in ('self', '__class__')}
         self._engine = None
+
+        # ---- scalars the engine reads
+        self.dim, self.channels, self.channels_out = dim, channels, default(channels_out, channels)
+        self.cond_dim = default(cond_dim, dim)
+        self.time_cond_dim = dim * 4 * (2 if lowres_cond else 1)
+        self.text_embed_dim, self.max_text_len = text_embed_dim, MAX_TEXT_LEN
+        self.num_time_tokens, self.attn_dim_head, self.attn_heads = NUM_TIME_TOKENS, ATTN_DIM_HEAD, attn_heads
+        self.lowres_cond, self.memory_efficient = lowres_cond, memory_efficient
+        self.skip_connect_scale = 2 ** -0.5
+        self.init_conv_to_final_conv_residual = False       # Unet.py:91
+        self.levels = level_plan(dim, dim_mults, num_resnet_blocks, layer_attns, layer_cross_attns)
+
+        # ---- conditioning path (Unet.py:104-168): one (hiddens, cond, tokens) trio per timestep input, then the text branch
+        for prefix in ("",) + (("lowres_",) if lowres_cond else ()):
+            for name, module in self._time_trio().items():
+                setattr(self, f"to_{prefix}{name}", module)
+        self.norm_cond = nn.LayerNorm(self.cond_dim)
+        self.text_to_cond = nn.Linear(text_embed_dim, self.cond_dim)
+        self.null_text_embed = nn.Parameter(torch.randn(1, MAX_TEXT_LEN, self.cond_dim))
+        self.null_text_hidden = nn.Parameter(torch.randn(1, self.time_cond_dim))
+        self.to_text_non_attn_cond = nn.Sequential(nn.LayerNorm(self.cond_dim), nn.Linear(self.cond_dim, self.time_cond_dim), nn.SiLU(),
+                                                   nn.Linear(self.time_cond_dim, self.time_cond_dim))
+
+        # ---- trunk, generated from the level table: stem, the way down, the middle, the way up (mirror of the table), head
+        self.init_conv = CrossEmbedLayer(channels * (2 if lowres_cond else 1), dim_out=dim, kernel_sizes=CROSS_EMBED_KERNELS, stride=1)
+        self.downs = nn.ModuleList(self._down_level(lv) for lv in self.levels)
+        self.ups = nn.ModuleList(self._up_level(lv) for lv in reversed(self.levels))
+        bottom = self.levels[-1]
+        self.mid_block1 = self._resblock(bottom.width_out, bottom.width_out, bottom.groups, cross_attention=True)
+        self.mid_attn = EinopsToAndFrom('b c h w', 'b (h w) c', Residual(Attention(bottom.width_out, heads=attn_heads, dim_head=ATTN_DIM_HEAD))) \
+            if attend_at_middle else None
+        self.mid_block2 = self._resblock(bottom.width_out, bottom.width_out, bottom.groups, cross_attention=True)
+        self.final_res_block = self._resblock(dim, dim, self.levels[0].groups, cross_attention=False)
+        self.final_conv = nn.Conv2d(dim, self.channels_out, 3, padding=1)
+
+    # ------------------------------------------------------------------ builders
+    def _time_trio(self):
+        tcd = self.time_cond_dim
+        return dict(time_hiddens=nn.Sequential(SinusoidalPosEmb(self.dim), nn.Linear(self.dim, tcd), nn.SiLU()),
+                    time_cond=nn.Sequential(nn.Linear(tcd, tcd)),
+                    time_tokens=nn.Sequential(nn.Linear(tcd, self.cond_dim * NUM_TIME_TOKENS), _Rearrange(NUM_TIME_TOKENS)))
+
+    def _resblock(self, width_in: int, width_out: int, groups: int, cross_attention: bool) -> ResnetBlock:
+        return ResnetBlock(width_in, width_out, cond_dim=self.cond_dim if cross_attention else None, time_cond_dim=self.time_cond_dim, groups=groups)
+
+    def _attention_slot(self, lv: LevelSpec, width: int) -> nn.Module:
+        return TransformerBlock(dim=width, heads=self.attn_heads, dim_head=ATTN_DIM_HEAD) if lv.self_attention else Identity()
+
+    def _down_level(self, lv: LevelSpec) -> nn.ModuleList:
+        """[pre-downsample | None, first ResnetBlock, ResnetBlocks, attention slot, post-downsample | None] (Unet.py:196-262): the
+        resolution changes before the blocks when memory_efficient, after them otherwise (the deepest level then keeps its resolution
+        and widens through Parallel(3x3, 1x1))"""
+        w = lv.trunk_width(self.memory_efficient)
+        before = Downsample(lv.width_in, lv.width_out) if self.memory_efficient else None
+        after = None
+        if not self.memory_efficient:
+            after = Parallel(nn.Conv2d(lv.width_in, lv.width_out, 3, padding=1), nn.Conv2d(lv.width_in, lv.width_out, 1)) if lv.deepest \
+                else Downsample(w, lv.width_out)
+        return nn.ModuleList([before, self._resblock(w, w, lv.groups, lv.cross_attention),
+                              nn.ModuleList(self._resblock(w, w, lv.groups, False) for _ in range(lv.res_blocks)),
+                              self._attention_slot(lv, w), after])
+
+    def _up_level(self, lv: LevelSpec) -> nn.ModuleList:
+        """[first ResnetBlock, ResnetBlocks, attention slot, upsample | Identity] (Unet.py:283-323); every ResnetBlock consumes the
+        running tensor concatenated with one skip tensor of the mirrored down level"""
+        skip = lv.trunk_width(self.memory_efficient)
+        w = lv.width_out
+        keeps_resolution = lv.index == 0 and not self.memory_efficient          # the outermost level of a non-memory-efficient net
+        return nn.ModuleList([self._resblock(w + skip, w, lv.groups, lv.cross_attention),
+                              nn.ModuleList(self._resblock(w + skip, w, lv.groups, False) for _ in range(lv.res_blocks)),
+                              self._attention_slot(lv, w),
+                              Identity() if keeps_resolution else Upsample(w, lv.width_in)])
+
+    # ------------------------------------------------------------------ packed-weight lifetime
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        if self._engine is not None:
+            self._engine.invalidate()
+        return out
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)           # .to() / .cuda() / .float(): the packed copies point at the old storage
+        if getattr(self, '_engine', None) is not None:
+            self._engine.invalidate()
+        return out
 
     # ------------------------------------------------------------------ reference API
     def _cast_model_parameters(self, *, lowres_cond, text_embed_dim, channels, channels_out):

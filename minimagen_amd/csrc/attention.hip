@@ -508,7 +508,9 @@ extern "C" int mi_cross_attn_fwd(const mi_cross_attn_params* pp, void* stream) {
     const mi_cross_attn_params& p = *pp;
     hipStream_t st = (hipStream_t)stream;
     const int JT = (p.J + 15) / 16;
-    if (JT != 17) { mi_set_error("mi_cross_attn_fwd: context of %d rows (%d tiles) not instantiated (MinImagen: 1 + time tokens + 256)", p.J, JT); return MI_ERR_UNSUPPORTED; }
+    // MinImagen's contexts: null + time tokens + 256 text rows (17 tiles), or null + time tokens only when the U-Net is called
+    // without text (Unet.py:572: text is optional; 1 tile, fp16 kernel only)
+    if (JT != 17 && !(JT == 1 && (p.variant == 6 || p.variant == 7))) { mi_set_error("mi_cross_attn_fwd: context of %d rows (%d tiles) not instantiated (MinImagen: 1 + time tokens [+ 256])", p.J, JT); return MI_ERR_UNSUPPORTED; }
     if (p.B2 <= 0 || p.HW <= 0) { mi_set_error("mi_cross_attn_fwd: empty problem"); return MI_ERR_INVALID; }
     // out_stats tiles are MI_ATTN_TOKENS_PER_WG tokens (NQ = 2); p.variant = 1 selects NQ = 1 (64-token tiles)
     if (p.variant == 6 || p.variant == 7) {      // fp16 MFMA (fragments from mi_attn_fold_rows with frag_f16 = 1): 6 = 3-term split (fp32-grade), 7 = single term
@@ -517,6 +519,10 @@ extern "C" int mi_cross_attn_fwd(const mi_cross_attn_params* pp, void* stream) {
         const int nwv = p.HW <= 1024 ? 16 : 8;
         const dim3 g6(((p.HW + 16 * nwv - 1) / (16 * nwv)) * p.B2);
 #define MI_ATTN16_LAUNCH(CC) \
+        if (JT == 1) { \
+            if (p.variant == 6) hipLaunchKernelGGL(HIP_KERNEL_NAME(cross_attn_f16x3_kernel<CC, 1, 4, false, 8>), dim3(((p.HW + 127) / 128) * p.B2), dim3(512), 0, st, p); \
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(cross_attn_f16x3_kernel<CC, 1, 4, true, 8>), dim3(((p.HW + 127) / 128) * p.B2), dim3(512), 0, st, p); \
+        } else \
         if (p.variant == 6 && nwv == 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(cross_attn_f16x3_kernel<CC, 17, 4, false, 8>), g6, dim3(512), 0, st, p); \
         else if (p.variant == 6) hipLaunchKernelGGL(HIP_KERNEL_NAME(cross_attn_f16x3_kernel<CC, 17, 4, false, 16>), g6, dim3(1024), 0, st, p); \
         else if (nwv == 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(cross_attn_f16x3_kernel<CC, 17, 4, true, 8>), g6, dim3(512), 0, st, p); \

@@ -9,8 +9,9 @@ from torch import nn
 class GaussianDiffusion(nn.Module):
     """Linear-beta DDPM schedule.  The twelve tables are computed in fp64 and stored as fp32
     non-persistent buffers exactly as diffusion_model.py:28-66 does, so every look-up value is
-    bit-identical to the reference's.  The per-timestep arithmetic that consumes them
-    (predict_start_from_noise / q_posterior / q_sample) runs inside the HIP sampler kernels."""
+    bit-identical to the reference's.  On the sampling path the per-timestep arithmetic that consumes them
+    (predict_start_from_noise / q_posterior / q_sample) runs inside the HIP sampler kernels; the methods of the
+    same names below are the tensor forms of the class API."""
 
     def __init__(self, *, timesteps: int):
         super().__init__()
@@ -62,11 +63,25 @@ class GaussianDiffusion(nn.Module):
         tab[:, 4] = nonzero * (0.5 * cpu(self.posterior_log_variance_clipped)).exp()
         return tab
 
-    def q_sample(self, *a, **k):
-        raise NotImplementedError("q_sample is fused into mi_lowres_augment on the sampling path; the training path is out of scope")
+    # ---- the per-timestep helpers of the reference's public API (diffusion_model.py:89-162).  The sampling hot path has them fused
+    # into the HIP sampler kernels (mi_lowres_augment, mi_cfg_x0_fwd, mi_posterior_fwd); these tensor forms serve callers of the class
+    # API and the training loss (Imagen.forward), on whatever device the tables live, and are differentiable.
+    @staticmethod
+    def _at(table: torch.Tensor, t: torch.Tensor, like: torch.Tensor) -> torch.Tensor:
+        """table[t] broadcast over an image batch: (b,) -> (b, 1, 1, 1) (helpers.extract, helpers.py:48-59)"""
+        return table.gather(-1, t).reshape(t.shape[0], *((1,) * (like.dim() - 1)))
 
-    def q_posterior(self, *a, **k):
-        raise NotImplementedError("q_posterior is fused into mi_posterior_fwd on the sampling path")
+    def q_sample(self, x_start: torch.Tensor, t: torch.Tensor, noise: torch.Tensor = None) -> torch.Tensor:
+        """x_t = sqrt(abar_t) x_0 + sqrt(1 - abar_t) eps (diffusion_model.py:127-147)"""
+        if noise is None:
+            noise = torch.randn_like(x_start)
+        return self._at(self.sqrt_alphas_cumprod, t, x_start) * x_start + self._at(self.sqrt_one_minus_alphas_cumprod, t, x_start) * noise
 
-    def predict_start_from_noise(self, *a, **k):
-        raise NotImplementedError("predict_start_from_noise is fused into mi_cfg_x0_fwd on the sampling path")
+    def q_posterior(self, x_start: torch.Tensor, x_t: torch.Tensor, t: torch.Tensor):
+        """mean, variance and clipped log-variance of q(x_{t-1} | x_t, x_0) (diffusion_model.py:89-125)"""
+        mean = self._at(self.posterior_mean_coef1, t, x_t) * x_start + self._at(self.posterior_mean_coef2, t, x_t) * x_t
+        return mean, self._at(self.posterior_variance, t, x_t), self._at(self.posterior_log_variance_clipped, t, x_t)
+
+    def predict_start_from_noise(self, x_t: torch.Tensor, t: torch.Tensor, noise: torch.Tensor) -> torch.Tensor:
+        """x_0 = sqrt(1 / abar_t) x_t - sqrt(1 / abar_t - 1) eps (diffusion_model.py:149-162)"""
+        return self._at(self.sqrt_recip_alphas_cumprod, t, x_t) * x_t - self._at(self.sqrt_recipm1_alphas_cumprod, t, x_t) * noise

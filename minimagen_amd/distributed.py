@@ -30,9 +30,15 @@ def gather_samples(local: torch.Tensor, batch: int, group=None) -> torch.Tensor:
     pad = local
     if local.shape[0] < maxn:
         pad = torch.cat((local, local.new_zeros(maxn - local.shape[0], *local.shape[1:])), 0)
-    out = [torch.empty_like(pad) for _ in range(ws)]
-    dist.all_gather(out, pad.contiguous(), group=group)
-    return torch.cat([o[:hi - lo] for o, (lo, hi) in zip(out, sizes)], 0)
+    pad = pad.contiguous()
+    if all(hi - lo == maxn for lo, hi in sizes):
+        # even shards (the benchmark case): ONE collective straight into the preallocated (batch, C, H, W) result, no list + cat copy
+        full = torch.empty(batch, *local.shape[1:], dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(full, pad, group=group)
+        return full
+    flat = torch.empty(ws * maxn, *local.shape[1:], dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(flat, pad, group=group)
+    return torch.cat([flat[r * maxn:r * maxn + (hi - lo)] for r, (lo, hi) in enumerate(sizes)], 0)
 
 
 def sample_distributed(imagen, *, text_embeds: torch.Tensor, text_masks: Optional[torch.Tensor] = None, gather: bool = True,
@@ -44,6 +50,13 @@ def sample_distributed(imagen, *, text_embeds: torch.Tensor, text_masks: Optiona
     batch = text_embeds.shape[0]
     lo, hi = shard_bounds(batch, ws, rank)
     seed_off = sample_kwargs.pop("_sample_offset", 0)
+    if hi == lo:
+        # more ranks than samples: this rank has nothing to sample but must still take part in the collective (a rank that raised
+        # or returned early would leave the others hanging in all_gather)
+        dev = next(imagen.parameters()).device
+        size = imagen.image_sizes[-1]
+        local = torch.zeros(0, imagen.channels, size, size, dtype=torch.float32, device=dev)
+        return gather_samples(local, batch, group) if (gather and ws > 1) else local
     local = imagen.sample(text_embeds=text_embeds[lo:hi].contiguous(),
                           text_masks=None if text_masks is None else text_masks[lo:hi].contiguous(),
                           _sample_offset=seed_off + lo, **sample_kwargs)

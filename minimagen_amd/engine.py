@@ -61,11 +61,24 @@ class Workspace:
     pass
 
 
+def _close_workspace(ws):
+    """Destroy the HIP graph execs cached on a workspace's sampler state (Imagen._p_sample_loop): they are raw handles, not tensors."""
+    lib = L.lib()
+    for st in getattr(ws, "sampler_state", {}).values():
+        for entry in getattr(st, "graphs", {}).values():
+            if entry.get("graph") is not None:
+                lib.mi_graph_destroy(entry["graph"])
+                entry["graph"] = None
+        if hasattr(st, "graphs"):
+            st.graphs.clear()
+
+
 class UnetEngine:
     def __init__(self, unet):
         self.unet = unet
         self._pack = None
         self._pack_key = None
+        self._pack_fp = None
         self._ws = {}
         # "fp32": every contraction fp32-grade (3-term fp16 splits on the matrix cores, fp32 VALU elsewhere);
         # "half": the matrix-core contractions use a single fp16 term (fp32 accumulate / softmax / statistics / storage) --
@@ -74,10 +87,24 @@ class UnetEngine:
 
     # ------------------------------------------------------------------ weights
     def _param_key(self):
+        """Identity of the weights the packed copies were derived from: device, every tensor's storage pointer and version counter."""
         u = self.unet
-        first = next(u.parameters())
-        ver = sum(p._version for p in u.parameters()) + sum(b._version for b in u.buffers())
-        return (str(first.device), first.data_ptr(), ver)
+        ts = list(u.parameters()) + list(u.buffers())
+        return (str(ts[0].device), tuple(t.data_ptr() for t in ts), sum(t._version for t in ts))
+
+    def _fingerprint(self):
+        """Cheap content fingerprint (L1 and L2 norm of every parameter, two fused multi-tensor launches): in-place updates through
+        ``p.data`` (EMA, ``.data.copy_``) do not bump ``p._version``, so identity alone would leave the packed copies stale."""
+        ts = [t.detach() for t in list(self.unet.parameters()) + list(self.unet.buffers()) if t.is_floating_point()]
+        return torch.stack(torch._foreach_norm(ts, 1) + torch._foreach_norm(ts, 2))
+
+    def invalidate(self):
+        """Drop every packed / folded weight copy, workspace and captured step graph (they are rebuilt on the next call).  Called
+        automatically when the weights' identity or content fingerprint changes, by ``Unet.load_state_dict`` and ``Unet._apply``."""
+        for ws in self._ws.values():
+            _close_workspace(ws)
+        self._ws = {}
+        self._pack = self._pack_key = self._pack_fp = None
 
     def _check_params(self):
         for name, t in list(self.unet.named_parameters()) + list(self.unet.named_buffers()):
@@ -89,8 +116,11 @@ class UnetEngine:
 
     def pack(self):
         key = self._param_key()
-        if self._pack is not None and key == self._pack_key:
+        fp = self._fingerprint()
+        if self._pack is not None and key == self._pack_key and torch.equal(fp, self._pack_fp):
             return self._pack
+        self.invalidate()
+        self._pack_fp = fp
         self._check_params()
         u = self.unet
         dev = next(u.parameters()).device
@@ -177,22 +207,22 @@ class UnetEngine:
         pk.conv[id(u.final_conv)] = conv_pack(u.final_conv)
         pk.ce_w = [c.weight.detach().permute(1, 2, 3, 0).contiguous() for c in u.init_conv.convs]
         self._pack, self._pack_key = pk, key
-        self._ws = {}
         return pk
 
     # ------------------------------------------------------------------ workspace / program
-    def workspace(self, B: int, B2: int, H: int, W: int) -> Workspace:
+    def workspace(self, B: int, B2: int, H: int, W: int, precision: Optional[str] = None, has_text: bool = True) -> Workspace:
         pk = self.pack()
         dev = next(self.unet.parameters()).device
-        assert self.precision in ("fp32", "half"), self.precision
-        key = (B, B2, H, W, str(dev), self.precision)
+        precision = self.precision if precision is None else precision
+        assert precision in ("fp32", "half"), precision
+        key = (B, B2, H, W, str(dev), precision, has_text)
         ws = self._ws.get(key)
         if ws is not None:
             return ws
         u = self.unet
         ws = Workspace()
         ws.B, ws.B2, ws.H, ws.W, ws.dev = B, B2, H, W, dev
-        ws.half = self.precision == "half"
+        ws.half = precision == "half"
         f = lambda *shape: torch.zeros(*shape, dtype=torch.float32, device=dev)
         ws.x = f(B, u.channels, H, W)
         ws.lowres = f(B, u.channels, H, W) if u.lowres_cond else None
@@ -202,7 +232,9 @@ class UnetEngine:
         ws.c_text = f(B2, MAX_TEXT_LEN, u.cond_dim)
         ws.text_hiddens = f(B2, u.time_cond_dim)
         ws.ntot = u.num_time_tokens * (2 if u.lowres_cond else 1)
-        ws.J = 1 + ws.ntot + MAX_TEXT_LEN
+        ws.has_text = has_text                       # Unet.py:572: text is optional -- without it the context is the null row + the time tokens
+        ws.J = 1 + ws.ntot + (MAX_TEXT_LEN if has_text else 0)
+        ws.JT = -(-ws.J // 16)
         ws.ss = f(B2, max(pk.R, 1))
         ws.c_time = f(B2, ws.ntot, u.cond_dim)
         ws.t_out = f(B2, u.time_cond_dim)
@@ -329,7 +361,7 @@ class UnetEngine:
         lib = L.lib()
         Cc, HW = h.C, h.H * h.W
         FR = lib.mi_attn_fragment_floats(Cc)
-        gv = torch.zeros(ws.B2, ca.heads, JT, 64, FR, dtype=torch.float32, device=ws.dev)      # zero-filled: padded context rows must read as finite
+        gv = torch.zeros(ws.B2, ca.heads, ws.JT, 64, FR, dtype=torch.float32, device=ws.dev)      # zero-filled: padded context rows must read as finite
         ws.gv[id(ca)] = gv
         nt = -(-HW // (128 if ATTN_VARIANT in (0, 5) else 64))
         out = self._new_act(ws, ws.B2, Cc, h.H, h.W, nt)
@@ -403,7 +435,7 @@ class UnetEngine:
                 chunk = ids[i0:i0 + 8]
                 ca0 = cas[chunk[0]]
                 p = L.MiAttnFoldParams()
-                p.B2, p.C, p.cd, p.heads, p.JT = ws.B2, ca0.to_q.in_features, self.unet.cond_dim, ca0.heads, JT
+                p.B2, p.C, p.cd, p.heads, p.JT = ws.B2, ca0.to_q.in_features, self.unet.cond_dim, ca0.heads, ws.JT
                 p.c_rows, p.c_stride_b, p.row0, p.nrows, p.write_null = L.ptr(rows_t), stride_b, row0, nrows, write_null
                 p.frag_f16 = 1 if ATTN_VARIANT == 6 else 0
                 p.n_blocks = len(chunk)
@@ -425,7 +457,7 @@ class UnetEngine:
         cp.th, cp.tc, cp.tt = _lin(u.to_time_hiddens[1]), _lin(u.to_time_cond[0]), _lin(u.to_time_tokens[0])
         if u.lowres_cond:
             cp.lth, cp.ltc, cp.ltt = _lin(u.to_lowres_time_hiddens[1]), _lin(u.to_lowres_time_cond[0]), _lin(u.to_lowres_time_tokens[0])
-        cp.text_hiddens = L.ptr(ws.text_hiddens)
+        cp.text_hiddens = L.ptr(ws.text_hiddens) if ws.has_text else 0
         cp.norm_w, cp.norm_b = L.ptr(u.norm_cond.weight), L.ptr(u.norm_cond.bias)
         cp.time_mlps = L.MiLinear(L.ptr(pk.tm_w), L.ptr(pk.tm_b), u.time_cond_dim, pk.R)
         cp.ss, cp.c_time, cp.t_out = L.ptr(ws.ss), L.ptr(ws.c_time), L.ptr(ws.t_out)
@@ -509,8 +541,14 @@ class UnetEngine:
     def set_text(self, ws, text_embeds: torch.Tensor, text_mask: Optional[torch.Tensor], keep: torch.Tensor):
         """K2 + the step-invariant part of the context fold.  Once per ``sample()`` / ``forward``."""
         u, pk, lib = self.unet, self.pack(), L.lib()
+        st = L.current_stream()
         if text_embeds is None:
-            raise NotImplementedError("text_embeds=None (time-token-only context) is not on the MinImagen sampling path")
+            # Unet.py:572-634 without text: no text hiddens are added to t, the context is [null | time tokens]; only the null row is written here
+            assert not ws.has_text, "workspace was built for a text-conditioned call"
+            for fn, fp, name in self._fold_params(ws, pk, ws.c_time, ws.ntot * u.cond_dim, 1, 0, 1):
+                L.check(fn(C.byref(fp), st), name)
+            return
+        assert ws.has_text, "workspace was built for a call without text"
         text_embeds = text_embeds.to(device=ws.dev, dtype=torch.float32).contiguous()
         assert text_embeds.shape[0] == ws.B and text_embeds.shape[-1] == u.text_embed_dim
         mask8 = None if text_mask is None else text_mask.to(device=ws.dev).to(torch.uint8).contiguous()
@@ -528,7 +566,6 @@ class UnetEngine:
         p.null_text_hidden = L.ptr(u.null_text_hidden)
         p.norm_w, p.norm_b = L.ptr(u.norm_cond.weight), L.ptr(u.norm_cond.bias)
         p.c_text, p.text_hiddens = L.ptr(ws.c_text), L.ptr(ws.text_hiddens)
-        st = L.current_stream()
         L.check(lib.mi_text_cond_fwd(C.byref(p), st), "mi_text_cond_fwd")
         for fn, fp, name in self._fold_params(ws, pk, ws.c_text, MAX_TEXT_LEN * u.cond_dim, 1 + ws.ntot, MAX_TEXT_LEN, 1):
             L.check(fn(C.byref(fp), st), name)
@@ -560,7 +597,7 @@ class UnetEngine:
             cp = L.MiCondStepParams.from_buffer_copy(ws.cond_params)
             cp.B2 = cp.B = n
             cp.time, cp.lowres_time = L.ptr(tb.times), L.ptr(tb.lowres_times)
-            cp.text_hiddens, cp.ss, cp.c_time, cp.t_out = L.ptr(tb.text_hiddens), L.ptr(tb.ss), L.ptr(tb.c_time), 0
+            cp.text_hiddens, cp.ss, cp.c_time, cp.t_out = (L.ptr(tb.text_hiddens) if ws.has_text else 0), L.ptr(tb.ss), L.ptr(tb.c_time), 0
             tb.cond = cp
             tb.fold, tb.tables = [], []
             stage_blocks = []
@@ -618,7 +655,7 @@ class UnetEngine:
         B, Cc, H, W = x.shape
         assert Cc == u.channels
         two = cond_scale is not None
-        ws = self.workspace(B, 2 * B if two else B, H, W)
+        ws = self.workspace(B, 2 * B if two else B, H, W, has_text=text_embeds is not None)
         ws.x.copy_(x)
         ws.times.copy_(time.to(torch.int64))
         if u.lowres_cond:

@@ -74,3 +74,26 @@ def test_sample_and_save_layout_and_pixels(backend, tmp_path, monkeypatch):
         G.sample_and_save(captions)
     with pytest.raises(AssertionError):
         G.sample_and_save(captions, minimagen=m, training_directory=d, save_directory=str(tmp_path / "z"))
+
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_control_flow_on_one_gpu(tmp_path):
+    """The N > 1 path of bench.py as the driver launches it (torch.distributed.run, one process per rank): sharded text rows, noise keyed
+    by the global row, the gather, the MAX-reduced timing and rank 0's JSON line.  MINIMAGEN_BENCH_ONE_GPU=1 puts both ranks on cuda:0
+    with gloo collectives (RCCL refuses two ranks on one device; a single-GPU box is all the test tier has) -- a control-flow check,
+    not a performance number."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MINIMAGEN_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = str(29000 + os.getpid() % 1500)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", port,
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--batch", "2", "--timesteps", "25",
+           "--no-breakdown", "--no-cpu-baseline", "--no-secondary"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 4 and line["config"]["parallelism"] == "dp2"
+    assert line["value"] > 0 and line["scaling"] == "weak" and line["steps"] == 1

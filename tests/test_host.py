@@ -72,11 +72,11 @@ import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, sys.argv[1])
 from minimagen_amd.distributed import shard_bounds, gather_samples
 dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{sys.argv[2]}", rank=int(sys.argv[3]), world_size=2)
-B = 5
-full = torch.arange(B * 3 * 4 * 4, dtype=torch.float32).reshape(B, 3, 4, 4)
-lo, hi = shard_bounds(B, 2, dist.get_rank())
-out = gather_samples(full[lo:hi].clone(), B)
-assert torch.equal(out, full), "gathered batch differs"
+for B in (5, 4, 1):                          # ragged shards, even shards (one collective straight into the result), a rank with NO rows
+    full = torch.arange(B * 3 * 4 * 4, dtype=torch.float32).reshape(B, 3, 4, 4)
+    lo, hi = shard_bounds(B, 2, dist.get_rank())
+    out = gather_samples(full[lo:hi].clone(), B)
+    assert torch.equal(out, full), f"gathered batch differs (B={B})"
 dist.destroy_process_group()
 print("ok")
 '''
@@ -111,6 +111,11 @@ assert out.shape == (B, 3, 32, 32)
 if dist.get_rank() == 0:
     whole = im.sample(text_embeds=emb, text_masks=mask, cond_scale=1., _seed=77)
     assert torch.equal(out, whole), "2-rank sharded sampling differs from the single-process batch"
+# more ranks than samples: rank 1 has an empty shard and must still take part in the collective (no hang, no raise)
+one = sample_distributed(im, text_embeds=emb[:1], text_masks=mask[:1], cond_scale=1., _seed=77)
+assert one.shape == (1, 3, 32, 32)
+if dist.get_rank() == 0:
+    assert torch.equal(one, whole[:1])
 dist.barrier()
 dist.destroy_process_group()
 print("ok")
@@ -144,3 +149,52 @@ def test_bench_contract_helpers():
     assert torch.equal(emb2, emb[26:30]) and torch.equal(mask2, mask[26:30])
     t = bench.pmc_traffic({"kernel": "cross_attn"}, 64, 256)
     assert t["traffic"] is None or 3e7 < t["traffic"] < 1e8
+
+
+def test_minimagen_import_path_is_the_amd_implementation():
+    """the reference's callers import ``minimagen.*`` (reference inference.py:2, generate.py:8-9): the alias package must resolve every
+    one of those names to the MI355X implementation (same objects, not copies)"""
+    import minimagen
+    import minimagen_amd.Imagen, minimagen_amd.Unet, minimagen_amd.generate, minimagen_amd.t5, minimagen_amd.diffusion_model
+    from minimagen.Imagen import Imagen
+    from minimagen.Unet import Unet, Base, Super, BaseTest, SuperTest
+    from minimagen.generate import load_minimagen, load_params, sample_and_save
+    from minimagen.t5 import t5_encode_text, get_encoded_dim
+    from minimagen.diffusion_model import GaussianDiffusion
+    from minimagen.helpers import cast_tuple, default, exists
+    assert Imagen is minimagen_amd.Imagen.Imagen and Unet is minimagen_amd.Unet.Unet and Super is minimagen_amd.Unet.Super
+    assert load_minimagen is minimagen_amd.generate.load_minimagen and GaussianDiffusion is minimagen_amd.diffusion_model.GaussianDiffusion
+    assert minimagen.Imagen is minimagen_amd.Imagen and get_encoded_dim("t5_small") == 512
+    # a reference-style construction through the alias path (reference README / main.py usage)
+    u = BaseTest.defaults
+    im = Imagen(unets=(Unet(**BaseTest.defaults), Unet(**SuperTest.defaults)), image_sizes=(32, 64), timesteps=25, text_encoder_name="t5_small")
+    assert len(im.unets) == 2 and im.unets[1].lowres_cond and u["dim"] == 8
+
+
+def test_gaussian_diffusion_public_methods():
+    """q_sample / q_posterior / predict_start_from_noise (diffusion_model.py:89-162) on the bit-identical tables: against the live
+    reference when it is present, always against the oracle's scalar forms"""
+    from minimagen_amd.diffusion_model import GaussianDiffusion
+    T = 100
+    gd = GaussianDiffusion(timesteps=T)
+    g = torch.Generator().manual_seed(3)
+    x0, eps = torch.randn(4, 3, 8, 8, generator=g), torch.randn(4, 3, 8, 8, generator=g)
+    t = torch.tensor([0, 1, 57, 99])
+    xt = gd.q_sample(x0, t, eps)
+    mean, var, logvar = gd.q_posterior(x0, xt, t)
+    x0_hat = gd.predict_start_from_noise(xt, t, eps)
+    assert mean.shape == x0.shape and var.shape == logvar.shape == (4, 1, 1, 1)
+    sched = R.Schedule(T)
+    for i, ti in enumerate(t.tolist()):
+        assert torch.equal(xt[i], sched.q_sample(x0[i:i + 1], ti, eps[i:i + 1])[0])
+        assert torch.equal(x0_hat[i], sched.predict_start_from_noise(xt[i:i + 1], ti, eps[i:i + 1])[0])
+        m_ref = sched.q_posterior(x0[i:i + 1], xt[i:i + 1], ti)
+        assert torch.equal(mean[i], m_ref[0][0])
+    assert gd.q_sample(x0, t).shape == x0.shape                     # noise defaults to randn_like
+    if os.path.isdir("/root/reference/minimagen"):
+        from oracle import ref_loader
+        ref = ref_loader.load_reference()
+        rgd = ref.diffusion_model.GaussianDiffusion(timesteps=T)
+        assert torch.equal(xt, rgd.q_sample(x0, t, eps)) and torch.equal(x0_hat, rgd.predict_start_from_noise(xt, t, eps))
+        for a, b in zip((mean, var, logvar), rgd.q_posterior(x0, xt, t)):
+            assert torch.equal(a, b)

@@ -104,6 +104,89 @@ def test_forward_full_size_vs_oracle(backend):
     assert (o.cpu() - ref).abs().max() < FWD_ATOL
 
 
+@pytest.mark.parametrize("backend", GPU_ONLY)
+def test_forward_1024_vs_oracle(backend):
+    """BASELINE config 5's third stage: the SR U-Net (unet_1 parameters) at 1024 x 1024, B = 1, against the oracle run on the host"""
+    dev = setup(backend)
+    u1, sd1 = make_unet("unet1", dev), I.load("unet1_sd.pt")
+    emb, mask = R.synthetic_text(1, length=40, seed=11)
+    x, lr = I.seeded((1, 3, 1024, 1024), 201), I.seeded((1, 3, 1024, 1024), 202)
+    tm, lt = torch.tensor([37]), torch.tensor([20])
+    o = u1(x.to(dev), tm.to(dev), lowres_cond_img=lr.to(dev), lowres_noise_times=lt.to(dev), text_embeds=emb.to(dev), text_mask=mask.to(dev))
+    ref = R.unet_forward(sd1, x, tm, lowres_cond_img=lr, lowres_noise_times=lt, text_embeds=emb, text_mask=mask)
+    d = (o.cpu() - ref).abs().max().item()
+    print(f"Unet.forward 1024^2 B=1 vs oracle: max|d| = {d:.2e}")
+    assert o.shape == (1, 3, 1024, 1024) and d < FWD_ATOL
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_forward_without_text_vs_oracle(backend):
+    """Unet.py:572: text conditioning is optional -- ``text_embeds=None`` runs with the context [null | time tokens] and no text hiddens"""
+    dev = setup(backend)
+    u0, sd0 = make_unet("unet0", dev), I.load("unet0_sd.pt")
+    x, tm = I.seeded((2, 3, 32, 32), 17), torch.tensor([40, 3])
+    o = u0(x.to(dev), tm.to(dev))
+    ref = R.unet_forward(sd0, x, tm, text_embeds=None, text_mask=None)
+    assert (o.cpu() - ref).abs().max() < FWD_ATOL
+    emb, mask = R.synthetic_text(2, length=12, seed=5)                 # and the same module still serves text-conditioned calls
+    o = u0(x.to(dev), tm.to(dev), text_embeds=emb.to(dev), text_mask=mask.to(dev))
+    assert (o.cpu() - R.unet_forward(sd0, x, tm, text_embeds=emb, text_mask=mask)).abs().max() < FWD_ATOL
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_repack_after_data_mutation(backend):
+    """in-place updates through ``p.data`` (EMA, ``.data.copy_``) do not bump ``p._version``: the content fingerprint must catch them"""
+    dev = setup(backend)
+    u0, sd0 = make_unet("unet0", dev), I.load("unet0_sd.pt")
+    m = I.load("fwdA.pt")["meta"]
+    emb, mask = I.text(m)
+    x, tm = I.seeded((2, 3, 32, 32), 1), torch.tensor([3, 4])
+    a = u0(x.to(dev), tm.to(dev), text_embeds=emb.to(dev), text_mask=mask.to(dev))
+    for prm in u0.parameters():
+        prm.data.mul_(1.05)
+    b = u0(x.to(dev), tm.to(dev), text_embeds=emb.to(dev), text_mask=mask.to(dev))
+    sd = {k: (v * 1.05 if v.is_floating_point() and k in dict(u0.named_parameters()) else v) for k, v in sd0.items()}
+    ref = R.unet_forward(sd, x, tm, text_embeds=emb, text_mask=mask)
+    assert (b.cpu() - ref).abs().max() < FWD_ATOL and (a - b).abs().max() > 1e-3
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("which", ["unet0", "unet1"])
+def test_conditioning_ops_vs_oracle(backend, which):
+    """op-level: mi_cond_step_fwd (Unet._generate_t_tokens, Unet.py:508-536, + norm_cond of the time tokens + every time_mlp) and
+    mi_text_cond_fwd (Unet._text_condition, Unet.py:571-634) against the oracle's functions -- ragged masks, a caption longer than one
+    row's mask, the conditional and the null half of a guidance batch"""
+    dev = setup(backend)
+    u, sd = make_unet(which, dev), I.load(f"{which}_sd.pt")
+    eng = u.engine()
+    B = 3
+    emb, mask = R.synthetic_text(B, length=20, seed=5)
+    mask[1, 7:] = False
+    ws = eng.workspace(B, 2 * B, 32, 32)
+    keep = torch.cat((torch.ones(B, dtype=torch.bool), torch.zeros(B, dtype=torch.bool)))
+    tm = torch.tensor([99, 13, 0])
+    lt = torch.tensor([20, 20, 20])
+    ws.times.copy_(tm)
+    if u.lowres_cond:
+        ws.lowres_times.copy_(lt)
+    eng.set_text(ws, emb.to(dev), mask.to(dev), keep)
+    import ctypes as C
+    from minimagen_amd import _lib as L
+    fn, cp, _ = ws.prog_cond[0]
+    L.check(fn(C.byref(cp), L.current_stream()), "mi_cond_step_fwd")
+    emb2, mask2, tm2 = emb.repeat(2, 1, 1), mask.repeat(2, 1), tm.repeat(2)
+    t_ref, tok_ref = R.generate_t_tokens(sd, tm2, lt.repeat(2) if u.lowres_cond else None)
+    t_ref, c_ref = R.text_condition(sd, emb2, mask2, keep, t_ref, tok_ref)
+    ntot = ws.ntot
+    assert (ws.t_out.cpu() - t_ref).abs().max() < 2e-5                                       # t = time cond + text hiddens
+    assert (ws.c_time.cpu() - c_ref[:, :ntot]).abs().max() < 2e-5                            # norm_cond(time tokens)
+    assert (ws.c_text.cpu() - c_ref[:, ntot:]).abs().max() < 2e-5                            # norm_cond(text / null tokens), 256 rows
+    # every ResnetBlock's time_mlp (layers.py:395-399): Linear(SiLU(t)) stacked in the engine's order
+    pk = eng.pack()
+    ss_ref = torch.nn.functional.silu(t_ref) @ pk.tm_w.cpu().t() + pk.tm_b.cpu()
+    assert (ws.ss.cpu() - ss_ref).abs().max() < 2e-5
+
+
 @pytest.mark.parametrize("backend", BACKENDS)
 def test_repack_after_weight_update(backend):
     """packed / folded weight copies must follow load_state_dict and in-place parameter updates"""

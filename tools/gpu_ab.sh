@@ -7,7 +7,7 @@ i=0
 for SET in "$@"; do
   i=$((i+1)); name=ab$i
   if [ "$SET" = "-" ]; then ENVS=""; else ENVS="$SET"; fi
-  env $ENVS timeout 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --breakdown-out $OUT/bd_$name.json > $OUT/bench_$name.log 2>&1
+  env $ENVS timeout 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --breakdown-out $OUT/bd_$name.json > $OUT/bench_$name.log 2>&1
   python - <<PY
 import json
 try:

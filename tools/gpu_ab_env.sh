@@ -5,8 +5,8 @@ OUT=gpurun_out; mkdir -p $OUT
 NAME=$1; shift
 for V in "$@"; do
   export $NAME=$V
-  timeout 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/ab_c_$V.log 2>&1
-  timeout 300 python bench.py --workload base64 --steps 2 --warmup 1 --no-cpu-baseline > $OUT/ab_b_$V.log 2>&1
+  timeout 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary > $OUT/ab_c_$V.log 2>&1
+  timeout 300 python bench.py --workload base64 --steps 2 --warmup 1 --no-cpu-baseline --no-secondary > $OUT/ab_b_$V.log 2>&1
   python - <<PY
 import json
 r = json.loads(open("$OUT/ab_c_$V.log").read().strip().splitlines()[-1])

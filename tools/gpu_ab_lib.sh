@@ -5,7 +5,7 @@ OUT=gpurun_out; mkdir -p $OUT
 for V in "$@"; do
   if [ "$V" = "-" ]; then V=""; fi
   export MINIMAGEN_HIP_LIB=$(pwd)/minimagen_amd/libminimagen_hip$V.so
-  timeout 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/ab_c$V.log 2>&1
+  timeout 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary > $OUT/ab_c$V.log 2>&1
   python - <<PY
 import json
 r = json.loads(open("$OUT/ab_c$V.log").read().strip().splitlines()[-1])

@@ -3,9 +3,9 @@
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 OUT=gpurun_out; mkdir -p $OUT
 timeout 900 python -m pytest tests/test_generate.py -m gpu -q --timeout 600 2>&1 | tail -1
-timeout 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --breakdown-out $OUT/bd_q.json > $OUT/bench_q.log 2>&1
-timeout 300 python bench.py --workload base64 --steps 2 --warmup 1 --no-cpu-baseline --breakdown-out $OUT/bd_qb.json > $OUT/bench_qb.log 2>&1
-timeout 300 python bench.py --precision half --steps 2 --warmup 1 --no-cpu-baseline --breakdown-out $OUT/bd_qh.json > $OUT/bench_qh.log 2>&1
+timeout 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --breakdown-out $OUT/bd_q.json > $OUT/bench_q.log 2>&1
+timeout 300 python bench.py --workload base64 --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --breakdown-out $OUT/bd_qb.json > $OUT/bench_qb.log 2>&1
+timeout 300 python bench.py --precision half --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --breakdown-out $OUT/bd_qh.json > $OUT/bench_qh.log 2>&1
 python -c "import json; r=json.loads(open(\"$OUT/bench_qh.log\").read().strip().splitlines()[-1]); print(\"HALF cascade\", round(r[\"value\"]), r[\"unet_eval\"][\"by_kernel_ms\"], r[\"roofline\"][\"frac\"])"
 python - <<PY
 import json

@@ -5,7 +5,7 @@ OUT=gpurun_out; mkdir -p $OUT
 timeout 600 python -m pytest tests/test_kernels.py tests/test_unet.py -m gpu -q -x --timeout 300 2>&1 | tail -3
 run() {  # name, env...
   local name=$1; shift
-  env "$@" timeout 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --breakdown-out $OUT/bd_$name.json > $OUT/bench_$name.log 2>&1
+  env "$@" timeout 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --breakdown-out $OUT/bd_$name.json > $OUT/bench_$name.log 2>&1
   python - <<PY
 import json
 try:
