@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MI_ABI_VERSION 2
+#define MI_ABI_VERSION 3
 
 enum mi_status {
     MI_OK = 0,
@@ -80,10 +80,6 @@ typedef struct mi_conv_params {
     float* out;             /* [B][Cout][H][W] */
     float* out_stats;       /* [B][Cout][out_nt][2] or NULL */
     int tile_cfg;           /* see mi_conv_tile_shape; | MI_CONV_SPLIT16: 16-channel outputs as two 8-channel workgroups */
-    /* matrix-core path (k3 s1 only, tile_cfg 3 or 4): weights as fp16 hi/lo MFMA A-fragments
-       [ceil(Cout/16)][ceil(Cin/16)][9 taps][64 lanes][4 hi | 4 lo halves]; res_w_f16 likewise with 1 tap over the residual channels */
-    const void* w_f16;
-    const void* res_w_f16;
     /* row-paired matrix-core path (conv_rp.hip; tile_cfg 5..7): B-operand fragments of v_mfma_f32_16x16x32_f16 with
        N = (output row parity dy, 8 output channels), K = (4 input rows, 8 input channels) per horizontal tap:
        [ceil(Cin/8)][steps][ceil(Cout/8)][64 lanes][8 hi | 8 lo halves] of w * 2^w_rp_exp (power-of-two pre-scaling keeps the
@@ -94,8 +90,7 @@ typedef struct mi_conv_params {
 } mi_conv_params;
 #define MI_CONV_SPLIT16 0x100
 #define MI_CONV_SPLIT8  0x800   /* 8-channel outputs as two 4-channel workgroups (small, latency-bound launches) */
-#define MI_CONV_HALF    0x400   /* matrix-core path: single fp16 term per product (reduced-precision configuration; parity gate 3e-2) */
-#define MI_CONV_WAVES8  0x200   /* matrix-core path: 8 waves x 4 pixel-tiles per workgroup instead of 4 x 8 */
+#define MI_CONV_HALF    0x400   /* row-paired matrix-core path: single fp16 term per product (reduced-precision configuration; parity gate 3e-2) */
 #define MI_CONV_RP_FIRST 5      /* tile_cfg 5: 16x64, 6: 8x64, 7: 8x32 output tiles of the row-paired matrix-core path */
 
 /* tile_cfg -> output tile (th x tw) handled by one workgroup; out_nt = ceil(H/th)*ceil(W/tw) */
@@ -195,6 +190,8 @@ typedef struct mi_attn_fold_params {
         const float* v0;            /* [heads][C]      Wo_h null_v */
         float* gv;
         float* table;               /* mode 1 / 2: compact folded rows [steps * B2][nrows][heads][C][2] = (g, vw) */
+        int g_exp, v_exp;           /* frag_f16: the fragments hold g * 2^g_exp and vw * 2^v_exp (exact power-of-two scalings chosen by
+                                       the host from the weights' magnitude so that the fp16 hi/lo split stays in the normal range) */
     } blk[MI_ATTN_MAX_BLOCKS];
     /* The timestep sequence of a sampling loop is known in advance (T-1 .. 0, the same for every sample), so everything that depends
        only on (timestep, text) is computed ONCE per sample() for all T steps and the per-step work shrinks to a scatter:
@@ -216,6 +213,8 @@ typedef struct mi_cross_attn_params {
     const float* n1_g; const float* n1_b;   /* CrossAttention.norm   gamma / beta */
     const float* n2_g; const float* n2_b;   /* to_out.1              gamma / beta */
     float* out; float* out_stats;   /* [B2][C][HW]; stats [B2][C][ceil(HW/tok)][2], tok = 128 (variant 0) or 64 (variant 1) */
+    int x_exp, g_exp, v_exp;        /* variants 6 / 7: LayerNorm(x) is scaled by 2^x_exp before its fp16 split, the fragments carry 2^g_exp /
+                                       2^v_exp (mi_attn_fold_params); the kernel undoes all three exactly (scores, output) */
     int variant;                    /* 0: 32 tokens per wave; 1,3,4: 16 tokens per wave (fp32 MFMA, exact); 6: 16 tokens per wave with the
                                        contractions as 3-term fp16 splits on v_mfma_f32_16x16x16_f16 (hi*hi + hi*lo + lo*hi, ~2^-21);
                                        7: as 6 with a single fp16 term (reduced-precision configuration, same frag_f16 fragments) */

@@ -32,7 +32,6 @@ class MiConvParams(C.Structure):
         ("scale_shift", C.c_void_p), ("ss_stride", C.c_int), ("ss_off", C.c_int),
         ("res0", MiAct), ("res1", MiAct), ("res_w", C.c_void_p), ("res_b", C.c_void_p),
         ("out", C.c_void_p), ("out_stats", C.c_void_p), ("tile_cfg", C.c_int),
-        ("w_f16", C.c_void_p), ("res_w_f16", C.c_void_p),
         ("w_rp", C.c_void_p), ("res_w_rp", C.c_void_p), ("w_rp_exp", C.c_int), ("res_w_rp_exp", C.c_int),
     ]
 
@@ -72,7 +71,8 @@ class MiCondStepParams(C.Structure):
 
 
 class MiAttnFoldBlk(C.Structure):
-    _fields_ = [("mg", C.c_void_p), ("mv", C.c_void_p), ("g0", C.c_void_p), ("v0", C.c_void_p), ("gv", C.c_void_p), ("table", C.c_void_p)]
+    _fields_ = [("mg", C.c_void_p), ("mv", C.c_void_p), ("g0", C.c_void_p), ("v0", C.c_void_p), ("gv", C.c_void_p), ("table", C.c_void_p),
+                ("g_exp", C.c_int), ("v_exp", C.c_int)]
 
 
 class MiAttnFoldParams(C.Structure):
@@ -88,7 +88,7 @@ class MiCrossAttnParams(C.Structure):
     _fields_ = [
         ("B2", C.c_int), ("C", C.c_int), ("HW", C.c_int), ("heads", C.c_int), ("J", C.c_int),
         ("x", MiAct), ("gv", C.c_void_p), ("n1_g", C.c_void_p), ("n1_b", C.c_void_p), ("n2_g", C.c_void_p), ("n2_b", C.c_void_p),
-        ("out", C.c_void_p), ("out_stats", C.c_void_p), ("variant", C.c_int),
+        ("out", C.c_void_p), ("out_stats", C.c_void_p), ("x_exp", C.c_int), ("g_exp", C.c_int), ("v_exp", C.c_int), ("variant", C.c_int),
     ]
 
 

@@ -324,7 +324,7 @@ __global__ __launch_bounds__(64 * NWV, WPS) void cross_attn_f16x3_kernel(const m
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int a = 16 * kc + 4 * lg + e;
-                xn[e] = (a < C) ? (xf[kc][e] - mean) * rstd * p.n1_g[a] + p.n1_b[a] : 0.0f;
+                xn[e] = (a < C) ? ldexpf((xf[kc][e] - mean) * rstd * p.n1_g[a] + p.n1_b[a], p.x_exp) : 0.0f;
             }
             split_f16(xn, xhi[kc], xlo[kc]);
         }
@@ -397,6 +397,7 @@ __global__ __launch_bounds__(64 * NWV, WPS) void cross_attn_f16x3_kernel(const m
             }
         m = fmaxf(m, __shfl_xor(m, 16));
         m = fmaxf(m, __shfl_xor(m, 32));
+        const float sc = ldexpf(1.0f, -(p.x_exp + p.g_exp)), msc = -m * sc;      // undo the operand scalings inside the subtraction's FMA
         float l = 0.0f;
         f32x4 oh[MT];
 #pragma unroll
@@ -412,7 +413,7 @@ __global__ __launch_bounds__(64 * NWV, WPS) void cross_attn_f16x3_kernel(const m
                 float pe[4] = {0.f, 0.f, 0.f, 0.f};
                 if (jt < JT) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) { pe[r] = __builtin_amdgcn_exp2f(s[jt < JT ? jt : 0][r] - m); l += pe[r]; }
+                    for (int r = 0; r < 4; ++r) { pe[r] = __builtin_amdgcn_exp2f(fmaf(s[jt < JT ? jt : 0][r], sc, msc)); l += pe[r]; }
                 }
                 if constexpr (HALF) {
 #pragma unroll
@@ -440,7 +441,7 @@ __global__ __launch_bounds__(64 * NWV, WPS) void cross_attn_f16x3_kernel(const m
         }
         l += __shfl_xor(l, 16);
         l += __shfl_xor(l, 32);
-        const float linv = 1.0f / l;
+        const float linv = ldexpf(1.0f / l, -p.v_exp);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll

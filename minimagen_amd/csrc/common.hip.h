@@ -209,7 +209,6 @@ __device__ __forceinline__ float mi_wave_max(float v) {
     return v;
 }
 
-int mi_conv_mfma_launch(const mi_conv_params& p, hipStream_t st);   // conv_mfma.hip
 int mi_conv_rp_launch(const mi_conv_params& p, hipStream_t st);     // conv_rp.hip
 
 // host-side error plumbing (capi.hip)

@@ -186,6 +186,8 @@ __global__ __launch_bounds__(256) void attn_fold_rows_kernel(const mi_attn_fold_
             // fp16x3 fragments: per lane and tile KC x {4 halves G hi, 4 halves G lo} then MT x {4 VW hi, 4 VW lo}
             const int KC = (C + 15) / 16, MTh = (C + 15) / 16, FRH = 8 * KC + 8 * MTh;          // halves per lane
             _Float16* th = reinterpret_cast<_Float16*>(p.blk[blk].gv) + (((size_t)bb * p.heads + h) * p.JT + jt) * 64 * FRH;
+            g = ldexpf(g, p.blk[blk].g_exp);            // exact power-of-two scalings: keep hi AND lo in the fp16 normal range
+            v = ldexpf(v, p.blk[blk].v_exp);
             const _Float16 ghi = (_Float16)g, glo = (_Float16)(g - (float)ghi);
             const _Float16 vhi = (_Float16)v, vlo = (_Float16)(v - (float)vhi);
             _Float16* lg = th + (size_t)(jm + 16 * ((a & 15) >> 2)) * FRH + 8 * (a >> 4);      // A[m=j][k=a]: lane (j, a/4), element a%4

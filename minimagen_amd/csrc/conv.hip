@@ -433,8 +433,6 @@ extern "C" int mi_conv_tile_shape(int tile_cfg, int* th, int* tw) {
         case 5: *th = 16; *tw = 64; return MI_OK;     // row-paired matrix-core path (conv_rp.hip)
         case 6: *th = 8; *tw = 64; return MI_OK;
         case 7: *th = 8; *tw = 32; return MI_OK;
-        case 3: *th = 8; *tw = 64; return MI_OK;      // matrix-core path (conv_mfma.hip)
-        case 4: *th = 16; *tw = 32; return MI_OK;
         case 0: *th = 16; *tw = 64; return MI_OK;
         case 1: *th = 32; *tw = 32; return MI_OK;
         case 2: *th = 8; *tw = 32; return MI_OK;
@@ -455,7 +453,6 @@ extern "C" int mi_conv_fwd(const mi_conv_params* pp, void* stream) {
     if (p.B <= 0 || p.H <= 0 || p.W <= 0 || p.Cout <= 0) { mi_set_error("mi_conv_fwd: empty problem"); return MI_ERR_INVALID; }
     if (p.up2 && ((p.H | p.W) & 1)) { mi_set_error("mi_conv_fwd: up2 needs even output size"); return MI_ERR_INVALID; }
     if (p.w_rp) return mi_conv_rp_launch(p, st);
-    if (p.w_f16) return mi_conv_mfma_launch(p, st);
     const int ct = mi_conv_cout_tile(p.Cout);
     // MI_CONV_SPLIT8: 8 output channels as two 4-channel workgroups -- twice the waves for the small (latency-bound) launches
     const bool split8 = (p.tile_cfg & MI_CONV_SPLIT8) && ct == 8 && p.Cout == 8;

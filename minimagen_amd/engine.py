@@ -28,8 +28,6 @@ MAX_TEXT_LEN = 256
 ATTN_VARIANT = int(os.environ.get("MINIMAGEN_ATTN_VARIANT", "6"))       # 6: fp16x3 MFMA (default); 0/1/3/4/5: exact-fp32 MFMA shapes
 CONV_SPLIT16 = int(os.environ.get("MINIMAGEN_CONV_SPLIT16", "1"))
 CONV_SPLIT8 = int(os.environ.get("MINIMAGEN_CONV_SPLIT8", "64"))        # 8-channel outputs of images up to SPLIT8^2 pixels as two 4-channel workgroups (0 = off)
-CONV_WAVES8 = int(os.environ.get("MINIMAGEN_CONV_WAVES8", "1"))        # matrix-core conv: 8 waves x 4 pixel-tiles per workgroup
-CONV_MFMA = int(os.environ.get("MINIMAGEN_CONV_MFMA", "1"))             # 1: wide (>=16 in, >=16 out) k3 s1 convs on the matrix cores; 2: all k3 s1
 CONV_RP = int(os.environ.get("MINIMAGEN_CONV_RP", "2"))                 # 1: narrow k3 s1 convs (channels in multiples of 8, <= 64 in) on the row-paired matrix-core kernel; 2: also nearest-x2 + k3 and k4 s2
 RP_TILE = {k: int(os.environ.get("MINIMAGEN_RP_TILE_" + k, d)) for k, d in (("L", "6"), ("M", "6"), ("S", "6"))}   # tile_cfg for images > 128^2 / > 64^2 / smaller
 RP_MIN_HW = int(os.environ.get("MINIMAGEN_RP_MIN_HW", "0"))             # ... for images of at least this many pixels
@@ -129,17 +127,15 @@ class UnetEngine:
         pk.keep = []           # keeps packed tensors alive
         pk.freq = P.sinusoid_freq(u.dim, dev)
         pk.conv = {}
-        pk.conv_f16 = {}
         pk.conv_rp = {}
         pk.attn = {}
+        pk.attn_exp = {}
 
         def conv_pack(mod: nn.Conv2d, w=None, b=None):
             w = mod.weight if w is None else w
             ct = lib.mi_conv_cout_tile(w.shape[0])
             wp = P.pack_conv_weight(w.to(dev), ct)
             pk.keep.append(wp)
-            if w.shape[-1] in (1, 3):
-                pk.conv_f16[id(wp)] = P.pack_conv_weight_f16frag(w.to(dev))
             if w.shape[-1] in (3, 4) and w.shape[1] % 8 == 0 and w.shape[1] <= 64 and w.shape[0] <= (32 if w.shape[-1] == 3 else 16):
                 pk.conv_rp[id(wp)] = P.pack_conv_weight_rp(w.to(dev))
             return wp
@@ -165,7 +161,6 @@ class UnetEngine:
                 ct = lib.mi_conv_cout_tile(rb.res_conv.weight.shape[0])
                 rw = P.pack_conv_weight(rb.res_conv.weight, ct).reshape(rb.res_conv.weight.shape[1], -1).contiguous()
                 pk.keep.append(rw)
-                pk.conv_f16[id(rw)] = P.pack_conv_weight_f16frag(rb.res_conv.weight)
                 if rb.res_conv.weight.shape[1] % 8 == 0 and rb.res_conv.weight.shape[1] <= 64:
                     pk.conv_rp[id(rw)] = P.pack_conv_weight_rp(rb.res_conv.weight)
                 pk.conv[id(rb.res_conv)] = rw
@@ -178,6 +173,9 @@ class UnetEngine:
                     raise NotImplementedError("norm_context=True cross-attention is not on the MinImagen hot path")
                 mg, mv, g0, v0 = P.fold_cross_attention(ca.to_q.weight, ca.to_kv.weight, ca.to_out[0].weight, ca.null_kv, ca.heads, ca.dim_head)
                 pk.attn[id(ca)] = (mg, mv, g0, v0)
+                # power-of-two operand scalings of the fp16x3 kernel from magnitude bounds of its inputs (both are LayerNorm outputs)
+                pk.attn_exp[id(ca)] = P.attn_f16_exponents(mg, mv, g0, v0, cmax=P.layernorm_bound(u.norm_cond.weight, u.norm_cond.bias, u.cond_dim),
+                                                           xmax=P.layernorm_bound(ca.norm.gamma, ca.norm.beta, Cc))
         # K10: multi-query self-attention (one shared 64-wide k/v head, layers.py:42) folded like K9 with the k/v rows repeated per head
         for m in u.modules():
             if isinstance(m, Attention):
@@ -278,18 +276,12 @@ class UnetEngine:
         ct = lib.mi_conv_cout_tile(Cout)
         cfg, nt = self._tile_cfg(Ho, Wo, batch, -(-Cout // ct))
         cin_tot = in0.C + (in1.C if in1 is not None else 0)
-        # matrix-core path: measured faster only where the 16x16x16 tile is full (>= 16 input and 16 output channels) and the
-        # residual is not an identity add (profiles/): narrow layers stay on the VALU kernel
-        wide = cin_tot >= 16 and Cout >= (8 if CONV_MFMA == 3 else 16)
-        mfma = (CONV_MFMA == 2 or (CONV_MFMA in (1, 3) and wide)) and ksize == 3 and stride == 1 and not up2 and Wo % 4 == 0 \
-            and id(wpack) in pk.conv_f16
         # row-paired matrix-core path (conv_rp.hip): every narrow k3 s1 conv whose channel counts come in octets
         rp = bool(CONV_RP) and ((ksize == 3 and stride == 1) or (ksize == 4 and stride == 2 and not up2 and CONV_RP >= 2)) \
             and (not up2 or (CONV_RP >= 2 and Cout <= 8)) and Wo % 4 == 0 and id(wpack) in pk.conv_rp and Ho * Wo >= RP_MIN_HW \
             and in0.C % 8 == 0 and (in1 is None or in1.C % 8 == 0) \
             and (res is None or res[2] is None or (id(res[2]) in pk.conv_rp and res[0].C % 8 == 0 and (res[1] is None or res[1].C % 8 == 0)))
         if rp:
-            mfma = False
             cfg = RP_TILE["L"] if Ho * Wo > 128 * 128 else (RP_TILE["M"] if Ho * Wo > 64 * 64 else RP_TILE["S"])
             if Cout > 8 and cfg == 5:
                 cfg = 6
@@ -300,10 +292,6 @@ class UnetEngine:
             if stride == 2:
                 cfg = 7
             th, tw = {5: (16, 64), 6: (8, 64), 7: (8, 32)}[cfg]
-            nt = -(-Ho // th) * -(-Wo // tw)
-        elif mfma:
-            cfg = 3 if Wo >= 64 else 4
-            th, tw = (8, 64) if cfg == 3 else (16, 32)
             nt = -(-Ho // th) * -(-Wo // tw)
         out = self._new_act(ws, batch, Cout, Ho, Wo, nt if want_stats else 0)
         p = L.MiConvParams()
@@ -323,7 +311,7 @@ class UnetEngine:
             if r1 is not None:
                 p.res1 = r1.c(batch, skip_scale)
             p.res_w, p.res_b = L.ptr(rw), L.ptr(rb)
-        p.out, p.out_stats, p.tile_cfg = L.ptr(out.t), L.ptr(out.stats), cfg | (0x100 if CONV_SPLIT16 else 0) | (0x200 if CONV_WAVES8 else 0) | (0x400 if ws.half else 0) | (0x800 if (CONV_SPLIT8 and Ho * Wo <= CONV_SPLIT8 * CONV_SPLIT8) else 0)
+        p.out, p.out_stats, p.tile_cfg = L.ptr(out.t), L.ptr(out.stats), cfg | (0x100 if CONV_SPLIT16 else 0) | (0x400 if ws.half else 0) | (0x800 if (CONV_SPLIT8 and Ho * Wo <= CONV_SPLIT8 * CONV_SPLIT8) else 0)
         if rp:
             p.tile_cfg |= (RP_NTILE & 0xf) << 12
             frag, p.w_rp_exp = pk.conv_rp[id(wpack)]
@@ -331,10 +319,6 @@ class UnetEngine:
             if res is not None and res[2] is not None:
                 rfrag, p.res_w_rp_exp = pk.conv_rp[id(res[2])]
                 p.res_w_rp = L.ptr(rfrag)
-        elif mfma:
-            p.w_f16 = L.ptr(pk.conv_f16[id(wpack)])
-            if res is not None and res[2] is not None:
-                p.res_w_f16 = L.ptr(pk.conv_f16[id(res[2])])
         ws.prog.append((lib.mi_conv_fwd, p, "conv"))
         return out
 
@@ -372,6 +356,8 @@ class UnetEngine:
         p.n1_g, p.n1_b = L.ptr(ca.norm.gamma), L.ptr(ca.norm.beta)
         p.n2_g, p.n2_b = L.ptr(ca.to_out[1].gamma), L.ptr(ca.to_out[1].beta)
         p.out, p.out_stats, p.variant = L.ptr(out.t), L.ptr(out.stats), (7 if (ws.half and ATTN_VARIANT == 6) else ATTN_VARIANT)
+        if ATTN_VARIANT == 6:
+            p.x_exp, p.g_exp, p.v_exp = pk.attn_exp[id(ca)]
         ws.prog.append((lib.mi_cross_attn_fwd, p, "cross_attn"))
         return out
 
@@ -441,6 +427,8 @@ class UnetEngine:
                 p.n_blocks = len(chunk)
                 for k, cid in enumerate(chunk):
                     mg, mv, g0, v0 = pk.attn[cid]
+                    if ATTN_VARIANT == 6:
+                        _, p.blk[k].g_exp, p.blk[k].v_exp = pk.attn_exp[cid]
                     p.blk[k].mg, p.blk[k].mv, p.blk[k].g0, p.blk[k].v0 = L.ptr(mg), L.ptr(mv), L.ptr(g0), L.ptr(v0)
                     p.blk[k].gv = L.ptr(ws.gv[cid])
                 calls.append((lib.mi_attn_fold_rows, p, "fold"))

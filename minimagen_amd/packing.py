@@ -21,23 +21,6 @@ def pack_conv_weight(w: torch.Tensor, cout_tile: int) -> torch.Tensor:
     return out.contiguous()
 
 
-def pack_conv_weight_f16frag(w: torch.Tensor) -> torch.Tensor:
-    """[Cout][Cin][kh][kw] fp32 -> MFMA A-operand fragments of v_mfma_f32_16x16x16_f16 for the matrix-core conv path:
-    [ceil(Cout/16)][ceil(Cin/16)][kh*kw][64 lanes][4 hi | 4 lo] fp16, lane (lq, lg) holding W[co = 16mz + lq][ci = 16kc + 4lg + e][tap]
-    split as hi = fp16(w), lo = fp16(w - hi)."""
-    cout, cin, kh, kw = w.shape
-    mz, kc, t = -(-cout // 16), -(-cin // 16), kh * kw
-    wp = torch.zeros(mz * 16, kc * 16, t, dtype=torch.float32, device=w.device)
-    wp[:cout, :cin] = w.detach().reshape(cout, cin, t)
-    hi = wp.half()
-    lo = (wp - hi.float()).half()
-
-    def frag(x):
-        x = x.reshape(mz, 16, kc, 4, 4, t)             # [mz][lq][kc][lg][e][tap]
-        return x.permute(0, 2, 5, 3, 1, 4).reshape(mz, kc, t, 64, 4)
-    return torch.cat((frag(hi), frag(lo)), dim=-1).contiguous()
-
-
 def fold_parallel_1x1(w3: torch.Tensor, b3, w1: torch.Tensor, b1):
     """Parallel(conv3x3, conv1x1) (layers.py:346-356, Unet.py:233-234) == one 3x3 conv whose centre tap
     carries the 1x1 weights (exact in real arithmetic)."""
@@ -134,3 +117,23 @@ def pack_conv_weight_rp(w: torch.Tensor):
     hi = out.float().half()
     lo = (out - hi.double()).float().half()
     return torch.cat((hi, lo), dim=-1).contiguous().to(w.device), exp
+
+
+def attn_f16_exponents(mg, mv, g0, v0, cmax: float, xmax: float):
+    """Power-of-two operand scalings (x_exp, g_exp, v_exp) of the fp16x3 cross-attention from magnitude BOUNDS: |x^| <= xmax,
+    |g_j| <= max_row sum_b |mg| * cmax (context rows bounded by cmax), likewise vw; each scaled bound lands at <= 2^12, which leaves a
+    factor 16 to the fp16 maximum and ~2^22 of dynamic range below it in which hi and lo are both normal numbers."""
+    def k(bound):
+        bound = float(bound)
+        if not math.isfinite(bound) or bound <= 0.0:
+            return 0
+        return max(-40, min(40, 12 - math.ceil(math.log2(bound))))
+    gb = max(float(mg.abs().sum(-1).max()) * cmax, float(g0.abs().max()))
+    vb = max(float(mv.abs().sum(-1).max()) * cmax, float(v0.abs().max()))
+    return k(xmax), k(gb), k(vb)
+
+
+def layernorm_bound(weight, bias, n: int) -> float:
+    """max |LayerNorm(x)_i| over any input: a normalised element is at most sqrt(n - 1) in magnitude"""
+    b = float(bias.abs().max()) if bias is not None else 0.0
+    return float(weight.abs().max()) * math.sqrt(max(n - 1, 1)) + b

@@ -109,76 +109,6 @@ def test_conv_family(backend, case):
     check_stats(ost.cpu(), ref)
 
 
-MFMA_CASES = [
-    # B, C0, C1, Cout, H, W, gn, ss, res, tile_cfg
-    (2, 16, 0, 16, 16, 64, True, True, 'none', 3),
-    (1, 16, 16, 16, 24, 72, True, True, 'conv2', 3),        # ragged tile edges, concat input, 1x1 residual over a concat
-    (2, 8, 0, 8, 32, 32, True, False, 'id', 4),
-    (1, 16, 8, 16, 32, 32, True, True, 'conv', 4),
-    (1, 8, 0, 3, 16, 64, False, False, 'none', 3),           # final conv
-]
-
-
-@pytest.mark.parametrize("backend", BACKENDS)
-@pytest.mark.parametrize("case", MFMA_CASES)
-def test_conv_matrix_core_path(backend, case):
-    """k3 s1 conv on v_mfma_f32_16x16x16_f16 with fp16x3 operand splits vs torch fp32 (same tolerance as the VALU path)"""
-    dev = setup(backend)
-    lib = L.lib()
-    B, C0, C1, Cout, H, W, gn, ss, res, cfg = case
-    g = torch.Generator().manual_seed(hash(case) & 0xffff)
-    rn = lambda *s_: torch.randn(*s_, generator=g)
-    x0 = rn(B, C0, H, W) * 1.5 + 0.3
-    x1 = rn(B, C1, H, W) if C1 else None
-    Cin = C0 + C1
-    w, bias = rn(Cout, Cin, 3, 3) * 0.2, rn(Cout)
-    gamma, beta = 1 + 0.2 * rn(Cin), 0.1 * rn(Cin)
-    sst = rn(B, 7 + 2 * Cin) * 0.3 if ss else None
-    sk = 2 ** -0.5
-    h = torch.cat((x0, x1 * sk), 1) if C1 else x0
-    if gn:
-        h = F.group_norm(h, 8, gamma, beta, 1e-5)
-        if ss:
-            h = h * (sst[:, 7:7 + Cin, None, None] + 1) + sst[:, 7 + Cin:7 + 2 * Cin, None, None]
-        h = F.silu(h)
-    ref = F.conv2d(h, w, bias, padding=1)
-    keep = {}
-    d = lambda name, t: keep.setdefault(name, t.to(dev).contiguous())
-    p = L.MiConvParams()
-    p.B, p.H, p.W = B, H, W
-    p.in0 = L.MiAct(d("x0", x0).data_ptr(), C0, d("s0", chan_stats(x0)).data_ptr(), 1, 1.0, 0)
-    if C1:
-        p.in1 = L.MiAct(d("x1", x1).data_ptr(), C1, d("s1", chan_stats(x1)).data_ptr(), 1, sk, 0)
-    p.Cout, p.ksize, p.stride, p.up2 = Cout, 3, 1, 0
-    p.w_f16, p.bias = d("wf", P.pack_conv_weight_f16frag(w)).data_ptr(), d("b", bias).data_ptr()
-    if gn:
-        p.gn_groups, p.gn_gamma, p.gn_beta, p.gn_eps = 8, d("g", gamma).data_ptr(), d("be", beta).data_ptr(), 1e-5
-        if ss:
-            p.scale_shift, p.ss_stride, p.ss_off = d("ss", sst).data_ptr(), sst.shape[1], 7
-    if res != 'none':
-        r0 = rn(B, Cout if res == 'id' else 5, H, W)
-        r1 = rn(B, 3, H, W) if res == 'conv2' else None
-        p.res0 = L.MiAct(d("r0", r0).data_ptr(), r0.shape[1], 0, 0, 1.0, 0)
-        if res == 'id':
-            ref = ref + r0
-        else:
-            rin = torch.cat((r0, r1 * sk), 1) if r1 is not None else r0
-            rw, rb = rn(Cout, rin.shape[1], 1, 1) * 0.3, rn(Cout)
-            ref = ref + F.conv2d(rin, rw, rb)
-            p.res_w = 1          # non-null marker: the residual is a 1x1 conv
-            p.res_w_f16 = d("rwf", P.pack_conv_weight_f16frag(rw)).data_ptr()
-            p.res_b = d("rb", rb).data_ptr()
-            if r1 is not None:
-                p.res1 = L.MiAct(d("r1", r1).data_ptr(), 3, 0, 0, sk, 0)
-    nt = tile_nt(lib, cfg, H, W)
-    out = torch.full((B, Cout, H, W), float('nan'), device=dev)
-    ost = torch.zeros(B, Cout, nt, 2, device=dev)
-    p.out, p.out_stats, p.tile_cfg = out.data_ptr(), ost.data_ptr(), cfg
-    L.check(lib.mi_conv_fwd(C.byref(p), L.current_stream()), "conv mfma")
-    assert (out.cpu() - ref).abs().max().item() < 2e-5
-    check_stats(ost.cpu(), ref)
-
-
 RP_CASES = [
     # B, C0, C1, Cout, H, W, gn, ss, res, tile_cfg, xscale, wscale
     (2, 8, 0, 8, 16, 64, True, True, 'id', 5, 1.0, 1.0),
@@ -366,20 +296,27 @@ def test_crossembed(backend, case):
 @pytest.mark.parametrize("backend", BACKENDS)
 @pytest.mark.parametrize("case", [(2, 16, 256, 8, 2, 0), (1, 16, 200, 8, 4, 0), (1, 8, 128, 8, 2, 0), (1, 32, 128, 16, 2, 0),
                                   (8, 16, 200, 8, 4, 1), (1, 8, 128, 8, 2, 1), (2, 16, 256, 8, 4, 2), (2, 16, 256, 8, 4, 3), (1, 8, 200, 8, 2, 4), (1, 16, 256, 8, 4, 5),
-                                  (2, 16, 200, 8, 4, 6), (1, 8, 128, 8, 2, 6), (1, 32, 128, 16, 2, 6)])
+                                  (2, 16, 200, 8, 4, 6), (1, 8, 128, 8, 2, 6), (1, 32, 128, 16, 2, 6),
+                                  # range safety of the fp16 split (variant 6): checkpoint weights / context rows far from unit scale
+                                  (1, 16, 128, 8, 2, 6, 256.0, 1.0 / 256, 1.0), (1, 16, 128, 8, 2, 6, 1.0 / 64, 300.0, 40.0), (1, 8, 128, 8, 4, 6, 30.0, 30.0, 0.01)])
 def test_cross_attention_folded(backend, case):
     """K9 against the oracle's unfolded CrossAttention (+ residual), incl. a ragged token count and both context lengths."""
     dev = setup(backend)
     lib = L.lib()
-    B2, Cc, HW, cd, ntok, variant = case
+    B2, Cc, HW, cd, ntok, variant = case[:6]
+    q_scale, v_scale, c_scale = case[6:] if len(case) > 6 else (1.0, 1.0, 1.0)
     heads, J = 8, 1 + ntok + 256
     g = torch.Generator().manual_seed(1)
     rn = lambda *s: torch.randn(*s, generator=g)
+    kv_w = rn(2 * heads * 64, cd) * cd ** -0.5
+    kv_w[heads * 64:] *= v_scale                                 # the value rows
     sd = {"a.norm.gamma": 1 + 0.2 * rn(Cc), "a.norm.beta": 0.1 * rn(Cc),
-          "a.to_q.weight": rn(heads * 64, Cc) * Cc ** -0.5, "a.to_kv.weight": rn(2 * heads * 64, cd) * cd ** -0.5,
+          "a.to_q.weight": rn(heads * 64, Cc) * Cc ** -0.5 * q_scale, "a.to_kv.weight": kv_w,
           "a.null_kv": rn(2, 64), "a.to_out.0.weight": rn(Cc, heads * 64) * (heads * 64) ** -0.5,
           "a.to_out.1.gamma": 1 + 0.2 * rn(Cc), "a.to_out.1.beta": 0.1 * rn(Cc)}
-    x, c = rn(B2, Cc, HW) * 1.3, rn(B2, J - 1, cd)
+    if q_scale != 1.0:
+        sd["a.to_q.weight"] = sd["a.to_q.weight"] / (1.0 + 0.3 * q_scale)     # keep the logits of a usable size: the test is about the operands' range
+    x, c = rn(B2, Cc, HW) * 1.3, rn(B2, J - 1, cd) * c_scale
     xt = x.permute(0, 2, 1)
     ref = (R.cross_attention(xt, c, sd, "a") + xt).permute(0, 2, 1).contiguous()
     mg, mv, g0, v0 = [t.to(dev) for t in P.fold_cross_attention(sd["a.to_q.weight"], sd["a.to_kv.weight"], sd["a.to_out.0.weight"], sd["a.null_kv"], heads)]
@@ -388,6 +325,9 @@ def test_cross_attention_folded(backend, case):
     fp = L.MiAttnFoldParams()
     fp.B2, fp.C, fp.cd, fp.heads, fp.JT, fp.n_blocks = B2, Cc, cd, heads, 17, 1
     fp.frag_f16 = 1 if variant == 6 else 0
+    x_exp, g_exp, v_exp = P.attn_f16_exponents(mg, mv, g0, v0, cmax=float(c.abs().max()), xmax=P.layernorm_bound(sd["a.norm.gamma"], sd["a.norm.beta"], Cc))
+    if variant == 6:
+        fp.blk[0].g_exp, fp.blk[0].v_exp = g_exp, v_exp
     fp.blk[0].mg, fp.blk[0].mv, fp.blk[0].g0, fp.blk[0].v0, fp.blk[0].gv = mg.data_ptr(), mv.data_ptr(), g0.data_ptr(), v0.data_ptr(), gv.data_ptr()
     ct, cx = c[:, :ntok].contiguous().to(dev), c[:, ntok:].contiguous().to(dev)
     fp.c_rows, fp.c_stride_b, fp.row0, fp.nrows, fp.write_null = cx.data_ptr(), 256 * cd, 1 + ntok, 256, 1
@@ -405,7 +345,10 @@ def test_cross_attention_folded(backend, case):
     out = torch.full(x.shape, float('nan'), device=dev)
     ost = torch.zeros(B2, Cc, nt, 2, device=dev)
     ap.out, ap.out_stats, ap.variant = out.data_ptr(), ost.data_ptr(), variant
+    if variant == 6:
+        ap.x_exp, ap.g_exp, ap.v_exp = x_exp, g_exp, v_exp
     L.check(lib.mi_cross_attn_fwd(C.byref(ap), L.current_stream()))
+    assert torch.isfinite(out).all()
     assert (out.cpu() - ref).abs().max().item() < 3e-5
     check_stats(ost.cpu(), ref)
 
@@ -505,9 +448,46 @@ def test_randn_keyed_by_global_sample(backend):
     assert abs(zc.mean()) < 0.01 and abs(zc.std() - 1) < 0.01 and abs((zc ** 4).mean() / zc.var() ** 2 - 3) < 0.1
 
 
+# The reflect-padded border of resize_right's cubic x4 up-sampling (64 -> 256), derived BY HAND from the published algorithm and not
+# from oracle/resize_restated.py: grid[o] = o/4 - 3/8, so output 0 sits 0.375 left of input 0 and its four taps are the inputs
+# -2, -1, 0, 1 at distances 1.625, 0.625, 0.375, 1.375; output 1 (grid -0.125): distances 1.875, 0.875, 0.125, 1.125.  Keys' cubic
+# (a = -1/2) at those distances, all exact in binary; 'reflect' maps input -1 -> 1 and -2 -> 2 (no edge repeat); the far end mirrors.
+BORDER_TAPS_X4 = {
+    0: ((2, 1, 0, 1), (-0.0439453125, 0.3896484375, 0.7275390625, -0.0732421875)),
+    1: ((2, 1, 0, 1), (-0.0068359375, 0.0908203125, 0.9638671875, -0.0478515625)),
+}
+
+
+def border_closed_form_check(dev, lib):
+    """the 4 x 4 corner outputs of a 64 -> 256 resize against the hand-derived border taps (both passes closed-form: no restatement involved)"""
+    from minimagen_amd.helpers import cubic_taps
+    n, N = 64, 256
+    _, idx, w = cubic_taps(n, N)
+    taps = {}
+    for o, (ii, ww) in BORDER_TAPS_X4.items():
+        taps[o] = (ii, ww)
+        taps[N - 1 - o] = (tuple(n - 1 - i for i in reversed(ii)), tuple(reversed(ww)))       # mirror image at the far end
+    for o, (ii, ww) in taps.items():       # the host tap tables first: indices after reflection and weights, exactly
+        assert tuple(idx[o].tolist()) == ii and tuple(w[o].tolist()) == ww, (o, idx[o], w[o])
+    g = torch.Generator().manual_seed(9)
+    img = torch.rand(1, 2, n, n, generator=g)
+    tabs = [t.to(dev) for t in (idx, w, idx, w)]
+    imgd, up = img.to(dev), torch.zeros(1, 2, N, N, device=dev)
+    rp = L.MiResizeParams(2, n, n, N, N, idx.shape[1], idx.shape[1], imgd.data_ptr(), up.data_ptr(),
+                          tabs[0].data_ptr(), tabs[1].data_ptr(), tabs[2].data_ptr(), tabs[3].data_ptr())
+    L.check(lib.mi_resize_fwd(C.byref(rp), L.current_stream()))
+    up = up.cpu().double()
+    x = img.double()
+    for oy, (iy, wy) in taps.items():
+        for ox, (ix, wx) in taps.items():
+            ref = sum(a * b * x[0, :, r, c] for r, a in zip(iy, wy) for c, b in zip(ix, wx))
+            assert (up[0, :, oy, ox] - ref).abs().max() < 5e-7, (oy, ox)
+
+
 @pytest.mark.parametrize("backend", BACKENDS)
 def test_resize_and_lowres_augment(backend):
-    """K14 against the oracle's restatement of resize_right (PARITY UNPINNED upstream) and q_sample, bit for bit."""
+    """K14 against the oracle's restatement of resize_right and q_sample, bit for bit; the restatement itself is pinned in the interior
+    against Pillow's bicubic (tests/test_oracle.py) and at the reflect-padded border against hand-derived closed-form taps (below)."""
     dev = setup(backend)
     lib = L.lib()
     from minimagen_amd.helpers import cubic_taps
@@ -523,6 +503,7 @@ def test_resize_and_lowres_augment(backend):
                               tabs[0].data_ptr(), tabs[1].data_ptr(), tabs[2].data_ptr(), tabs[3].data_ptr())
         L.check(lib.mi_resize_fwd(C.byref(rp), L.current_stream()))
         assert torch.equal(up.cpu(), ref)
+    border_closed_form_check(dev, lib)
     sched = R.Schedule(100)
     noise = torch.randn(2, 3, 64, 64, generator=g)
     out = torch.zeros(2, 3, 64, 64, device=dev)

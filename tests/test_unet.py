@@ -52,7 +52,7 @@ def test_forward_A_half_precision(backend):
     d = (oc.cpu() - g["out_cond"]).abs()
     scale = g["out_cond"].abs().max()
     assert d.max() < 3e-2 * scale and d.mean() < 3e-3 * scale, (d.max(), d.mean(), scale)
-    assert d.max() > 3 * FWD_ATOL                                    # not the fp32-grade path (attention alone when MINIMAGEN_CONV_MFMA=0)
+    assert d.max() > 3 * FWD_ATOL                                    # not the fp32-grade path
     assert (of.cpu() - g["out_cond"]).abs().max() < FWD_ATOL         # switching back restores it
 
 

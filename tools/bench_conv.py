@@ -42,10 +42,6 @@ def run(B, C0, Cout, H, W, gn, res, path, C1=0, reps=20, nt_in=None):
         wf = wf.to(dev); keep.append(wf)
         p.w_rp = wf.data_ptr()
         cfg = int(path[2:3]) | (int(os.environ.get("NTILE", "0")) << 12)
-    elif path == "mfma":
-        wf = P.pack_conv_weight_f16frag(w).to(dev); keep.append(wf)
-        p.w_f16 = wf.data_ptr()
-        cfg = (3 if W >= 64 else 4) | 0x200
     else:
         ct = lib.mi_conv_cout_tile(Cout)
         wp = P.pack_conv_weight(w, ct).to(dev); keep.append(wp)
@@ -65,8 +61,6 @@ def run(B, C0, Cout, H, W, gn, res, path, C1=0, reps=20, nt_in=None):
         p.res_w = 1
         if path.startswith("rp"):
             rwf, p.res_w_rp_exp = P.pack_conv_weight_rp(rw); rwf = rwf.to(dev); keep.append(rwf); p.res_w_rp = rwf.data_ptr()
-        elif path == "mfma":
-            rwf = P.pack_conv_weight_f16frag(rw).to(dev); keep.append(rwf); p.res_w_f16 = rwf.data_ptr()
         else:
             rwp = P.pack_conv_weight(rw, lib.mi_conv_cout_tile(Cout)).reshape(Cin, -1).contiguous().to(dev); keep.append(rwp); p.res_w = rwp.data_ptr()
     th, tw = C.c_int(), C.c_int()
