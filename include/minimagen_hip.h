@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MI_ABI_VERSION 3
+#define MI_ABI_VERSION 4
 
 enum mi_status {
     MI_OK = 0,
@@ -87,6 +87,11 @@ typedef struct mi_conv_params {
     const void* w_rp;
     const void* res_w_rp;
     int w_rp_exp, res_w_rp_exp;
+    /* wide-channel regime (more than 64 input or 32 output channels: Unet() default, Base, Super): the per-channel affine of the fused
+       GroupNorm / scale-shift and the power-of-two operand exponents are computed per image by mi_gn_coef_fwd(p) into these buffers
+       BEFORE mi_conv_fwd(p); non-NULL gn_coef selects the wide kernel (output channels tiled over the grid) */
+    float* gn_coef;         /* [B][Cin][4] = {A 2^ka, B 2^ka, -log2(e) A, -log2(e) B} */
+    int* gn_exps;           /* [B][2] = {ka, largest safe exponent of the 1x1-residual input} */
 } mi_conv_params;
 #define MI_CONV_SPLIT16 0x100
 #define MI_CONV_SPLIT8  0x800   /* 8-channel outputs as two 4-channel workgroups (small, latency-bound launches) */
@@ -97,6 +102,7 @@ typedef struct mi_conv_params {
 int mi_conv_tile_shape(int tile_cfg, int* th, int* tw);
 int mi_conv_cout_tile(int Cout);               /* channel tile (4, 8 or 16) the kernels use for this Cout */
 int mi_conv_fwd(const mi_conv_params* p, void* stream);
+int mi_gn_coef_fwd(const mi_conv_params* p, void* stream);     /* fills p->gn_coef / p->gn_exps (wide-channel regime) */
 
 /* ---- K3: CrossEmbedLayer (layers.py:298-305): parallel k=3,7,15 convs, concat on channels --- */
 typedef struct mi_crossembed_params {

@@ -33,6 +33,7 @@ class MiConvParams(C.Structure):
         ("res0", MiAct), ("res1", MiAct), ("res_w", C.c_void_p), ("res_b", C.c_void_p),
         ("out", C.c_void_p), ("out_stats", C.c_void_p), ("tile_cfg", C.c_int),
         ("w_rp", C.c_void_p), ("res_w_rp", C.c_void_p), ("w_rp_exp", C.c_int), ("res_w_rp_exp", C.c_int),
+        ("gn_coef", C.c_void_p), ("gn_exps", C.c_void_p),
     ]
 
 
@@ -142,7 +143,7 @@ def _bind(lib):
     lib.mi_backend.restype = C.c_char_p
     lib.mi_struct_size.argtypes = [C.c_int]
     vp, i32, i64, u64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float
-    for name in ("mi_conv_fwd", "mi_crossembed_fwd", "mi_text_cond_fwd", "mi_cond_step_fwd", "mi_attn_fold_rows", "mi_cross_attn_fwd",
+    for name in ("mi_conv_fwd", "mi_gn_coef_fwd", "mi_crossembed_fwd", "mi_text_cond_fwd", "mi_cond_step_fwd", "mi_attn_fold_rows", "mi_cross_attn_fwd",
                  "mi_cfg_x0_fwd", "mi_quantile_fwd", "mi_posterior_fwd", "mi_resize_fwd", "mi_self_attn_fwd", "mi_chan_ff_fwd"):
         getattr(lib, name).argtypes = [vp, vp]
         getattr(lib, name).restype = i32

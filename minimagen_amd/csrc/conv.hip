@@ -446,13 +446,19 @@ extern "C" int mi_conv_fwd(const mi_conv_params* pp, void* stream) {
     const mi_conv_params& p = *pp;
     hipStream_t st = (hipStream_t)stream;
     const int Cin = p.in0.C + (p.in1.data ? p.in1.C : 0);
+    if (p.w_rp) {           // row-paired matrix-core family (narrow and wide regimes): its own limits
+        if (p.gn_groups > MI_MAX_GROUPS || (p.gn_groups > 0 && (Cin % p.gn_groups) != 0)) { mi_set_error("mi_conv_fwd: Cin %d / groups %d", Cin, p.gn_groups); return MI_ERR_INVALID; }
+        if (p.gn_groups > 0 && (!p.in0.stats || (p.in1.data && !p.in1.stats))) { mi_set_error("mi_conv_fwd: GroupNorm input without channel statistics"); return MI_ERR_INVALID; }
+        if (p.res0.data && !p.res_w && p.res0.C != p.Cout) { mi_set_error("mi_conv_fwd: identity residual needs Cres == Cout"); return MI_ERR_INVALID; }
+        if (p.B <= 0 || p.H <= 0 || p.W <= 0 || p.Cout <= 0) { mi_set_error("mi_conv_fwd: empty problem"); return MI_ERR_INVALID; }
+        return mi_conv_rp_launch(p, st);
+    }
     if (Cin > MI_MAX_CIN || p.gn_groups > MI_MAX_GROUPS) { mi_set_error("mi_conv_fwd: Cin %d / groups %d too large for the direct-conv family", Cin, p.gn_groups); return MI_ERR_UNSUPPORTED; }
     if (p.gn_groups > 0 && (Cin % p.gn_groups) != 0) { mi_set_error("mi_conv_fwd: Cin %d not divisible by groups %d", Cin, p.gn_groups); return MI_ERR_INVALID; }
     if (p.gn_groups > 0 && (!p.in0.stats || (p.in1.data && !p.in1.stats))) { mi_set_error("mi_conv_fwd: GroupNorm input without channel statistics"); return MI_ERR_INVALID; }
     if (p.res0.data && !p.res_w && p.res0.C != p.Cout) { mi_set_error("mi_conv_fwd: identity residual needs Cres == Cout"); return MI_ERR_INVALID; }
     if (p.B <= 0 || p.H <= 0 || p.W <= 0 || p.Cout <= 0) { mi_set_error("mi_conv_fwd: empty problem"); return MI_ERR_INVALID; }
     if (p.up2 && ((p.H | p.W) & 1)) { mi_set_error("mi_conv_fwd: up2 needs even output size"); return MI_ERR_INVALID; }
-    if (p.w_rp) return mi_conv_rp_launch(p, st);
     const int ct = mi_conv_cout_tile(p.Cout);
     // MI_CONV_SPLIT8: 8 output channels as two 4-channel workgroups -- twice the waves for the small (latency-bound) launches
     const bool split8 = (p.tile_cfg & MI_CONV_SPLIT8) && ct == 8 && p.Cout == 8;

@@ -100,9 +100,13 @@ __device__ __forceinline__ int rp_clamp_exp(int k) { return k < -60 ? -60 : (k >
 // BASELINE U-Nets), -1 = read from the parameters: with the round structure static the whole tile loop is straight-line code, which
 // is what lets the compiler keep the next tile's loads in flight across the MFMA loop and the epilogue (with run-time rounds it
 // falls back to s_waitcnt vmcnt(0) at every join).
-template <int TH_, int TW_, int NJ_, bool GN_, bool HALF_, int MODE_, int KO_ = -1, int RO_ = -1>
+// WIDE_: the wide-channel regime (Unet() default, Base, Super: 128 .. 2048+ channels).  The output channels are tiled over blockIdx.y
+// (8 NJ, or 16 NJ for MODE 2, per workgroup), the rounds are run-time, and the per-channel GroupNorm affine / the operand exponents come
+// precomputed from gn_coef_kernel (global memory) instead of the in-kernel statistics prologue, which is sized for <= 64 channels.
+template <int TH_, int TW_, int NJ_, bool GN_, bool HALF_, int MODE_, int KO_ = -1, int RO_ = -1, bool WIDE_ = false>
 struct RpCfg {
     static constexpr int TH = TH_, TW = TW_, NJ = NJ_, MODE = MODE_, KO_T = KO_, RO_T = RO_;
+    static constexpr bool WIDE = WIDE_;
     static constexpr bool GN = GN_, HALF = HALF_;
     // staged source window (rows x units) and LDS pitch in 16-byte chunks
     static constexpr int IH = MODE_ == 0 ? TH_ + 2 : (MODE_ == 1 ? TH_ / 2 + 2 : 2 * TH_ + 2);
@@ -119,7 +123,8 @@ struct RpCfg {
 
 template <class CFG>
 __global__ __launch_bounds__(256, CFG::WPS) void conv_rp_kernel(const mi_conv_params p, const uint4* __restrict__ wrp, const uint4* __restrict__ rwrp,
-                                                                const int ntile) {
+                                                                const int ntile, const float4* __restrict__ coef, const int* __restrict__ exps) {
+    constexpr bool WIDE = CFG::WIDE;
     constexpr int TH = CFG::TH, TW = CFG::TW, NJ = CFG::NJ, IH = CFG::IH, UW = CFG::UW, PW = CFG::PW, MODE = CFG::MODE;
     constexpr int NU = CFG::NU, PER = CFG::PER, GX = CFG::GX, GPW = CFG::GPW, NSTEP = CFG::NSTEP;
     constexpr bool GN = CFG::GN, HALF = CFG::HALF;
@@ -155,6 +160,9 @@ __global__ __launch_bounds__(256, CFG::WPS) void conv_rp_kernel(const mi_conv_pa
     const int tile_lo = strip * ntile, tile_hi = (tile_lo + ntile < tiles) ? tile_lo + ntile : tiles;
     const int C0 = p.in0.C, C1 = p.in1.data ? p.in1.C : 0, Cin = C0 + C1;
     const int Cr0 = (p.res0.data && rwrp) ? p.res0.C : 0, Cr1 = (Cr0 && p.res1.data) ? p.res1.C : 0, Cres = Cr0 + Cr1;
+    constexpr int CPT = MODE == 2 ? 16 : 8;                               // output channels per N tile
+    const int jt0 = WIDE ? (int)blockIdx.y * NJ : 0;                      // first N tile of this workgroup
+    const int njt = (p.Cout + CPT - 1) / CPT;                             // N tiles of the whole layer (the fragments' jt stride)
     constexpr bool STATIC_ROUNDS = CFG::KO_T >= 0;
     const int KO = STATIC_ROUNDS ? CFG::KO_T : (Cin >> 3), RO = STATIC_ROUNDS ? CFG::RO_T : (Cres >> 3), rounds = KO + RO;
     constexpr int RT = STATIC_ROUNDS ? CFG::KO_T + CFG::RO_T : 1;         // static round count (1 slot in the generic kernel)
@@ -223,8 +231,8 @@ __global__ __launch_bounds__(256, CFG::WPS) void conv_rp_kernel(const mi_conv_pa
     // ---------------- the small loads first (statistics of the inputs: GroupNorm moments / magnitude for the fp16 scaling; the
     // per-channel affine parameters), the first tile's bulk loads right behind them: ONE memory round trip for the whole prologue, and
     // the statistics are reduced while the bulk loads are still in flight (vmcnt is in order)
-    const bool have_stats = GN || p.in0.stats != nullptr;
-    const bool res_stats = RO > 0 && p.res0.stats != nullptr && (Cr1 == 0 || p.res1.stats != nullptr);
+    const bool have_stats = !WIDE && (GN || p.in0.stats != nullptr);
+    const bool res_stats = !WIDE && RO > 0 && p.res0.stats != nullptr && (Cr1 == 0 || p.res1.stats != nullptr);
     constexpr int WPER = (WTOT + 255) / 256;           // 16-byte weight chunks per work-item
     uint4 wreg[WPER];
     if constexpr (STATIC_ROUNDS) {                     // every round's weight fragments: two linear copies (conv rounds, residual rounds)
@@ -240,7 +248,7 @@ __global__ __launch_bounds__(256, CFG::WPS) void conv_rp_kernel(const mi_conv_pa
     const bool fast = have_stats && mi_gn_totals_issue(p.in0, p.in1, C0, Cin, b, tid, 256, sr);
     const bool fast2 = res_stats && mi_gn_totals_issue(p.res0, p.res1, Cr0, Cres, b, tid, 256, sr2);
     float pg = 0.f, pb = 0.f, psc = 1.f, psh = 0.f;        // lane c < Cin: gamma, beta, scale + 1, shift of channel c
-    if constexpr (GN) {
+    if constexpr (GN && !WIDE) {
         const int c = lane < Cin ? lane : 0;
         pg = p.gn_gamma[c];
         pb = p.gn_beta[c];
@@ -267,13 +275,17 @@ __global__ __launch_bounds__(256, CFG::WPS) void conv_rp_kernel(const mi_conv_pa
 
     // ---------------- per-channel affine of the fused GroupNorm / scale-shift, and the power-of-two operand scalings
     if (have_stats || res_stats) __syncthreads();
-    if constexpr (GN) {
+    if constexpr (WIDE) {
+        // final exponents from gn_coef_kernel (already reconciled between the conv and the 1x1-residual operands): exps[2b] = ka, [2b + 1] = kr
+        if (tid == 0) { sExp[0] = exps[2 * b]; sExp[1] = exps[2 * b + 1]; sExp[2] = exps[2 * b] + p.w_rp_exp; }
+    }
+    if constexpr (GN && !WIDE) {
         const int cpg = Cin / p.gn_groups;
         for (int g = tid; g < p.gn_groups; g += 256)
             mi_gn_group_moments(chS, chQ, g * cpg, (g + 1) * cpg, (double)cpg * (double)HWs, p.gn_eps, gMean[g], gRstd[g]);
         __syncthreads();
     }
-    if (wave == 0) {
+    if (!WIDE && wave == 0) {
         const int c = lane;
         float A = 0.f, Bc = 0.f, m = 0.f;
         if constexpr (GN) {
@@ -340,12 +352,16 @@ __global__ __launch_bounds__(256, CFG::WPS) void conv_rp_kernel(const mi_conv_pa
     auto load_b = [&](int rnd) {
         const bool isres = rnd >= KO;
         const int k8 = isres ? rnd - KO : rnd;
-        const uint4* src = isres ? rwrp + (size_t)k8 * NJ * 128 : wrp + (size_t)k8 * WCH;
-        const int n = isres ? NJ * 128 : WCH;
+        const int nstep = isres ? 1 : NSTEP;
+        const uint4* src = isres ? rwrp + (size_t)k8 * njt * 128 : wrp + (size_t)k8 * NSTEP * njt * 128;     // [step][jt of the layer][lane][2]
+        const int n = nstep * NJ * 128;
 #pragma unroll
         for (int i = 0; i < WPER; ++i) {
             const int k = tid + i * 256;
-            wreg[i] = mi_ldg4u(src + (k < n ? k : 0));
+            const int kc = k < n ? k : 0;
+            const int s_ = kc / (NJ * 128), rem = kc % (NJ * 128);            // this workgroup's NJ tiles out of the layer's njt
+            const int jt = jt0 + rem / 128;
+            wreg[i] = (jt < njt) ? mi_ldg4u(src + ((size_t)s_ * njt + jt) * 128 + rem % 128) : make_uint4(0u, 0u, 0u, 0u);
         }
     };
     auto store_b = [&](int rnd) {
@@ -360,7 +376,7 @@ __global__ __launch_bounds__(256, CFG::WPS) void conv_rp_kernel(const mi_conv_pa
     float bvv[NJ];
 #pragma unroll
     for (int jt = 0; jt < NJ; ++jt) {
-        const int co = MODE == 2 ? 16 * jt + lq : 8 * jt + (lq & 7);
+        const int co = MODE == 2 ? 16 * (jt0 + jt) + lq : 8 * (jt0 + jt) + (lq & 7);
         bvv[jt] = (p.bias && co < p.Cout) ? p.bias[co] : 0.0f;
         if (Cres && p.res_b && co < p.Cout) bvv[jt] += p.res_b[co];
     }
@@ -401,7 +417,7 @@ __global__ __launch_bounds__(256, CFG::WPS) void conv_rp_kernel(const mi_conv_pa
                         if (isres) {
                             y[j] = x * rsc;
                         } else {
-                            const float4 P = chP[8 * k8 + j];
+                            const float4 P = WIDE ? coef[(size_t)b * Cin + 8 * k8 + j] : chP[8 * k8 + j];
                             if constexpr (GN) {
                                 const float a = fmaf(x, P.x, P.y);
                                 const float ex = __builtin_amdgcn_exp2f(fmaf(x, P.z, P.w));       // exp(-a)
@@ -427,7 +443,7 @@ __global__ __launch_bounds__(256, CFG::WPS) void conv_rp_kernel(const mi_conv_pa
             if (rnd + 1 == rounds && idres) {
 #pragma unroll
                 for (int jt = 0; jt < NJ; ++jt) {
-                    const int co = MODE == 2 ? 16 * jt + lq : 8 * jt + (lq & 7);
+                    const int co = MODE == 2 ? 16 * (jt0 + jt) + lq : 8 * (jt0 + jt) + (lq & 7);
                     const int dy = MODE == 2 ? 0 : lq >> 3;
 #pragma unroll
                     for (int g = 0; g < GPW; ++g) {
@@ -504,7 +520,7 @@ __global__ __launch_bounds__(256, CFG::WPS) void conv_rp_kernel(const mi_conv_pa
 #pragma unroll
         for (int jt = 0; jt < NJ; ++jt) {
             csum[jt] = 0.f; csq[jt] = 0.f;
-            const int co = MODE == 2 ? 16 * jt + lq : 8 * jt + (lq & 7);
+            const int co = MODE == 2 ? 16 * (jt0 + jt) + lq : 8 * (jt0 + jt) + (lq & 7);
             const int dy = MODE == 2 ? 0 : lq >> 3;
             const float bv = bvv[jt];
             const float rs = idres ? p.res0.scale : 0.0f;
@@ -535,7 +551,6 @@ __global__ __launch_bounds__(256, CFG::WPS) void conv_rp_kernel(const mi_conv_pa
             }
         }
         if (p.out_stats) {
-            constexpr int CPT = MODE == 2 ? 16 : 8;               // channels per N tile
 #pragma unroll
             for (int jt = 0; jt < NJ; ++jt) {
                 if (MODE != 2) { csum[jt] += __shfl_xor(csum[jt], 8); csq[jt] += __shfl_xor(csq[jt], 8); }
@@ -544,14 +559,108 @@ __global__ __launch_bounds__(256, CFG::WPS) void conv_rp_kernel(const mi_conv_pa
                 if (lane < CPT) { red[wave][2 * (CPT * jt + lane)] = csum[jt]; red[wave][2 * (CPT * jt + lane) + 1] = csq[jt]; }
             }
             __syncthreads();
-            if (tid < 2 * CPT * NJ && (tid >> 1) < p.Cout)
-                p.out_stats[((size_t)(b * p.Cout + (tid >> 1)) * tiles + tile) * 2 + (tid & 1)] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+            if (tid < 2 * CPT * NJ && CPT * jt0 + (tid >> 1) < p.Cout)
+                p.out_stats[((size_t)(b * p.Cout + CPT * jt0 + (tid >> 1)) * tiles + tile) * 2 + (tid & 1)] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
         }
         RP_TPHASE(5);       // epilogue
     };
     for (int tile = tile_lo; tile + 1 < tile_hi; ++tile) do_tile(tile, std::true_type{});
     do_tile(tile_hi - 1, std::false_type{});
     RP_TEND();
+}
+
+
+// Wide-channel regime: per image, the per-channel affine of the fused GroupNorm -> scale/shift (or the plain input scale) and the
+// power-of-two operand exponents -- what the narrow kernel's prologue computes in LDS for <= 64 channels -- into global memory.
+// One workgroup per image; Cin <= MI_COEF_MAXC.
+#define MI_COEF_MAXC 4096
+__global__ __launch_bounds__(256) void gn_coef_kernel(const mi_conv_params p) {
+    __shared__ double chS[MI_COEF_MAXC], chQ[MI_COEF_MAXC];
+    __shared__ float gMean[MI_MAX_GROUPS], gRstd[MI_MAX_GROUPS];
+    __shared__ float redm[4];
+    __shared__ double redq[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
+    const int C0 = p.in0.C, C1 = p.in1.data ? p.in1.C : 0, Cin = C0 + C1;
+    const bool gn = p.gn_groups > 0;
+    const int mode = p.up2 ? 1 : (p.stride == 2 ? 2 : 0);
+    const double HWs = mode == 0 ? (double)p.H * p.W : (mode == 1 ? (double)(p.H / 2) * (p.W / 2) : 4.0 * p.H * p.W);
+    const bool have_stats = gn || p.in0.stats != nullptr;
+    if (have_stats) mi_gn_channel_totals(p.in0, p.in1, C0, Cin, b, tid, 256, chS, chQ);
+    __syncthreads();
+    float m = 0.f;
+    if (gn) {
+        const int cpg = Cin / p.gn_groups;
+        for (int g = tid; g < p.gn_groups; g += 256)
+            mi_gn_group_moments(chS, chQ, g * cpg, (g + 1) * cpg, (double)cpg * HWs, p.gn_eps, gMean[g], gRstd[g]);
+        __syncthreads();
+        for (int c = tid; c < Cin; c += 256) {
+            float An = p.gn_gamma[c], Bn = p.gn_beta[c];
+            if (p.scale_shift) {
+                const float* ss = p.scale_shift + (size_t)b * p.ss_stride + p.ss_off;
+                const float sc = ss[c] + 1.0f, sh = ss[Cin + c];
+                An *= sc;
+                Bn = Bn * sc + sh;
+            }
+            m = fmaxf(m, 4.0f * fabsf(An) + fabsf(Bn));
+        }
+        m = mi_wave_max(m);
+    } else if (have_stats) {
+        double q = 0.0;
+        for (int c = tid; c < Cin; c += 256) q += chQ[c];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+        if (lane == 0) redq[wave] = q;
+        __syncthreads();
+        m = 4.0f * sqrtf((float)(((redq[0] + redq[1]) + (redq[2] + redq[3])) / ((double)Cin * HWs)));
+    }
+    if (lane == 0) redm[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(redm[0], redm[1]), fmaxf(redm[2], redm[3]));
+    int ka = (m > 0.f) ? rp_clamp_exp(4 - rp_exponent(m)) : 0;
+    // 1x1 residual conv input: the largest exponent that keeps it inside the fp16 range (from its statistics; 4 sigma -> [8, 16)); both
+    // products go into ONE accumulator, so they must carry the same total exponent: lower the larger one (always safe)
+    int kr = 0;
+    if (p.res0.data && p.res_w_rp) {
+        const int Cr0 = p.res0.C, Cr1 = p.res1.data ? p.res1.C : 0, Cres = Cr0 + Cr1;
+        float mr = 4.0f;
+        if (p.res0.stats && (Cr1 == 0 || p.res1.stats)) {
+            __syncthreads();
+            mi_gn_channel_totals(p.res0, p.res1, Cr0, Cres, b, tid, 256, chS, chQ);
+            __syncthreads();
+            double q = 0.0;
+            for (int c = tid; c < Cres; c += 256) q += chQ[c];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+            if (lane == 0) redq[wave] = q;
+            __syncthreads();
+            mr = 4.0f * sqrtf((float)(((redq[0] + redq[1]) + (redq[2] + redq[3])) / ((double)Cres * (double)p.H * p.W)));
+        }
+        const int kr_max = (mr > 0.f) ? rp_clamp_exp(4 - rp_exponent(mr)) : 0;
+        int E = ka + p.w_rp_exp;
+        if (kr_max + p.res_w_rp_exp < E) E = kr_max + p.res_w_rp_exp;
+        ka = E - p.w_rp_exp;
+        kr = E - p.res_w_rp_exp;
+    }
+    for (int c = tid; c < Cin; c += 256) {
+        float4 o;
+        if (gn) {
+            const int cpg = Cin / p.gn_groups, g = c / cpg;
+            float A = gRstd[g] * p.gn_gamma[c];
+            float Bc = p.gn_beta[c] - gMean[g] * A;
+            if (p.scale_shift) {
+                const float* ss = p.scale_shift + (size_t)b * p.ss_stride + p.ss_off;
+                const float sc = ss[c] + 1.0f, sh = ss[Cin + c];
+                A *= sc;
+                Bc = Bc * sc + sh;
+            }
+            A *= (c >= C0) ? p.in1.scale : p.in0.scale;
+            o = make_float4(ldexpf(A, ka), ldexpf(Bc, ka), A * -1.44269504088896340736f, Bc * -1.44269504088896340736f);
+        } else {
+            o = make_float4(ldexpf((c >= C0) ? p.in1.scale : p.in0.scale, ka), 0.f, 0.f, 0.f);
+        }
+        reinterpret_cast<float4*>(p.gn_coef)[(size_t)b * Cin + c] = o;
+    }
+    if (tid == 0) { p.gn_exps[2 * b] = ka; p.gn_exps[2 * b + 1] = kr; }
 }
 
 template <int TH, int TW, int NJ, bool GN, bool HALF, int MODE, int KO, int RO>
@@ -563,8 +672,35 @@ int launch_rp(const mi_conv_params& p, hipStream_t st) {
     int ntile = (p.tile_cfg >> 12) & 0xf;
     if (ntile == 0) { ntile = 1; while (ntile < 8 && (size_t)p.B * (tiles / (2 * ntile)) >= 2048) ntile *= 2; }
     const int strips = (tiles + ntile - 1) / ntile;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_rp_kernel<CFG>), dim3(strips * p.B), dim3(256), 0, st, p, (const uint4*)p.w_rp, (const uint4*)p.res_w_rp, ntile);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_rp_kernel<CFG>), dim3(strips * p.B), dim3(256), 0, st, p, (const uint4*)p.w_rp, (const uint4*)p.res_w_rp, ntile,
+                       (const float4*)nullptr, (const int*)nullptr);
     return mi_check_launch("conv_rp_kernel");
+}
+
+// wide-channel regime: 8x32 pixel tiles, NJ N tiles per workgroup, the layer's output channels over blockIdx.y
+template <int NJ, bool GN, bool HALF, int MODE>
+int launch_rp_wide(const mi_conv_params& p, hipStream_t st) {
+    using CFG = RpCfg<8, 32, NJ, GN, HALF, MODE, -1, -1, true>;
+    const int tiles = ((p.H + 7) / 8) * ((p.W + 31) / 32);
+    const int cpt = MODE == 2 ? 16 : 8, njt = (p.Cout + cpt - 1) / cpt;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_rp_kernel<CFG>), dim3(tiles * p.B, (njt + NJ - 1) / NJ), dim3(256), 0, st, p, (const uint4*)p.w_rp,
+                       (const uint4*)p.res_w_rp, 1, (const float4*)p.gn_coef, (const int*)p.gn_exps);
+    return mi_check_launch("conv_rp_kernel (wide)");
+}
+
+template <int MODE>
+int launch_rp_wide_m(const mi_conv_params& p, hipStream_t st) {
+    const bool half = (p.tile_cfg & MI_CONV_HALF) != 0;
+    const int cpt = MODE == 2 ? 16 : 8, njt = (p.Cout + cpt - 1) / cpt;
+    if constexpr (MODE == 0) {
+        if (p.gn_groups > 0) {
+            if (njt >= 4) return half ? launch_rp_wide<4, true, true, MODE>(p, st) : launch_rp_wide<4, true, false, MODE>(p, st);
+            return half ? launch_rp_wide<1, true, true, MODE>(p, st) : launch_rp_wide<1, true, false, MODE>(p, st);
+        }
+    }
+    if (njt >= 4 && MODE != 2) return half ? launch_rp_wide<4, false, true, MODE>(p, st) : launch_rp_wide<4, false, false, MODE>(p, st);
+    if (njt >= 2 && MODE == 2) return half ? launch_rp_wide<2, false, true, MODE>(p, st) : launch_rp_wide<2, false, false, MODE>(p, st);
+    return half ? launch_rp_wide<1, false, true, MODE>(p, st) : launch_rp_wide<1, false, false, MODE>(p, st);
 }
 
 template <int TH, int TW, int NJ, int MODE, int KO, int RO>
@@ -619,20 +755,36 @@ int launch_rp_nj(const mi_conv_params& p, hipStream_t st) {
 
 }  // namespace
 
+extern "C" int mi_gn_coef_fwd(const mi_conv_params* pp, void* stream) {
+    const mi_conv_params& p = *pp;
+    const int Cin = p.in0.C + (p.in1.data ? p.in1.C : 0);
+    if (!p.gn_coef || !p.gn_exps || p.B <= 0) { mi_set_error("mi_gn_coef_fwd: gn_coef / gn_exps buffers missing or empty batch"); return MI_ERR_INVALID; }
+    if (Cin > MI_COEF_MAXC || p.gn_groups > MI_MAX_GROUPS || (p.gn_groups > 0 && Cin % p.gn_groups)) { mi_set_error("mi_gn_coef_fwd: %d channels / %d groups unsupported", Cin, p.gn_groups); return MI_ERR_UNSUPPORTED; }
+    if (p.gn_groups > 0 && (!p.in0.stats || (p.in1.data && !p.in1.stats))) { mi_set_error("mi_gn_coef_fwd: GroupNorm input without channel statistics"); return MI_ERR_INVALID; }
+    hipLaunchKernelGGL(gn_coef_kernel, dim3(p.B), dim3(256), 0, (hipStream_t)stream, p);
+    return mi_check_launch("gn_coef_kernel");
+}
+
 int mi_conv_rp_launch(const mi_conv_params& p, hipStream_t st) {
     const int C0 = p.in0.C, C1 = p.in1.data ? p.in1.C : 0, Cin = C0 + C1;
     const int mode = p.up2 ? 1 : (p.stride == 2 ? 2 : 0);
     if (!((p.ksize == 3 && p.stride == 1) || (p.ksize == 4 && p.stride == 2 && !p.up2))) { mi_set_error("mi_conv_fwd: row-paired path is k3 s1 (optionally nearest x2) or k4 s2"); return MI_ERR_UNSUPPORTED; }
     if (mode != 0 && p.res0.data) { mi_set_error("mi_conv_fwd: row-paired path: no residual on the up / down-sampling convs"); return MI_ERR_UNSUPPORTED; }
     if (mode == 1 && ((p.H | p.W) & 1)) { mi_set_error("mi_conv_fwd: up2 needs even output size"); return MI_ERR_INVALID; }
-    if ((p.W & 3) || (C0 & 7) || (C1 & 7) || Cin > RP_MAXC) { mi_set_error("mi_conv_fwd: row-paired path needs W %% 4 == 0 and channel counts in multiples of 8 up to %d", RP_MAXC); return MI_ERR_UNSUPPORTED; }
+    const bool wide = p.gn_coef != nullptr;
+    if ((p.W & 3) || (C0 & 7) || (C1 & 7) || Cin > (wide ? MI_COEF_MAXC : RP_MAXC)) { mi_set_error("mi_conv_fwd: row-paired path needs W %% 4 == 0 and channel counts in multiples of 8 up to %d", wide ? MI_COEF_MAXC : RP_MAXC); return MI_ERR_UNSUPPORTED; }
     if (mode != 0 && p.gn_groups > 0) { mi_set_error("mi_conv_fwd: GroupNorm prologue is only built for the k3 s1 family"); return MI_ERR_UNSUPPORTED; }
     if (p.res0.data && p.res_w) {
         const int Cres = p.res0.C + (p.res1.data ? p.res1.C : 0);
-        if (!p.res_w_rp || (p.res0.C & 7) || (p.res1.data && (p.res1.C & 7)) || Cres > RP_MAXC) { mi_set_error("mi_conv_fwd: row-paired path needs res_w_rp and residual channels in multiples of 8"); return MI_ERR_INVALID; }
+        if (!p.res_w_rp || (p.res0.C & 7) || (p.res1.data && (p.res1.C & 7)) || Cres > (wide ? MI_COEF_MAXC : RP_MAXC)) { mi_set_error("mi_conv_fwd: row-paired path needs res_w_rp and residual channels in multiples of 8"); return MI_ERR_INVALID; }
     }
     const size_t biggest = (size_t)(C0 > C1 ? C0 : C1) * p.H * p.W * (mode == 2 ? 4 : 1);
     if (biggest >= (1ull << 31)) { mi_set_error("mi_conv_fwd: row-paired path indexes one image with 32-bit offsets"); return MI_ERR_UNSUPPORTED; }
+    if (wide) {
+        if (!p.gn_exps) { mi_set_error("mi_conv_fwd: wide regime needs gn_exps (mi_gn_coef_fwd first)"); return MI_ERR_INVALID; }
+        if ((p.tile_cfg & 0xff) != 7) { mi_set_error("mi_conv_fwd: the wide regime uses tile_cfg 7 (8x32)"); return MI_ERR_INVALID; }
+        return mode == 0 ? launch_rp_wide_m<0>(p, st) : (mode == 1 ? launch_rp_wide_m<1>(p, st) : launch_rp_wide_m<2>(p, st));
+    }
     if (mode == 1) {
         if ((p.tile_cfg & 0xff) == 6) return launch_rp_nj<8, 64, 1>(p, st);
         mi_set_error("mi_conv_fwd: row-paired up-sampling conv uses tile_cfg 6 (8x64)");

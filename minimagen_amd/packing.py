@@ -87,11 +87,9 @@ def pack_conv_weight_rp(w: torch.Tensor):
         wp[:cout, :cin] = ws
         lane = torch.arange(64)
         lq, lg = lane & 15, lane >> 4
-        out = torch.zeros(ko, 4, nj, 64, 8, dtype=torch.float64)
-        for k in range(ko):
-            for s in range(4):
-                for jt in range(nj):
-                    out[k, s, jt] = wp[16 * jt + lq, 8 * k:8 * k + 8, :, s][lane, :, lg]
+        co = 16 * torch.arange(nj)[:, None] + lq[None, :]
+        ci = 8 * torch.arange(ko)[:, None] + torch.arange(8)[None, :]
+        out = wp[co[None, None, :, :, None], ci[:, None, None, None, :], lg[None, None, None, :, None], torch.arange(4)[None, :, None, None, None]]
         hi = out.float().half()
         lo = (out - hi.double()).float().half()
         return torch.cat((hi, lo), dim=-1).contiguous().to(w.device), exp
@@ -107,13 +105,11 @@ def pack_conv_weight_rp(w: torch.Tensor):
     ky = r - (lq >> 3)
     live = ((ky >= 0) & (ky <= 2)).double()
     kyc = ky.clamp(0, 2)
-    out = torch.zeros(ko, steps, nj, 64, 8, dtype=torch.float64)
-    for k in range(ko):
-        for s in range(steps):
-            for jt in range(nj):
-                co = 8 * jt + (lq & 7)
-                vals = wp[co, 8 * k:8 * k + 8, :, s]                   # [64 lanes][8 ci][3 ky]
-                out[k, s, jt] = vals[lane, :, kyc] * live[:, None]
+    co = (8 * torch.arange(nj)[:, None] + (lq & 7)[None, :])                 # [nj][64]
+    ci = (8 * torch.arange(ko)[:, None] + torch.arange(8)[None, :])         # [ko][8]
+    # out[k, s, jt, lane, e] = wp[co[jt, lane], ci[k, e], ky[lane], s]  (one gather, no Python loop over the channel tiles)
+    out = wp[co[None, None, :, :, None], ci[:, None, None, None, :], kyc[None, None, None, :, None], torch.arange(steps)[None, :, None, None, None]]
+    out = out * live[None, None, None, :, None]
     hi = out.float().half()
     lo = (out - hi.double()).float().half()
     return torch.cat((hi, lo), dim=-1).contiguous().to(w.device), exp

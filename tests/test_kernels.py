@@ -240,6 +240,91 @@ def test_conv_row_paired_resampling(backend, case):
     check_stats(ost.cpu(), ref.float())
 
 
+WIDE_CASES = [
+    # B, C0, C1, Cout, H, W (output), ks, stride, up2, gn, ss, res
+    (1, 128, 0, 128, 16, 32, 3, 1, 0, True, True, 'id'),
+    (2, 96, 64, 72, 8, 32, 3, 1, 0, True, True, 'conv'),          # concat input, 1x1 residual over the concat, Cout not a multiple of 32
+    (2, 96, 64, 72, 8, 32, 3, 1, 0, True, True, 'none'),
+    (2, 96, 64, 64, 8, 32, 3, 1, 0, True, True, 'conv'),
+    (2, 160, 0, 64, 8, 32, 3, 1, 0, True, True, 'none'),
+    (2, 160, 0, 64, 8, 32, 3, 1, 0, False, False, 'none'),
+    (1, 72, 0, 3, 16, 32, 3, 1, 0, False, False, 'none'),         # final conv of a wide net
+    (1, 128, 0, 64, 16, 32, 3, 1, 1, False, False, 'none'),       # nearest x2 + conv
+    (1, 64, 0, 136, 8, 32, 4, 2, 0, False, False, 'none'),        # downsample k4 s2
+]
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("case", WIDE_CASES)
+def test_conv_wide_regime(backend, case):
+    """the wide-channel regime of the row-paired matrix-core conv (output channels tiled over the grid, per-channel affine and operand
+    exponents from mi_gn_coef_fwd) vs torch fp32"""
+    dev = setup(backend)
+    lib = L.lib()
+    B, C0, C1, Cout, H, W, ks, stride, up2, gn, ss, res = case
+    g = torch.Generator().manual_seed(sum(int(v) if not isinstance(v, str) else len(v) for v in case))
+    rn = lambda *s_: torch.randn(*s_, generator=g)
+    Hin, Win = (H // 2, W // 2) if up2 else (H * stride, W * stride)
+    x0 = rn(B, C0, Hin, Win) * 1.5 + 0.3
+    x1 = rn(B, C1, Hin, Win) if C1 else None
+    Cin = C0 + C1
+    w, bias = rn(Cout, Cin, ks, ks) * (0.5 / (Cin * ks * ks) ** 0.5), rn(Cout)
+    gamma, beta = 1 + 0.2 * rn(Cin), 0.1 * rn(Cin)
+    sst = rn(B, 7 + 2 * Cin) * 0.3 if ss else None
+    sk = 2 ** -0.5
+    h = torch.cat((x0, x1 * sk), 1) if C1 else x0
+    if gn:
+        h = F.group_norm(h, 8, gamma, beta, 1e-5)
+        if ss:
+            h = h * (sst[:, 7:7 + Cin, None, None] + 1) + sst[:, 7 + Cin:7 + 2 * Cin, None, None]
+        h = F.silu(h)
+    if up2:
+        h = F.interpolate(h, scale_factor=2, mode='nearest')
+    ref = F.conv2d(h.double(), w.double(), bias.double(), stride=stride, padding=1)
+    keep = {}
+    d = lambda name, t: keep.setdefault(name, t.to(dev).contiguous())
+    p = L.MiConvParams()
+    p.B, p.H, p.W = B, H, W
+    p.in0 = L.MiAct(d("x0", x0).data_ptr(), C0, d("s0", chan_stats(x0)).data_ptr(), 1, 1.0, 0)
+    if C1:
+        p.in1 = L.MiAct(d("x1", x1).data_ptr(), C1, d("s1", chan_stats(x1)).data_ptr(), 1, sk, 0)
+    p.Cout, p.ksize, p.stride, p.up2 = Cout, ks, stride, up2
+    wf, wexp = P.pack_conv_weight_rp(w)
+    p.w_rp, p.w_rp_exp, p.bias = d("wf", wf).data_ptr(), wexp, d("b", bias).data_ptr()
+    if gn:
+        p.gn_groups, p.gn_gamma, p.gn_beta, p.gn_eps = 8, d("g", gamma).data_ptr(), d("be", beta).data_ptr(), 1e-5
+        if ss:
+            p.scale_shift, p.ss_stride, p.ss_off = d("ss", sst).data_ptr(), sst.shape[1], 7
+    if res == 'id':
+        r0 = rn(B, Cout, H, W)
+        p.res0 = L.MiAct(d("r0", r0).data_ptr(), Cout, 0, 0, 1.0, 0)
+        ref = ref + r0
+    elif res == 'conv':
+        r0, r1 = rn(B, 96, H, W), rn(B, 64, H, W)
+        rin = torch.cat((r0, r1 * sk), 1)
+        rw, rb = rn(Cout, 160, 1, 1) * 0.1, rn(Cout)
+        ref = ref + F.conv2d(rin.double(), rw.double(), rb.double())
+        p.res0 = L.MiAct(d("r0", r0).data_ptr(), 96, d("rs0", chan_stats(r0)).data_ptr(), 1, 1.0, 0)
+        p.res1 = L.MiAct(d("r1", r1).data_ptr(), 64, d("rs1", chan_stats(r1)).data_ptr(), 1, sk, 0)
+        p.res_w = 1
+        rwf, p.res_w_rp_exp = P.pack_conv_weight_rp(rw)
+        p.res_w_rp, p.res_b = d("rwf", rwf).data_ptr(), d("rb", rb).data_ptr()
+    coef = torch.zeros(B, Cin, 4, device=dev)
+    exps = torch.zeros(B, 2, dtype=torch.int32, device=dev)
+    p.gn_coef, p.gn_exps = coef.data_ptr(), exps.data_ptr()
+    nt = tile_nt(lib, 7, H, W)
+    out = torch.full((B, Cout, H, W), float('nan'), device=dev)
+    ost = torch.zeros(B, Cout, nt, 2, device=dev)
+    p.out, p.out_stats, p.tile_cfg = out.data_ptr(), ost.data_ptr(), 7
+    L.check(lib.mi_gn_coef_fwd(C.byref(p), L.current_stream()), "gn coef")
+    L.check(lib.mi_conv_fwd(C.byref(p), L.current_stream()), "conv wide")
+    scale = max(1.0, ref.abs().max().item() / 8.0)
+    err = (out.cpu().double() - ref).abs().max().item()
+    print(f"wide conv {case}: max|d| = {err:.2e} (gate {2e-5 * scale:.2e}, exps {exps.cpu().tolist()})")
+    assert err < 2e-5 * scale
+    check_stats(ost.cpu(), ref.float())
+
+
 def test_conv_rejects_bad_arguments():
     setup("emu")
     lib = L.lib()
