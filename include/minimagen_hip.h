@@ -334,10 +334,36 @@ typedef struct mi_chan_ff_params {
 } mi_chan_ff_params;
 int mi_chan_ff_fwd(const mi_chan_ff_params* p, void* stream);
 
+/* ---- wide-channel attention (C > 32: Unet() default, Base, Super): the reference's own factorisation as token-major building blocks,
+ * exact fp32 on the matrix cores: mi_ln_tokens_fwd -> mi_gemm_f32 (to_q / to_kv) -> mi_flash_attn_fwd -> mi_gemm_f32 (to_out.0)
+ * -> mi_tokens_to_nchw_fwd (to_out.1 LayerNorm + residual + NCHW + statistics); ChanFeedForward: mi_ln_tokens_fwd -> mi_gemm_f32
+ * (GELU) -> mi_ln_rows_fwd -> mi_gemm_f32 -> mi_tokens_to_nchw_fwd. */
+typedef struct mi_flash_attn_params {
+    int B, HW, heads, kv_heads;     /* dim_head 64; kv_heads = heads (CrossAttention, layers.py:226-233) or 1 (multi-query Attention, :42) */
+    const float* q; float q_scale;  /* [B][HW][heads*64]; q_scale = dim_head^-0.5 * log2(e) */
+    const float* null_k; const float* null_v;   /* [64] each: the null key / value prepended to every head's context, or NULL */
+    /* up to two context segments after the null row (time tokens | text tokens; or the image tokens themselves):
+       row r of batch b at k + b * bs + r * ld (+ 64 * head when kv_heads > 1) */
+    const float* k0; const float* v0; int n0, ld0; long long bs0;
+    const float* k1; const float* v1; int n1, ld1; long long bs1;
+    float* out;                     /* [B][HW][heads*64] */
+} mi_flash_attn_params;
+int mi_flash_attn_fwd(const mi_flash_attn_params* p, void* stream);
+typedef struct mi_tokens_to_nchw_params {
+    int B, HW, C;
+    const float* tokens;            /* [B][HW][C] */
+    const float* gamma; const float* beta; float eps;   /* LayerNorm over C first (gamma NULL: none; beta may be NULL) */
+    mi_act res;                     /* NCHW residual added (data NULL: none) */
+    float* out; float* out_stats;   /* [B][C][HW]; stats [B][C][ceil(HW/64)][2] or NULL */
+} mi_tokens_to_nchw_params;
+int mi_tokens_to_nchw_fwd(const mi_tokens_to_nchw_params* p, void* stream);
+/* y[row] = LayerNorm(x[row]) * gamma (+ beta, may be NULL) over the last dimension of [rows][dim] */
+int mi_ln_rows_fwd(const float* x, const float* gamma, const float* beta, float* y, int rows, int dim, float eps, void* stream);
+
 /* ---- K16: T5 encoder (minimagen/t5.py:71-84 -> transformers T5Stack, third party) -------
  * fp32; dense contractions on v_mfma_f32_16x16x4_f32.  All matrices in torch nn.Linear layout. */
-/* C[M][N] = act(A[M][K] . W[N][K]^T) + R[M][N]   (R may be NULL; act: 0 none, 1 ReLU, 2 gelu_new)
- * gate != NULL (gated-gelu FF of T5 v1.1): C = act(A.W^T) * (A.gate^T).   N % 64 == 0, K % 16 == 0. */
+/* C[M][N] = act(A[M][K] . W[N][K]^T) + R[M][N]   (R may be NULL; act: 0 none, 1 ReLU, 2 gelu_new (tanh form), 3 exact GELU (erf form, nn.GELU))
+ * gate != NULL (gated-gelu FF of T5 v1.1): C = act(A.W^T) * (A.gate^T).   K % 16 == 0 (N % 64 == 0 for the gated form). */
 int mi_gemm_f32(const float* A, const float* W, const float* gate, const float* R, float* Cout, int M, int N, int K, int act, void* stream);
 /* y = x * rsqrt(mean(x^2) + eps) * w per row (T5LayerNorm); zero_mask != NULL: rows with zero_mask[row]==0 are zeroed (t5.py:82) */
 int mi_rmsnorm(const float* x, const float* w, float* y, int rows, int dim, float eps, const uint8_t* zero_mask, void* stream);

@@ -103,6 +103,18 @@ class MiChanFFParams(C.Structure):
                 ("g2", C.c_void_p), ("w2", C.c_void_p), ("out", C.c_void_p), ("out_stats", C.c_void_p)]
 
 
+class MiFlashAttnParams(C.Structure):
+    _fields_ = [("B", C.c_int), ("HW", C.c_int), ("heads", C.c_int), ("kv_heads", C.c_int), ("q", C.c_void_p), ("q_scale", C.c_float),
+                ("null_k", C.c_void_p), ("null_v", C.c_void_p),
+                ("k0", C.c_void_p), ("v0", C.c_void_p), ("n0", C.c_int), ("ld0", C.c_int), ("bs0", C.c_longlong),
+                ("k1", C.c_void_p), ("v1", C.c_void_p), ("n1", C.c_int), ("ld1", C.c_int), ("bs1", C.c_longlong), ("out", C.c_void_p)]
+
+
+class MiTokensToNchwParams(C.Structure):
+    _fields_ = [("B", C.c_int), ("HW", C.c_int), ("C", C.c_int), ("tokens", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p),
+                ("eps", C.c_float), ("res", MiAct), ("out", C.c_void_p), ("out_stats", C.c_void_p)]
+
+
 class MiCfgX0Params(C.Structure):
     _fields_ = [("B", C.c_int), ("n", C.c_int), ("pred2", C.c_void_p), ("two", C.c_int), ("cond_scale", C.c_float),
                 ("x_t", C.c_void_p), ("coef", C.c_void_p), ("t_state", C.c_void_p), ("pred_out", C.c_void_p), ("x0", C.c_void_p),
@@ -127,7 +139,7 @@ class MiResizeParams(C.Structure):
 
 _STRUCTS = {0: MiAct, 1: MiConvParams, 2: MiCrossEmbedParams, 3: MiLinear, 4: MiTextCondParams, 5: MiCondStepParams,
             6: MiAttnFoldParams, 7: MiCrossAttnParams, 8: MiCfgX0Params, 9: MiQuantileParams, 10: MiPosteriorParams,
-            11: MiResizeParams, 12: MiSelfAttnParams, 13: MiChanFFParams}
+            11: MiResizeParams, 12: MiSelfAttnParams, 13: MiChanFFParams, 14: MiFlashAttnParams, 15: MiTokensToNchwParams}
 
 _lib = None
 _backend = None
@@ -144,7 +156,8 @@ def _bind(lib):
     lib.mi_struct_size.argtypes = [C.c_int]
     vp, i32, i64, u64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float
     for name in ("mi_conv_fwd", "mi_gn_coef_fwd", "mi_crossembed_fwd", "mi_text_cond_fwd", "mi_cond_step_fwd", "mi_attn_fold_rows", "mi_cross_attn_fwd",
-                 "mi_cfg_x0_fwd", "mi_quantile_fwd", "mi_posterior_fwd", "mi_resize_fwd", "mi_self_attn_fwd", "mi_chan_ff_fwd"):
+                 "mi_cfg_x0_fwd", "mi_quantile_fwd", "mi_posterior_fwd", "mi_resize_fwd", "mi_self_attn_fwd", "mi_chan_ff_fwd",
+                 "mi_flash_attn_fwd", "mi_tokens_to_nchw_fwd"):
         getattr(lib, name).argtypes = [vp, vp]
         getattr(lib, name).restype = i32
     lib.mi_step_advance.argtypes = [vp, vp, i32, vp]
@@ -157,6 +170,7 @@ def _bind(lib):
     lib.mi_embed_rows.argtypes = [vp, vp, vp, i32, i32, vp]
     lib.mi_t5_attention.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp]
     lib.mi_ln_tokens_fwd.argtypes = [vp, i32, i32, vp, vp, vp, vp]
+    lib.mi_ln_rows_fwd.argtypes = [vp, vp, vp, vp, i32, i32, f32, vp]
     lib.mi_graph_begin.argtypes = [vp]
     lib.mi_graph_end.argtypes = [vp, C.POINTER(vp)]
     lib.mi_graph_launch.argtypes = [vp, vp]

@@ -40,6 +40,8 @@ extern "C" int mi_struct_size(int which) {
         case 11: return (int)sizeof(mi_resize_params);
         case 12: return (int)sizeof(mi_self_attn_params);
         case 13: return (int)sizeof(mi_chan_ff_params);
+        case 14: return (int)sizeof(mi_flash_attn_params);
+        case 15: return (int)sizeof(mi_tokens_to_nchw_params);
     }
     return -1;
 }

@@ -28,7 +28,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     for (int k0 = 0; k0 < K; k0 += BK) {
         float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (m0 + lr < M) a4 = *reinterpret_cast<const float4*>(A + (size_t)(m0 + lr) * K + k0 + lc);
-        const float4 w4 = *reinterpret_cast<const float4*>(W + (size_t)(n0 + lr) * K + k0 + lc);
+        float4 w4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n0 + lr < N) w4 = *reinterpret_cast<const float4*>(W + (size_t)(n0 + lr) * K + k0 + lc);
         float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (GATED) g4 = *reinterpret_cast<const float4*>(G + (size_t)(n0 + lr) * K + k0 + lc);
         __syncthreads();
@@ -63,10 +64,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int m = m0 + wm * 32 + i * 16 + 4 * (lane >> 4) + r, n = n0 + wn * 32 + j * 16 + (lane & 15);
-                if (m < M) {
+                if (m < M && n < N) {
                     float v = acc[i][j][r];
                     if (act == 1) v = fmaxf(v, 0.0f);
                     else if (act == 2) v = gelu_new(v);
+                    else if (act == 3) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
                     if (GATED) v *= accg[i][j][r];
                     if (R) v += R[(size_t)m * N + n];
                     Cout[(size_t)m * N + n] = v;
@@ -173,8 +175,8 @@ __global__ __launch_bounds__(256) void t5_attention_kernel(const float* __restri
 }  // namespace
 
 extern "C" int mi_gemm_f32(const float* A, const float* W, const float* gate, const float* R, float* Cout, int M, int N, int K, int act, void* stream) {
-    if (M <= 0 || (N % 64) != 0 || (K % 16) != 0) { mi_set_error("mi_gemm_f32: need M>0, N%%64==0, K%%16==0 (got %d,%d,%d)", M, N, K); return MI_ERR_INVALID; }
-    const dim3 grid(N / 64, (M + 63) / 64);
+    if (M <= 0 || N <= 0 || (gate && (N % 64) != 0) || (K % 16) != 0) { mi_set_error("mi_gemm_f32: need M>0, K%%16==0 (and N%%64==0 when gated) (got %d,%d,%d)", M, N, K); return MI_ERR_INVALID; }
+    const dim3 grid((N + 63) / 64, (M + 63) / 64);
     if (gate) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_f32_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, A, W, gate, R, Cout, M, N, K, act);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_f32_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, A, W, gate, R, Cout, M, N, K, act);
     return mi_check_launch("gemm_f32_kernel");

@@ -136,7 +136,7 @@ class UnetEngine:
             ct = lib.mi_conv_cout_tile(w.shape[0])
             wp = P.pack_conv_weight(w.to(dev), ct)
             pk.keep.append(wp)
-            if w.shape[-1] in (3, 4) and w.shape[1] % 8 == 0 and w.shape[1] <= 64 and w.shape[0] <= (32 if w.shape[-1] == 3 else 16):
+            if w.shape[-1] in (3, 4) and w.shape[1] % 8 == 0:
                 pk.conv_rp[id(wp)] = P.pack_conv_weight_rp(w.to(dev))
             return wp
 
@@ -161,14 +161,18 @@ class UnetEngine:
                 ct = lib.mi_conv_cout_tile(rb.res_conv.weight.shape[0])
                 rw = P.pack_conv_weight(rb.res_conv.weight, ct).reshape(rb.res_conv.weight.shape[1], -1).contiguous()
                 pk.keep.append(rw)
-                if rb.res_conv.weight.shape[1] % 8 == 0 and rb.res_conv.weight.shape[1] <= 64:
+                if rb.res_conv.weight.shape[1] % 8 == 0:
                     pk.conv_rp[id(rw)] = P.pack_conv_weight_rp(rb.res_conv.weight)
                 pk.conv[id(rb.res_conv)] = rw
             if rb.cross_attn is not None:
                 ca: CrossAttention = rb.cross_attn.fn
                 Cc = ca.to_q.in_features
-                if Cc not in (8, 16, 32) or ca.dim_head != 64:
-                    raise NotImplementedError(f"cross-attention over {Cc} channels: only the folded path (C in 8/16/32, dim_head 64) is built")
+                if ca.dim_head != 64:
+                    raise NotImplementedError("cross-attention with dim_head != 64")
+                if Cc not in (8, 16, 32):
+                    if Cc % 16 or u.cond_dim % 16:
+                        raise NotImplementedError(f"cross-attention over {Cc} channels / {u.cond_dim}-wide context: the wide path needs multiples of 16")
+                    continue                 # wide path (unfolded, attention_wide.hip): works on the module's own weights
                 if not isinstance(ca.norm_context, Identity):
                     raise NotImplementedError("norm_context=True cross-attention is not on the MinImagen hot path")
                 mg, mv, g0, v0 = P.fold_cross_attention(ca.to_q.weight, ca.to_kv.weight, ca.to_out[0].weight, ca.null_kv, ca.heads, ca.dim_head)
@@ -181,8 +185,12 @@ class UnetEngine:
             if isinstance(m, Attention):
                 Cc = m.to_q.in_features
                 dh = m.to_kv.out_features // 2
-                if Cc not in (8, 16, 32) or dh != 64:
-                    raise NotImplementedError(f"self-attention over {Cc} channels: only the folded path (C in 8/16/32, dim_head 64) is built")
+                if dh != 64:
+                    raise NotImplementedError("self-attention with dim_head != 64")
+                if Cc not in (8, 16, 32):
+                    if Cc % 16:
+                        raise NotImplementedError(f"self-attention over {Cc} channels: the wide path needs a multiple of 16")
+                    continue
                 kv = m.to_kv.weight.detach()
                 kv_full = torch.cat((kv[:dh].repeat(m.heads, 1), kv[dh:].repeat(m.heads, 1)), 0)
                 pk.attn[id(m)] = P.fold_cross_attention(m.to_q.weight, kv_full, m.to_out[0].weight, m.null_kv, m.heads, dh)
@@ -240,6 +248,8 @@ class UnetEngine:
         ws.tensors = []
         ws.text_L = None
         ws.prog = []
+        ws.prog_text = []          # once per sample() after the text conditioning: the wide cross-attentions' text keys / values
+        ws.wide_attn = False
         self._build_program(ws, pk)
         self._ws[key] = ws
         return ws
@@ -276,11 +286,16 @@ class UnetEngine:
         ct = lib.mi_conv_cout_tile(Cout)
         cfg, nt = self._tile_cfg(Ho, Wo, batch, -(-Cout // ct))
         cin_tot = in0.C + (in1.C if in1 is not None else 0)
-        # row-paired matrix-core path (conv_rp.hip): every narrow k3 s1 conv whose channel counts come in octets
+        # row-paired matrix-core path (conv_rp.hip): every conv whose channel counts come in octets.  Narrow layers (<= 64 in, <= 32 out: the
+        # BASELINE U-Nets) run the tuned single-kernel form; wider ones (Unet() default, Base, Super) the wide regime: output channels
+        # tiled over the grid, GroupNorm affine + operand exponents from a small per-image launch (mi_gn_coef_fwd) ahead of the conv
+        cres = 0 if (res is None or res[2] is None) else res[0].C + (res[1].C if res[1] is not None else 0)
         rp = bool(CONV_RP) and ((ksize == 3 and stride == 1) or (ksize == 4 and stride == 2 and not up2 and CONV_RP >= 2)) \
-            and (not up2 or (CONV_RP >= 2 and Cout <= 8)) and Wo % 4 == 0 and id(wpack) in pk.conv_rp and Ho * Wo >= RP_MIN_HW \
+            and (not up2 or CONV_RP >= 2) and Wo % 4 == 0 and id(wpack) in pk.conv_rp and Ho * Wo >= RP_MIN_HW \
             and in0.C % 8 == 0 and (in1 is None or in1.C % 8 == 0) \
             and (res is None or res[2] is None or (id(res[2]) in pk.conv_rp and res[0].C % 8 == 0 and (res[1] is None or res[1].C % 8 == 0)))
+        narrow = cin_tot <= 64 and cres <= 64 and Cout <= (16 if stride == 2 else (8 if up2 else 32))
+        wide = rp and not narrow
         if rp:
             cfg = RP_TILE["L"] if Ho * Wo > 128 * 128 else (RP_TILE["M"] if Ho * Wo > 64 * 64 else RP_TILE["S"])
             if Cout > 8 and cfg == 5:
@@ -289,7 +304,7 @@ class UnetEngine:
                 cfg = 7                  # four N tiles are only instantiated for the 8x32 tile
             if up2:
                 cfg = 6                  # the up- / down-sampling members have one tile shape each
-            if stride == 2:
+            if stride == 2 or wide:
                 cfg = 7
             th, tw = {5: (16, 64), 6: (8, 64), 7: (8, 32)}[cfg]
             nt = -(-Ho // th) * -(-Wo // tw)
@@ -312,6 +327,11 @@ class UnetEngine:
                 p.res1 = r1.c(batch, skip_scale)
             p.res_w, p.res_b = L.ptr(rw), L.ptr(rb)
         p.out, p.out_stats, p.tile_cfg = L.ptr(out.t), L.ptr(out.stats), cfg | (0x100 if CONV_SPLIT16 else 0) | (0x400 if ws.half else 0) | (0x800 if (CONV_SPLIT8 and Ho * Wo <= CONV_SPLIT8 * CONV_SPLIT8) else 0)
+        if wide:
+            coef = torch.zeros(batch, cin_tot, 4, dtype=torch.float32, device=ws.dev)
+            exps = torch.zeros(batch, 2, dtype=torch.int32, device=ws.dev)
+            ws.tensors += [coef, exps]
+            p.gn_coef, p.gn_exps = L.ptr(coef), L.ptr(exps)
         if rp:
             p.tile_cfg |= (RP_NTILE & 0xf) << 12
             frag, p.w_rp_exp = pk.conv_rp[id(wpack)]
@@ -319,6 +339,8 @@ class UnetEngine:
             if res is not None and res[2] is not None:
                 rfrag, p.res_w_rp_exp = pk.conv_rp[id(res[2])]
                 p.res_w_rp = L.ptr(rfrag)
+        if wide:
+            ws.prog.append((lib.mi_gn_coef_fwd, p, "gn_coef"))
         ws.prog.append((lib.mi_conv_fwd, p, "conv"))
         return out
 
@@ -341,9 +363,96 @@ class UnetEngine:
         return self._emit_conv(ws, pk, h, None, wpack=pk.conv[id(rb.block2.project)], bias=rb.block2.project.bias, Cout=Cout,
                                gn=rb.block2.groupnorm, ss_off=ss_off, res=res, conditioned=ss_off is not None, skip_scale=s)
 
+    # ------------------------------------------------------------------ wide-channel attention (C > 32): token-major chains
+    @staticmethod
+    def _call(fn, name, *args):
+        """program entry for a positional-argument C-ABI function (the struct-taking ones are (fn, params, name))"""
+        return (lambda _p, st, fn=fn, args=args: fn(*args, st)), None, name
+
+    def _buf(self, ws, *shape):
+        t = torch.empty(*shape, dtype=torch.float32, device=ws.dev)
+        ws.tensors.append(t)
+        return t
+
+    def _emit_tokens_out(self, ws, tokens, batch, Cc, H, W, ln, res: Act, want_stats: bool) -> Act:
+        lib = L.lib()
+        HW = H * W
+        out = self._new_act(ws, batch, Cc, H, W, -(-HW // 64) if want_stats else 0)
+        p = L.MiTokensToNchwParams()
+        p.B, p.HW, p.C, p.tokens = batch, HW, Cc, L.ptr(tokens)
+        if ln is not None:
+            p.gamma, p.beta, p.eps = L.ptr(ln.gamma), L.ptr(ln.beta), 1e-5
+        p.res = res.c(batch)
+        p.out, p.out_stats = L.ptr(out.t), L.ptr(out.stats)
+        ws.prog.append((lib.mi_tokens_to_nchw_fwd, p, "tokens_to_nchw"))
+        return out
+
+    def _emit_cross_attn_wide(self, ws, ca: CrossAttention, h: Act) -> Act:
+        """layers.py:220-251 unfolded: LN(x) -> to_q | context -> to_kv -> flash attention over [null | time tokens | text tokens] -> to_out.0
+        -> to_out.1 LayerNorm + residual.  The text rows' keys / values are step-invariant: projected once per sample() (ws.prog_text)."""
+        lib, u = L.lib(), self.unet
+        Cc, HW, B2, inner = h.C, h.H * h.W, ws.B2, ca.heads * 64
+        xh, q, o, t = self._buf(ws, B2, HW, Cc), self._buf(ws, B2, HW, inner), self._buf(ws, B2, HW, inner), self._buf(ws, B2, HW, Cc)
+        kv_time = self._buf(ws, B2, ws.ntot, 2 * inner)
+        kv_text = self._buf(ws, B2, MAX_TEXT_LEN, 2 * inner) if ws.has_text else None
+        xa = h.c(B2)
+        ws.tensors.append(xa)
+        ws.prog.append(self._call(lib.mi_ln_tokens_fwd, "ln_tokens", C.byref(xa), B2, HW, L.ptr(ca.norm.gamma), L.ptr(ca.norm.beta), L.ptr(xh)))
+        ws.prog.append(self._call(lib.mi_gemm_f32, "gemm_q", L.ptr(xh), L.ptr(ca.to_q.weight), 0, 0, L.ptr(q), B2 * HW, inner, Cc, 0))
+        ws.prog.append(self._call(lib.mi_gemm_f32, "gemm_kv_time", L.ptr(ws.c_time), L.ptr(ca.to_kv.weight), 0, 0, L.ptr(kv_time), B2 * ws.ntot, 2 * inner, u.cond_dim, 0))
+        if ws.has_text:
+            ws.prog_text.append(self._call(lib.mi_gemm_f32, "gemm_kv_text", L.ptr(ws.c_text), L.ptr(ca.to_kv.weight), 0, 0, L.ptr(kv_text), B2 * MAX_TEXT_LEN, 2 * inner, u.cond_dim, 0))
+        p = L.MiFlashAttnParams()
+        p.B, p.HW, p.heads, p.kv_heads, p.q, p.q_scale = B2, HW, ca.heads, ca.heads, L.ptr(q), 64 ** -0.5 * P.LOG2E
+        p.null_k, p.null_v = L.ptr(ca.null_kv), L.ptr(ca.null_kv) + 4 * 64
+        p.k0, p.v0, p.n0, p.ld0, p.bs0 = L.ptr(kv_time), L.ptr(kv_time) + 4 * inner, ws.ntot, 2 * inner, ws.ntot * 2 * inner
+        if ws.has_text:
+            p.k1, p.v1, p.n1, p.ld1, p.bs1 = L.ptr(kv_text), L.ptr(kv_text) + 4 * inner, MAX_TEXT_LEN, 2 * inner, MAX_TEXT_LEN * 2 * inner
+        p.out = L.ptr(o)
+        ws.prog.append((lib.mi_flash_attn_fwd, p, "flash_attn"))
+        ws.prog.append(self._call(lib.mi_gemm_f32, "gemm_out", L.ptr(o), L.ptr(ca.to_out[0].weight), 0, 0, L.ptr(t), B2 * HW, Cc, inner, 0))
+        ws.wide_attn = True
+        return self._emit_tokens_out(ws, t, B2, Cc, h.H, h.W, ca.to_out[1], h, True)
+
+    def _emit_self_attn_wide(self, ws, at: Attention, x: Act, want_stats: bool) -> Act:
+        """layers.py:52-104 (multi-query: one shared 64-wide key / value head) + the residual"""
+        lib = L.lib()
+        Cc, HW, batch, inner = x.C, x.H * x.W, x.batch, at.heads * 64
+        xh, q, kv = self._buf(ws, batch, HW, Cc), self._buf(ws, batch, HW, inner), self._buf(ws, batch, HW, 128)
+        o, t = self._buf(ws, batch, HW, inner), self._buf(ws, batch, HW, Cc)
+        xa = x.c(batch)
+        ws.tensors.append(xa)
+        ws.prog.append(self._call(lib.mi_ln_tokens_fwd, "ln_tokens", C.byref(xa), batch, HW, L.ptr(at.norm.gamma), L.ptr(at.norm.beta), L.ptr(xh)))
+        ws.prog.append(self._call(lib.mi_gemm_f32, "gemm_q", L.ptr(xh), L.ptr(at.to_q.weight), 0, 0, L.ptr(q), batch * HW, inner, Cc, 0))
+        ws.prog.append(self._call(lib.mi_gemm_f32, "gemm_kv", L.ptr(xh), L.ptr(at.to_kv.weight), 0, 0, L.ptr(kv), batch * HW, 128, Cc, 0))
+        p = L.MiFlashAttnParams()
+        p.B, p.HW, p.heads, p.kv_heads, p.q, p.q_scale = batch, HW, at.heads, 1, L.ptr(q), 64 ** -0.5 * P.LOG2E
+        p.null_k, p.null_v = L.ptr(at.null_kv), L.ptr(at.null_kv) + 4 * 64
+        p.k0, p.v0, p.n0, p.ld0, p.bs0 = L.ptr(kv), L.ptr(kv) + 4 * 64, HW, 128, HW * 128
+        p.out = L.ptr(o)
+        ws.prog.append((lib.mi_flash_attn_fwd, p, "flash_attn"))
+        ws.prog.append(self._call(lib.mi_gemm_f32, "gemm_out", L.ptr(o), L.ptr(at.to_out[0].weight), 0, 0, L.ptr(t), batch * HW, Cc, inner, 0))
+        return self._emit_tokens_out(ws, t, batch, Cc, x.H, x.W, at.to_out[1], x, want_stats)
+
+    def _emit_chan_ff_wide(self, ws, tb: TransformerBlock, y: Act) -> Act:
+        """layers.py:148-161 + the residual of :498 in token layout: ChanLayerNorm -> 1x1 conv -> GELU -> ChanLayerNorm -> 1x1 conv"""
+        lib = L.lib()
+        Cc, HW, batch, Chid = y.C, y.H * y.W, y.batch, tb.ff[1].out_channels
+        t0, h1, h2, t = self._buf(ws, batch, HW, Cc), self._buf(ws, batch, HW, Chid), self._buf(ws, batch, HW, Chid), self._buf(ws, batch, HW, Cc)
+        zeros = torch.zeros(Cc, dtype=torch.float32, device=ws.dev)
+        ya = y.c(batch)
+        ws.tensors += [zeros, ya]
+        ws.prog.append(self._call(lib.mi_ln_tokens_fwd, "ln_tokens", C.byref(ya), batch, HW, L.ptr(tb.ff[0].g), L.ptr(zeros), L.ptr(t0)))
+        ws.prog.append(self._call(lib.mi_gemm_f32, "gemm_ff1", L.ptr(t0), L.ptr(tb.ff[1].weight), 0, 0, L.ptr(h1), batch * HW, Chid, Cc, 3))
+        ws.prog.append(self._call(lib.mi_ln_rows_fwd, "ln_rows", L.ptr(h1), L.ptr(tb.ff[3].g), 0, L.ptr(h2), batch * HW, Chid, 1e-5))
+        ws.prog.append(self._call(lib.mi_gemm_f32, "gemm_ff2", L.ptr(h2), L.ptr(tb.ff[4].weight), 0, 0, L.ptr(t), batch * HW, Cc, Chid, 0))
+        return self._emit_tokens_out(ws, t, batch, Cc, y.H, y.W, None, y, True)
+
     def _emit_cross_attn(self, ws, pk, ca: CrossAttention, h: Act) -> Act:
         lib = L.lib()
         Cc, HW = h.C, h.H * h.W
+        if Cc not in (8, 16, 32):
+            return self._emit_cross_attn_wide(ws, ca, h)
         FR = lib.mi_attn_fragment_floats(Cc)
         gv = torch.zeros(ws.B2, ca.heads, ws.JT, 64, FR, dtype=torch.float32, device=ws.dev)      # zero-filled: padded context rows must read as finite
         ws.gv[id(ca)] = gv
@@ -365,6 +474,8 @@ class UnetEngine:
         """layers.py:52-104 + residual: LayerNorm tokens -> fold them as their own context -> chunked online-softmax attention"""
         lib = L.lib()
         Cc, HW, batch = x.C, x.H * x.W, x.batch
+        if Cc not in (8, 16, 32):
+            return self._emit_self_attn_wide(ws, at, x, want_stats)
         xh = torch.empty(batch, HW, Cc, dtype=torch.float32, device=ws.dev)
         J = HW + 1
         jt = -(-J // 16)
@@ -397,6 +508,8 @@ class UnetEngine:
         """layers.py:496-499: x = attn(x) + x ; x = ff(x) + x"""
         lib = L.lib()
         y = self._emit_self_attn(ws, pk, tb.attn.fn, x, want_stats=False)
+        if y.C not in (8, 16, 32):
+            return self._emit_chan_ff_wide(ws, tb, y)
         HW = y.H * y.W
         out = self._new_act(ws, y.batch, y.C, y.H, y.W, -(-HW // 256))
         p = L.MiChanFFParams()
@@ -557,6 +670,8 @@ class UnetEngine:
         L.check(lib.mi_text_cond_fwd(C.byref(p), st), "mi_text_cond_fwd")
         for fn, fp, name in self._fold_params(ws, pk, ws.c_text, MAX_TEXT_LEN * u.cond_dim, 1 + ws.ntot, MAX_TEXT_LEN, 1):
             L.check(fn(C.byref(fp), st), name)
+        for fn, fp, name in ws.prog_text:
+            L.check(fn(None, st), name)
 
     def prepare_lowres(self, ws, stream=None):
         """Once per ``sample()`` stage / ``forward``: everything that depends only on ws.lowres (the low-res half of CrossEmbed)."""
@@ -572,6 +687,9 @@ class UnetEngine:
         u, pk, lib = self.unet, self.pack(), L.lib()
         st = L.current_stream() if stream is None else stream
         B2, dev = ws.B2, ws.dev
+        if ws.wide_attn:                 # the wide cross-attention projects the time tokens per step from ws.c_time: keep the per-step conditioning
+            ws.prog_stage = ws.prog_cond
+            return
         key = (T, t_state.data_ptr())
         tb = ws.__dict__.setdefault("step_tables", {}).get(key)
         if tb is None:
@@ -623,7 +741,7 @@ class UnetEngine:
         prepare_step_tables), then the image kernels."""
         st = L.current_stream() if stream is None else stream
         for fn, p, name in ws.prog_stage + ws.prog:
-            rc = fn(C.byref(p), st)
+            rc = fn(C.byref(p), st) if p is not None else fn(None, st)
             if rc != 0:
                 L.check(rc, name)
 

@@ -119,6 +119,61 @@ def test_forward_1024_vs_oracle(backend):
     assert o.shape == (1, 3, 1024, 1024) and d < FWD_ATOL
 
 
+WIDE_SMALL = dict(dim=64, dim_mults=(1, 2), num_resnet_blocks=1, layer_attns=(False, True), layer_cross_attns=(False, True),
+                  attend_at_middle=True, memory_efficient=False)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_wide_channel_unet_vs_oracle(backend):
+    """the wide-channel regime end to end on a small net (64 / 128 channels: wide row-paired convs with grid-tiled output channels,
+    unfolded flash cross-attention, multi-query self-attention, token-layout ChanFeedForward, attend_at_middle) vs the oracle"""
+    dev = setup(backend)
+    torch.manual_seed(5)
+    u = Unet(**WIDE_SMALL)
+    sd = {k: v.clone() for k, v in u.state_dict().items()}
+    u = u.to(dev)
+    B, S = (2, 32) if backend == "gpu" else (1, 16)
+    emb, mask = R.synthetic_text(B, length=12, seed=4)
+    x, tm = I.seeded((B, 3, S, S), 31), torch.tensor([77, 5][:B])
+    o = u(x.to(dev), tm.to(dev), text_embeds=emb.to(dev), text_mask=mask.to(dev))
+    ref = R.unet_forward(sd, x, tm, text_embeds=emb, text_mask=mask)
+    d = (o.cpu() - ref).abs().max().item()
+    print(f"wide small U-Net {S}x{S} B={B}: max|d| = {d:.2e} (|ref| max {ref.abs().max():.2f})")
+    assert d < FWD_ATOL * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("backend", GPU_ONLY)
+def test_default_unet_vs_oracle(backend):
+    """``Unet()`` with the reference's default arguments (dim 128, dim_mults (1, 2, 4), self- and cross-attention at every level,
+    Unet.py:31-48) at 64 x 64, B = 2, with classifier-free guidance, against the oracle run on the host; and the reference's Base /
+    Super presets construct and run at a reduced width"""
+    dev = setup(backend)
+    torch.manual_seed(6)
+    u = Unet()
+    sd = {k: v.clone() for k, v in u.state_dict().items()}
+    u = u.to(dev)
+    emb, mask = R.synthetic_text(2, length=20, seed=8)
+    x, tm = I.seeded((2, 3, 64, 64), 41), torch.tensor([90, 11])
+    o = u.forward_with_cond_scale(x.to(dev), tm.to(dev), text_embeds=emb.to(dev), text_mask=mask.to(dev), cond_scale=3.)
+    ref = R.unet_forward_with_cond_scale(sd, x, tm, cond_scale=3., text_embeds=emb, text_mask=mask)
+    d = (o.cpu() - ref).abs().max().item()
+    print(f"Unet() default 64x64 B=2 cond_scale 3: max|d| = {d:.2e} (|ref| max {ref.abs().max():.2f})")
+    assert d < 3 * FWD_ATOL * max(1.0, ref.abs().max().item())
+    for klass, kw in ((Base, dict(dim=64)), (Super, dict(dim=32, lowres_cond=True))):
+        torch.manual_seed(7)
+        m = klass(**kw)
+        sdm = {k: v.clone() for k, v in m.state_dict().items()}
+        m = m.to(dev)
+        xm = I.seeded((1, 3, 64, 64), 43)
+        extra = dict(lowres_cond_img=I.seeded((1, 3, 64, 64), 44), lowres_noise_times=torch.tensor([20])) if m.lowres_cond else {}
+        om = m(xm.to(dev), torch.tensor([50]).to(dev), text_embeds=emb[:1].to(dev), text_mask=mask[:1].to(dev),
+               **{k: v.to(dev) for k, v in extra.items()})
+        refm = R.unet_forward(sdm, xm, torch.tensor([50]), text_embeds=emb[:1], text_mask=mask[:1], **extra)
+        dm = (om.cpu() - refm).abs().max().item()
+        print(f"{klass.__name__}({kw}) 64x64: max|d| = {dm:.2e} (|ref| max {refm.abs().max():.2f})")
+        assert dm < 3 * FWD_ATOL * max(1.0, refm.abs().max().item())
+
+
 @pytest.mark.parametrize("backend", BACKENDS)
 def test_forward_without_text_vs_oracle(backend):
     """Unet.py:572: text conditioning is optional -- ``text_embeds=None`` runs with the context [null | time tokens] and no text hiddens"""
