@@ -8,12 +8,14 @@ from typing import Callable, List, Literal, Tuple, Union
 import os
 
 import torch
+import torch.nn.functional as F
 from torch import nn
 
 from . import _lib as L
 from .Unet import Unet
 from .diffusion_model import GaussianDiffusion
-from .helpers import cast_tuple, cubic_taps, default, eval_decorator, exists, module_device, quantile_rank
+from .helpers import (cast_tuple, cubic_taps, default, eval_decorator, exists, module_device, normalize_neg_one_to_one, quantile_rank,
+                      resize_image_to)
 from .t5 import get_encoded_dim, t5_encode_text
 
 
@@ -88,8 +90,59 @@ class Imagen(nn.Module):
         self._reset_unets_all_one_device()
         return super().load_state_dict(*args, **kwargs)
 
-    def forward(self, images, texts=None, text_embeds=None, text_masks=None, unet_number=None):
-        raise NotImplementedError("Imagen.forward is the training loss path (Imagen.py:575-650): out of scope for the sampling hot path")
+    # ------------------------------------------------------------------ training (Imagen.py:512-650)
+    def _get_unet(self, unet_number: int) -> Unet:
+        """Imagen.py:221-259.  All U-Nets stay on the GPU (288 GB of HBM); only the bookkeeping of the reference is kept."""
+        assert 0 < unet_number <= len(self.unets)
+        self.unet_being_trained_index = unet_number - 1
+        return self.unets[unet_number - 1]
+
+    def _p_losses(self, unet: Unet, x_start, times, *, noise_scheduler: GaussianDiffusion, lowres_cond_img=None, lowres_aug_times=None,
+                  text_embeds=None, text_mask=None, noise=None):
+        """Imagen.py:512-573: corrupt x_0 with q_sample, predict the noise, loss against the true noise"""
+        noise = default(noise, lambda: torch.randn_like(x_start))
+        norm = normalize_neg_one_to_one if self.auto_normalize_img else (lambda v: v)
+        x_start = norm(x_start)
+        x_noisy = noise_scheduler.q_sample(x_start=x_start, t=times, noise=noise)
+        lowres_noisy = None
+        if exists(lowres_cond_img):
+            lowres_aug_times = default(lowres_aug_times, times)
+            lowres_cond_img = norm(lowres_cond_img)
+            lowres_noisy = self.lowres_noise_schedule.q_sample(x_start=lowres_cond_img, t=lowres_aug_times, noise=torch.randn_like(lowres_cond_img))
+        pred = unet.forward(x_noisy, times, text_embeds=text_embeds, text_mask=text_mask, lowres_noise_times=lowres_aug_times,
+                            lowres_cond_img=lowres_noisy, cond_drop_prob=self.cond_drop_prob)
+        return {'l1': F.l1_loss, 'l2': F.mse_loss, 'huber': F.smooth_l1_loss}[self.loss_type](pred, noise)
+
+    def forward(self, images, texts: List[str] = None, text_embeds: torch.Tensor = None, text_masks: torch.Tensor = None, unet_number: int = None):
+        """Imagen.py:575-650: the training loss of ONE U-Net of the cascade on a batch of images + captions.  The U-Net runs through its
+        differentiable torch-op form when it is in train mode with autograd on (Unet._forward_train) and through the HIP engine otherwise
+        (evaluation of the loss)."""
+        assert not (len(self.unets) > 1 and not exists(unet_number)), \
+            f'you must specify which unet you want trained, from a range of 1 to {len(self.unets)}, if you are training cascading DDPM (multiple unets)'
+        unet_number = default(unet_number, 1)
+        assert not exists(self.only_train_unet_number) or self.only_train_unet_number == unet_number, \
+            f'you can only train on unet #{self.only_train_unet_number}'
+        k = unet_number - 1
+        unet, noise_scheduler, target = self._get_unet(unet_number), self.noise_schedulers[k], self.image_sizes[k]
+        prev = self.image_sizes[k - 1] if k > 0 else None
+        assert images.dim() == 4 and images.shape[1] == self.channels, f'images must be (b, {self.channels}, h, w)'
+        b, _, h, w = images.shape
+        assert h >= target and w >= target
+        times = noise_scheduler._sample_random_times(b, device=images.device)
+        if exists(texts) and not exists(text_embeds):
+            assert len(texts) == len(images), 'number of text captions does not match up with the number of images given'
+            text_embeds, text_masks = t5_encode_text(texts, name=self.text_encoder_name)
+            text_embeds, text_masks = text_embeds.to(images.device), text_masks.to(images.device)
+        assert exists(text_embeds), 'text or text encodings must be passed into decoder'
+        assert text_embeds.shape[-1] == self.text_embed_dim, f'invalid text embedding dimension being passed in (should be {self.text_embed_dim})'
+        lowres_cond_img = lowres_aug_times = None
+        if exists(prev):
+            lowres_cond_img = resize_image_to(images, prev, clamp_range=self.input_image_range, pad_mode='reflect')
+            lowres_cond_img = resize_image_to(lowres_cond_img, target, clamp_range=self.input_image_range, pad_mode='reflect')
+            lowres_aug_times = self.lowres_noise_schedule._sample_random_times(1, device=images.device).expand(b)
+        images = resize_image_to(images, target)
+        return self._p_losses(unet, images, times, text_embeds=text_embeds, text_mask=text_masks, noise_scheduler=noise_scheduler,
+                              lowres_cond_img=lowres_cond_img, lowres_aug_times=lowres_aug_times)
 
     # ------------------------------------------------------------------ sampling
     def _stage_state(self, ws, sched: GaussianDiffusion, B: int, n: int):

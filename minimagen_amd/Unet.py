@@ -6,6 +6,7 @@ from dataclasses import dataclass
 from typing import List, Union
 
 import torch
+import torch.nn.functional as F
 from torch import nn
 
 from .helpers import default, exists, cast_tuple, prob_mask_like
@@ -190,11 +191,75 @@ class Unet(nn.Module):
         """Unet.py:355-472 (noise prediction)."""
         assert not (self.lowres_cond and not exists(lowres_cond_img)), 'low resolution conditioning image must be present'
         assert not (self.lowres_cond and not exists(lowres_noise_times)), 'low resolution conditioning noise time must be present'
+        if self.training and torch.is_grad_enabled():
+            # training (Imagen.forward): the differentiable torch-op form of the same module tree; sampling / evaluation takes the HIP engine
+            return self._forward_train(x, time, lowres_cond_img=lowres_cond_img, lowres_noise_times=lowres_noise_times,
+                                       text_embeds=text_embeds, text_mask=text_mask, cond_drop_prob=cond_drop_prob)
         keep = prob_mask_like((x.shape[0],), 1 - cond_drop_prob, device='cpu')      # Unet.py:587
         with torch.no_grad():
             return self.engine().forward_once(x, time, lowres_cond_img=lowres_cond_img if self.lowres_cond else None,
                                               lowres_noise_times=lowres_noise_times if self.lowres_cond else None,
                                               text_embeds=text_embeds, text_mask=text_mask, keep=keep)
+
+    def _forward_train(self, x, time, *, lowres_cond_img=None, lowres_noise_times=None, text_embeds=None, text_mask=None,
+                       cond_drop_prob: float = 0.) -> torch.Tensor:
+        """Unet.py:355-472 as differentiable torch ops over the layers' own ``forward`` methods (minimagen_amd/layers.py): the training
+        path.  Same order of operations as the reference; per-sample conditioning dropout with probability ``cond_drop_prob``."""
+        b = x.shape[0]
+        # ---- conditioning (Unet.py:508-634)
+        hid = self.to_time_hiddens(time)
+        t, tokens = self.to_time_cond(hid), self.to_time_tokens[0](hid).reshape(b, self.num_time_tokens, self.cond_dim)
+        if self.lowres_cond:
+            lhid = self.to_lowres_time_hiddens(lowres_noise_times)
+            t = t + self.to_lowres_time_cond(lhid)
+            tokens = torch.cat((tokens, self.to_lowres_time_tokens[0](lhid).reshape(b, self.num_time_tokens, self.cond_dim)), dim=-2)
+        c = tokens
+        if exists(text_embeds):
+            text_tokens = self.text_to_cond(text_embeds)[:, :self.max_text_len]
+            pad = self.max_text_len - text_tokens.shape[1]
+            if pad > 0:
+                text_tokens = F.pad(text_tokens, (0, 0, 0, pad))
+            keep = prob_mask_like((b,), 1 - cond_drop_prob, device=x.device)
+            keep_embed = keep[:, None, None]
+            if exists(text_mask):
+                tm = text_mask[:, :self.max_text_len]
+                if pad > 0:
+                    tm = F.pad(tm, (0, pad), value=False)
+                keep_embed = tm[:, :, None] & keep_embed
+            text_tokens = torch.where(keep_embed, text_tokens, self.null_text_embed.to(text_tokens.dtype))
+            text_hiddens = self.to_text_non_attn_cond(text_tokens.mean(dim=-2))
+            t = t + torch.where(keep[:, None], text_hiddens, self.null_text_hidden.to(t.dtype))
+            c = torch.cat((tokens, text_tokens), dim=-2)
+        c = self.norm_cond(c)
+        # ---- trunk (Unet.py:396-472)
+        if self.lowres_cond:
+            x = torch.cat((x, lowres_cond_img), dim=1)
+        x = self.init_conv(x)
+        hiddens = []
+        for pre, first, blocks, attn, post in self.downs:
+            if exists(pre):
+                x = pre(x)
+            x = first(x, t, c)
+            for blk in blocks:
+                x = blk(x, t)
+                hiddens.append(x)
+            x = attn(x)
+            hiddens.append(x)
+            if exists(post):
+                x = post(x)
+        x = self.mid_block1(x, t, c)
+        if exists(self.mid_attn):
+            x = self.mid_attn(x)
+        x = self.mid_block2(x, t, c)
+        with_skip = lambda v: torch.cat((v, hiddens.pop() * self.skip_connect_scale), dim=1)
+        for first, blocks, attn, up in self.ups:
+            x = first(with_skip(x), t, c)
+            for blk in blocks:
+                x = blk(with_skip(x), t)
+            x = attn(x)
+            x = up(x)
+        x = self.final_res_block(x, t)
+        return self.final_conv(x)
 
     def forward_with_cond_scale(self, *args, cond_scale: float = 1., **kwargs) -> torch.Tensor:
         """Unet.py:474-506: both guidance halves run as ONE batch of 2B rows through the engine."""

@@ -125,8 +125,32 @@ def quantile_rank(n: int, q: float):
 
 
 def normalize_neg_one_to_one(img):
-    raise NotImplementedError("elementwise helpers run inside the HIP sampler kernels (mi_lowres_augment)")
+    """[0, 1] -> [-1, 1] (helpers.py:99-107).  The sampling path has this fused into mi_lowres_augment; this is the tensor form."""
+    return img * 2 - 1
 
 
 def unnormalize_zero_to_one(img):
-    raise NotImplementedError("elementwise helpers run inside the HIP sampler kernels (mi_finalize_images)")
+    """[-1, 1] -> [0, 1] (helpers.py:110-118; fused into mi_finalize_images on the sampling path)"""
+    return (img + 1) * 0.5
+
+
+def resize_image_to(image: torch.Tensor, target_image_size: int, clamp_range: tuple = None, pad_mode: str = 'reflect') -> torch.Tensor:
+    """helpers.py:138-164 as tensor ops (training path; the sampling path runs mi_resize_fwd on the same tap tables): resize_right's
+    cubic resampling, H pass then W pass, antialiased when shrinking; identity when the size already matches."""
+    orig = image.shape[-1]
+    if orig == target_image_size:
+        return image
+    out = image
+    for dim, in_sz in ((-2, image.shape[-2]), (-1, image.shape[-1])):
+        _, idx, w = cubic_taps(in_sz, int(round(target_image_size * in_sz / orig)), pad_mode)
+        idx, w = idx.long().to(out.device), w.to(out.device, out.dtype)
+        g = out.index_select(dim, idx.reshape(-1))
+        if dim == -2:
+            g = g.reshape(*out.shape[:-2], idx.shape[0], idx.shape[1], out.shape[-1])
+            out = (g * w[:, :, None]).sum(-2)
+        else:
+            g = g.reshape(*out.shape[:-1], idx.shape[0], idx.shape[1])
+            out = (g * w).sum(-1)
+    if exists(clamp_range):
+        out = out.clamp(*clamp_range)
+    return out

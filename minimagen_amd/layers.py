@@ -1,26 +1,44 @@
-"""Parameter containers with the reference's layer names (minimagen/layers.py).
+"""The reference's layers (minimagen/layers.py) under the reference's names and state-dict keys.
 
-These modules only HOLD parameters under the reference's state-dict keys and
-carry the default initialisation of the torch modules the reference uses.  They have no compute of
-their own: the arithmetic of each layer is a HIP kernel scheduled by ``minimagen_amd.engine`` from
-``Unet.forward``.  Calling one directly is an error.
+Two execution paths share these modules' parameters:
+
+* **sampling / inference** (the hot path): ``Unet.forward`` hands the whole module tree to ``minimagen_amd.engine``, which runs every
+  layer as hand-written HIP kernels -- the ``forward`` methods below are NOT on that path;
+* **training** (``Imagen.forward`` -> ``Unet.forward`` in train mode with autograd on): the ``forward`` methods below, plain
+  differentiable torch ops on whatever device the parameters live on.  They state each layer's arithmetic once more in the
+  reference's own order of operations, so the two paths can be tested against each other.
 """
 from __future__ import annotations
 
+import math
+
 import torch
+import torch.nn.functional as F
 from torch import nn
 
 from .helpers import default, exists
 
 
+def _tokens(x: torch.Tensor) -> torch.Tensor:
+    """'b c h w -> b (h w) c'"""
+    return x.flatten(2).transpose(1, 2)
+
+
+def _image(t: torch.Tensor, like: torch.Tensor) -> torch.Tensor:
+    """'b (h w) c -> b c h w'"""
+    return t.transpose(1, 2).reshape(like.shape[0], -1, *like.shape[2:])
+
+
 class _Container(nn.Module):
-    def forward(self, *args, **kwargs):
-        raise RuntimeError(f"{type(self).__name__} is a parameter container; its arithmetic runs in the HIP engine via Unet.forward")
+    pass
 
 
 class Identity(_Container):
     def __init__(self, *args, **kwargs):
         super().__init__()
+
+    def forward(self, x, *args, **kwargs):
+        return x
 
 
 class LayerNorm(_Container):
@@ -31,6 +49,9 @@ class LayerNorm(_Container):
         self.gamma = nn.Parameter(torch.ones(dim))
         self.register_buffer('beta', torch.zeros(dim))
 
+    def forward(self, x):
+        return F.layer_norm(x, x.shape[-1:], self.gamma, self.beta)
+
 
 class ChanLayerNorm(_Container):
     """layers.py:164-177"""
@@ -39,6 +60,11 @@ class ChanLayerNorm(_Container):
         super().__init__()
         self.eps = eps
         self.g = nn.Parameter(torch.ones(1, dim, 1, 1))
+
+    def forward(self, x):
+        var = torch.var(x, dim=1, unbiased=False, keepdim=True)
+        mean = torch.mean(x, dim=1, keepdim=True)
+        return (x - mean) / (var + self.eps).sqrt() * self.g
 
 
 class EinopsToAndFrom(_Container):
@@ -49,6 +75,10 @@ class EinopsToAndFrom(_Container):
         self.from_einops, self.to_einops = from_einops, to_einops
         self.fn = fn
 
+    def forward(self, x, **kwargs):
+        """only the 'b c h w' <-> 'b (h w) c' pair is used (layers.py:398, Unet.py:273)"""
+        return _image(self.fn(_tokens(x), **kwargs), x)
+
 
 class Residual(_Container):
     """layers.py:359-368"""
@@ -56,6 +86,9 @@ class Residual(_Container):
     def __init__(self, fn):
         super().__init__()
         self.fn = fn
+
+    def forward(self, x, **kwargs):
+        return self.fn(x, **kwargs) + x
 
 
 class Parallel(_Container):
@@ -65,6 +98,9 @@ class Parallel(_Container):
         super().__init__()
         self.fns = nn.ModuleList(fns)
 
+    def forward(self, x):
+        return sum(fn(x) for fn in self.fns)
+
 
 class SinusoidalPosEmb(_Container):
     """layers.py:442-465"""
@@ -72,6 +108,12 @@ class SinusoidalPosEmb(_Container):
     def __init__(self, dim: int):
         super().__init__()
         self.dim = dim
+
+    def forward(self, x):
+        half = self.dim // 2
+        freq = torch.exp(torch.arange(half, device=x.device) * -(math.log(10000) / (half - 1)))
+        arg = x[:, None] * freq[None, :]
+        return torch.cat((arg.sin(), arg.cos()), dim=-1)
 
 
 class Attention(_Container):
@@ -89,6 +131,26 @@ class Attention(_Container):
         self.to_context = nn.Sequential(nn.LayerNorm(context_dim), nn.Linear(context_dim, dim_head * 2)) if exists(context_dim) else None
         self.to_out = nn.Sequential(nn.Linear(inner_dim, dim, bias=False), LayerNorm(dim))
 
+    def forward(self, x, context=None, mask=None, attn_bias=None):
+        """layers.py:52-104: one key / value head shared by all query heads, a learned null key / value in front"""
+        b, n, _ = x.shape
+        x = self.norm(x)
+        q = self.to_q(x).reshape(b, n, self.heads, -1).transpose(1, 2) * self.scale
+        k, v = self.to_kv(x).chunk(2, dim=-1)
+        if exists(context) and exists(self.to_context):
+            ck, cv = self.to_context(context).chunk(2, dim=-1)
+            k, v = torch.cat((ck, k), dim=-2), torch.cat((cv, v), dim=-2)
+        nk, nv = (t.expand(b, 1, -1) for t in self.null_kv.unbind(dim=-2))
+        k, v = torch.cat((nk, k), dim=-2), torch.cat((nv, v), dim=-2)
+        sim = torch.einsum('bhid,bjd->bhij', q, k)
+        if exists(attn_bias):
+            sim = sim + attn_bias
+        if exists(mask):
+            sim = sim.masked_fill(~F.pad(mask, (1, 0), value=True)[:, None, None, :], -torch.finfo(sim.dtype).max)
+        attn = sim.softmax(dim=-1, dtype=torch.float32)
+        out = torch.einsum('bhij,bjd->bhid', attn, v).transpose(1, 2).reshape(b, n, -1)
+        return self.to_out(out)
+
 
 class Block(_Container):
     """layers.py:107-129"""
@@ -98,6 +160,13 @@ class Block(_Container):
         self.groupnorm = nn.GroupNorm(groups, dim) if norm else Identity()
         self.activation = nn.SiLU()
         self.project = nn.Conv2d(dim, dim_out, 3, padding=1)
+
+    def forward(self, x, scale_shift=None):
+        x = self.groupnorm(x)
+        if exists(scale_shift):
+            scale, shift = scale_shift
+            x = x * (scale + 1) + shift
+        return self.project(self.activation(x))
 
 
 def ChanFeedForward(dim: int, mult: int = 2) -> nn.Sequential:
@@ -129,6 +198,22 @@ class CrossAttention(_Container):
         self.to_kv = nn.Linear(context_dim, inner_dim * 2, bias=False)
         self.to_out = nn.Sequential(nn.Linear(inner_dim, dim, bias=False), LayerNorm(dim))
 
+    def forward(self, x, context, mask=None):
+        """layers.py:220-251"""
+        b, n, _ = x.shape
+        x, context = self.norm(x), self.norm_context(context)
+        heads = lambda t: t.reshape(b, t.shape[1], self.heads, -1).transpose(1, 2)
+        q = heads(self.to_q(x)) * self.scale
+        k, v = (heads(t) for t in self.to_kv(context).chunk(2, dim=-1))
+        nk, nv = (t.expand(b, self.heads, 1, -1) for t in self.null_kv.unbind(dim=-2))
+        k, v = torch.cat((nk, k), dim=-2), torch.cat((nv, v), dim=-2)
+        sim = torch.einsum('bhid,bhjd->bhij', q, k)
+        if exists(mask):
+            sim = sim.masked_fill(~F.pad(mask, (1, 0), value=True)[:, None, None, :], -torch.finfo(sim.dtype).max)
+        attn = sim.softmax(dim=-1, dtype=torch.float32)
+        out = torch.einsum('bhij,bhjd->bhid', attn, v).transpose(1, 2).reshape(b, n, -1)
+        return self.to_out(out)
+
 
 class CrossEmbedLayer(_Container):
     """layers.py:254-300"""
@@ -145,6 +230,9 @@ class CrossEmbedLayer(_Container):
         self.convs = nn.ModuleList([])
         for kernel, dim_scale in zip(kernel_sizes, dim_scales):
             self.convs.append(nn.Conv2d(dim_in, dim_scale, kernel, stride=stride, padding=(kernel - stride) // 2))
+
+    def forward(self, x):
+        return torch.cat([conv(x) for conv in self.convs], dim=1)
 
 
 def Downsample(dim: int, dim_out: int = None) -> nn.Conv2d:
@@ -169,6 +257,18 @@ class ResnetBlock(_Container):
         self.res_conv = nn.Conv2d(dim, dim_out, 1) if dim != dim_out else Identity()
         self.groups = groups
 
+    def forward(self, x, time_emb=None, cond=None):
+        """layers.py:417-439"""
+        scale_shift = None
+        if exists(self.time_mlp) and exists(time_emb):
+            scale_shift = self.time_mlp(time_emb)[:, :, None, None].chunk(2, dim=1)
+        h = self.block1(x)
+        if exists(self.cross_attn):
+            assert exists(cond)
+            h = self.cross_attn(h, context=cond) + h
+        h = self.block2(h, scale_shift=scale_shift)
+        return h + self.res_conv(x)
+
 
 class TransformerBlock(_Container):
     """layers.py:468-494"""
@@ -177,6 +277,10 @@ class TransformerBlock(_Container):
         super().__init__()
         self.attn = EinopsToAndFrom('b c h w', 'b (h w) c', Attention(dim=dim, heads=heads, dim_head=dim_head, context_dim=context_dim))
         self.ff = ChanFeedForward(dim=dim, mult=ff_mult)
+
+    def forward(self, x, context=None):
+        x = self.attn(x, context=context) + x
+        return self.ff(x) + x
 
 
 def Upsample(dim: int, dim_out: int = None) -> nn.Sequential:

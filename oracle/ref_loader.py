@@ -120,16 +120,25 @@ def load_reference():
     if not reference_available():
         raise RuntimeError(f"reference not found at {REFERENCE_ROOT}")
     _install_shims()
-    # the reference package is called ``minimagen``; make sure we import *it*
-    if REFERENCE_ROOT not in sys.path:
-        sys.path.insert(0, REFERENCE_ROOT)
+    # The reference package is called ``minimagen`` -- and so is the repo's drop-in alias package (minimagen/__init__.py re-exports
+    # minimagen_amd).  Load the reference under a PRIVATE package name from its own directory (its modules import each other
+    # relatively), so that "the reference" can never silently resolve to the implementation under test.
+    import importlib.util
+    pkg_dir = os.path.join(REFERENCE_ROOT, "minimagen")
+    name = "_reference_minimagen"
+    spec = importlib.util.spec_from_file_location(name, os.path.join(pkg_dir, "__init__.py"), submodule_search_locations=[pkg_dir])
+    pkg = importlib.util.module_from_spec(spec)
+    sys.modules[name] = pkg
+    spec.loader.exec_module(pkg)
     ns = types.SimpleNamespace()
-    ns.Imagen_mod = importlib.import_module("minimagen.Imagen")
-    ns.Unet_mod = importlib.import_module("minimagen.Unet")
-    ns.layers = importlib.import_module("minimagen.layers")
-    ns.helpers = importlib.import_module("minimagen.helpers")
-    ns.diffusion_model = importlib.import_module("minimagen.diffusion_model")
-    ns.t5 = importlib.import_module("minimagen.t5")
+    ns.Imagen_mod = importlib.import_module(name + ".Imagen")
+    ns.Unet_mod = importlib.import_module(name + ".Unet")
+    ns.layers = importlib.import_module(name + ".layers")
+    ns.helpers = importlib.import_module(name + ".helpers")
+    ns.diffusion_model = importlib.import_module(name + ".diffusion_model")
+    ns.t5 = importlib.import_module(name + ".t5")
+    for m in (ns.Imagen_mod, ns.Unet_mod, ns.layers, ns.helpers, ns.diffusion_model, ns.t5):
+        assert os.path.abspath(m.__file__).startswith(os.path.abspath(pkg_dir)), f"{m.__name__} was not loaded from the reference tree"
     ns.Imagen = ns.Imagen_mod.Imagen
     ns.Unet = ns.Unet_mod.Unet
     ns.GaussianDiffusion = ns.diffusion_model.GaussianDiffusion
