@@ -272,6 +272,7 @@ def main():
     ap.add_argument("--t5", action="store_true", help="also time the T5 text-embedding pass (K16) for the batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true", help="make every sample() call wait for the previous one (no cross-call stage pipelining)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short runs of the other single-GPU BASELINE configurations")
     ap.add_argument("--breakdown-out", default="")
     args = ap.parse_args()
@@ -306,7 +307,12 @@ def main():
     emb, mask = emb.to(dev), mask.to(dev)
 
     def one_step(k):
-        out = im.sample(text_embeds=emb, text_masks=mask, cond_scale=args.cond_scale, _seed=1234 + k, _sample_offset=rank * B, _precision=args.precision)
+        # successive sample() calls are pipelined across the per-stage HIP streams (_async: the caller's stream is not made to wait; the
+        # timed region ends with a device-wide synchronize, so every image is finished inside it)
+        out = im.sample(text_embeds=emb, text_masks=mask, cond_scale=args.cond_scale, _seed=1234 + k, _sample_offset=rank * B, _precision=args.precision,
+                        _async=not args.no_pipeline)
+        if world > 1:
+            torch.cuda.current_stream().wait_event(im.last_sample_done) if not args.no_pipeline else None
         if world > 1 and one_gpu:
             host = out.cpu()
             pad = [torch.empty_like(host) for _ in range(world)]

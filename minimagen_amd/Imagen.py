@@ -255,11 +255,16 @@ class Imagen(nn.Module):
         t_low = int(self.lowres_noise_schedule.num_timesteps * lowres_noise_level)          # diffusion_model.py:68-69
         ws.lowres_times.fill_(t_low)
         if Hin != image_size:
-            _, idx_h, w_h = cubic_taps(Hin, image_size)
-            _, idx_w, w_w = cubic_taps(Win, image_size)
-            tabs = [t.to(ws.dev) for t in (idx_h, w_h, idx_w, w_w)]
+            # tap tables: built and uploaded once per (workspace, source size) -- an upload from pageable host memory per call would
+            # block the host behind the previous call still running on this stage's stream
+            cache = ws.__dict__.setdefault("resize_tabs", {})
+            if (Hin, Win) not in cache:
+                _, idx_h, w_h = cubic_taps(Hin, image_size)
+                _, idx_w, w_w = cubic_taps(Win, image_size)
+                cache[(Hin, Win)] = ([t.to(ws.dev) for t in (idx_h, w_h, idx_w, w_w)], idx_h.shape[1], idx_w.shape[1])
+            tabs, kh, kw = cache[(Hin, Win)]
             up = torch.empty(B, Cc, image_size, image_size, dtype=torch.float32, device=ws.dev)
-            rp = L.MiResizeParams(B * Cc, Hin, Win, image_size, image_size, idx_h.shape[1], idx_w.shape[1], L.ptr(img), L.ptr(up),
+            rp = L.MiResizeParams(B * Cc, Hin, Win, image_size, image_size, kh, kw, L.ptr(img), L.ptr(up),
                                   L.ptr(tabs[0]), L.ptr(tabs[1]), L.ptr(tabs[2]), L.ptr(tabs[3]))
             L.check(lib.mi_resize_fwd(C.byref(rp), stream), "mi_resize_fwd")
             ws.resize_keepalive = tabs
@@ -271,8 +276,8 @@ class Imagen(nn.Module):
         else:
             noise = torch.empty_like(up)
             L.check(lib.mi_randn_fill(L.ptr(noise), B, n, seed, sample0, (stage << 20) | (1 << 19), stream), "mi_randn_fill")
-        a = float(self.lowres_noise_schedule.sqrt_alphas_cumprod[t_low])
-        b = float(self.lowres_noise_schedule.sqrt_one_minus_alphas_cumprod[t_low])
+        a = self.lowres_noise_schedule._host_sqrt_alphas_cumprod[t_low]
+        b = self.lowres_noise_schedule._host_sqrt_one_minus_alphas_cumprod[t_low]
         L.check(lib.mi_lowres_augment(L.ptr(up), L.ptr(noise), L.ptr(ws.lowres), B * n, a, b, 1 if self.auto_normalize_img else 0, stream), "mi_lowres_augment")
         ws.lowres_keepalive = (up, noise)
         unet = [u for u in self.unets if u.engine()._ws and ws in u.engine()._ws.values()][0]
@@ -283,11 +288,13 @@ class Imagen(nn.Module):
     def sample(self, texts: List[str] = None, text_masks: torch.Tensor = None, text_embeds: torch.Tensor = None,
                cond_scale: float = 1., lowres_sample_noise_level: float = None, return_pil_images: bool = False,
                device: torch.device = None, *, _noise: Callable = None, _seed: int = 1234, _sample_offset: int = 0,
-               _use_graph: bool = True, _precision: str = None):
+               _use_graph: bool = True, _precision: str = None, _async: bool = False):
         """minimagen/Imagen.py:424-510.  Private keyword-only extras (not in the reference): ``_noise(shape)`` injects a
         host noise stream in the reference's draw order (parity runs); otherwise noise is Philox keyed by
         (``_seed``, ``_sample_offset`` + row, stage, step, element) so a sharded batch reproduces the unsharded one;
-        ``_precision`` = "fp32" (default) or "half" (single-fp16-term matrix-core contractions, see engine.UnetEngine.precision)."""
+        ``_precision`` = "fp32" (default) or "half" (single-fp16-term matrix-core contractions, see engine.UnetEngine.precision);
+        ``_async=True`` returns without making the caller's stream wait (``self.last_sample_done`` is the completion event): successive
+        calls then pipeline across the per-stage streams (the base stage of the next batch under the super-resolution stage of this one)."""
         device = default(device, self.device)
         self._reset_unets_all_one_device(device=device)
         if exists(texts) and not exists(text_embeds):
@@ -307,33 +314,53 @@ class Imagen(nn.Module):
         text_embeds = text_embeds.to(device)
         text_masks = text_masks.to(device) if exists(text_masks) else None
 
-        # HIP graphs cannot be captured on the legacy default stream: the whole cascade runs on a dedicated stream
+        # One HIP stream PER STAGE (graphs cannot be captured on the legacy default stream anyway).  Within a call stage s + 1 waits for
+        # stage s through an event; ACROSS calls the stages form a pipeline: with ``_async=True`` the caller's stream is never made to
+        # wait, so the (small, latency-bound) base stage of call k + 1 runs on its stream while the super-resolution stage of call k
+        # still occupies the other -- each stage owns its workspace, so nothing is shared but the finished image handed down the cascade.
         on_gpu = L.backend() == "hip-gfx950"
+        for unet in self.unets:
+            unet.engine().pack()                         # validate / refresh the packed weights once per call, on the caller's stream
         if on_gpu:
-            if getattr(self, "_stream", None) is None or self._stream.device != device:
-                self._stream = torch.cuda.Stream(device=device)
+            streams = getattr(self, "_stage_streams", None)
+            if streams is None or len(streams) != len(self.unets) or streams[0].device != device:
+                # earlier (smaller-image, latency-bound) stages get the higher stream priority: their short kernels then slot in between the
+                # workgroups of the later stages' large ones instead of queueing behind them
+                prio = int(os.environ.get("MINIMAGEN_STAGE_PRIORITY", "1"))
+                streams = self._stage_streams = [torch.cuda.Stream(device=device, priority=(-1 if (prio and k + 1 < len(self.unets)) else 0))
+                                                 for k in range(len(self.unets))]
+            self._stream = streams[-1]                   # (benchmarks time the last stage's captured graph on its own stream)
             caller_stream = torch.cuda.current_stream(device)
-            self._stream.wait_stream(caller_stream)
-            ctx = torch.cuda.stream(self._stream)
-        else:
-            from .helpers import null_context
-            ctx = null_context()
-        img = None
-        with ctx:
-            for stage, (unet, channel, image_size, noise_scheduler) in enumerate(
-                    zip(self.unets, self.sample_channels, self.image_sizes, self.noise_schedulers)):
+            inputs_ready = caller_stream.record_event()
+        from .helpers import null_context
+        img, prev_done = None, None
+        for stage, (unet, channel, image_size, noise_scheduler) in enumerate(
+                zip(self.unets, self.sample_channels, self.image_sizes, self.noise_schedulers)):
+            if on_gpu:
+                streams[stage].wait_event(inputs_ready)
+                if prev_done is not None:
+                    streams[stage].wait_event(prev_done)
+            with (torch.cuda.stream(streams[stage]) if on_gpu else null_context()):
                 eng = unet.engine()
                 # per call, never sticky engine state: a later Unet.forward stays on the engine's default precision
                 ws = eng.workspace(batch_size, B2, image_size, image_size,
                                    precision=_precision if _precision is not None else os.environ.get("MINIMAGEN_PRECISION", "fp32"))
                 eng.set_text(ws, text_embeds, text_masks, keep)
                 if unet.lowres_cond:
+                    if on_gpu:
+                        img.record_stream(streams[stage])
                     self._lowres_conditioning(img, image_size, ws, lowres_sample_noise_level, _noise, _seed, _sample_offset, stage)
                 img = self._p_sample_loop(unet, (batch_size, self.channels, image_size, image_size), noise_scheduler=noise_scheduler,
                                           ws=ws, cond_scale=cond_scale, noise_fn=_noise, seed=_seed, sample0=_sample_offset,
                                           stage=stage, use_graph=_use_graph)
+                if on_gpu:
+                    prev_done = streams[stage].record_event()
         if on_gpu:
-            caller_stream.wait_stream(self._stream)
+            if _async:
+                # pipelined use: the result is ready when ``done`` is (the caller synchronises / waits on it before touching the images)
+                self.last_sample_done = prev_done
+                return img if not return_pil_images else _to_pil_images(img)
+            caller_stream.wait_event(prev_done)
             img.record_stream(caller_stream)
         if not return_pil_images:
             return img

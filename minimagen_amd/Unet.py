@@ -165,9 +165,10 @@ class Unet(nn.Module):
         return out
 
     def _apply(self, fn, *args, **kwargs):
-        out = super()._apply(fn, *args, **kwargs)           # .to() / .cuda() / .float(): the packed copies point at the old storage
-        if getattr(self, '_engine', None) is not None:
-            self._engine.invalidate()
+        before = [t.data_ptr() for t in self.parameters()]
+        out = super()._apply(fn, *args, **kwargs)           # .to() / .cuda() / .float(): the packed copies point at the old storage ...
+        if getattr(self, '_engine', None) is not None and before != [t.data_ptr() for t in self.parameters()]:
+            self._engine.invalidate()                       # ... but a no-op move (Imagen.sample re-homes the U-Nets on every call) keeps them
         return out
 
     # ------------------------------------------------------------------ reference API
@@ -263,9 +264,13 @@ class Unet(nn.Module):
 
     def forward_with_cond_scale(self, *args, cond_scale: float = 1., **kwargs) -> torch.Tensor:
         """Unet.py:474-506: both guidance halves run as ONE batch of 2B rows through the engine."""
-        if cond_scale == 1:
-            return self.forward(*args, **kwargs)
         x, time = args
+        if cond_scale == 1:         # the sampling API: always the HIP engine (no conditioning dropout), whatever the module's train flag
+            with torch.no_grad():
+                return self.engine().forward_once(x, time, lowres_cond_img=kwargs.get('lowres_cond_img') if self.lowres_cond else None,
+                                                  lowres_noise_times=kwargs.get('lowres_noise_times') if self.lowres_cond else None,
+                                                  text_embeds=kwargs.get('text_embeds'), text_mask=kwargs.get('text_mask'),
+                                                  keep=torch.ones(x.shape[0], dtype=torch.bool))
         assert not (self.lowres_cond and not exists(kwargs.get('lowres_cond_img'))), 'low resolution conditioning image must be present'
         assert not (self.lowres_cond and not exists(kwargs.get('lowres_noise_times'))), 'low resolution conditioning noise time must be present'
         with torch.no_grad():

@@ -36,6 +36,10 @@ class GaussianDiffusion(nn.Module):
         reg('posterior_log_variance_clipped', torch.log(posterior_variance.clamp(min=1e-20)))
         reg('posterior_mean_coef1', betas * torch.sqrt(alphas_cumprod_prev) / (1. - alphas_cumprod))
         reg('posterior_mean_coef2', (1. - alphas_cumprod_prev) * torch.sqrt(alphas) / (1. - alphas_cumprod))
+        # host copies of the two q_sample tables (same fp32 values): the sampler reads one scalar of each per stage, and reading it from
+        # the device buffer would synchronise the host with that stage's stream -- i.e. with the previous call still running on it
+        self._host_sqrt_alphas_cumprod = self.sqrt_alphas_cumprod.tolist()
+        self._host_sqrt_one_minus_alphas_cumprod = self.sqrt_one_minus_alphas_cumprod.tolist()
 
     def _get_times(self, batch_size: int, noise_level: float, *, device) -> torch.Tensor:
         """diffusion_model.py:68-69"""

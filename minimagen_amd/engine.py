@@ -216,8 +216,14 @@ class UnetEngine:
         return pk
 
     # ------------------------------------------------------------------ workspace / program
+    def packed(self):
+        """The packed weights as validated by the last ``pack()`` (one validation -- a device-side fingerprint compare, i.e. a host
+        synchronisation -- per public call, not one per internal step: in the pipelined sampler a sync on a stage's stream would stall the
+        host behind that stage's queued work)."""
+        return self._pack if self._pack is not None else self.pack()
+
     def workspace(self, B: int, B2: int, H: int, W: int, precision: Optional[str] = None, has_text: bool = True) -> Workspace:
-        pk = self.pack()
+        pk = self.packed()
         dev = next(self.unet.parameters()).device
         precision = self.precision if precision is None else precision
         assert precision in ("fp32", "half"), precision
@@ -641,7 +647,7 @@ class UnetEngine:
     # ------------------------------------------------------------------ execution
     def set_text(self, ws, text_embeds: torch.Tensor, text_mask: Optional[torch.Tensor], keep: torch.Tensor):
         """K2 + the step-invariant part of the context fold.  Once per ``sample()`` / ``forward``."""
-        u, pk, lib = self.unet, self.pack(), L.lib()
+        u, pk, lib = self.unet, self.packed(), L.lib()
         st = L.current_stream()
         if text_embeds is None:
             # Unet.py:572-634 without text: no text hiddens are added to t, the context is [null | time tokens]; only the null row is written here
@@ -653,7 +659,12 @@ class UnetEngine:
         text_embeds = text_embeds.to(device=ws.dev, dtype=torch.float32).contiguous()
         assert text_embeds.shape[0] == ws.B and text_embeds.shape[-1] == u.text_embed_dim
         mask8 = None if text_mask is None else text_mask.to(device=ws.dev).to(torch.uint8).contiguous()
-        ws.keep.copy_(keep.to(torch.uint8))
+        # a host -> device copy from pageable memory blocks the host behind everything queued on this stream (the previous call's stage,
+        # in the pipelined sampler): skip it when the guidance pattern is the one already on the device (every sampling call)
+        k8 = keep.to(device='cpu', dtype=torch.uint8)
+        if getattr(ws, "keep_host", None) is None or not torch.equal(ws.keep_host, k8):
+            ws.keep.copy_(k8)
+            ws.keep_host = k8.clone()
         ws.text_keepalive = (text_embeds, mask8)
         L.require_device(text_embeds, mask8)
         p = L.MiTextCondParams()
@@ -684,7 +695,7 @@ class UnetEngine:
         cross-attention context) for ALL T timesteps -- the sequence T-1 .. 0 is known in advance and identical for every sample -- so
         that the denoising step only scatters row ``t`` of the tables (one small launch instead of cond_step + fold).  Same kernels,
         same arithmetic, same bits as the step-at-a-time path."""
-        u, pk, lib = self.unet, self.pack(), L.lib()
+        u, pk, lib = self.unet, self.packed(), L.lib()
         st = L.current_stream() if stream is None else stream
         B2, dev = ws.B2, ws.dev
         if ws.wide_attn:                 # the wide cross-attention projects the time tokens per step from ws.c_time: keep the per-step conditioning

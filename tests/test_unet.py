@@ -15,7 +15,7 @@ def make_unet(which, dev):
     p = I.unet_params()
     u = Unet(**p[which])
     u.load_state_dict(I.load(f"{which}_sd.pt"), strict=True)
-    return u.to(dev)
+    return u.to(dev).eval()          # inference: the HIP engine (train mode + autograd would take the differentiable torch-op path)
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
@@ -131,7 +131,7 @@ def test_wide_channel_unet_vs_oracle(backend):
     torch.manual_seed(5)
     u = Unet(**WIDE_SMALL)
     sd = {k: v.clone() for k, v in u.state_dict().items()}
-    u = u.to(dev)
+    u = u.to(dev).eval()
     B, S = (2, 32) if backend == "gpu" else (1, 16)
     emb, mask = R.synthetic_text(B, length=12, seed=4)
     x, tm = I.seeded((B, 3, S, S), 31), torch.tensor([77, 5][:B])
@@ -151,7 +151,7 @@ def test_default_unet_vs_oracle(backend):
     torch.manual_seed(6)
     u = Unet()
     sd = {k: v.clone() for k, v in u.state_dict().items()}
-    u = u.to(dev)
+    u = u.to(dev).eval()
     emb, mask = R.synthetic_text(2, length=20, seed=8)
     x, tm = I.seeded((2, 3, 64, 64), 41), torch.tensor([90, 11])
     o = u.forward_with_cond_scale(x.to(dev), tm.to(dev), text_embeds=emb.to(dev), text_mask=mask.to(dev), cond_scale=3.)
@@ -163,7 +163,7 @@ def test_default_unet_vs_oracle(backend):
         torch.manual_seed(7)
         m = klass(**kw)
         sdm = {k: v.clone() for k, v in m.state_dict().items()}
-        m = m.to(dev)
+        m = m.to(dev).eval()
         xm = I.seeded((1, 3, 64, 64), 43)
         extra = dict(lowres_cond_img=I.seeded((1, 3, 64, 64), 44), lowres_noise_times=torch.tensor([20])) if m.lowres_cond else {}
         om = m(xm.to(dev), torch.tensor([50]).to(dev), text_embeds=emb[:1].to(dev), text_mask=mask[:1].to(dev),
@@ -305,7 +305,7 @@ def test_attention_bearing_unet_vs_oracle(backend):
             if n.endswith(("gamma", ".g")) or "norm" in n and n.endswith("weight"):
                 p.copy_(1 + 0.2 * torch.randn(p.shape))
     sd = {k: v.clone() for k, v in u.state_dict().items()}
-    u = u.to(dev)
+    u = u.to(dev).eval()
     emb, mask = R.synthetic_text(2, length=12, seed=3)
     x = I.seeded((2, 3, 32, 32), 6)
     tm = torch.tensor([3, 9])
@@ -340,7 +340,7 @@ def test_config_sweep_vs_oracle(backend, case):
     torch.manual_seed(1)
     u = Unet(**kw)
     sd = {k: v.clone() for k, v in u.state_dict().items()}
-    u = u.to(dev)
+    u = u.to(dev).eval()
     E, ch = extra.get("E", 512), extra.get("ch", 3)
     emb, mask = R.synthetic_text(2, length=10, seed=3)
     if E != 512:
@@ -361,7 +361,7 @@ def test_self_attention_4096_tokens(backend):
     torch.manual_seed(5)
     u = Unet(dim=8, dim_mults=(1, 2), num_resnet_blocks=1, layer_attns=(True, True), layer_cross_attns=False, memory_efficient=True, lowres_cond=True)
     sd = {k: v.clone() for k, v in u.state_dict().items()}
-    u = u.to(dev)
+    u = u.to(dev).eval()
     emb, mask = R.synthetic_text(2, length=20, seed=3)
     x, lr = I.seeded((2, 3, 128, 128), 6), I.seeded((2, 3, 128, 128), 7)
     tm, lt = torch.tensor([3, 90]), torch.tensor([20, 20])
