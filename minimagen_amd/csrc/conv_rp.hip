@@ -26,12 +26,13 @@ typedef _Float16 rp_f16x2 __attribute__((ext_vector_type(2)));
 typedef float rp_f32x2 __attribute__((ext_vector_type(2)));
 
 #ifdef MI_TRACE
-// development aid (tools/bench_conv.py): accumulated shader-clock time per phase of the first workgroups of the last launch
+// development aid (tools/bench_conv.py): accumulated shader-clock time per phase of the first workgroups of the last launch, and
+// (slot 7) their start / end on the 100 MHz wall clock
 __device__ unsigned long long mi_trace_rp_buf[1024 * 8];
 extern "C" int mi_debug_read_trace_rp(void* dst, size_t bytes) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(mi_trace_rp_buf), bytes); }
-#define RP_TSTART() unsigned long long rp_t_last = clock64(), rp_t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define RP_TSTART() const unsigned long long rp_t_wall0 = wall_clock64(); unsigned long long rp_t_last = clock64(), rp_t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
 #define RP_TPHASE(k) do { const unsigned long long rp_t_now = clock64(); rp_t_acc[k] += rp_t_now - rp_t_last; rp_t_last = rp_t_now; } while (0)
-#define RP_TEND() do { if (threadIdx.x == 0 && blockIdx.x < 1024) for (int k = 0; k < 8; ++k) mi_trace_rp_buf[blockIdx.x * 8 + k] = rp_t_acc[k]; } while (0)
+#define RP_TEND() do { rp_t_acc[7] = (rp_t_wall0 << 32) | (wall_clock64() & 0xffffffffull); if (threadIdx.x == 0 && blockIdx.x < 1024) for (int k = 0; k < 8; ++k) mi_trace_rp_buf[blockIdx.x * 8 + k] = rp_t_acc[k]; } while (0)
 #else
 #define RP_TSTART() do { } while (0)
 #define RP_TPHASE(k) do { } while (0)

@@ -90,6 +90,21 @@ def run(B, C0, Cout, H, W, gn, res, path, C1=0, reps=20, nt_in=None):
         for i, n in enumerate(names):
             print(f"      {n:34s} {np.median(t[:, i]):9.0f} {np.percentile(t[:, i], 10):9.0f} {np.percentile(t[:, i], 90):9.0f}")
         print(f"      total                              {np.median(t[:, :7].sum(1)):9.0f}")
+        w = buf.reshape(1024, 8)[:, 7]
+        w0 = ((w >> np.uint64(32)) & np.uint64(0xffffffff)).astype(np.int64); w1 = (w & np.uint64(0xffffffff)).astype(np.int64)
+        ok = w1 > 0
+        if ok.any():
+            w0, w1 = w0[ok], w1[ok]; base = w0.min()
+            life = (w1 - w0) / 100.0
+            idx = np.nonzero(ok)[0]
+            for x in range(8):
+                m = (idx % 8) == x
+                print(f"        xcd {x}: end med {np.median(w1[m] - base) / 100.0:6.1f} min {np.min(w1[m] - base) / 100.0:6.1f} max {np.max(w1[m] - base) / 100.0:6.1f} us")
+            q = (idx // 8) % 4
+            print("        by (blockIdx/8)%4:", [float(np.median(w1[q == k] - base)) / 100.0 for k in range(4)])
+            print("        by blockIdx range quartile:", [float(np.median(w1[(idx * 4 // 1024) == k] - base)) / 100.0 for k in range(4)])
+            print(f"      wall: starts {np.percentile(w0 - base, [0, 50, 90, 100]) / 100.0} us, ends {np.percentile(w1 - base, [0, 50, 90, 100]) / 100.0} us, life med {np.median(life):.1f} us"
+                  f" -> clock {np.median(t[ok][:, :7].sum(1) / np.maximum(life, 1e-3)) / 1e3:.2f} GHz")
     return us
 
 

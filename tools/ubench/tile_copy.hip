@@ -10,7 +10,7 @@
 #include <cstdlib>
 
 template <int LOADP, int STOREP>
-__global__ __launch_bounds__(256, 4) void k(const float* __restrict__ in, float* __restrict__ out, int B, int H, int W, int ntile) {
+__global__ __launch_bounds__(256, 4) void k(const float* __restrict__ in, float* __restrict__ out, int B, int H, int W, int ntile, int ilv) {
     constexpr int TH = 8, TW = 64;
     __shared__ float lds[10 * 72 * 8];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lq = lane & 15, lg = lane >> 4;
@@ -52,9 +52,11 @@ __global__ __launch_bounds__(256, 4) void k(const float* __restrict__ in, float*
             }
         }
     };
-    load(strip * ntile);
+    // ilv 1: workgroup s walks tiles s, s + strips, s + 2 strips, ... instead of a contiguous strip
+    auto tile_of = [&](int t) { return ilv ? strip + t * strips : strip * ntile + t; };
+    load(tile_of(0));
     for (int t = 0; t < ntile; ++t) {
-        const int tile = strip * ntile + t;
+        const int tile = tile_of(t);
         const int oy0 = (tile / tiles_x) * TH, ox0 = (tile % tiles_x) * TW;
         __syncthreads();
         // stage through LDS as [ch][row 10][col 72] floats
@@ -80,7 +82,7 @@ __global__ __launch_bounds__(256, 4) void k(const float* __restrict__ in, float*
             }
         }
         __syncthreads();
-        if (t + 1 < ntile) load(tile + 1);
+        if (t + 1 < ntile) load(tile_of(t + 1));
         if (STOREP == 0) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -102,7 +104,7 @@ __global__ __launch_bounds__(256, 4) void k(const float* __restrict__ in, float*
 }
 
 template <int LOADP, int STOREP>
-void run(int ntile) {
+void run(int ntile, int ilv = 0) {
     const int B = 64, H = 256, W = 256;
     const size_t n = (size_t)B * 8 * H * W;
     float *in, *out;
@@ -111,17 +113,18 @@ void run(int ntile) {
     const int tiles = (H / 8) * (W / 64);
     dim3 grid(B * tiles / ntile);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(HIP_KERNEL_NAME(k<LOADP, STOREP>), grid, dim3(256), 0, 0, in, out, B, H, W, ntile);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(HIP_KERNEL_NAME(k<LOADP, STOREP>), grid, dim3(256), 0, 0, in, out, B, H, W, ntile, ilv);
     hipEventRecord(e0);
-    for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(HIP_KERNEL_NAME(k<LOADP, STOREP>), grid, dim3(256), 0, 0, in, out, B, H, W, ntile);
+    for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(HIP_KERNEL_NAME(k<LOADP, STOREP>), grid, dim3(256), 0, 0, in, out, B, H, W, ntile, ilv);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
-    printf("load pattern %d, store pattern %d, %d tiles/WG: %.1f us  (%.2f TB/s of 268 MB)\n", LOADP, STOREP, ntile, ms / 20 * 1e3, 2.0 * n * 4 / (ms / 20 * 1e-3) * 1e-12);
+    printf("load pattern %d, store pattern %d, %d tiles/WG%s: %.1f us  (%.2f TB/s of 268 MB)\n", LOADP, STOREP, ntile, ilv ? " interleaved" : "", ms / 20 * 1e3, 2.0 * n * 4 / (ms / 20 * 1e-3) * 1e-12);
     hipFree(in); hipFree(out);
 }
 int main() {
     for (int nt : {1, 4, 8}) {
         run<0, 0>(nt); run<0, 1>(nt); run<1, 0>(nt); run<1, 1>(nt); run<2, 1>(nt); run<2, 0>(nt);
     }
+    for (int nt : {4, 8}) { run<0, 0>(nt, 1); run<2, 1>(nt, 1); }
     return 0;
 }
