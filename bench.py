@@ -191,7 +191,7 @@ def pmc_traffic(dom, rows, S):
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_cascade_T25_pmc_by_launch_shape.csv")))
     if not files or dom["kernel"] != "cross_attn":
         return {"traffic": None}
-    grid = rows * (-(-(S // 4) * (S // 4) // 64)) * 256          # bottleneck level = S/4; 64 tokens per 256-thread workgroup
+    grid = rows * (-(-(S // 4) * (S // 4) // 128)) * 512         # bottleneck level = S/4; 128 tokens per 512-thread workgroup (attention.hip launcher)
     for r in csv.DictReader(open(files[-1])):
         if "cross_attn" in r["kernel"] and int(r["grid"]) == grid and r["fetch_MB_x2"] not in ("", "None") and r["write_MB"] not in ("", "None"):
             return {"traffic": (float(r["fetch_MB_x2"]) + float(r["write_MB"])) * 1e6,

@@ -734,6 +734,8 @@ int launch_rp_kr(const mi_conv_params& p, hipStream_t st) {
         if (ko == 2 && ro == 0) return launch_rp_v<TH, TW, NJ, MODE, 2, 0>(p, st);
         if (ko == 4 && ro == 0) return launch_rp_v<TH, TW, NJ, MODE, 4, 0>(p, st);
         if (ko == 2 && ro == 4) return launch_rp_v<TH, TW, NJ, MODE, 2, 4>(p, st);
+        if (ko == 3 && ro == 0) return launch_rp_v<TH, TW, NJ, MODE, 3, 0>(p, st);      // 16 + 8 skip channels (base U-Net, 32^2 level)
+        if (ko == 2 && ro == 3) return launch_rp_v<TH, TW, NJ, MODE, 2, 3>(p, st);
     }
     return launch_rp_v<TH, TW, NJ, MODE, -1, -1>(p, st);
 }

@@ -123,6 +123,9 @@ RP_CASES = [
     (1, 8, 0, 8, 16, 32, False, False, 'id', 7, 4096.0, 1.0 / 300),
     (2, 8, 0, 8, 40, 128, True, True, 'id', 6 | (3 << 12), 1.0, 1.0),        # strips of 3 tiles per workgroup (ragged last strip)
     (1, 16, 16, 16, 24, 64, True, True, 'conv2', 7 | (4 << 12), 1.0, 1.0),   # strips x several rounds (concat input + 1x1 residual)
+    (2, 16, 8, 16, 32, 64, True, True, 'none', 6 | (2 << 12), 1.0, 1.0),     # 16 + 8 skip channels -> 16 (base U-Net up path, Unet.py:166-178)
+    (2, 16, 0, 16, 32, 32, True, True, 'conv2', 7, 1.0, 1.0),                # ... and its second conv with the 1x1 residual over the 24
+    (1, 16, 0, 16, 16, 64, True, False, 'conv2', 6, 1.0 / 256, 1.0),
 ]
 
 

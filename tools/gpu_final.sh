@@ -2,7 +2,7 @@
 # Round deliverables on the GPU box: GPU test-suite, smoke, default bench (with cpu_baseline), rocprofv3 trace + PMC passes.
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 ROOTDIR=$(pwd); OUT=$ROOTDIR/gpurun_out; mkdir -p $OUT
-timeout 900 python -m pytest tests -m gpu -q --timeout 600 > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -4 $OUT/pytest_gpu.log
+timeout 1500 python -m pytest tests -m gpu -q --timeout 900 > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -4 $OUT/pytest_gpu.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke rc=$?"; tail -1 $OUT/smoke.log
 timeout 600 python bench.py --breakdown-out $OUT/bd_cascade.json > $OUT/bench_cascade.log 2>&1; echo "bench rc=$?"; tail -1 $OUT/bench_cascade.log
 timeout 300 python bench.py --precision half --no-cpu-baseline --no-secondary --breakdown-out $OUT/bd_half.json > $OUT/bench_half.log 2>&1; tail -1 $OUT/bench_half.log | cut -c1-200

@@ -57,3 +57,27 @@ with open(f"profiles/{tag}_cascade_T25_pmc_by_launch_shape.csv", "w", newline=""
     wr.writeheader()
     wr.writerows(rows)
 print("wrote", len(rows), "rows")
+
+# per launch shape from the plain --kernel-trace run (no counters: undisturbed durations)
+tr = collections.defaultdict(list)
+for r in csv.DictReader(open(f"{G}/prof_trace/cascade_kernel_trace.csv")):
+    grid = int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"])
+    wg = int(r["Workgroup_Size_X"]) * int(r["Workgroup_Size_Y"]) * int(r["Workgroup_Size_Z"])
+    tr[(short(r["Kernel_Name"]), grid, wg)].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+trows = sorted(({"kernel": k[0], "grid": k[1], "wg": k[2], "launches": len(v), "avg_us": round(st.mean(v) / 1e3, 2), "min_us": round(min(v) / 1e3, 2),
+                 "total_ms": round(sum(v) / 1e6, 3)} for k, v in tr.items()), key=lambda r: -r["total_ms"])
+with open(f"profiles/{tag}_cascade_T25_kernel_trace_by_launch_shape.csv", "w", newline="") as fh:
+    wr = csv.DictWriter(fh, fieldnames=list(trows[0].keys()))
+    wr.writeheader()
+    wr.writerows(trows)
+# the bench lines, breakdowns and the GPU test log of the same gpurun call
+for src, dst in (("bench_cascade.log", f"{tag}_bench_cascade64_256_n1.json"), ("bench_half.log", f"{tag}_bench_cascade64_256_half_n1.json"),
+                 ("bench_base.log", f"{tag}_bench_base64_n1.json")):
+    if os.path.exists(f"{G}/{src}"):
+        lines = [l for l in open(f"{G}/{src}") if l.startswith("{")]
+        if lines:
+            open(f"profiles/{dst}", "w").write(lines[-1])
+for src, dst in (("bd_cascade.json", f"{tag}_bench_breakdown_stage1_256.json"), ("bd_base.json", f"{tag}_bench_breakdown_stage0_64.json"),
+                 ("pytest_gpu.log", f"{tag}_pytest_gpu.log")):
+    if os.path.exists(f"{G}/{src}"):
+        shutil.copy(f"{G}/{src}", f"profiles/{dst}")
