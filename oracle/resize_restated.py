@@ -8,7 +8,9 @@ TEST INFRASTRUCTURE ONLY.  The package is neither installed nor vendored under
 PARITY UNPINNED on the package itself: there is no resize-right implementation or golden
 vector in the container.  Independent evidence: away from the (reflect-padded) border the
 result agrees with Pillow's BICUBIC -- the same Keys a = -1/2 kernel and pixel-centre
-convention -- to fp32 rounding (tests/test_oracle.py::test_cubic_resize_interior_matches_pillow_bicubic).
+convention -- to fp32 rounding (tests/test_oracle.py::test_cubic_resize_interior_matches_pillow_bicubic);
+at the border the x4 case of the cascade is checked against hand-derived closed-form taps,
+exact in binary (tests/test_kernels.py::BORDER_TAPS_X4 / border_closed_form_check).
 
 Algorithm (per resized dim, dims processed in order of increasing scale factor,
 ties in dim order => H then W for a (B,C,H,W) tensor and a scalar factor):
