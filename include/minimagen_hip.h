@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MI_ABI_VERSION 4
+#define MI_ABI_VERSION 5
 
 enum mi_status {
     MI_OK = 0,
@@ -120,6 +120,11 @@ typedef struct mi_crossembed_params {
     int tile_cfg;
     const float* addend;           /* [B][sum cout][H][W] added to the result (the step-invariant low-res half of the
                                       convolution, computed once per sample()), or NULL; bias[] entries may be NULL */
+    /* non-NULL: the matrix-core kernel (dim_scales (4,2,2), kernel sizes (3,7,15), in1 == NULL, C0 <= 4, W % 4 == 0, tile_cfg 8 =
+       32x64 or 9 = 16x32 tiles, | 0x400 for single-term fp16): the Toeplitz weight table of packing.pack_crossembed_mfma,
+       [32 rows][256] fp16, and the power-of-two exponent each conv's weights were pre-scaled by.  w[] is then unused. */
+    const void* w_mfma;
+    int w_mfma_exp[3];
 } mi_crossembed_params;
 int mi_crossembed_fwd(const mi_crossembed_params* p, void* stream);
 

@@ -44,6 +44,7 @@ class MiCrossEmbedParams(C.Structure):
         ("in1_batch_mod", C.c_int), ("in0_batch_mod", C.c_int), ("n_kernels", C.c_int),
         ("ksize", C.c_int * 3), ("cout", C.c_int * 3), ("w", C.c_void_p * 3), ("bias", C.c_void_p * 3),
         ("out", C.c_void_p), ("out_stats", C.c_void_p), ("tile_cfg", C.c_int), ("addend", C.c_void_p),
+        ("w_mfma", C.c_void_p), ("w_mfma_exp", C.c_int * 3),
     ]
 
 

@@ -436,6 +436,8 @@ extern "C" int mi_conv_tile_shape(int tile_cfg, int* th, int* tw) {
         case 0: *th = 16; *tw = 64; return MI_OK;
         case 1: *th = 32; *tw = 32; return MI_OK;
         case 2: *th = 8; *tw = 32; return MI_OK;
+        case 8: *th = 32; *tw = 64; return MI_OK;     // matrix-core CrossEmbed (crossembed.hip)
+        case 9: *th = 16; *tw = 32; return MI_OK;
     }
     return MI_ERR_INVALID;
 }

@@ -6,6 +6,7 @@
 // their own pointers (the concat is never materialised); per-channel partial statistics for the
 // first GroupNorm come out of the epilogue.
 #include "common.hip.h"
+#include <type_traits>
 
 namespace {
 
@@ -172,6 +173,242 @@ __global__ __launch_bounds__(NT) void crossembed_422_kernel(const mi_crossembed_
     }
 }
 
+// ---- matrix cores: dim_scales (4,2,2), kernel sizes (3,7,15), <= 4 input channels ----
+// The three convs as ONE Toeplitz GEMM per group of 16 pixels x 8 output rows on v_mfma_f32_16x16x32_f16:
+//   D[px m][(co2, dy)] += A[m][(r; lg, dx, ci)] . B[(r; lg, dx, ci)][(co2, dy)]        r = input row of the group's 22-row window
+//   A = act[row r][column x0 - 7 + m + 2 lg + 8 h + dx][ci]    (16 bytes per lane: two adjacent pixels x 4 channels, fp16)
+//   B = W[co][ci][ky = r - dy - off][kx = 2 lg + 8 h + dx - off], off = 7 - pad  -- depends on r - dy only, so the table in LDS has
+//       one row per vertical tap and every lane reads its own row (packing.pack_crossembed_mfma)
+// Four N tiles share every A fragment: k3 channels 0-1, k3 channels 2-3, k7, k15 (the narrower kernels skip the rows / halves where
+// their taps are all zero).  fp32 operands as 3-term fp16 splits; the inputs are scaled per workgroup by a power of two taken from
+// the staged tile's max |x| (exact, undone in the epilogue), the weights at pack time -- any input range is safe.
+typedef _Float16 ce_f16x8 __attribute__((ext_vector_type(8)));
+
+#ifdef MI_TRACE
+// development aid (tools/bench_ce.py): shader-clock time per phase of the first workgroups of the last launch + wall-clock start / end
+__device__ unsigned long long mi_trace_ce_buf[1024 * 8];
+extern "C" int mi_debug_read_trace_ce(void* dst, size_t bytes) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(mi_trace_ce_buf), bytes); }
+#define CE_TSTART() const unsigned long long ce_w0 = wall_clock64(); unsigned long long ce_last = clock64(), ce_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define CE_TPHASE(k) do { const unsigned long long n_ = clock64(); ce_acc[k] += n_ - ce_last; ce_last = n_; } while (0)
+#define CE_TEND() do { ce_acc[7] = (ce_w0 << 32) | (wall_clock64() & 0xffffffffull); const int wg_ = blockIdx.y * gridDim.x + blockIdx.x; if (threadIdx.x == 0 && wg_ < 1024) for (int k = 0; k < 8; ++k) mi_trace_ce_buf[wg_ * 8 + k] = ce_acc[k]; } while (0)
+#else
+#define CE_TSTART() do { } while (0)
+#define CE_TPHASE(k) do { } while (0)
+#define CE_TEND() do { } while (0)
+#endif
+
+template <int GY, int GX, bool HALF>
+__global__ __launch_bounds__(256, 2) void crossembed_mfma_kernel(const mi_crossembed_params p, const uint4* __restrict__ wtab) {
+    constexpr int TH = 8 * GY, TW = 16 * GX, G = GY * GX / 4;             // 4 waves x G groups of (16 px x 8 rows)
+    constexpr int IH = TH + 14, PW = TW + 16, NW4 = PW / 4, NU = IH * NW4, PER = (NU + 255) / 256;
+    constexpr int TP = 33;                                                // table row pitch in 16-byte chunks: 32 + 1, so the 8 rows
+                                                                          // (r - dy) a wave reads at once fall into different banks
+    __shared__ __attribute__((aligned(16))) uint2 actH[IH * PW];
+    __shared__ __attribute__((aligned(16))) uint2 actL[HALF ? 2 : IH * PW];
+    __shared__ __attribute__((aligned(16))) uint4 tab[32 * TP];
+    __shared__ float red[4][16];
+    __shared__ float smax[4];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lq = lane & 15, lg = lane >> 4;
+    const int H = p.H, W = p.W, HW = H * W;
+    const int tiles_x = (W + TW - 1) / TW, tile = blockIdx.x;
+    const int oy0 = (tile / tiles_x) * TH, ox0 = (tile % tiles_x) * TW;
+    const int b = blockIdx.y, Cin = p.C0;
+    const int b0 = p.in0_batch_mod > 0 ? b % p.in0_batch_mod : b;
+    const float* src = p.in0 + (size_t)b0 * Cin * HW;
+
+    CE_TSTART();
+    // ---- stage the (TH + 14) x (TW + 16) window: one unit = 4 pixels x all channels
+    float4 raw[PER][4];
+    unsigned inm = 0;
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int q = tid + u * 256, iy = q / NW4, xq = q - iy * NW4;
+        const int gy = oy0 - 7 + iy, gx = ox0 - 8 + 4 * xq;
+        const bool in = q < NU && gy >= 0 && gy < H && gx >= 0 && gx < W;          // W % 4 == 0: a float4 is inside or outside as a whole
+        inm |= in ? (1u << u) : 0u;
+        const int off = in ? gy * W + gx : 0;
+#pragma unroll
+        for (int ci = 0; ci < 4; ++ci) raw[u][ci] = ci < Cin ? mi_ldg4(src + (size_t)ci * HW + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int i = tid; i < 32 * 32; i += 256) tab[(i >> 5) * TP + (i & 31)] = mi_ldg4u(wtab + i);
+    // the addend (the step-invariant low-res half of the convolution) is as many bytes as the output: requested now, consumed in the
+    // epilogue, so that its latency hides under the GEMM
+    const int dy = lq & 7, co2 = lq >> 3;
+    float4 addv[G][4];
+    if (p.addend) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int gi = wave * G + g, gyy = gi / GX, gxx = gi % GX;
+            const int oy = oy0 + 8 * gyy + dy, ox = ox0 + 16 * gxx + 4 * lg;
+            const bool ok = oy < H && ox < W;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                addv[g][t] = mi_ldg4(p.addend + ((size_t)(b * 8 + 2 * t + co2) * H + (ok ? oy : 0)) * W + (ok ? ox : 0));
+        }
+    }
+    CE_TPHASE(0);
+    float m = 0.0f;
+#pragma unroll
+    for (int u = 0; u < PER; ++u)
+#pragma unroll
+        for (int ci = 0; ci < 4; ++ci) {
+            const float4 v = raw[u][ci];
+            const float a = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+            m = ((inm >> u) & 1u) ? fmaxf(m, a) : m;
+        }
+    m = mi_wave_max(m);
+    if (lane == 0) smax[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
+    int ex = 0;                                     // max |x| 2^ex in [128, 256); no scaling for an all-zero or non-finite tile
+    {
+        const int be = (int)((__float_as_uint(m) & 0x7fffffffu) >> 23);
+        if (be != 0 && be != 255) ex = 8 - (be - 126);
+    }
+    const float sc = ldexpf(1.0f, ex);
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int q = tid + u * 256, iy = q / NW4, xq = q - iy * NW4;
+        if (q >= NU) continue;
+        const bool in = (inm >> u) & 1u;
+        uint2 hh[4], ll[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float y[4];
+#pragma unroll
+            for (int ci = 0; ci < 4; ++ci) {
+                const float4 v = raw[u][ci];
+                const float x = j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w));
+                y[ci] = in ? x * sc : 0.0f;                                              // zero padding of the conv
+            }
+            mi_f16x4 h4, l4;
+            mi_split_f16(y, h4, l4);
+            hh[j] = __builtin_bit_cast(uint2, h4);
+            ll[j] = __builtin_bit_cast(uint2, l4);
+        }
+        const int d = iy * PW + 4 * xq;
+        *reinterpret_cast<uint4*>(&actH[d]) = make_uint4(hh[0].x, hh[0].y, hh[1].x, hh[1].y);
+        *reinterpret_cast<uint4*>(&actH[d + 2]) = make_uint4(hh[2].x, hh[2].y, hh[3].x, hh[3].y);
+        if constexpr (!HALF) {
+            *reinterpret_cast<uint4*>(&actL[d]) = make_uint4(ll[0].x, ll[0].y, ll[1].x, ll[1].y);
+            *reinterpret_cast<uint4*>(&actL[d + 2]) = make_uint4(ll[2].x, ll[2].y, ll[3].x, ll[3].y);
+        }
+    }
+    __syncthreads();
+    CE_TPHASE(1);
+
+    // ---- the GEMM: rows of the window outermost, B fragments shared by the wave's G groups
+    f32x4 acc[G][4];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[g][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int bch = co2 * 4 + lg;                           // this lane's chunk within a (row, h, hi | lo) block of the table
+    // One step = (window row r, column half h): the B fragments of the N tiles that can hold a tap there (shared by the wave's G
+    // groups) and one A fragment per group.  The operands of step s + 1 are read from LDS while the MFMAs of step s run (two register
+    // sets); the rows are walked in five segments with a compile-time set of live N tiles so that there is no branch between the
+    // reads and their use (the waits stay counted).
+    struct Ops { ce_f16x8 bh[4], bl[4], ah[G], al[G]; };
+    auto load = [&](auto mask_tag, int r, int h, Ops& o) {
+        constexpr int MASK = decltype(mask_tag)::value;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (!((MASK >> t) & 1)) continue;
+            const int K = t == 3 ? 15 : (t == 2 ? 7 : 3), row0 = t == 3 ? 16 : (t == 2 ? 8 : 4 * t), off = t == 3 ? 0 : (t == 2 ? 4 : 6);
+            const int q = r - dy - off;
+            const int row = row0 + ((unsigned)q < (unsigned)K ? q : K);               // taps outside the kernel: the zero row
+            o.bh[t] = __builtin_bit_cast(ce_f16x8, tab[row * TP + (2 * h) * 8 + bch]);
+            if constexpr (!HALF) o.bl[t] = __builtin_bit_cast(ce_f16x8, tab[row * TP + (2 * h + 1) * 8 + bch]);
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int gi = wave * G + g, gyy = gi / GX, gxx = gi % GX;
+            const int idx = (8 * gyy + r) * PW + 16 * gxx + 1 + lq + 2 * lg + 8 * h;
+            const uint2 h0 = actH[idx], h1 = actH[idx + 1];
+            o.ah[g] = __builtin_bit_cast(ce_f16x8, make_uint4(h0.x, h0.y, h1.x, h1.y));
+            if constexpr (!HALF) {
+                const uint2 l0 = actL[idx], l1 = actL[idx + 1];
+                o.al[g] = __builtin_bit_cast(ce_f16x8, make_uint4(l0.x, l0.y, l1.x, l1.y));
+            }
+        }
+    };
+    auto mma = [&](auto mask_tag, const Ops& o) {
+        constexpr int MASK = decltype(mask_tag)::value;
+        // term-major over the wave's groups: consecutive MFMAs write different accumulators (no back-to-back dependency)
+#pragma unroll
+        for (int t = 3; t >= 0; --t) {
+            if (!((MASK >> t) & 1)) continue;
+            if constexpr (!HALF) {
+#pragma unroll
+                for (int g = 0; g < G; ++g) acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(o.al[g], o.bh[t], acc[g][t], 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < G; ++g) acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(o.ah[g], o.bl[t], acc[g][t], 0, 0, 0);
+            }
+#pragma unroll
+            for (int g = 0; g < G; ++g) acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(o.ah[g], o.bh[t], acc[g][t], 0, 0, 0);
+        }
+    };
+    auto segment = [&](auto mask_tag, int r_lo, int r_hi) {
+        Ops o0, o1;
+        load(mask_tag, r_lo, 0, o0);
+#pragma unroll 1
+        for (int r = r_lo; r < r_hi; ++r) {
+            load(mask_tag, r, 1, o1);
+            mma(mask_tag, o0);
+            load(mask_tag, r + 1 < r_hi ? r + 1 : r, 0, o0);         // (the last one is a harmless re-read: no branch around the reads)
+            mma(mask_tag, o1);
+        }
+    };
+    segment(std::integral_constant<int, 8>{}, 0, 4);            // rows that hold taps of the 15x15 kernel only
+    segment(std::integral_constant<int, 12>{}, 4, 6);           // + the 7x7 kernel (window rows 4 .. 17)
+    segment(std::integral_constant<int, 15>{}, 6, 16);          // + the 3x3 kernel (window rows 6 .. 15)
+    segment(std::integral_constant<int, 12>{}, 16, 18);
+    segment(std::integral_constant<int, 8>{}, 18, 22);
+    CE_TPHASE(2);
+
+    // ---- epilogue: lane (lq = 8 co2 + dy, lg) holds pixels 4 lg .. 4 lg + 3 of output row dy, channel 2 t + co2 of every group
+    float ssum[4], ssq[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int k = t < 2 ? 0 : t - 1;                                   // conv of this N tile
+        const int c = 2 * t + co2;                                          // channel in the concatenated output
+        const float us = ldexpf(1.0f, -(ex + p.w_mfma_exp[k]));
+        const float* bp = p.bias[k];
+        const float bv = bp ? bp[t == 1 ? 2 + co2 : co2] : 0.0f;
+        float s = 0.0f, q2 = 0.0f;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int gi = wave * G + g, gyy = gi / GX, gxx = gi % GX;
+            const int oy = oy0 + 8 * gyy + dy, ox = ox0 + 16 * gxx + 4 * lg;
+            const bool ok = oy < H && ox < W;
+            const size_t o = ((size_t)(b * 8 + c) * H + (ok ? oy : 0)) * W + (ok ? ox : 0);
+            float4 y = make_float4(fmaf(acc[g][t][0], us, bv), fmaf(acc[g][t][1], us, bv), fmaf(acc[g][t][2], us, bv), fmaf(acc[g][t][3], us, bv));
+            if (p.addend) { const float4 a = addv[g][t]; y.x += a.x; y.y += a.y; y.z += a.z; y.w += a.w; }
+            if (ok) {
+                mi_stg4(p.out + o, y);
+                s += (y.x + y.y) + (y.z + y.w);
+                q2 += fmaf(y.x, y.x, fmaf(y.y, y.y, fmaf(y.z, y.z, y.w * y.w)));
+            }
+        }
+        ssum[t] = s; ssq[t] = q2;
+    }
+    if (p.out_stats) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            float s = ssum[t], q2 = ssq[t];
+#pragma unroll
+            for (int o = 1; o <= 4; o <<= 1) { s += __shfl_xor(s, o); q2 += __shfl_xor(q2, o); }
+            s += __shfl_xor(s, 16); q2 += __shfl_xor(q2, 16);
+            s += __shfl_xor(s, 32); q2 += __shfl_xor(q2, 32);
+            if (dy == 0 && lg == 0) { red[wave][2 * (2 * t + co2)] = s; red[wave][2 * (2 * t + co2) + 1] = q2; }
+        }
+        __syncthreads();
+        if (tid < 16) p.out_stats[((size_t)(b * 8 + (tid >> 1)) * gridDim.x + tile) * 2 + (tid & 1)] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+    }
+    CE_TPHASE(3);
+    CE_TEND();
+}
+
 // ---- generic (any dim / kernel sizes): one work-item per output pixel, one output channel per
 // blockIdx.z; taps read through L1/L2.  Correct for every constructor argument, not tuned.
 template <int NT, int TW>
@@ -235,8 +472,25 @@ extern "C" int mi_crossembed_fwd(const mi_crossembed_params* pp, void* stream) {
     const bool fast = p.n_kernels == 3 && p.ksize[0] == 3 && p.ksize[1] == 7 && p.ksize[2] == 15 &&
                       p.cout[0] == 4 && p.cout[1] == 2 && p.cout[2] == 2;
     int th, tw;
-    if (mi_conv_tile_shape(p.tile_cfg, &th, &tw) != MI_OK) { mi_set_error("mi_crossembed_fwd: bad tile_cfg"); return MI_ERR_INVALID; }
+    if (mi_conv_tile_shape(p.tile_cfg & 0xff, &th, &tw) != MI_OK) { mi_set_error("mi_crossembed_fwd: bad tile_cfg"); return MI_ERR_INVALID; }
     const int tiles = ((p.H + th - 1) / th) * ((p.W + tw - 1) / tw);
+    if (p.w_mfma) {             // matrix-core kernel: tile_cfg 8 (32 x 64) / 9 (16 x 32), | 0x400 = single fp16 term
+        const int cfg = p.tile_cfg & 0xff;
+        if (!fast || p.in1 || p.C0 < 1 || p.C0 > 4 || (p.W & 3) || (cfg != 8 && cfg != 9)) {
+            mi_set_error("mi_crossembed_fwd: the matrix-core kernel is built for dim_scales (4,2,2), kernel sizes (3,7,15), one input of <= 4 channels, W %% 4 == 0, tile_cfg 8 / 9");
+            return MI_ERR_UNSUPPORTED;
+        }
+        const bool half = (p.tile_cfg & 0x400) != 0;
+        const uint4* wt = (const uint4*)p.w_mfma;
+        if (cfg == 8) {
+            if (half) hipLaunchKernelGGL(HIP_KERNEL_NAME(crossembed_mfma_kernel<4, 4, true>), dim3(tiles, p.B), dim3(256), 0, st, p, wt);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(crossembed_mfma_kernel<4, 4, false>), dim3(tiles, p.B), dim3(256), 0, st, p, wt);
+        } else {
+            if (half) hipLaunchKernelGGL(HIP_KERNEL_NAME(crossembed_mfma_kernel<2, 2, true>), dim3(tiles, p.B), dim3(256), 0, st, p, wt);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(crossembed_mfma_kernel<2, 2, false>), dim3(tiles, p.B), dim3(256), 0, st, p, wt);
+        }
+        return mi_check_launch("crossembed_mfma");
+    }
     if (fast) {
         switch (p.tile_cfg) {
             case 0: hipLaunchKernelGGL(HIP_KERNEL_NAME(crossembed_422_kernel<256, 64>), dim3(tiles, p.B), dim3(256), 0, st, p, p.w[0], p.w[1], p.w[2]); break;

@@ -31,6 +31,7 @@ CONV_SPLIT8 = int(os.environ.get("MINIMAGEN_CONV_SPLIT8", "64"))        # 8-chan
 CONV_RP = int(os.environ.get("MINIMAGEN_CONV_RP", "2"))                 # 1: narrow k3 s1 convs (channels in multiples of 8, <= 64 in) on the row-paired matrix-core kernel; 2: also nearest-x2 + k3 and k4 s2
 RP_TILE = {k: int(os.environ.get("MINIMAGEN_RP_TILE_" + k, d)) for k, d in (("L", "6"), ("M", "6"), ("S", "6"))}   # tile_cfg for images > 128^2 / > 64^2 / smaller
 RP_MIN_HW = int(os.environ.get("MINIMAGEN_RP_MIN_HW", "0"))             # ... for images of at least this many pixels
+CE_MFMA = os.environ.get("MINIMAGEN_CE_MFMA", "1") != "0"                  # CrossEmbed on the matrix cores (0: the fp32 VALU kernel)
 RP_NTILE = int(os.environ.get("MINIMAGEN_RP_NTILE", "0"))               # tiles per workgroup of the row-paired kernel (0 = the library's choice)
 TILE64 = int(os.environ.get("MINIMAGEN_TILE64", "-1"))                  # force a conv tile shape at 64x64 / 128x128 (experiments)
 TILE128 = int(os.environ.get("MINIMAGEN_TILE128", "-1"))       # 1: 16-channel 3x3 outputs as two 8-channel workgroups
@@ -212,6 +213,13 @@ class UnetEngine:
                 pk.conv[id(up[1])] = conv_pack(up[1])
         pk.conv[id(u.final_conv)] = conv_pack(u.final_conv)
         pk.ce_w = [c.weight.detach().permute(1, 2, 3, 0).contiguous() for c in u.init_conv.convs]
+        # matrix-core CrossEmbed (the BASELINE configuration: dim_scales (4, 2, 2), kernels (3, 7, 15), <= 4 image channels): one Toeplitz
+        # table per input half (x / low-res conditioning image)
+        pk.ce_mfma = {}
+        cvs = u.init_conv.convs
+        if CE_MFMA and [c.kernel_size[0] for c in cvs] == [3, 7, 15] and [c.out_channels for c in cvs] == [4, 2, 2] and u.channels <= 4:
+            for chan0 in range(0, cvs[0].in_channels, u.channels):
+                pk.ce_mfma[chan0] = P.pack_crossembed_mfma([c.weight for c in cvs], chan0, u.channels)
         self._pack, self._pack_key = pk, key
         return pk
 
@@ -579,6 +587,12 @@ class UnetEngine:
         cin = u.init_conv.convs[0].in_channels
         assert cin == u.channels * (2 if u.lowres_cond else 1)
         cfg, nt = self._tile_cfg(H, W, B)
+        ce_mfma = bool(pk.ce_mfma) and W % 4 == 0
+        if ce_mfma:                       # its own tile shapes: 32 x 64 for large images, 16 x 32 below (enough workgroups at 64 x 64)
+            cfg = 8 if H * W >= 128 * 128 else 9
+            th, tw = C.c_int(), C.c_int()
+            lib.mi_conv_tile_shape(cfg, C.byref(th), C.byref(tw))
+            nt = -(-H // th.value) * -(-W // tw.value)
         ctot = sum(u.init_conv.dim_scales)
         cur = self._new_act(ws, B, ctot, H, W, nt)
         if len(u.init_conv.convs) > 3:
@@ -595,6 +609,11 @@ class UnetEngine:
                 ce.w[i] = L.ptr(pk.ce_w[i]) + 4 * chan0 * k * k * co        # packed [Cin][k][k][co]: a channel offset is a pointer offset
                 ce.bias[i] = L.ptr(cv.bias) if with_bias else 0
             ce.out, ce.out_stats, ce.tile_cfg, ce.addend = L.ptr(out_t), L.ptr(out_stats), cfg, L.ptr(addend)
+            if ce_mfma:
+                tab, exps = pk.ce_mfma[chan0]
+                ce.w_mfma, ce.tile_cfg = L.ptr(tab), cfg | (0x400 if ws.half else 0)
+                for i in range(3):
+                    ce.w_mfma_exp[i] = exps[i]
             return ce
 
         ws.prog_pre = []

@@ -133,3 +133,46 @@ def layernorm_bound(weight, bias, n: int) -> float:
     """max |LayerNorm(x)_i| over any input: a normalised element is at most sqrt(n - 1) in magnitude"""
     b = float(bias.abs().max()) if bias is not None else 0.0
     return float(weight.abs().max()) * math.sqrt(max(n - 1, 1)) + b
+
+
+CE_TILES = ((0, 0), (0, 2), (1, 0), (2, 0))       # N tiles of the matrix-core CrossEmbed: (conv index, first output channel)
+CE_ROWS = (0, 4, 8, 16)                            # first table row of each tile (K + 1 rows each: 3+1, 3+1, 7+1, 15+1)
+CE_TABLE_ROWS = 32
+
+
+def pack_crossembed_mfma(ws, chan0: int, cin: int):
+    """CrossEmbedLayer weights (dim_scales (4, 2, 2), kernel sizes (3, 7, 15); layers.py:254-305) for crossembed_mfma_kernel.
+
+    The three convs are one Toeplitz GEMM per 16-pixel x 8-row group: N = (output channel pair co2, output row dy), K = (input row r
+    of the 22-row window; 2 adjacent columns x 4 channels per lane, lane group lg and half h select the column pair 2 lg + 8 h of the
+    16-column window).  B[(r, h, lg, dx, ci)][(co2, dy)] = W[co][ci][ky = r - dy - off][kx = 2 lg + dx + 8 h - off], off = 7 - pad --
+    a function of r - dy only, so the table holds one row per vertical tap (plus a zero row for taps outside the kernel) and every
+    lane picks its own row: [tile 4 -> 32 rows][h 2][hi | lo][co2 2][lg 4][8 fp16].  ws: the three [cout][Cin_total][k][k] weights;
+    channels chan0 .. chan0 + cin - 1 are packed (cin <= 4).  Returns (table [32][256] fp16, [3] power-of-two exponents: each conv is
+    pre-scaled so that max|w| lands in [128, 256))."""
+    assert cin <= 4 and len(ws) == 3 and [w.shape[-1] for w in ws] == [3, 7, 15] and [w.shape[0] for w in ws] == [4, 2, 2]
+    exps, scaled = [], []
+    for w in ws:
+        wd = w.detach().double().cpu()[:, chan0:chan0 + cin]
+        mx = float(wd.abs().max())
+        e = 0 if (mx == 0.0 or not math.isfinite(mx)) else 7 - math.floor(math.log2(mx))
+        e = max(-100, min(100, e))
+        exps.append(e)
+        scaled.append(wd * (2.0 ** e))
+    tab = torch.zeros(CE_TABLE_ROWS, 2, 2, 2, 4, 8, dtype=torch.float64)       # [row][h][hi|lo][co2][lg][e = 4 dx + ci]
+    for (k, co0), row0 in zip(CE_TILES, CE_ROWS):
+        w = scaled[k]
+        K = w.shape[-1]
+        off = 7 - (K - 1) // 2
+        for h in range(2):
+            for lg in range(4):
+                for dx in range(2):
+                    kx = 2 * lg + dx + 8 * h - off
+                    if 0 <= kx < K:
+                        # [co2][ci][q] -> rows q, channels co0 + co2
+                        v = w[co0:co0 + 2, :, :, kx]                            # [2][cin][K]
+                        tab[row0:row0 + K, h, 0, :, lg, 4 * dx:4 * dx + cin] = v.permute(2, 0, 1)
+    hi = tab[:, :, 0].float().half()
+    lo = (tab[:, :, 0] - hi.double()).float().half()
+    out = torch.stack((hi, lo), dim=2)                                           # [row][h][hl][co2][lg][8]
+    return out.reshape(CE_TABLE_ROWS, 256).contiguous().to(ws[0].device), exps

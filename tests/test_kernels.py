@@ -381,6 +381,65 @@ def test_crossembed(backend, case):
     check_stats(ost.cpu(), ref)
 
 
+CE_MFMA_CASES = [
+    # B, Cin, channels of the full weight, first channel, H, W, tile_cfg, in0_batch_mod, addend, xscale, wscale
+    (2, 3, 3, 0, 64, 64, 9, 0, False, 1.0, 1.0),
+    (2, 3, 6, 3, 40, 72, 8, 0, True, 1.0, 1.0),           # ragged tile edges; the low-res half of a 6-channel weight; addend
+    (4, 3, 3, 0, 16, 32, 9, 2, False, 300.0, 1.0 / 64),   # shared input rows (guidance halves); range safety of the fp16 split
+    (1, 4, 4, 0, 32, 64, 8, 0, True, 1.0 / 256, 30.0),
+    (1, 1, 3, 1, 24, 40, 9, 0, False, 1.0, 1.0),
+    (1, 3, 3, 0, 72, 136, 8, 0, False, 1.0, 1.0),         # several tiles per image in both directions
+]
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("case", CE_MFMA_CASES)
+def test_crossembed_matrix_core(backend, case):
+    """CrossEmbedLayer (layers.py:298-305) as a Toeplitz GEMM on the matrix cores (3-term fp16 splits) vs torch: same gate as the
+    VALU kernel, relative to the output magnitude for the scaled cases; an all-zero image must give exactly bias (+ addend)"""
+    dev = setup(backend)
+    lib = L.lib()
+    B, Cin, Cw, c0, H, W, cfg, mod, with_add, xs, wsc = case
+    g = torch.Generator().manual_seed(hash(case) & 0xffff)
+    rn = lambda *s_: torch.randn(*s_, generator=g)
+    ks, cout = (3, 7, 15), (4, 2, 2)
+    Bx = mod if mod else B
+    x = rn(Bx, Cin, H, W) * xs
+    ws = [rn(co, Cw, k, k) * 0.1 * wsc for k, co in zip(ks, cout)]
+    bs = [rn(co) * xs * wsc for co in cout]
+    add = rn(B, 8, H, W) * xs * wsc if with_add else None
+    tab, exps = P.pack_crossembed_mfma(ws, c0, Cin)
+    for zero in (False, True):
+        xe = (torch.zeros_like(x) if zero else x).repeat(B // Bx, 1, 1, 1)
+        ref = torch.cat([F.conv2d(xe.double(), w[:, c0:c0 + Cin].double(), b.double(), padding=(k - 1) // 2) for w, b, k in zip(ws, bs, ks)], 1)
+        if with_add:
+            ref = ref + add.double()
+        p = L.MiCrossEmbedParams()
+        p.B, p.H, p.W = B, H, W
+        xd, tabd = (torch.zeros_like(x) if zero else x).to(dev), tab.to(dev)
+        p.in0, p.C0, p.in0_batch_mod = xd.data_ptr(), Cin, mod
+        p.n_kernels = 3
+        bd = [b.to(dev) for b in bs]
+        for i in range(3):
+            p.ksize[i], p.cout[i], p.bias[i], p.w_mfma_exp[i] = ks[i], cout[i], bd[i].data_ptr(), exps[i]
+        p.w_mfma = tabd.data_ptr()
+        addd = add.to(dev) if with_add else None
+        p.addend = addd.data_ptr() if with_add else 0
+        nt = tile_nt(lib, cfg, H, W)
+        out = torch.full(ref.shape, float('nan'), device=dev)
+        ost = torch.zeros(B, 8, nt, 2, device=dev)
+        p.out, p.out_stats, p.tile_cfg = out.data_ptr(), ost.data_ptr(), cfg
+        L.check(lib.mi_crossembed_fwd(C.byref(p), L.current_stream()), "crossembed (matrix cores)")
+        err = (out.cpu().double() - ref).abs().max().item()
+        if zero:
+            assert torch.equal(out.cpu(), ref.float())
+            continue
+        scale = max(1.0, ref.abs().max().item() / 4.0)
+        print(f"crossembed mfma {case}: max|d| = {err:.2e} (gate {2e-5 * scale:.2e}, |ref|max {ref.abs().max().item():.3g})")
+        assert err < 2e-5 * scale
+        check_stats(ost.cpu(), ref.float())
+
+
 @pytest.mark.parametrize("backend", BACKENDS)
 @pytest.mark.parametrize("case", [(2, 16, 256, 8, 2, 0), (1, 16, 200, 8, 4, 0), (1, 8, 128, 8, 2, 0), (1, 32, 128, 16, 2, 0),
                                   (8, 16, 200, 8, 4, 1), (1, 8, 128, 8, 2, 1), (2, 16, 256, 8, 4, 2), (2, 16, 256, 8, 4, 3), (1, 8, 200, 8, 2, 4), (1, 16, 256, 8, 4, 5),
