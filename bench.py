@@ -306,20 +306,26 @@ def main():
     emb, mask = synthetic_text(B, row0=rank * B)
     emb, mask = emb.to(dev), mask.to(dev)
 
+    gstream = torch.cuda.Stream(device=dev) if (world > 1 and not one_gpu) else None
+
     def one_step(k):
         # successive sample() calls are pipelined across the per-stage HIP streams (_async: the caller's stream is not made to wait; the
         # timed region ends with a device-wide synchronize, so every image is finished inside it)
         out = im.sample(text_embeds=emb, text_masks=mask, cond_scale=args.cond_scale, _seed=1234 + k, _sample_offset=rank * B, _precision=args.precision,
                         _async=not args.no_pipeline)
-        if world > 1:
-            torch.cuda.current_stream().wait_event(im.last_sample_done) if not args.no_pipeline else None
         if world > 1 and one_gpu:
+            torch.cuda.current_stream().wait_event(im.last_sample_done)
             host = out.cpu()
             pad = [torch.empty_like(host) for _ in range(world)]
             dist.all_gather(pad, host)
             out = torch.cat(pad, 0).to(dev)
         elif world > 1:
-            out = gather_samples(out, gB)                  # RCCL over xGMI, the only collective of the path: one all_gather_into_tensor
+            # RCCL over xGMI, the only collective of the path: one all_gather_into_tensor of the finished images, on its own stream behind
+            # the last stage's event -- the caller's stream stays free, so the next call's base stage still starts under this call's SR stage
+            gstream.wait_event(im.last_sample_done)
+            with torch.cuda.stream(gstream):
+                out.record_stream(gstream)
+                out = gather_samples(out, gB)
         return out
 
     for k in range(args.warmup):

@@ -671,7 +671,9 @@ int launch_rp(const mi_conv_params& p, hipStream_t st) {
     // tiles per workgroup (speed only; the per-tile statistics do not depend on it): tile_cfg bits 12..15, default such that the chip
     // still gets >= ~8 workgroups per CU
     int ntile = (p.tile_cfg >> 12) & 0xf;
-    if (ntile == 0) { ntile = 1; while (ntile < 8 && (size_t)p.B * (tiles / (2 * ntile)) >= 2048) ntile *= 2; }
+    // strip length: up to 4 tiles per workgroup while that leaves >= 1024 workgroups (one full wave of 4 per CU); measured on the SR
+    // U-Net's shapes (tools/gpu_rp_shapes.sh): 256^2 -> 4, 128^2 -> 2, <= 64^2 -> 1
+    if (ntile == 0) { ntile = 1; while (ntile < 4 && (size_t)p.B * (tiles / (2 * ntile)) >= 1024) ntile *= 2; }
     const int strips = (tiles + ntile - 1) / ntile;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_rp_kernel<CFG>), dim3(strips * p.B), dim3(256), 0, st, p, (const uint4*)p.w_rp, (const uint4*)p.res_w_rp, ntile,
                        (const float4*)nullptr, (const int*)nullptr);
