@@ -22,28 +22,41 @@ __global__ __launch_bounds__(256) void cfg_x0_kernel(const mi_cfg_x0_params p) {
         for (int i = threadIdx.x; i < MI_Q_BINS; i += 256) lh[i] = 0u;
         __syncthreads();
     }
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < p.n; i += gridDim.x * 256) {
-        const float c = p.pred2[(size_t)b * p.n + i];
-        float pred = c;
-        if (p.two) {
-            const float nl = p.pred2[(size_t)(b + p.B) * p.n + i];
-            pred = __fadd_rn(nl, __fmul_rn(__fsub_rn(c, nl), p.cond_scale));     // Unet.py:506
+    auto one = [&](float c, float nl, float xt, float& pred, float& x0) {
+        pred = c;
+        if (p.two) pred = __fadd_rn(nl, __fmul_rn(__fsub_rn(c, nl), p.cond_scale));     // Unet.py:506
+        x0 = __fsub_rn(__fmul_rn(ca, xt), __fmul_rn(cb, pred));                          // diffusion_model.py:159-162
+        if constexpr (HIST) { if (p.x0) atomicAdd(&lh[__float_as_uint(fabsf(x0)) >> 20], 1u); }
+    };
+    if ((p.n & 3) == 0) {                           // 16-byte accesses (every image size the cascade uses)
+        const size_t ob = (size_t)b * p.n, on = (size_t)(b + p.B) * p.n;
+        for (int q = blockIdx.x * 256 + threadIdx.x; q < (p.n >> 2); q += gridDim.x * 256) {
+            const float4 c = mi_ldg4(p.pred2 + ob + 4 * q);
+            const float4 nl = p.two ? mi_ldg4(p.pred2 + on + 4 * q) : c;
+            const float4 xt = p.x0 ? mi_ldg4(p.x_t + ob + 4 * q) : c;
+            float4 pr, x0;
+            one(c.x, nl.x, xt.x, pr.x, x0.x); one(c.y, nl.y, xt.y, pr.y, x0.y); one(c.z, nl.z, xt.z, pr.z, x0.z); one(c.w, nl.w, xt.w, pr.w, x0.w);
+            if (p.pred_out) mi_stg4(p.pred_out + ob + 4 * q, pr);
+            if (p.x0) mi_stg4(p.x0 + ob + 4 * q, x0);
         }
-        if (p.pred_out) p.pred_out[(size_t)b * p.n + i] = pred;
-        if (p.x0) {
-            const float xt = p.x_t[(size_t)b * p.n + i];
-            const float x0 = __fsub_rn(__fmul_rn(ca, xt), __fmul_rn(cb, pred));   // diffusion_model.py:159-162
-            p.x0[(size_t)b * p.n + i] = x0;
-            if constexpr (HIST) atomicAdd(&lh[__float_as_uint(fabsf(x0)) >> 20], 1u);
+    } else {
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < p.n; i += gridDim.x * 256) {
+            const float c = p.pred2[(size_t)b * p.n + i];
+            const float nl = p.two ? p.pred2[(size_t)(b + p.B) * p.n + i] : c;
+            const float xt = p.x0 ? p.x_t[(size_t)b * p.n + i] : c;
+            float pred, x0;
+            one(c, nl, xt, pred, x0);
+            if (p.pred_out) p.pred_out[(size_t)b * p.n + i] = pred;
+            if (p.x0) p.x0[(size_t)b * p.n + i] = x0;
         }
     }
     if constexpr (HIST) {
         __syncthreads();
-        // both order statistics share the pass-0 histogram (no prefix yet): the same counts go to the two selector slots
+        // both order statistics share the pass-0 histogram (no prefix yet): selector slot 0 only, read for both
         unsigned* gh = p.hist0 + ((size_t)b * 2) * MI_Q_BINS;
         for (int i = threadIdx.x; i < MI_Q_BINS; i += 256) {
             const unsigned v = lh[i];
-            if (v) { atomicAdd(&gh[i], v); atomicAdd(&gh[MI_Q_BINS + i], v); }
+            if (v) atomicAdd(&gh[i], v);
         }
     }
 }
@@ -97,7 +110,7 @@ __global__ __launch_bounds__(256) void quantile_hist_kernel(const mi_quantile_pa
 #pragma unroll
         for (int sel = 0; sel < 2; ++sel) {
             unsigned bin, rr;
-            q_find_bin(p.hist + (((size_t)ps * p.B + b) * 2 + sel) * MI_Q_BINS, rk[sel], scratch, bin, rr);
+            q_find_bin(p.hist + (((size_t)ps * p.B + b) * 2 + (ps == 0 ? 0 : sel)) * MI_Q_BINS, rk[sel], scratch, bin, rr);      // pass 0: shared slot
             prefix[sel] = (prefix[sel] << q_bits(ps)) | bin;
             rk[sel] = rr;
         }
@@ -107,16 +120,24 @@ __global__ __launch_bounds__(256) void quantile_hist_kernel(const mi_quantile_pa
     const int shift = q_shift(PASS), nb = q_bits(PASS);
     const unsigned mask = (1u << nb) - 1u;
     const float* xb = p.x0 + (size_t)b * p.n;
-    for (int i = blockIdx.x * 256 + tid; i < p.n; i += gridDim.x * 256) {
-        const unsigned key = __float_as_uint(fabsf(xb[i]));
+    auto count = [&](float v) {
+        const unsigned key = __float_as_uint(fabsf(v));
         const unsigned hi = PASS == 0 ? 0u : (key >> (shift + nb));
         const unsigned bin = (key >> shift) & mask;
         if (hi == prefix[0]) atomicAdd(&lh[0][bin], 1u);
-        if (hi == prefix[1]) atomicAdd(&lh[1][bin], 1u);
+        if (PASS > 0 && hi == prefix[1]) atomicAdd(&lh[1][bin], 1u);              // pass 0: one histogram serves both order statistics
+    };
+    if ((p.n & 3) == 0) {
+        for (int q = blockIdx.x * 256 + tid; q < (p.n >> 2); q += gridDim.x * 256) {
+            const float4 v = mi_ldg4(xb + 4 * q);
+            count(v.x); count(v.y); count(v.z); count(v.w);
+        }
+    } else {
+        for (int i = blockIdx.x * 256 + tid; i < p.n; i += gridDim.x * 256) count(xb[i]);
     }
     __syncthreads();
     unsigned* gh = p.hist + (((size_t)PASS * p.B + b) * 2) * MI_Q_BINS;
-    for (int i = tid; i < 2 * MI_Q_BINS; i += 256) {
+    for (int i = tid; i < (PASS == 0 ? 1 : 2) * MI_Q_BINS; i += 256) {
         const unsigned v = (&lh[0][0])[i];
         if (v) atomicAdd(&gh[i], v);
     }
@@ -131,7 +152,7 @@ __global__ __launch_bounds__(256) void quantile_finish_kernel(const mi_quantile_
 #pragma unroll
         for (int sel = 0; sel < 2; ++sel) {
             unsigned bin, rr;
-            q_find_bin(p.hist + (((size_t)ps * p.B + b) * 2 + sel) * MI_Q_BINS, rk[sel], scratch, bin, rr);
+            q_find_bin(p.hist + (((size_t)ps * p.B + b) * 2 + (ps == 0 ? 0 : sel)) * MI_Q_BINS, rk[sel], scratch, bin, rr);
             prefix[sel] = (prefix[sel] << q_bits(ps)) | bin;
             rk[sel] = rr;
         }
@@ -211,23 +232,35 @@ __global__ __launch_bounds__(256) void posterior_kernel(const mi_posterior_param
     const int k = (p.T - 1) - t;
     const float* nz = p.noise ? p.noise + ((size_t)k * p.B + b) * p.n : nullptr;
     const int nq = (p.n + 3) / 4;
+    const bool vec = (p.n & 3) == 0;
+    auto one = [&](float x0, float x, float z) {
+        x0 = __fdiv_rn(x0 != x0 ? x0 : fminf(fmaxf(x0, -s), s), s);               // Imagen.py:323 (torch.clamp propagates NaN)
+        const float mean = __fadd_rn(__fmul_rn(c1, x0), __fmul_rn(c2, x));          // diffusion_model.py:118-121
+        return __fadd_rn(mean, __fmul_rn(sigma, z));                               // Imagen.py:370
+    };
     for (int qd = blockIdx.x * 256 + threadIdx.x; qd < nq; qd += gridDim.x * 256) {
         float z[4];
         if (nz) {
+            if (vec) { const float4 v = mi_ldg4(nz + 4 * qd); z[0] = v.x; z[1] = v.y; z[2] = v.z; z[3] = v.w; }
+            else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) z[e] = (4 * qd + e < p.n) ? nz[4 * qd + e] : 0.0f;
+                for (int e = 0; e < 4; ++e) z[e] = (4 * qd + e < p.n) ? nz[4 * qd + e] : 0.0f;
+            }
         } else {
             randn4(p.seed_dev ? *p.seed_dev : p.seed, (unsigned)(p.sample0 + b), (unsigned)(p.stream_base + k), (unsigned)qd, z);
         }
+        if (vec) {
+            const size_t o = (size_t)b * p.n + 4 * qd;
+            const float4 x0 = mi_ldg4(p.x0 + o), x = mi_ldg4(p.x + o);
+            mi_stg4(p.x + o, make_float4(one(x0.x, x.x, z[0]), one(x0.y, x.y, z[1]), one(x0.z, x.z, z[2]), one(x0.w, x.w, z[3])));
+        } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int i = 4 * qd + e;
-            if (i < p.n) {
-                const size_t o = (size_t)b * p.n + i;
-                float x0 = p.x0[o];
-                x0 = __fdiv_rn(x0 != x0 ? x0 : fminf(fmaxf(x0, -s), s), s);       // Imagen.py:323 (torch.clamp propagates NaN)
-                const float mean = __fadd_rn(__fmul_rn(c1, x0), __fmul_rn(c2, p.x[o]));   // diffusion_model.py:118-121
-                p.x[o] = __fadd_rn(mean, __fmul_rn(sigma, z[e]));               // Imagen.py:370
+            for (int e = 0; e < 4; ++e) {
+                const int i = 4 * qd + e;
+                if (i < p.n) {
+                    const size_t o = (size_t)b * p.n + i;
+                    p.x[o] = one(p.x0[o], p.x[o], z[e]);
+                }
             }
         }
     }
@@ -277,6 +310,9 @@ __global__ __launch_bounds__(256) void resize_kernel(const mi_resize_params p) {
     }
 }
 
+#ifndef Q_WGS
+#define Q_WGS 16
+#endif
 inline int grid_for(long long n, int cap = 2048) {
     long long g = (n + 255) / 256;
     return (int)(g < 1 ? 1 : (g > cap ? cap : g));
@@ -298,7 +334,7 @@ extern "C" int mi_quantile_fwd(const mi_quantile_params* p, void* stream) {
     if (p->B <= 0 || p->n <= 0 || p->k_lo < 0 || p->k_hi >= p->n || p->k_lo > p->k_hi) { mi_set_error("mi_quantile_fwd: bad ranks"); return MI_ERR_INVALID; }
     if (p->pass0_done && !p->self_cleaning) { mi_set_error("mi_quantile_fwd: pass0_done needs self_cleaning (the memset would erase pass 0)"); return MI_ERR_INVALID; }
     if (!p->self_cleaning && hipMemsetAsync(p->hist, 0, (size_t)3 * p->B * 2 * MI_Q_BINS * sizeof(unsigned), st) != hipSuccess) { mi_set_error("mi_quantile_fwd: memset failed"); return MI_ERR_LAUNCH; }
-    const dim3 grid(grid_for((p->n + 15) / 16, 64), p->B);
+    const dim3 grid(grid_for((p->n + 15) / 16, Q_WGS), p->B);        // few workgroups per image: every one flushes its histogram with atomics
     if (!p->pass0_done) hipLaunchKernelGGL(HIP_KERNEL_NAME(quantile_hist_kernel<0>), grid, dim3(256), 0, st, *p);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(quantile_hist_kernel<1>), grid, dim3(256), 0, st, *p);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(quantile_hist_kernel<2>), grid, dim3(256), 0, st, *p);

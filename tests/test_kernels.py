@@ -506,7 +506,7 @@ def test_quantile_bit_exact(backend):
     dev = setup(backend)
     lib = L.lib()
     g = torch.Generator().manual_seed(5)
-    sizes = (48, 1000, 12288, 196608) + ((3145728,) if backend == "gpu" else ())
+    sizes = (48, 1000, 1001, 12288, 196608) + ((3145728,) if backend == "gpu" else ())      # 1001: the 4-byte access path (n % 4 != 0)
     for n in sizes:
         for ties in (False, True):
             B = 3
@@ -526,12 +526,14 @@ def test_quantile_bit_exact(backend):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
-def test_sampler_elementwise_bit_exact(backend):
-    """K11 epilogue + K13 + schedule look-ups against the oracle, bit for bit (t = 13 and the t = 0 no-noise step)."""
+@pytest.mark.parametrize("side", [16, 15])
+def test_sampler_elementwise_bit_exact(backend, side):
+    """K11 epilogue + K13 + schedule look-ups against the oracle, bit for bit (t = 13 and the t = 0 no-noise step); side 15: an image
+    whose element count is not a multiple of 4 (the kernels' 4-byte access path)"""
     dev = setup(backend)
     lib = L.lib()
     from minimagen_amd.diffusion_model import GaussianDiffusion
-    T, B, n = 25, 2, 3 * 16 * 16
+    T, B, n = 25, 2, 3 * side * side
     sched = R.Schedule(T)
     gd = GaussianDiffusion(timesteps=T)
     for k in ("sqrt_recip_alphas_cumprod", "posterior_mean_coef1", "posterior_log_variance_clipped", "sqrt_alphas_cumprod"):
@@ -567,8 +569,8 @@ def test_sampler_elementwise_bit_exact(backend):
         x = xtd.clone()
         pp = L.MiPosteriorParams(B, n, T, x0.data_ptr(), s.data_ptr(), x.data_ptr(), coef.data_ptr(), tstate.data_ptr(), noised.data_ptr(), 0, 0, 0)
         L.check(lib.mi_posterior_fwd(C.byref(pp), L.current_stream()))
-        xr, _ = R.p_sample(None, sched, xt.reshape(B, 3, 16, 16), t, noise[T - 1 - t].reshape(B, 3, 16, 16), pred=pred.reshape(B, 3, 16, 16))
-        assert torch.equal(x.cpu().reshape(B, 3, 16, 16), xr)
+        xr, _ = R.p_sample(None, sched, xt.reshape(B, 3, side, side), t, noise[T - 1 - t].reshape(B, 3, side, side), pred=pred.reshape(B, 3, side, side))
+        assert torch.equal(x.cpu().reshape(B, 3, side, side), xr)
     # timestep bookkeeping (bit-exact integers)
     times = torch.zeros(5, dtype=torch.int64, device=dev)
     ts = torch.zeros(1, dtype=torch.int32, device=dev)
