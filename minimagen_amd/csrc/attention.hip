@@ -398,7 +398,8 @@ __global__ __launch_bounds__(64 * NWV, WPS) void cross_attn_f16x3_kernel(const m
         m = fmaxf(m, __shfl_xor(m, 16));
         m = fmaxf(m, __shfl_xor(m, 32));
         const float sc = ldexpf(1.0f, -(p.x_exp + p.g_exp)), msc = -m * sc;      // undo the operand scalings inside the subtraction's FMA
-        float l = 0.0f;
+        mi_f32x2 l2 = {0.0f, 0.0f};
+        const mi_f32x2 sc2 = {sc, sc}, msc2 = {msc, msc};
         f32x4 oh[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) oh[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -412,8 +413,13 @@ __global__ __launch_bounds__(64 * NWV, WPS) void cross_attn_f16x3_kernel(const m
                 const int jt = 2 * jp + ts;
                 float pe[4] = {0.f, 0.f, 0.f, 0.f};
                 if (jt < JT) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) { pe[r] = __builtin_amdgcn_exp2f(fmaf(s[jt < JT ? jt : 0][r], sc, msc)); l += pe[r]; }
+                    // exponent arguments and the running sum on packed pairs (v_pk_fma_f32 / v_pk_add_f32)
+                    const f32x4 sv = s[jt < JT ? jt : 0];
+                    const mi_f32x2 a01 = mi_pk_fma((mi_f32x2){sv[0], sv[1]}, sc2, msc2), a23 = mi_pk_fma((mi_f32x2){sv[2], sv[3]}, sc2, msc2);
+                    pe[0] = __builtin_amdgcn_exp2f(a01[0]); pe[1] = __builtin_amdgcn_exp2f(a01[1]);
+                    pe[2] = __builtin_amdgcn_exp2f(a23[0]); pe[3] = __builtin_amdgcn_exp2f(a23[1]);
+                    l2 = mi_pk_add(l2, (mi_f32x2){pe[0], pe[1]});
+                    l2 = mi_pk_add(l2, (mi_f32x2){pe[2], pe[3]});
                 }
                 if constexpr (HALF) {
 #pragma unroll
@@ -439,6 +445,7 @@ __global__ __launch_bounds__(64 * NWV, WPS) void cross_attn_f16x3_kernel(const m
                 oh[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vhi, phi, oh[mt], 0, 0, 0);
             }
         }
+        float l = l2[0] + l2[1];
         l += __shfl_xor(l, 16);
         l += __shfl_xor(l, 32);
         const float linv = ldexpf(1.0f / l, -p.v_exp);

@@ -31,33 +31,52 @@ __device__ __forceinline__ float mi_silu(float v) {
 }
 
 // fp16 hi/lo split of four fp32 values for the 3-term MFMA products: hi = fp16(x), lo = fp16(x - hi) (22 mantissa bits kept).
-// (A mask + v_cvt_pkrtz formulation was measured 16 % slower on MI355X than plain conversions; the v_fma_mix_f32 form below 4 % faster
-//  on the attention kernel.  -DMI_SPLIT_PLAIN builds the plain form on the device too.)
+// (A mask + v_cvt_pkrtz formulation was measured 16 % slower on MI355X than plain conversions.  -DMI_SPLIT_PLAIN builds the plain form
+//  on the device too.)
 typedef _Float16 mi_f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 mi_f16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void mi_split_f16(const float (&x)[4], mi_f16x4& hi, mi_f16x4& lo) {
+// lo halves of two values whose fp16 hi halves are packed in hb: x - float(hi) straight from the packed halves with v_fma_mix_f32
+// (fma(f16 -> f32, -1, x); exact, Sterbenz), then one packed conversion.  The emulator build takes the plain form, which computes the
+// same bits.  NOTE on inline asm here: the compiler's hazard recogniser does not look inside inline asm (MFMA / transcendental results
+// read too early, asm results read too early by an MFMA).  This form is framed by compiler-generated instructions on both sides (the
+// packed conversions); v_fma_mixlo_f16 / v_fma_mixhi_f16 (which would save the second conversion) and v_pk_* written as asm returned
+// wrong results on the MI355X inside the attention kernel for exactly that reason.
+__device__ __forceinline__ unsigned mi_split_lo2(unsigned hb, float x0, float x1) {
 #if !defined(MI_SPLIT_PLAIN) && !defined(HIPEMU)
-    // x - float(hi) straight from the packed halves with v_fma_mix_f32 (fma(f16 -> f32, -1, x); exact, Sterbenz): no separate
-    // v_cvt_f32_f16 per element.  The emulator build takes the plain form below, which computes the same bits.
-#pragma unroll
-    for (int e = 0; e < 4; e += 2) {
-        const mi_f16x2 h2 = {(_Float16)x[e], (_Float16)x[e + 1]};
-        const unsigned hb = __builtin_bit_cast(unsigned, h2);
-        float l0, l1;
-        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(hb), "v"(x[e]));
-        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(hb), "v"(x[e + 1]));
-        hi[e] = h2[0]; hi[e + 1] = h2[1];
-        lo[e] = (_Float16)l0; lo[e + 1] = (_Float16)l1;
-    }
+    float l0, l1;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(hb), "v"(x0));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(hb), "v"(x1));
+    const mi_f16x2 l2 = {(_Float16)l0, (_Float16)l1};
+    return __builtin_bit_cast(unsigned, l2);
 #else
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const _Float16 h = (_Float16)x[e];
-        hi[e] = h;
-        lo[e] = (_Float16)(x[e] - (float)h);
-    }
+    const mi_f16x2 h2 = __builtin_bit_cast(mi_f16x2, hb);
+    const mi_f16x2 l2 = {(_Float16)(x0 - (float)h2[0]), (_Float16)(x1 - (float)h2[1])};
+    return __builtin_bit_cast(unsigned, l2);
 #endif
 }
+__device__ __forceinline__ void mi_split_f16(const float (&x)[4], mi_f16x4& hi, mi_f16x4& lo) {
+    unsigned hb[2], lb[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const mi_f16x2 h2 = {(_Float16)x[2 * e], (_Float16)x[2 * e + 1]};
+        hb[e] = __builtin_bit_cast(unsigned, h2);
+        lb[e] = mi_split_lo2(hb[e], x[2 * e], x[2 * e + 1]);
+    }
+    hi = __builtin_bit_cast(mi_f16x4, make_uint2(hb[0], hb[1]));
+    lo = __builtin_bit_cast(mi_f16x4, make_uint2(lb[0], lb[1]));
+}
+
+// packed fp32 pairs: the compiler selects v_pk_fma_f32 / v_pk_add_f32 for two-element vectors (two lanes' worth of work per issue
+// slot) and keeps track of the hazards around them, which inline asm would not
+typedef float mi_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ mi_f32x2 mi_pk_fma(mi_f32x2 a, mi_f32x2 b, mi_f32x2 c) {
+#if !defined(HIPEMU)
+    return __builtin_elementwise_fma(a, b, c);
+#else
+    return (mi_f32x2){fmaf(a[0], b[0], c[0]), fmaf(a[1], b[1], c[1])};
+#endif
+}
+__device__ __forceinline__ mi_f32x2 mi_pk_add(mi_f32x2 a, mi_f32x2 b) { return a + b; }
 
 // mi_act.bmod: row b of a tensor shared between the guidance halves lives at b % bmod.  The engine only ever shares between two
 // halves (B2 = 2 bmod), so the (wave-uniform but ~40-instruction) integer division is kept off the common path.

@@ -58,16 +58,7 @@ __device__ __forceinline__ void rp_split8(const float (&y)[8], uint4& hi, uint4&
         const rp_f32x2 v = {y[2 * i], y[2 * i + 1]};
         const rp_f16x2 h2 = __builtin_convertvector(v, rp_f16x2);
         h[i] = __builtin_bit_cast(unsigned, h2);
-        float l0, l1;
-#if !defined(HIPEMU)
-        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(h[i]), "v"(y[2 * i]));
-        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(h[i]), "v"(y[2 * i + 1]));
-#else
-        l0 = y[2 * i] - (float)h2[0];
-        l1 = y[2 * i + 1] - (float)h2[1];
-#endif
-        const rp_f32x2 lv = {l0, l1};
-        l[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(lv, rp_f16x2));
+        l[i] = mi_split_lo2(h[i], y[2 * i], y[2 * i + 1]);
     }
     hi = make_uint4(h[0], h[1], h[2], h[3]);
     lo = make_uint4(l[0], l[1], l[2], l[3]);
