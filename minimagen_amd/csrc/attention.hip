@@ -256,6 +256,9 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 // ATTN_QK32=1: QK^T as {G hi | G lo}.{x hi | x hi} (K = 32) + G hi . x lo (K = 16).  Correct on the SIMT emulator, WRONG on the MI355X
 // (round 1 and round 2, every ordering; the same pair is correct in isolation, tools/ubench/mfma32_layout.hip) and worth only 2 % of the
 // kernel (measured 0.413 vs 0.421 ms per pair of launches): off.
+#ifndef ATTN_QPF
+#define ATTN_QPF 1          // prefetch the next QK^T fragment (one tile ahead) in the 3-term kernel
+#endif
 #ifndef ATTN_QK32
 #define ATTN_QK32 0
 #endif
@@ -358,13 +361,21 @@ __global__ __launch_bounds__(64 * NWV, WPS) void cross_attn_f16x3_kernel(const m
         __syncthreads();                                  // ... everybody's has, and nobody reads head h - 1's buffer any more
         if (h + 1 < p.heads) issue_head(h + 1, hb ^ 1);
         f32x4 s[JT];
+        uint4 gq[2];                                       // 3-term, one channel chunk: the next tile's fragment is read while this tile multiplies
+        constexpr bool QPF = !HALF && KC == 1 && ATTN_QPF;
+        if constexpr (QPF) gq[0] = frag[hb][lane];
 #pragma unroll
         for (int jt = 0; jt < JT; ++jt) {
             f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if constexpr (QPF) {
+                if (jt + 1 < JT) gq[(jt + 1) & 1] = frag[hb][((jt + 1) * QC) * 64 + lane];
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
             for (int kc = 0; kc < KC; ++kc) {
                 union { uint4 u; f16x4 h2[2]; uint2 u2; } g;
                 if constexpr (HALF) g.u2 = reinterpret_cast<const uint2*>(&frag[hb][0])[2 * ((jt * QC + kc) * 64 + lane)];    // hi halves only
+                else if constexpr (QPF) g.u = gq[jt & 1];
                 else g.u = frag[hb][(jt * QC + kc) * 64 + lane];
                 const f16x4 ghi = g.h2[0];
                 if constexpr (!HALF) {
