@@ -212,6 +212,7 @@ typedef struct mi_attn_fold_params {
                  step's ss_n scale/shift values per row from ss_all to ss (the ResnetBlocks' time_mlp outputs) */
     int mode;
     const int* t_state;
+    int t_off;              /* mode 2: the step is *t_state - t_off */
     const float* ss_all; float* ss; int ss_n;
 } mi_attn_fold_params;
 int mi_attn_fold_rows(const mi_attn_fold_params* p, void* stream);
@@ -254,6 +255,7 @@ typedef struct mi_cfg_x0_params {
     float* x0;                    /* [B][n] or NULL */
     unsigned* hist0;              /* optional: pass-0 slice [B][2][MI_Q_BINS] of the quantile histograms (zero on entry): the radix
                                      select's first pass over |x0| is accumulated here while x0 is produced (see mi_quantile_params.pass0_done) */
+    int t_off;                    /* the step is *t_state - t_off: several steps of one captured graph share one advance of t_state */
 } mi_cfg_x0_params;
 int mi_cfg_x0_fwd(const mi_cfg_x0_params* p, void* stream);
 
@@ -286,11 +288,22 @@ typedef struct mi_posterior_params {
     const float* noise;
     uint64_t seed; int sample0; int stream_base;
     const uint64_t* seed_dev;     /* when non-NULL the seed is read from device memory (lets one captured graph serve every call) */
+    int t_off;                    /* the step is *t_state - t_off */
 } mi_posterior_params;
 int mi_posterior_fwd(const mi_posterior_params* p, void* stream);
 
+/* K11 epilogue + K12 + K13 of one denoising step in ONE launch, for images that fit a workgroup's registers (n <= MI_SAMPLER_SMALL_N, the
+ * base stage): guidance combine, x0, the exact radix select of the two order statistics (histograms in LDS, no global atomics), the
+ * threshold and the posterior draw.  Same operations in the same order as mi_cfg_x0_fwd -> mi_quantile_fwd -> mi_posterior_fwd (bit-identical
+ * results); c->x0 / c->pred_out / q->s_out / q->v_out are written when non-NULL, c->hist0 / q->hist are not used.  MI_ERR_UNSUPPORTED for
+ * larger images. */
+#define MI_SAMPLER_SMALL_N 16384
+int mi_sampler_step_small_fwd(const mi_cfg_x0_params* c, const mi_quantile_params* q, const mi_posterior_params* pp, void* stream);
+
 /* t -= 1 ; times[b] = t  (diffusion_model.py:81-87, one step of the list) */
 int mi_step_advance(int* t_state, int64_t* times, int B, void* stream);
+/* t -= n ; times[b] = t  (the steps of one captured graph address *t_state - k and advance once) */
+int mi_step_advance_by(int* t_state, int64_t* times, int B, int n, void* stream);
 /* t = value ; times[b] = value */
 int mi_step_set(int* t_state, int64_t* times, int B, int value, void* stream);
 

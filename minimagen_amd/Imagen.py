@@ -206,21 +206,44 @@ class Imagen(nn.Module):
                                      L.ptr(noise_dev), int(seed) & 0x7FFFFFFFFFFFFFFF, sample0, stage << 20,
                                      L.ptr(st.seed_dev) if noise_dev is None else 0)
 
-            def one_step():
-                eng.run_step(ws, stream)
-                L.check(lib.mi_cfg_x0_fwd(C.byref(cp), stream), "mi_cfg_x0_fwd")
-                L.check(lib.mi_quantile_fwd(C.byref(qp), stream), "mi_quantile_fwd")
-                L.check(lib.mi_posterior_fwd(C.byref(pp), stream), "mi_posterior_fwd")
-                L.check(lib.mi_step_advance(L.ptr(st.t_state), L.ptr(ws.times), B, stream), "mi_step_advance")
+            small = n <= 16384 and os.environ.get("MINIMAGEN_SAMPLER_FUSED", "1") != "0"      # MI_SAMPLER_SMALL_N: the whole tail in one launch
+            offsets = eng.step_offsets_supported(ws)          # the k-th step of a graph addresses *t_state - k; one advance per graph
+
+            def tail_params(k):
+                c_, p_ = L.MiCfgX0Params.from_buffer_copy(cp), L.MiPosteriorParams.from_buffer_copy(pp)
+                c_.t_off = p_.t_off = k
+                if small:
+                    c_.x0 = c_.hist0 = 0                      # x0 stays in registers, the histograms in LDS
+                return c_, p_
+            tails = {}
+
+            def one_step(k=0, advance=1):
+                eng.run_step(ws, stream, t_off=k)
+                if k not in tails:
+                    tails[k] = tail_params(k)
+                c_, p_ = tails[k]
+                if small:
+                    L.check(lib.mi_sampler_step_small_fwd(C.byref(c_), C.byref(qp), C.byref(p_), stream), "mi_sampler_step_small_fwd")
+                else:
+                    L.check(lib.mi_cfg_x0_fwd(C.byref(c_), stream), "mi_cfg_x0_fwd")
+                    L.check(lib.mi_quantile_fwd(C.byref(qp), stream), "mi_quantile_fwd")
+                    L.check(lib.mi_posterior_fwd(C.byref(p_), stream), "mi_posterior_fwd")
+                if advance == 1:
+                    L.check(lib.mi_step_advance(L.ptr(st.t_state), L.ptr(ws.times), B, stream), "mi_step_advance")
+                elif advance > 1:
+                    L.check(lib.mi_step_advance_by(L.ptr(st.t_state), L.ptr(ws.times), B, advance, stream), "mi_step_advance_by")
             # several denoising steps per captured graph: one replay boundary (~9 us of idle GPU) per `per` steps instead of per step
             cap = int(os.environ.get("MINIMAGEN_STEPS_PER_GRAPH", "5"))
             per = next(k for k in (5, 4, 3, 2, 1) if k <= cap and T % k == 0)
-            entry = dict(step=one_step, graph=None, keep=(cp, qp, pp), per=per)
+            entry = dict(step=one_step, graph=None, keep=(cp, qp, pp, tails), per=per)
             if use_graph:
                 L.check(lib.mi_graph_begin(stream), "mi_graph_begin")
                 try:
-                    for _ in range(per):
-                        one_step()
+                    for k in range(per):
+                        if offsets:
+                            one_step(k, per if k == per - 1 else 0)
+                        else:
+                            one_step()
                 finally:
                     g = C.c_void_p()
                     rc = lib.mi_graph_end(stream, C.byref(g))

@@ -82,7 +82,7 @@ class MiAttnFoldParams(C.Structure):
         ("B2", C.c_int), ("C", C.c_int), ("cd", C.c_int), ("heads", C.c_int), ("JT", C.c_int),
         ("c_rows", C.c_void_p), ("c_stride_b", C.c_int), ("row0", C.c_int), ("nrows", C.c_int), ("write_null", C.c_int), ("frag_f16", C.c_int),
         ("n_blocks", C.c_int), ("blk", MiAttnFoldBlk * 8),
-        ("mode", C.c_int), ("t_state", C.c_void_p), ("ss_all", C.c_void_p), ("ss", C.c_void_p), ("ss_n", C.c_int),
+        ("mode", C.c_int), ("t_state", C.c_void_p), ("t_off", C.c_int), ("ss_all", C.c_void_p), ("ss", C.c_void_p), ("ss_n", C.c_int),
     ]
 
 
@@ -119,7 +119,7 @@ class MiTokensToNchwParams(C.Structure):
 class MiCfgX0Params(C.Structure):
     _fields_ = [("B", C.c_int), ("n", C.c_int), ("pred2", C.c_void_p), ("two", C.c_int), ("cond_scale", C.c_float),
                 ("x_t", C.c_void_p), ("coef", C.c_void_p), ("t_state", C.c_void_p), ("pred_out", C.c_void_p), ("x0", C.c_void_p),
-                ("hist0", C.c_void_p)]
+                ("hist0", C.c_void_p), ("t_off", C.c_int)]
 
 
 class MiQuantileParams(C.Structure):
@@ -130,7 +130,7 @@ class MiQuantileParams(C.Structure):
 class MiPosteriorParams(C.Structure):
     _fields_ = [("B", C.c_int), ("n", C.c_int), ("T", C.c_int), ("x0", C.c_void_p), ("s_q", C.c_void_p), ("x", C.c_void_p),
                 ("coef", C.c_void_p), ("t_state", C.c_void_p), ("noise", C.c_void_p),
-                ("seed", C.c_uint64), ("sample0", C.c_int), ("stream_base", C.c_int), ("seed_dev", C.c_void_p)]
+                ("seed", C.c_uint64), ("sample0", C.c_int), ("stream_base", C.c_int), ("seed_dev", C.c_void_p), ("t_off", C.c_int)]
 
 
 class MiResizeParams(C.Structure):
@@ -162,6 +162,9 @@ def _bind(lib):
         getattr(lib, name).argtypes = [vp, vp]
         getattr(lib, name).restype = i32
     lib.mi_step_advance.argtypes = [vp, vp, i32, vp]
+    lib.mi_step_advance_by.argtypes = [vp, vp, i32, i32, vp]
+    lib.mi_sampler_step_small_fwd.argtypes = [vp, vp, vp, vp]
+    lib.mi_sampler_step_small_fwd.restype = i32
     lib.mi_step_set.argtypes = [vp, vp, i32, i32, vp]
     lib.mi_randn_fill.argtypes = [vp, i32, i32, u64, i32, i32, vp]
     lib.mi_finalize_images.argtypes = [vp, vp, i64, i32, vp]

@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void cond_step_kernel(const mi_cond_step_param
 __global__ __launch_bounds__(256) void attn_fold_rows_kernel(const mi_attn_fold_params p) {
     const int bb = blockIdx.x, blk = blockIdx.y;
     if (blk == p.n_blocks) {          // mode 2 only: this step's scale/shift rows
-        const float* src = p.ss_all + ((size_t)(*p.t_state) * gridDim.x + bb) * p.ss_n;
+        const float* src = p.ss_all + ((size_t)(*p.t_state - p.t_off) * gridDim.x + bb) * p.ss_n;
         for (int i = threadIdx.x; i < p.ss_n; i += 256) p.ss[(size_t)bb * p.ss_n + i] = src[i];
         return;
     }
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void attn_fold_rows_kernel(const mi_attn_fold_
     float* gv = p.blk[blk].gv + (size_t)bb * p.heads * p.JT * 64 * FR;
     const int first = p.write_null ? -1 : 0;
     const int total = (p.nrows - first) * p.heads * C;
-    const size_t trow = p.mode == 2 ? (size_t)(*p.t_state) * gridDim.x + bb : (size_t)bb;      // row of the compact table
+    const size_t trow = p.mode == 2 ? (size_t)(*p.t_state - p.t_off) * gridDim.x + bb : (size_t)bb;      // row of the compact table
     for (int idx = threadIdx.x; idx < total; idx += 256) {
         const int a = idx % C, h = (idx / C) % p.heads, r = idx / (C * p.heads) + first;
         float g, v;

@@ -16,7 +16,7 @@ template <bool HIST>
 __global__ __launch_bounds__(256) void cfg_x0_kernel(const mi_cfg_x0_params p) {
     __shared__ unsigned lh[HIST ? MI_Q_BINS : 1];      // pass 0 of the radix select (bits 30..20 of |x0|), fused into the producer of x0
     const int b = blockIdx.y;
-    const int t = p.t_state ? *p.t_state : 0;
+    const int t = p.t_state ? *p.t_state - p.t_off : 0;
     const float ca = p.coef ? p.coef[t * 8 + 0] : 0.0f, cb = p.coef ? p.coef[t * 8 + 1] : 0.0f;
     if constexpr (HIST) {
         for (int i = threadIdx.x; i < MI_Q_BINS; i += 256) lh[i] = 0u;
@@ -68,24 +68,26 @@ __device__ __forceinline__ int q_bits(int pass) { return pass == 2 ? 9 : 11; }
 
 // Block-wide: locate the bin of `hist` (MI_Q_BINS entries) that holds 0-based rank r; returns bin and the
 // rank inside the bin.  All 256 work-items call it; result broadcast through LDS.
-__device__ void q_find_bin(const unsigned* hist, unsigned r, int* sh_scratch, unsigned& bin_out, unsigned& r_out) {
-    unsigned* wsum = reinterpret_cast<unsigned*>(sh_scratch);       // [4] wave totals, [4..5] result
+__device__ void q_find_bin(const unsigned* hist, unsigned r, int* sh_scratch, unsigned& bin_out, unsigned& r_out, bool active = true) {
+    // `active`: the first 256 work-items of the workgroup scan (8 bins each); larger workgroups pass false for the rest, which only
+    // take part in the barriers and receive the broadcast
+    unsigned* wsum = reinterpret_cast<unsigned*>(sh_scratch);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     unsigned c[8], tot = 0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { c[k] = hist[tid * 8 + k]; tot += c[k]; }
+    for (int k = 0; k < 8; ++k) { c[k] = active ? hist[tid * 8 + k] : 0u; tot += c[k]; }
     unsigned inc = tot;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
         const unsigned v = __shfl_up(inc, o);
         if (lane >= o) inc += v;
     }
-    if (lane == 63) wsum[wave] = inc;
+    if (active && lane == 63) wsum[wave] = inc;
     __syncthreads();
     unsigned base = 0;
-    for (int w = 0; w < wave; ++w) base += wsum[w];
+    for (int w = 0; w < wave && w < 4; ++w) base += wsum[w];
     unsigned excl = base + inc - tot;
-    if (r >= excl && r < excl + tot) {
+    if (active && r >= excl && r < excl + tot) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             if (r < excl + c[k]) { wsum[4] = (unsigned)(tid * 8 + k); wsum[5] = r - excl; break; }
@@ -225,7 +227,7 @@ __global__ __launch_bounds__(256) void randn_fill_kernel(float* out, int n, unsi
 // ------------------------------------------------------------------ K13
 __global__ __launch_bounds__(256) void posterior_kernel(const mi_posterior_params p) {
     const int b = blockIdx.y;
-    const int t = *p.t_state;
+    const int t = *p.t_state - p.t_off;
     const float c1 = p.coef[t * 8 + 2], c2 = p.coef[t * 8 + 3], sigma = p.coef[t * 8 + 4];
     const float sq = p.s_q[b];
     const float s = (sq < 1.0f) ? 1.0f : sq;                                     // Imagen.py:320 clamp_(min=1.): a NaN threshold stays NaN, as in torch
@@ -266,8 +268,129 @@ __global__ __launch_bounds__(256) void posterior_kernel(const mi_posterior_param
     }
 }
 
+// ------------------------------------------------------------------ K11 epilogue + K12 + K13 in one launch (small images)
+// One workgroup of 1024 work-items per image; every work-item keeps its quads of x0 in registers, the three radix passes run on
+// histograms in LDS.  Operation order per element as in cfg_x0_kernel / quantile_*_kernel / posterior_kernel: bit-identical results.
+constexpr int SS_NT = 1024, SS_MAXQ = MI_SAMPLER_SMALL_N / 4 / SS_NT;      // quads per work-item
+__global__ __launch_bounds__(SS_NT) void sampler_small_kernel(const mi_cfg_x0_params c, const mi_quantile_params q, const mi_posterior_params pp) {
+    __shared__ unsigned lh[2][MI_Q_BINS];
+    __shared__ int scratch[8];
+    __shared__ unsigned nan_sh;
+    const int tid = threadIdx.x, b = blockIdx.x, n = c.n, nq = (n + 3) / 4;
+    const int t = *c.t_state - c.t_off;
+    const float ca = c.coef[t * 8 + 0], cb = c.coef[t * 8 + 1];
+    const float c1 = c.coef[t * 8 + 2], c2 = c.coef[t * 8 + 3], sigma = c.coef[t * 8 + 4];
+    const bool vec = (n & 3) == 0;
+    const size_t ob = (size_t)b * n, on = (size_t)(b + c.B) * n;
+    float x0v[SS_MAXQ][4], xtv[SS_MAXQ][4];
+    for (int i = tid; i < 2 * MI_Q_BINS; i += SS_NT) (&lh[0][0])[i] = 0u;
+    if (tid == 0) nan_sh = 0u;
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < SS_MAXQ; ++u) {
+        const int qd = tid + u * SS_NT;
+        float cc[4], nl[4], pr[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { cc[e] = nl[e] = xtv[u][e] = x0v[u][e] = 0.0f; }
+        if (qd < nq) {
+            if (vec) {
+                const float4 a = mi_ldg4(c.pred2 + ob + 4 * qd), xx = mi_ldg4(c.x_t + ob + 4 * qd);
+                const float4 d = c.two ? mi_ldg4(c.pred2 + on + 4 * qd) : a;
+                cc[0] = a.x; cc[1] = a.y; cc[2] = a.z; cc[3] = a.w; nl[0] = d.x; nl[1] = d.y; nl[2] = d.z; nl[3] = d.w;
+                xtv[u][0] = xx.x; xtv[u][1] = xx.y; xtv[u][2] = xx.z; xtv[u][3] = xx.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (4 * qd + e < n) { cc[e] = c.pred2[ob + 4 * qd + e]; nl[e] = c.two ? c.pred2[on + 4 * qd + e] : cc[e]; xtv[u][e] = c.x_t[ob + 4 * qd + e]; }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                pr[e] = cc[e];
+                if (c.two) pr[e] = __fadd_rn(nl[e], __fmul_rn(__fsub_rn(cc[e], nl[e]), c.cond_scale));       // Unet.py:506
+                x0v[u][e] = __fsub_rn(__fmul_rn(ca, xtv[u][e]), __fmul_rn(cb, pr[e]));                      // diffusion_model.py:159-162
+                if (4 * qd + e < n) {
+                    atomicAdd(&lh[0][__float_as_uint(fabsf(x0v[u][e])) >> 20], 1u);
+                    if (c.pred_out) c.pred_out[ob + 4 * qd + e] = pr[e];
+                    if (c.x0) c.x0[ob + 4 * qd + e] = x0v[u][e];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // torch.quantile returns NaN for a row that contains a NaN: NaN patterns sit in the top bins of pass 0 (as quantile_finish_kernel)
+    if (tid < MI_Q_BINS - 0x7F9) { const unsigned v = lh[0][0x7F9 + tid]; if (v) atomicAdd(&nan_sh, v); }
+    unsigned prefix[2] = {0u, 0u}, rk[2] = {(unsigned)q.k_lo, (unsigned)q.k_hi};
+#pragma unroll
+    for (int ps = 0; ps < 3; ++ps) {
+        if (ps > 0) {
+            // histogram of the next digit over the elements that carry each selected prefix
+            __syncthreads();
+            for (int i = tid; i < 2 * MI_Q_BINS; i += SS_NT) (&lh[0][0])[i] = 0u;
+            __syncthreads();
+            const int shift = q_shift(ps), nb = q_bits(ps);
+            const unsigned mask = (1u << nb) - 1u;
+#pragma unroll
+            for (int u = 0; u < SS_MAXQ; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int i = 4 * (tid + u * SS_NT) + e;
+                    if (i < n) {
+                        const unsigned key = __float_as_uint(fabsf(x0v[u][e]));
+                        const unsigned hi = key >> (shift + nb), bin = (key >> shift) & mask;
+                        if (hi == prefix[0]) atomicAdd(&lh[0][bin], 1u);
+                        if (hi == prefix[1]) atomicAdd(&lh[1][bin], 1u);
+                    }
+                }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int sel = 0; sel < 2; ++sel) {
+            unsigned bin, rr;
+            q_find_bin(&lh[ps == 0 ? 0 : sel][0], rk[sel], scratch, bin, rr, tid < 256);
+            prefix[sel] = (prefix[sel] << q_bits(ps)) | bin;
+            rk[sel] = rr;
+        }
+    }
+    float a = __uint_as_float(prefix[0]), bb = __uint_as_float(prefix[1]);
+    if (nan_sh) a = bb = __uint_as_float(0x7FC00000u);
+    const float d = __fsub_rn(bb, a);
+    const float sq = (fabsf(q.w) < 0.5f) ? fmaf(q.w, d, a) : fmaf(__fsub_rn(q.w, 1.0f), d, bb);      // ATen lerp (fused multiply-add)
+    if (tid == 0) {
+        if (q.s_out) q.s_out[b] = sq;
+        if (q.v_out) { q.v_out[2 * b] = a; q.v_out[2 * b + 1] = bb; }
+    }
+    const float s = (sq < 1.0f) ? 1.0f : sq;                                     // Imagen.py:320 clamp_(min=1.): a NaN threshold stays NaN
+    const int k = (pp.T - 1) - t;
+    const float* nz = pp.noise ? pp.noise + ((size_t)k * pp.B + b) * n : nullptr;
+#pragma unroll
+    for (int u = 0; u < SS_MAXQ; ++u) {
+        const int qd = tid + u * SS_NT;
+        if (qd >= nq) continue;
+        float z[4];
+        if (nz) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) z[e] = (4 * qd + e < n) ? nz[4 * qd + e] : 0.0f;
+        } else {
+            randn4(pp.seed_dev ? *pp.seed_dev : pp.seed, (unsigned)(pp.sample0 + b), (unsigned)(pp.stream_base + k), (unsigned)qd, z);
+        }
+        float r[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float x0 = x0v[u][e];
+            x0 = __fdiv_rn(x0 != x0 ? x0 : fminf(fmaxf(x0, -s), s), s);                  // Imagen.py:323 (torch.clamp propagates NaN)
+            const float mean = __fadd_rn(__fmul_rn(c1, x0), __fmul_rn(c2, xtv[u][e]));     // diffusion_model.py:118-121
+            r[e] = __fadd_rn(mean, __fmul_rn(sigma, z[e]));                               // Imagen.py:370
+        }
+        if (vec) mi_stg4(pp.x + ob + 4 * qd, make_float4(r[0], r[1], r[2], r[3]));
+        else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (4 * qd + e < n) pp.x[ob + 4 * qd + e] = r[e];
+        }
+    }
+}
+
 __global__ void step_advance_kernel(int* t_state, long long* times, int B, int set, int value) {
-    const int t = set ? value : (*t_state - 1);
+    const int t = set == 1 ? value : (*t_state - (set == 2 ? value : 1));
     __syncthreads();
     for (int b = threadIdx.x; b < B; b += blockDim.x) times[b] = (long long)t;
     if (threadIdx.x == 0) *t_state = t;
@@ -342,6 +465,17 @@ extern "C" int mi_quantile_fwd(const mi_quantile_params* p, void* stream) {
     return mi_check_launch("quantile kernels");
 }
 
+extern "C" int mi_sampler_step_small_fwd(const mi_cfg_x0_params* c, const mi_quantile_params* q, const mi_posterior_params* pp, void* stream) {
+    if (c->B <= 0 || c->n <= 0 || q->B != c->B || pp->B != c->B || q->n != c->n || pp->n != c->n) { mi_set_error("mi_sampler_step_small_fwd: inconsistent B / n"); return MI_ERR_INVALID; }
+    if (c->n > MI_SAMPLER_SMALL_N) { mi_set_error("mi_sampler_step_small_fwd: n = %d > %d", c->n, MI_SAMPLER_SMALL_N); return MI_ERR_UNSUPPORTED; }
+    if (!c->x_t || !c->coef || !c->t_state || !pp->x || c->t_state != pp->t_state || c->t_off != pp->t_off || c->coef != pp->coef || c->x_t != pp->x) {
+        mi_set_error("mi_sampler_step_small_fwd: needs x_t == x, one coef table and one t_state / t_off for the step"); return MI_ERR_INVALID;
+    }
+    if (q->k_lo < 0 || q->k_hi >= q->n || q->k_lo > q->k_hi) { mi_set_error("mi_sampler_step_small_fwd: bad ranks"); return MI_ERR_INVALID; }
+    hipLaunchKernelGGL(sampler_small_kernel, dim3(c->B), dim3(SS_NT), 0, (hipStream_t)stream, *c, *q, *pp);
+    return mi_check_launch("sampler_small_kernel");
+}
+
 extern "C" int mi_posterior_fwd(const mi_posterior_params* p, void* stream) {
     if (p->B <= 0 || p->n <= 0) { mi_set_error("mi_posterior_fwd: empty"); return MI_ERR_INVALID; }
     hipLaunchKernelGGL(posterior_kernel, dim3(grid_for((p->n + 3) / 4, 256), p->B), dim3(256), 0, (hipStream_t)stream, *p);
@@ -350,6 +484,10 @@ extern "C" int mi_posterior_fwd(const mi_posterior_params* p, void* stream) {
 
 extern "C" int mi_step_advance(int* t_state, int64_t* times, int B, void* stream) {
     hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, t_state, (long long*)times, B, 0, 0);
+    return mi_check_launch("step_advance_kernel");
+}
+extern "C" int mi_step_advance_by(int* t_state, int64_t* times, int B, int n, void* stream) {
+    hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, t_state, (long long*)times, B, 2, n);
     return mi_check_launch("step_advance_kernel");
 }
 extern "C" int mi_step_set(int* t_state, int64_t* times, int B, int value, void* stream) {

@@ -766,11 +766,32 @@ class UnetEngine:
             L.check(lib.mi_attn_fold_rows(C.byref(f1), st), "mi_attn_fold_rows (all steps)")
         ws.prog_stage = tb.stage
 
-    def run_step(self, ws, stream=None):
+    def stage_prog(self, ws, t_off: int = 0):
+        """The per-step conditioning launches for the step ``*t_state - t_off`` (the steps of one captured graph share one advance of
+        the device-resident timestep); only the table scatter takes an offset -- the per-step ``prog_cond`` of the wide presets reads
+        ``ws.times`` and needs t_off == 0."""
+        if t_off == 0:
+            return ws.prog_stage
+        assert ws.prog_stage is not ws.prog_cond, "the step-at-a-time conditioning cannot address a timestep offset"
+        cache = ws.__dict__.setdefault("prog_stage_off", {})
+        key = (id(ws.prog_stage), t_off)
+        if key not in cache:
+            prog = []
+            for fn, p, name in ws.prog_stage:
+                q = L.MiAttnFoldParams.from_buffer_copy(p)
+                q.t_off = t_off
+                prog.append((fn, q, name))
+            cache[key] = prog
+        return cache[key]
+
+    def step_offsets_supported(self, ws) -> bool:
+        return ws.prog_stage is not ws.prog_cond
+
+    def run_step(self, ws, stream=None, t_off: int = 0):
         """One denoising step's U-Net evaluation inside the sampling loop: scatter the current step's conditioning (see
         prepare_step_tables), then the image kernels."""
         st = L.current_stream() if stream is None else stream
-        for fn, p, name in ws.prog_stage + ws.prog:
+        for fn, p, name in self.stage_prog(ws, t_off) + ws.prog:
             rc = fn(C.byref(p), st) if p is not None else fn(None, st)
             if rc != 0:
                 L.check(rc, name)

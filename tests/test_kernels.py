@@ -571,6 +571,21 @@ def test_sampler_elementwise_bit_exact(backend, side):
         L.check(lib.mi_posterior_fwd(C.byref(pp), L.current_stream()))
         xr, _ = R.p_sample(None, sched, xt.reshape(B, 3, side, side), t, noise[T - 1 - t].reshape(B, 3, side, side), pred=pred.reshape(B, 3, side, side))
         assert torch.equal(x.cpu().reshape(B, 3, side, side), xr)
+        # the whole tail in one launch (images that fit a workgroup's registers: the base stage), addressed as step *t_state - t_off:
+        # same bits as the three launches, with the injected noise and with the on-device generator
+        for off in (0, 2):
+            ts2 = torch.tensor([t + off], dtype=torch.int32, device=dev)
+            for use_noise in (True, False):
+                xa, xb = xtd.clone(), xtd.clone()
+                sf, vf, pgf = torch.zeros(B, device=dev), torch.zeros(B, 2, device=dev), torch.zeros(B, n, device=dev)
+                nzp = noised.data_ptr() if use_noise else 0
+                ppa = L.MiPosteriorParams(B, n, T, x0.data_ptr(), s.data_ptr(), xa.data_ptr(), coef.data_ptr(), tstate.data_ptr(), nzp, 77, 5, 3 << 20)
+                L.check(lib.mi_posterior_fwd(C.byref(ppa), L.current_stream()))
+                cf = L.MiCfgX0Params(B, n, pred2d.data_ptr(), 1, 3.0, xb.data_ptr(), coef.data_ptr(), ts2.data_ptr(), pgf.data_ptr(), 0, 0, off)
+                qf = L.MiQuantileParams(B, n, 0, k_lo, k_hi, w, 0, sf.data_ptr(), vf.data_ptr(), 0, 0)
+                ppf = L.MiPosteriorParams(B, n, T, 0, 0, xb.data_ptr(), coef.data_ptr(), ts2.data_ptr(), nzp, 77, 5, 3 << 20, 0, off)
+                L.check(lib.mi_sampler_step_small_fwd(C.byref(cf), C.byref(qf), C.byref(ppf), L.current_stream()), "fused tail")
+                assert torch.equal(xb, xa) and torch.equal(sf, s) and torch.equal(pgf, pg), (off, use_noise)
     # timestep bookkeeping (bit-exact integers)
     times = torch.zeros(5, dtype=torch.int64, device=dev)
     ts = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -578,6 +593,8 @@ def test_sampler_elementwise_bit_exact(backend, side):
     assert ts.item() == 24 and times.tolist() == [24] * 5
     lib.mi_step_advance(ts.data_ptr(), times.data_ptr(), 5, L.current_stream())
     assert ts.item() == 23 and times.tolist() == [23] * 5
+    lib.mi_step_advance_by(ts.data_ptr(), times.data_ptr(), 5, 5, L.current_stream())
+    assert ts.item() == 18 and times.tolist() == [18] * 5
     xx = torch.randn(1000, generator=g) * 2
     oo = torch.zeros(1000, device=dev)
     lib.mi_finalize_images(xx.to(dev).data_ptr(), oo.data_ptr(), 1000, 1, L.current_stream())
