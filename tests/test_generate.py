@@ -18,12 +18,12 @@ IMAGEN_PARAMS = {"text_embed_dim": None, "channels": 3, "timesteps": 25, "cond_d
                  "only_train_unet_number": None, "image_sizes": [64], "text_encoder_name": "t5_small"}
 
 
-def make_training_dir(root, where="state_dicts"):
+def make_training_dir(root, where="state_dicts", image_size=64):
     for sub in ("parameters", "state_dicts", "tmp"):
         os.makedirs(os.path.join(root, sub))
     stamp = "20220816_165729"
     json.dump(I.unet_params()["unet0"], open(os.path.join(root, "parameters", f"unet_0_params_{stamp}.json"), "w"))
-    json.dump(IMAGEN_PARAMS, open(os.path.join(root, "parameters", f"imagen_params_{stamp}.json"), "w"))
+    json.dump(dict(IMAGEN_PARAMS, image_sizes=[image_size]), open(os.path.join(root, "parameters", f"imagen_params_{stamp}.json"), "w"))
     open(os.path.join(root, "parameters", f"training_parameters_{stamp}.txt"), "w").write("--BATCH_SIZE=2\n")
     if where == "state_dicts":
         torch.save(I.load("unet0_sd.pt"), os.path.join(root, "state_dicts", "unet_0_state_0_2_0.512.pth"))
@@ -50,8 +50,9 @@ def test_load_params_and_checkpoint_selection(tmp_path):
 @pytest.mark.parametrize("backend", BACKENDS)
 def test_sample_and_save_layout_and_pixels(backend, tmp_path, monkeypatch):
     dev = setup(backend)
-    d = make_training_dir(tmp_path / "train")
-    captions = ["a happy dog", "a blue house"][:2 if backend == "gpu" else 1]      # the emulator is slow: one caption there
+    size = 64 if backend == "gpu" else 32                                           # the emulator is slow: one caption and a 32 x 32 image there
+    d = make_training_dir(tmp_path / "train", image_size=size)
+    captions = ["a happy dog", "a blue house"][:2 if backend == "gpu" else 1]
     n = len(captions)
     emb, mask = R.synthetic_text(n, length=8, seed=3)
     monkeypatch.setattr(imagen_module, "t5_encode_text", lambda texts, name=None: (emb.clone(), mask.clone()))   # no T5 files offline
@@ -65,7 +66,7 @@ def test_sample_and_save_layout_and_pixels(backend, tmp_path, monkeypatch):
     ref = m.sample(text_embeds=emb.to(dev), text_masks=mask.to(dev), cond_scale=1.).cpu()
     for i in range(n):
         px = np.asarray(Image.open(out / "generated_images" / f"image_{i}.png"))
-        assert px.shape == (64, 64, 3) and px.dtype == np.uint8
+        assert px.shape == (size, size, 3) and px.dtype == np.uint8
         want = ref[i].mul(255).to(torch.uint8).permute(1, 2, 0).numpy()              # ToPILImage: scale then truncate
         assert np.array_equal(px, want)
     with pytest.raises(FileExistsError):                                             # generate.py:21-22
