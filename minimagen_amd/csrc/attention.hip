@@ -274,15 +274,13 @@ __global__ __launch_bounds__(64 * NWV, WPS) void cross_attn_f16x3_kernel(const m
     constexpr int KC = (C + 15) / 16, MT = (C + 15) / 16, FRH = 8 * KC + 8 * MT, TOK_WG = 16 * NWV, NT = 64 * NWV;
     constexpr int JP = (JT + 1) / 2;
     __shared__ float red[NWV][2 * 16 * MT];
-    // One head's context fragments, staged once per workgroup (the four waves share them; measured: per-wave global loads of the
-    // fragments cost 16-50 % of the kernel).  G as loaded: [tile][kc][lane]{4 hi, 4 lo}; V re-paired for the K = 32 instruction:
-    // [tile pair][mt][lane]{4 hi(t0), 4 hi(t1)} and the same for lo.
-    // One head's context fragments as they lie in global memory, [tile][chunk q][lane] 16 bytes (q < KC: G {4 hi | 4 lo}, else V {4 hi | 4 lo}),
-    // DOUBLE-buffered and filled by LDS-DMA (global_load_lds_dwordx4: no registers, asynchronous): head h + 1 streams in under head h's
-    // MFMA / softmax work, one barrier per head.  (Round 1 staged them with a synchronous barrier - copy - barrier per head: measured
-    // 19 % of the kernel.)  Tile JT is an all-zero tile: the partner of the odd last tile in the K = 32 PV instruction.
-    constexpr int QC = KC + MT, ROWS = JT * QC;
-    __shared__ __attribute__((aligned(16))) uint4 frag[2][(ROWS + QC) * 64];
+    // One head's context fragments as they lie in global memory, [tile][chunk q][lane] 16 bytes: q < KC: G {4 hi | 4 lo}; q >= KC: the V
+    // chunks, arranged per PAIR of tiles for the K = 32 PV instruction (even tile: {4 hi(t0) | 4 hi(t1)}, odd tile: {4 lo(t0) | 4 lo(t1)},
+    // written that way by attn_fold_rows_kernel; tile count padded to even, the pad stays zero).  DOUBLE-buffered and filled by LDS-DMA
+    // (global_load_lds_dwordx4: no registers, asynchronous): head h + 1 streams in under head h's MFMA / softmax work, one barrier per
+    // head.  (Round 1 staged them with a synchronous barrier - copy - barrier per head: measured 19 % of the kernel.)
+    constexpr int QC = KC + MT, JTS = (JT + 1) & ~1, ROWS = JTS * QC;
+    __shared__ __attribute__((aligned(16))) uint4 frag[2][ROWS * 64];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lq = lane & 15, lg = lane >> 4;
     const int tiles = (p.HW + TOK_WG - 1) / TOK_WG;
     int b, tile;
@@ -335,11 +333,10 @@ __global__ __launch_bounds__(64 * NWV, WPS) void cross_attn_f16x3_kernel(const m
     f32x4 oacc[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) oacc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const _Float16* gvb = reinterpret_cast<const _Float16*>(p.gv) + (size_t)b * p.heads * JT * 64 * FRH;
+    const _Float16* gvb = reinterpret_cast<const _Float16*>(p.gv) + (size_t)b * p.heads * JTS * 64 * FRH;
     const int jlast = p.J - 1;
-    for (int i = tid; i < 2 * QC * 64; i += NT) frag[i / (QC * 64)][ROWS * 64 + i % (QC * 64)] = make_uint4(0u, 0u, 0u, 0u);
     auto issue_head = [&](int h, int buf) {
-        const _Float16* gvh = gvb + (size_t)h * JT * 64 * FRH;
+        const _Float16* gvh = gvb + (size_t)h * JTS * 64 * FRH;
         for (int r = wave; r < ROWS; r += NWV) {             // one 1 KB row (64 lanes x 16 bytes) per instruction
             const int jt = r / QC, q = r % QC;
             const _Float16* src = gvh + ((size_t)(jt * 64 + lane) * QC + q) * 8;
@@ -442,14 +439,10 @@ __global__ __launch_bounds__(64 * NWV, WPS) void cross_attn_f16x3_kernel(const m
             const f16x8 phi = __builtin_shufflevector(ph[0], ph[1], 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                const uint2* f2 = reinterpret_cast<const uint2*>(&frag[hb][0]);
-                const int i0 = ((2 * jp) * QC + KC + mt) * 64 + lane, i1 = ((2 * jp + 1) * QC + KC + mt) * 64 + lane;
-                const uint2 a0 = f2[2 * i0], a1 = f2[2 * i1];
-                const f16x8 vhi = __builtin_bit_cast(f16x8, make_uint4(a0.x, a0.y, a1.x, a1.y));
+                const f16x8 vhi = __builtin_bit_cast(f16x8, frag[hb][((2 * jp) * QC + KC + mt) * 64 + lane]);         // {V hi(t0) | V hi(t1)} as stored
                 if constexpr (!HALF) {
                     const f16x8 plo = __builtin_shufflevector(pl[0], pl[1], 0, 1, 2, 3, 4, 5, 6, 7);
-                    const uint2 b0 = f2[2 * i0 + 1], b1 = f2[2 * i1 + 1];
-                    const f16x8 vlo = __builtin_bit_cast(f16x8, make_uint4(b0.x, b0.y, b1.x, b1.y));
+                    const f16x8 vlo = __builtin_bit_cast(f16x8, frag[hb][((2 * jp + 1) * QC + KC + mt) * 64 + lane]); // {V lo(t0) | V lo(t1)}
                     oh[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vlo, phi, oh[mt], 0, 0, 0);
                     oh[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vhi, plo, oh[mt], 0, 0, 0);
                 }

@@ -183,9 +183,14 @@ __global__ __launch_bounds__(256) void attn_fold_rows_kernel(const mi_attn_fold_
         }
         const int jt = j >> 4, jm = j & 15;
         if (p.frag_f16) {
-            // fp16x3 fragments: per lane and tile KC x {4 halves G hi, 4 halves G lo} then MT x {4 VW hi, 4 VW lo}
+            // fp16x3 fragments, per lane and tile: KC x {4 halves G hi, 4 halves G lo}, then MT V chunks of 8 halves.  The V chunks are
+            // arranged for the K = 32 PV instruction, which contracts a PAIR of context tiles (t0, t1 = t0 + 1): the chunk of the even
+            // tile holds {4 VW hi(t0), 4 VW hi(t1)}, the chunk of the odd tile {4 VW lo(t0), 4 VW lo(t1)} -- each is one 16-byte A
+            // operand as it lies.  The tile count is padded to even (the partner of an odd last tile stays zero: the buffer is
+            // allocated zero-filled).
             const int KC = (C + 15) / 16, MTh = (C + 15) / 16, FRH = 8 * KC + 8 * MTh;          // halves per lane
-            _Float16* th = reinterpret_cast<_Float16*>(p.blk[blk].gv) + (((size_t)bb * p.heads + h) * p.JT + jt) * 64 * FRH;
+            const int JTS = (p.JT + 1) & ~1;
+            _Float16* th = reinterpret_cast<_Float16*>(p.blk[blk].gv) + (((size_t)bb * p.heads + h) * JTS + jt) * 64 * FRH;
             g = ldexpf(g, p.blk[blk].g_exp);            // exact power-of-two scalings: keep hi AND lo in the fp16 normal range
             v = ldexpf(v, p.blk[blk].v_exp);
             const _Float16 ghi = (_Float16)g, glo = (_Float16)(g - (float)ghi);
@@ -193,9 +198,10 @@ __global__ __launch_bounds__(256) void attn_fold_rows_kernel(const mi_attn_fold_
             _Float16* lg = th + (size_t)(jm + 16 * ((a & 15) >> 2)) * FRH + 8 * (a >> 4);      // A[m=j][k=a]: lane (j, a/4), element a%4
             lg[a & 3] = ghi;
             lg[4 + (a & 3)] = glo;
-            _Float16* lv = th + (size_t)((a & 15) + 16 * (jm >> 2)) * FRH + 8 * KC + 8 * (a >> 4);   // A[m=a][k=j]: lane (a, j/4), element j%4
+            _Float16* tv = th - (size_t)(jt & 1) * 64 * FRH;                                     // the even tile of the pair
+            _Float16* lv = tv + (size_t)((a & 15) + 16 * (jm >> 2)) * FRH + 8 * KC + 8 * (a >> 4) + 4 * (jt & 1);   // A[m=a][k=j]: lane (a, j/4), element j%4
             lv[jm & 3] = vhi;
-            lv[4 + (jm & 3)] = vlo;
+            lv[(size_t)64 * FRH + (jm & 3)] = vlo;                                               // same slot of the odd tile's chunk
             continue;
         }
         float* tilep = gv + ((size_t)h * p.JT + jt) * 64 * FR;

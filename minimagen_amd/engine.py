@@ -468,7 +468,8 @@ class UnetEngine:
         if Cc not in (8, 16, 32):
             return self._emit_cross_attn_wide(ws, ca, h)
         FR = lib.mi_attn_fragment_floats(Cc)
-        gv = torch.zeros(ws.B2, ca.heads, ws.JT, 64, FR, dtype=torch.float32, device=ws.dev)      # zero-filled: padded context rows must read as finite
+        jts = ws.JT + (ws.JT & 1) if ATTN_VARIANT == 6 else ws.JT            # fp16 fragments: V chunks live per PAIR of context tiles
+        gv = torch.zeros(ws.B2, ca.heads, jts, 64, FR, dtype=torch.float32, device=ws.dev)        # zero-filled: padded context rows must read as finite
         ws.gv[id(ca)] = gv
         nt = -(-HW // (128 if ATTN_VARIANT in (0, 5) else 64))
         out = self._new_act(ws, ws.B2, Cc, h.H, h.W, nt)

@@ -468,7 +468,7 @@ def test_cross_attention_folded(backend, case):
     ref = (R.cross_attention(xt, c, sd, "a") + xt).permute(0, 2, 1).contiguous()
     mg, mv, g0, v0 = [t.to(dev) for t in P.fold_cross_attention(sd["a.to_q.weight"], sd["a.to_kv.weight"], sd["a.to_out.0.weight"], sd["a.null_kv"], heads)]
     FR = lib.mi_attn_fragment_floats(Cc)
-    gv = torch.zeros(B2, heads, 17, 64, FR, device=dev)
+    gv = torch.zeros(B2, heads, 18 if variant == 6 else 17, 64, FR, device=dev)      # fp16 fragments: tile count padded to even (V chunks per tile pair)
     fp = L.MiAttnFoldParams()
     fp.B2, fp.C, fp.cd, fp.heads, fp.JT, fp.n_blocks = B2, Cc, cd, heads, 17, 1
     fp.frag_f16 = 1 if variant == 6 else 0
