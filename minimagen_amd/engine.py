@@ -312,6 +312,9 @@ class UnetEngine:
         wide = rp and not narrow
         if rp:
             cfg = RP_TILE["L"] if Ho * Wo > 128 * 128 else (RP_TILE["M"] if Ho * Wo > 64 * 64 else RP_TILE["S"])
+            if Ho * Wo <= 64 * 64 and (Wo <= 32 or Cout <= 8) and "MINIMAGEN_RP_TILE_S" not in os.environ:
+                cfg = 7                  # measured: 8x32 tiles for 8-channel layers at <= 64^2 (twice the workgroups) and for images no
+                                         # wider than a tile; 16 output channels at 64^2 stay on 8x64 (B fragments staged per workgroup)
             if Cout > 8 and cfg == 5:
                 cfg = 6
             if Cout > 16:
