@@ -260,8 +260,8 @@ def secondary_lines(dev, timesteps, cond_scale):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="cascade64_256", choices=["cascade64_256", "base64", "cascade64_256_1024"])
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
     ap.add_argument("--timesteps", type=int, default=100)
