@@ -51,6 +51,9 @@ typedef struct mi_act {
     float scale;         /* multiplies the data when consumed (skip connections: 2^-1/2, Unet.py:445) */
     int bmod;            /* >0: the tensor has only `bmod` batch rows, row b%bmod is used (tensors shared by the
                             conditional and null halves of a classifier-free-guidance batch) */
+    int st;              /* storage: 0 = fp32; 1 = bf16 (2 bytes per element, `data` then points at bf16 values) -- the
+                            reduced-precision configuration only (BASELINE configs 3-5), honoured by the single-term kernels
+                            (tile_cfg | 0x400, attention variant 7); statistics stay fp32 */
 } mi_act;
 
 /* ---- K4/K6/K7/K8/K11: the conv family --------------------------------------------------
@@ -78,6 +81,7 @@ typedef struct mi_conv_params {
     const float* res_w;     /* [Cres][Cout_pad] 1x1 weights, NULL = identity */
     const float* res_b;     /* [Cout] or NULL */
     float* out;             /* [B][Cout][H][W] */
+    int out_st;             /* storage of `out` (as mi_act.st; single-term kernels only) */
     float* out_stats;       /* [B][Cout][out_nt][2] or NULL */
     int tile_cfg;           /* see mi_conv_tile_shape; | MI_CONV_SPLIT16: 16-channel outputs as two 8-channel workgroups */
     /* row-paired matrix-core path (conv_rp.hip; tile_cfg 5..7): B-operand fragments of v_mfma_f32_16x16x32_f16 with
@@ -117,6 +121,7 @@ typedef struct mi_crossembed_params {
     const float* w[3];             /* packed [Cin][k][k][cout_i] */
     const float* bias[3];
     float* out; float* out_stats;  /* [B][sum cout][H][W], [B][C][nt][2] */
+    int out_st;                    /* storage of `out` AND of `addend` (as mi_act.st; matrix-core kernel with tile_cfg | 0x400 only) */
     int tile_cfg;
     const float* addend;           /* [B][sum cout][H][W] added to the result (the step-invariant low-res half of the
                                       convolution, computed once per sample()), or NULL; bias[] entries may be NULL */
@@ -225,6 +230,7 @@ typedef struct mi_cross_attn_params {
     const float* n1_g; const float* n1_b;   /* CrossAttention.norm   gamma / beta */
     const float* n2_g; const float* n2_b;   /* to_out.1              gamma / beta */
     float* out; float* out_stats;   /* [B2][C][HW]; stats [B2][C][ceil(HW/tok)][2], tok = 128 (variant 0) or 64 (variant 1) */
+    int out_st;                     /* storage of `out` (as mi_act.st; variant 7 only) */
     int x_exp, g_exp, v_exp;        /* variants 6 / 7: LayerNorm(x) is scaled by 2^x_exp before its fp16 split, the fragments carry 2^g_exp /
                                        2^v_exp (mi_attn_fold_params); the kernel undoes all three exactly (scores, output) */
     int variant;                    /* 0: 32 tokens per wave; 1,3,4: 16 tokens per wave (fp32 MFMA, exact); 6: 16 tokens per wave with the

@@ -19,7 +19,8 @@ c_float_p = C.c_void_p   # raw device pointers travel as integers
 
 
 class MiAct(C.Structure):
-    _fields_ = [("data", C.c_void_p), ("C", C.c_int), ("stats", C.c_void_p), ("nt", C.c_int), ("scale", C.c_float), ("bmod", C.c_int)]
+    _fields_ = [("data", C.c_void_p), ("C", C.c_int), ("stats", C.c_void_p), ("nt", C.c_int), ("scale", C.c_float), ("bmod", C.c_int),
+                ("st", C.c_int)]
 
 
 class MiConvParams(C.Structure):
@@ -31,7 +32,7 @@ class MiConvParams(C.Structure):
         ("gn_groups", C.c_int), ("gn_gamma", C.c_void_p), ("gn_beta", C.c_void_p), ("gn_eps", C.c_float),
         ("scale_shift", C.c_void_p), ("ss_stride", C.c_int), ("ss_off", C.c_int),
         ("res0", MiAct), ("res1", MiAct), ("res_w", C.c_void_p), ("res_b", C.c_void_p),
-        ("out", C.c_void_p), ("out_stats", C.c_void_p), ("tile_cfg", C.c_int),
+        ("out", C.c_void_p), ("out_st", C.c_int), ("out_stats", C.c_void_p), ("tile_cfg", C.c_int),
         ("w_rp", C.c_void_p), ("res_w_rp", C.c_void_p), ("w_rp_exp", C.c_int), ("res_w_rp_exp", C.c_int),
         ("gn_coef", C.c_void_p), ("gn_exps", C.c_void_p),
     ]
@@ -43,7 +44,7 @@ class MiCrossEmbedParams(C.Structure):
         ("in0", C.c_void_p), ("C0", C.c_int), ("in1", C.c_void_p), ("C1", C.c_int),
         ("in1_batch_mod", C.c_int), ("in0_batch_mod", C.c_int), ("n_kernels", C.c_int),
         ("ksize", C.c_int * 3), ("cout", C.c_int * 3), ("w", C.c_void_p * 3), ("bias", C.c_void_p * 3),
-        ("out", C.c_void_p), ("out_stats", C.c_void_p), ("tile_cfg", C.c_int), ("addend", C.c_void_p),
+        ("out", C.c_void_p), ("out_stats", C.c_void_p), ("out_st", C.c_int), ("tile_cfg", C.c_int), ("addend", C.c_void_p),
         ("w_mfma", C.c_void_p), ("w_mfma_exp", C.c_int * 3),
     ]
 
@@ -90,7 +91,7 @@ class MiCrossAttnParams(C.Structure):
     _fields_ = [
         ("B2", C.c_int), ("C", C.c_int), ("HW", C.c_int), ("heads", C.c_int), ("J", C.c_int),
         ("x", MiAct), ("gv", C.c_void_p), ("n1_g", C.c_void_p), ("n1_b", C.c_void_p), ("n2_g", C.c_void_p), ("n2_b", C.c_void_p),
-        ("out", C.c_void_p), ("out_stats", C.c_void_p), ("x_exp", C.c_int), ("g_exp", C.c_int), ("v_exp", C.c_int), ("variant", C.c_int),
+        ("out", C.c_void_p), ("out_stats", C.c_void_p), ("out_st", C.c_int), ("x_exp", C.c_int), ("g_exp", C.c_int), ("v_exp", C.c_int), ("variant", C.c_int),
     ]
 
 

@@ -296,6 +296,12 @@ __global__ __launch_bounds__(64 * NWV, WPS) void cross_attn_f16x3_kernel(const m
     const int i = (tile * NWV + wave) * 16 + lq;
     const bool ok = i < p.HW;
     const float* xb = p.x.data + (size_t)bx * C * p.HW;
+    // single-term variant: x and out may be stored as bf16 (mi_act.st / out_st)
+    const bool x16 = HALF && p.x.st != 0, o16 = HALF && p.out_st != 0;
+    auto ldx = [&](int a) -> float {
+        if (x16) return mi_bf16_to_f32(reinterpret_cast<const unsigned short*>(p.x.data)[((size_t)bx * C + a) * p.HW + i]);
+        return xb[(size_t)a * p.HW + i];
+    };
 
     // LayerNorm(x) -> B operand of QK^T: this lane supplies channels a = 16kc + 4lg + e of token lq
     f16x4 xhi[KC], xlo[KC];
@@ -307,7 +313,7 @@ __global__ __launch_bounds__(64 * NWV, WPS) void cross_attn_f16x3_kernel(const m
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int a = 16 * kc + 4 * lg + e;
-                xf[kc][e] = (ok && a < C) ? xb[(size_t)a * p.HW + i] * p.x.scale : 0.0f;
+                xf[kc][e] = (ok && a < C) ? ldx(a) * p.x.scale : 0.0f;
                 s += xf[kc][e];
             }
         s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
@@ -484,8 +490,9 @@ __global__ __launch_bounds__(64 * NWV, WPS) void cross_attn_f16x3_kernel(const m
             for (int r = 0; r < 4; ++r) {
                 const int a = 16 * mt + 4 * lg + r;
                 if (a < C && ok) {
-                    const float y = (oacc[mt][r] - mean) * rstd * p.n2_g[a] + p.n2_b[a] + xb[(size_t)a * p.HW + i] * p.x.scale;
-                    p.out[((size_t)b * C + a) * p.HW + i] = y;
+                    const float y = (oacc[mt][r] - mean) * rstd * p.n2_g[a] + p.n2_b[a] + ldx(a) * p.x.scale;
+                    if (o16) reinterpret_cast<unsigned short*>(p.out)[((size_t)b * C + a) * p.HW + i] = (unsigned short)(mi_f32_to_bf16x2(y, 0.0f) & 0xffffu);
+                    else p.out[((size_t)b * C + a) * p.HW + i] = y;
                     csum[4 * mt + r] = y;
                     csq[4 * mt + r] = y * y;
                 }

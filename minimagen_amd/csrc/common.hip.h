@@ -66,6 +66,39 @@ __device__ __forceinline__ void mi_split_f16(const float (&x)[4], mi_f16x4& hi, 
     lo = __builtin_bit_cast(mi_f16x4, make_uint2(lb[0], lb[1]));
 }
 
+// bf16 activation storage of the reduced-precision configuration (mi_act.st == 1): expansion is a shift, rounding is to nearest even
+// (v_cvt_pk_bf16_f32 on gfx950)
+__device__ __forceinline__ float mi_bf16_to_f32(unsigned u16) { return __uint_as_float(u16 << 16); }
+__device__ __forceinline__ unsigned mi_f32_to_bf16x2(float a, float b) {        // a in the low half
+#if !defined(HIPEMU)
+    typedef __bf16 mi_bf16x2 __attribute__((ext_vector_type(2)));
+    typedef float mi_cvt_f32x2 __attribute__((ext_vector_type(2)));
+    const mi_cvt_f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, mi_bf16x2));
+#else
+    auto one = [](float x) -> unsigned {
+        const unsigned u = __float_as_uint(x);
+        if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;          // NaN stays NaN
+        return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+    };
+    return one(a) | (one(b) << 16);
+#endif
+}
+__device__ __forceinline__ float4 mi_bf16x4_to_f32(uint2 v) {
+    return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u));
+}
+__device__ __forceinline__ uint2 mi_f32x4_to_bf16(float4 v) { return make_uint2(mi_f32_to_bf16x2(v.x, v.y), mi_f32_to_bf16x2(v.z, v.w)); }
+
+__device__ __forceinline__ uint2 mi_ldg2u(const void* p) {          // 8 bytes (four bf16) through a global-address-space pointer
+    typedef unsigned mi_u32x2 __attribute__((ext_vector_type(2)));
+    const mi_u32x2 v = *reinterpret_cast<mi_gptr<const mi_u32x2>>(mi_global(reinterpret_cast<const float*>(p)));
+    return make_uint2(v[0], v[1]);
+}
+__device__ __forceinline__ void mi_stg2u(void* p, uint2 v) {
+    typedef unsigned mi_u32x2 __attribute__((ext_vector_type(2)));
+    *reinterpret_cast<mi_gptr<mi_u32x2>>(mi_global(reinterpret_cast<float*>(p))) = (mi_u32x2){v.x, v.y};
+}
+
 // packed fp32 pairs: the compiler selects v_pk_fma_f32 / v_pk_add_f32 for two-element vectors (two lanes' worth of work per issue
 // slot) and keeps track of the hazards around them, which inline asm would not
 typedef float mi_f32x2 __attribute__((ext_vector_type(2)));

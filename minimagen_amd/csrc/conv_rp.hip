@@ -177,6 +177,7 @@ __global__ __launch_bounds__(256, CFG::WPS) void conv_rp_kernel(const mi_conv_pa
         else ldst[u] = valid ? iy * PW + c : -1;
     }
     float raw[NSLOT][PER][8];
+    bool rst[NSLOT];                  // the slot's loads are 16-bit values (bf16 storage, single-term kernels only)
     unsigned inmask[NSLOT];           // bit u: unit u of the tile whose loads are in the slot lies inside the image
     auto load_raw = [&](int tile, int rnd, auto slot_tag) {
         constexpr int slot = decltype(slot_tag)::value;
@@ -190,7 +191,13 @@ __global__ __launch_bounds__(256, CFG::WPS) void conv_rp_kernel(const mi_conv_pa
         const int Ca = isres ? Cr0 : C0, Cb = isres ? Cr1 : C1;
         const bool second = c0 >= Ca;
         const int bb = mi_row_of(b, second ? t1.bmod : t0.bmod);
-        const float* basep = second ? t1.data + ((size_t)bb * Cb + (c0 - Ca)) * HWs : t0.data + ((size_t)bb * Ca + c0) * HWs;
+        const size_t e0 = second ? ((size_t)bb * Cb + (c0 - Ca)) * HWs : ((size_t)bb * Ca + c0) * HWs;      // first element of the round's planes
+        const float* basep = (second ? t1.data : t0.data) + e0;
+        // single-term kernels: the tensor may be stored as bf16 (mi_act.st); the raw registers then hold the 16 bits, expanded in the transform
+        bool s16 = false;
+        if constexpr (HALF) s16 = (second ? t1.st : t0.st) != 0;
+        rst[slot] = s16;
+        const mi_gptr<const unsigned short> base16 = mi_global(reinterpret_cast<const unsigned short*>(second ? t1.data : t0.data) + e0);
 #if RP_BUF
         const mi_buf base = mi_make_buf(basep);
 #else
@@ -215,7 +222,10 @@ __global__ __launch_bounds__(256, CFG::WPS) void conv_rp_kernel(const mi_conv_pa
 #if RP_BUF
                 raw[slot][u][j] = mi_buf_load_f32(base, off[u], (unsigned)(j * HWs) * 4u);
 #else
-                raw[slot][u][j] = *reinterpret_cast<mi_gptr<const float>>(reinterpret_cast<mi_gptr<const char>>(base + (size_t)j * HWs) + off[u]);
+                if (HALF && s16)
+                    raw[slot][u][j] = __uint_as_float((unsigned)*reinterpret_cast<mi_gptr<const unsigned short>>(reinterpret_cast<mi_gptr<const char>>(base16 + (size_t)j * HWs) + (off[u] >> 1)));
+                else
+                    raw[slot][u][j] = *reinterpret_cast<mi_gptr<const float>>(reinterpret_cast<mi_gptr<const char>>(base + (size_t)j * HWs) + off[u]);
 #endif
             }
         inmask[slot] = im;
@@ -335,8 +345,11 @@ __global__ __launch_bounds__(256, CFG::WPS) void conv_rp_kernel(const mi_conv_pa
     const mi_buf obuf = mi_make_buf(p.out + (size_t)b * p.Cout * H * W);
     const mi_buf rbuf = mi_make_buf(idres ? p.res0.data + (size_t)mi_row_of(b, p.res0.bmod) * p.res0.C * H * W : p.out);
 #else
-    const mi_gptr<float> obuf = mi_global(p.out + (size_t)b * p.Cout * H * W);
-    const mi_gptr<const float> rbuf = mi_global(idres ? p.res0.data + (size_t)mi_row_of(b, p.res0.bmod) * p.res0.C * H * W : p.out);
+    // (bf16 storage in the single-term kernels: the image's first element sits at half the byte offset)
+    const size_t oel = (size_t)b * p.Cout * H * W, rel = idres ? (size_t)mi_row_of(b, p.res0.bmod) * p.res0.C * H * W : 0;
+    const mi_gptr<float> obuf = mi_global(reinterpret_cast<float*>(reinterpret_cast<char*>(p.out) + oel * ((HALF && p.out_st) ? 2 : 4)));
+    const mi_gptr<const float> rbuf = mi_global(reinterpret_cast<const float*>(
+        reinterpret_cast<const char*>(idres ? p.res0.data : p.out) + rel * ((HALF && idres && p.res0.st) ? 2 : 4)));
 #endif
     constexpr bool idres_any = !(CFG::RO_T > 0);          // a 1x1 residual conv excludes the identity residual
 
@@ -405,7 +418,8 @@ __global__ __launch_bounds__(256, CFG::WPS) void conv_rp_kernel(const mi_conv_pa
                     float y[8];
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        const float x = raw[slot][u][j];
+                        float x = raw[slot][u][j];
+                        if constexpr (HALF) { if (rst[slot]) x = __uint_as_float(__float_as_uint(x) << 16); }
                         if (isres) {
                             y[j] = x * rsc;
                         } else {
@@ -447,7 +461,15 @@ __global__ __launch_bounds__(256, CFG::WPS) void conv_rp_kernel(const mi_conv_pa
 #if RP_BUF
                         const f32x4 r4 = mi_buf_load_f32x4(rbuf, o, 0u);
 #else
-                        const f32x4 r4 = *reinterpret_cast<mi_gptr<const f32x4>>(reinterpret_cast<mi_gptr<const char>>(rbuf) + o);
+                        f32x4 r4;
+                        if (HALF && p.res0.st) {
+                            typedef unsigned rp_u32x2 __attribute__((ext_vector_type(2)));
+                            const rp_u32x2 r2 = *reinterpret_cast<mi_gptr<const rp_u32x2>>(reinterpret_cast<mi_gptr<const char>>(rbuf) + (o >> 1));
+                            const float4 e = mi_bf16x4_to_f32(make_uint2(r2[0], r2[1]));
+                            r4 = (f32x4){e.x, e.y, e.z, e.w};
+                        } else {
+                            r4 = *reinterpret_cast<mi_gptr<const f32x4>>(reinterpret_cast<mi_gptr<const char>>(rbuf) + o);
+                        }
 #endif
                         rv[g][jt] = make_float4(r4[0], r4[1], r4[2], r4[3]);
                     }
@@ -536,7 +558,13 @@ __global__ __launch_bounds__(256, CFG::WPS) void conv_rp_kernel(const mi_conv_pa
 #if RP_BUF
                 if (ok) mi_buf_store_f32x4(obuf, (unsigned)((co * H + oy) * W + ox) * 4u, 0u, (f32x4){y.x, y.y, y.z, y.w});
 #else
-                if (ok) *reinterpret_cast<mi_gptr<f32x4>>(reinterpret_cast<mi_gptr<char>>(obuf) + (unsigned)((co * H + oy) * W + ox) * 4u) = (f32x4){y.x, y.y, y.z, y.w};
+                if (HALF && p.out_st) {
+                    typedef unsigned rp_u32x2 __attribute__((ext_vector_type(2)));
+                    const uint2 q = mi_f32x4_to_bf16(y);
+                    if (ok) *reinterpret_cast<mi_gptr<rp_u32x2>>(reinterpret_cast<mi_gptr<char>>(obuf) + (unsigned)((co * H + oy) * W + ox) * 2u) = (rp_u32x2){q.x, q.y};
+                } else {
+                    if (ok) *reinterpret_cast<mi_gptr<f32x4>>(reinterpret_cast<mi_gptr<char>>(obuf) + (unsigned)((co * H + oy) * W + ox) * 4u) = (f32x4){y.x, y.y, y.z, y.w};
+                }
 #endif
                 csum[jt] += ok ? (y.x + y.y) + (y.z + y.w) : 0.0f;
                 csq[jt] += ok ? fmaf(y.x, y.x, fmaf(y.y, y.y, fmaf(y.z, y.z, y.w * y.w))) : 0.0f;

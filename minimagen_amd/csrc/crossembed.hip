@@ -242,8 +242,11 @@ __global__ __launch_bounds__(256, 2) void crossembed_mfma_kernel(const mi_crosse
             const int oy = oy0 + 8 * gyy + dy, ox = ox0 + 16 * gxx + 4 * lg;
             const bool ok = oy < H && ox < W;
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
-                addv[g][t] = mi_ldg4(p.addend + ((size_t)(b * 8 + 2 * t + co2) * H + (ok ? oy : 0)) * W + (ok ? ox : 0));
+            for (int t = 0; t < 4; ++t) {
+                const size_t o = ((size_t)(b * 8 + 2 * t + co2) * H + (ok ? oy : 0)) * W + (ok ? ox : 0);
+                if (HALF && p.out_st) addv[g][t] = mi_bf16x4_to_f32(mi_ldg2u(reinterpret_cast<const unsigned short*>(p.addend) + o));     // bf16 storage
+                else addv[g][t] = mi_ldg4(p.addend + o);
+            }
         }
     }
     CE_TPHASE(0);
@@ -385,7 +388,8 @@ __global__ __launch_bounds__(256, 2) void crossembed_mfma_kernel(const mi_crosse
             float4 y = make_float4(fmaf(acc[g][t][0], us, bv), fmaf(acc[g][t][1], us, bv), fmaf(acc[g][t][2], us, bv), fmaf(acc[g][t][3], us, bv));
             if (p.addend) { const float4 a = addv[g][t]; y.x += a.x; y.y += a.y; y.z += a.z; y.w += a.w; }
             if (ok) {
-                mi_stg4(p.out + o, y);
+                if (HALF && p.out_st) mi_stg2u(reinterpret_cast<unsigned short*>(p.out) + o, mi_f32x4_to_bf16(y));
+                else mi_stg4(p.out + o, y);
                 s += (y.x + y.y) + (y.z + y.w);
                 q2 += fmaf(y.x, y.x, fmaf(y.y, y.y, fmaf(y.z, y.z, y.w * y.w)));
             }

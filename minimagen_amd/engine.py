@@ -32,6 +32,7 @@ CONV_RP = int(os.environ.get("MINIMAGEN_CONV_RP", "2"))                 # 1: nar
 RP_TILE = {k: int(os.environ.get("MINIMAGEN_RP_TILE_" + k, d)) for k, d in (("L", "6"), ("M", "6"), ("S", "6"))}   # tile_cfg for images > 128^2 / > 64^2 / smaller
 RP_MIN_HW = int(os.environ.get("MINIMAGEN_RP_MIN_HW", "0"))             # ... for images of at least this many pixels
 CE_MFMA = os.environ.get("MINIMAGEN_CE_MFMA", "1") != "0"                  # CrossEmbed on the matrix cores (0: the fp32 VALU kernel)
+STORE16 = os.environ.get("MINIMAGEN_STORE16", "1") != "0"                  # reduced-precision configuration: bf16 activation storage
 RP_NTILE = int(os.environ.get("MINIMAGEN_RP_NTILE", "0"))               # tiles per workgroup of the row-paired kernel (0 = the library's choice)
 TILE64 = int(os.environ.get("MINIMAGEN_TILE64", "-1"))                  # force a conv tile shape at 64x64 / 128x128 (experiments)
 TILE128 = int(os.environ.get("MINIMAGEN_TILE128", "-1"))       # 1: 16-channel 3x3 outputs as two 8-channel workgroups
@@ -39,15 +40,24 @@ JT = 17     # context tiles of 16 rows: 1 null + (2|4) time tokens + 256 text ro
 
 
 class Act:
-    """An NCHW fp32 activation plus the per-channel partial statistics its producer emitted."""
+    """An NCHW activation (fp32, or bf16 in the reduced-precision configuration) plus the per-channel partial statistics its producer
+    emitted (always fp32)."""
     __slots__ = ("t", "stats", "nt", "C", "H", "W", "batch")
 
     def __init__(self, t, stats, nt, C_, H, W, batch):
         self.t, self.stats, self.nt, self.C, self.H, self.W, self.batch = t, stats, nt, C_, H, W, batch
 
+    @property
+    def st(self) -> int:
+        return 1 if self.t.dtype == torch.bfloat16 else 0
+
     def c(self, consumer_batch: int, scale: float = 1.0) -> L.MiAct:
         bmod = self.batch if self.batch != consumer_batch else 0
-        return L.MiAct(L.ptr(self.t), self.C, L.ptr(self.stats), self.nt, scale, bmod)
+        return L.MiAct(L.ptr(self.t), self.C, L.ptr(self.stats), self.nt, scale, bmod, self.st)
+
+
+class _Store16Unsupported(Exception):
+    """raised while a launch plan is built with bf16 activation storage and a layer needs a kernel that only reads fp32"""
 
 
 def _lin(m: Optional[nn.Linear]) -> L.MiLinear:
@@ -261,10 +271,16 @@ class UnetEngine:
         ws.gv = {}
         ws.tensors = []
         ws.text_L = None
-        ws.prog = []
-        ws.prog_text = []          # once per sample() after the text conditioning: the wide cross-attentions' text keys / values
-        ws.wide_attn = False
-        self._build_program(ws, pk)
+        # reduced-precision configuration: activations in bf16 (BASELINE configs 3-5) when every layer runs on a kernel that reads them
+        # (row-paired convs, matrix-core CrossEmbed, fp16 cross-attention: the BASELINE U-Nets); otherwise fp32 storage
+        for store16 in ((True, False) if (ws.half and STORE16) else (False,)):
+            ws.store16 = store16
+            ws.gv, ws.tensors, ws.prog, ws.prog_text, ws.wide_attn = {}, [], [], [], False     # (prog_text: the wide cross-attentions' text keys / values)
+            try:
+                self._build_program(ws, pk)
+                break
+            except _Store16Unsupported:
+                continue
         self._ws[key] = ws
         return ws
 
@@ -281,15 +297,15 @@ class UnetEngine:
         lib.mi_conv_tile_shape(best, C.byref(th), C.byref(tw))
         return best, -(-H // th.value) * -(-W // tw.value)
 
-    def _new_act(self, ws, batch, Cc, H, W, nt) -> Act:
-        t = torch.empty(batch, Cc, H, W, dtype=torch.float32, device=ws.dev)
+    def _new_act(self, ws, batch, Cc, H, W, nt, fp32: bool = False) -> Act:
+        t = torch.empty(batch, Cc, H, W, dtype=torch.float32 if (fp32 or not ws.store16) else torch.bfloat16, device=ws.dev)
         st = torch.zeros(batch, Cc, max(nt, 1), 2, dtype=torch.float32, device=ws.dev) if nt else None
         ws.tensors += [t, st]
         return Act(t, st, nt, Cc, H, W, batch)
 
     def _emit_conv(self, ws, pk, in0: Act, in1: Optional[Act], *, wpack, bias, Cout, ksize=3, stride=1, up2=0,
                    gn: Optional[nn.GroupNorm] = None, ss_off: Optional[int] = None, res=None, conditioned=False,
-                   want_stats=True, skip_scale=1.0) -> Act:
+                   want_stats=True, skip_scale=1.0, out_fp32=False) -> Act:
         lib = L.lib()
         Ho = in0.H * 2 if up2 else in0.H // stride
         Wo = in0.W * 2 if up2 else in0.W // stride
@@ -325,7 +341,9 @@ class UnetEngine:
                 cfg = 7
             th, tw = {5: (16, 64), 6: (8, 64), 7: (8, 32)}[cfg]
             nt = -(-Ho // th) * -(-Wo // tw)
-        out = self._new_act(ws, batch, Cout, Ho, Wo, nt if want_stats else 0)
+        if ws.store16 and (not rp or wide):
+            raise _Store16Unsupported()          # only the narrow row-paired kernels read bf16 activations
+        out = self._new_act(ws, batch, Cout, Ho, Wo, nt if want_stats else 0, fp32=out_fp32)
         p = L.MiConvParams()
         p.B, p.H, p.W = batch, Ho, Wo
         p.in0 = in0.c(batch)
@@ -343,6 +361,7 @@ class UnetEngine:
             if r1 is not None:
                 p.res1 = r1.c(batch, skip_scale)
             p.res_w, p.res_b = L.ptr(rw), L.ptr(rb)
+        p.out_st = out.st
         p.out, p.out_stats, p.tile_cfg = L.ptr(out.t), L.ptr(out.stats), cfg | (0x100 if CONV_SPLIT16 else 0) | (0x400 if ws.half else 0) | (0x800 if (CONV_SPLIT8 and Ho * Wo <= CONV_SPLIT8 * CONV_SPLIT8) else 0)
         if wide:
             coef = torch.zeros(batch, cin_tot, 4, dtype=torch.float32, device=ws.dev)
@@ -392,6 +411,8 @@ class UnetEngine:
         return t
 
     def _emit_tokens_out(self, ws, tokens, batch, Cc, H, W, ln, res: Act, want_stats: bool) -> Act:
+        if ws.store16:
+            raise _Store16Unsupported()
         lib = L.lib()
         HW = H * W
         out = self._new_act(ws, batch, Cc, H, W, -(-HW // 64) if want_stats else 0)
@@ -407,6 +428,8 @@ class UnetEngine:
     def _emit_cross_attn_wide(self, ws, ca: CrossAttention, h: Act) -> Act:
         """layers.py:220-251 unfolded: LN(x) -> to_q | context -> to_kv -> flash attention over [null | time tokens | text tokens] -> to_out.0
         -> to_out.1 LayerNorm + residual.  The text rows' keys / values are step-invariant: projected once per sample() (ws.prog_text)."""
+        if ws.store16:
+            raise _Store16Unsupported()
         lib, u = L.lib(), self.unet
         Cc, HW, B2, inner = h.C, h.H * h.W, ws.B2, ca.heads * 64
         xh, q, o, t = self._buf(ws, B2, HW, Cc), self._buf(ws, B2, HW, inner), self._buf(ws, B2, HW, inner), self._buf(ws, B2, HW, Cc)
@@ -433,6 +456,8 @@ class UnetEngine:
 
     def _emit_self_attn_wide(self, ws, at: Attention, x: Act, want_stats: bool) -> Act:
         """layers.py:52-104 (multi-query: one shared 64-wide key / value head) + the residual"""
+        if ws.store16:
+            raise _Store16Unsupported()
         lib = L.lib()
         Cc, HW, batch, inner = x.C, x.H * x.W, x.batch, at.heads * 64
         xh, q, kv = self._buf(ws, batch, HW, Cc), self._buf(ws, batch, HW, inner), self._buf(ws, batch, HW, 128)
@@ -453,6 +478,8 @@ class UnetEngine:
 
     def _emit_chan_ff_wide(self, ws, tb: TransformerBlock, y: Act) -> Act:
         """layers.py:148-161 + the residual of :498 in token layout: ChanLayerNorm -> 1x1 conv -> GELU -> ChanLayerNorm -> 1x1 conv"""
+        if ws.store16:
+            raise _Store16Unsupported()
         lib = L.lib()
         Cc, HW, batch, Chid = y.C, y.H * y.W, y.batch, tb.ff[1].out_channels
         t0, h1, h2, t = self._buf(ws, batch, HW, Cc), self._buf(ws, batch, HW, Chid), self._buf(ws, batch, HW, Chid), self._buf(ws, batch, HW, Cc)
@@ -470,6 +497,8 @@ class UnetEngine:
         Cc, HW = h.C, h.H * h.W
         if Cc not in (8, 16, 32):
             return self._emit_cross_attn_wide(ws, ca, h)
+        if ws.store16 and ATTN_VARIANT != 6:
+            raise _Store16Unsupported()
         FR = lib.mi_attn_fragment_floats(Cc)
         jts = ws.JT + (ws.JT & 1) if ATTN_VARIANT == 6 else ws.JT            # fp16 fragments: V chunks live per PAIR of context tiles
         gv = torch.zeros(ws.B2, ca.heads, jts, 64, FR, dtype=torch.float32, device=ws.dev)        # zero-filled: padded context rows must read as finite
@@ -482,6 +511,7 @@ class UnetEngine:
         p.gv = L.ptr(gv)
         p.n1_g, p.n1_b = L.ptr(ca.norm.gamma), L.ptr(ca.norm.beta)
         p.n2_g, p.n2_b = L.ptr(ca.to_out[1].gamma), L.ptr(ca.to_out[1].beta)
+        p.out_st = out.st
         p.out, p.out_stats, p.variant = L.ptr(out.t), L.ptr(out.stats), (7 if (ws.half and ATTN_VARIANT == 6) else ATTN_VARIANT)
         if ATTN_VARIANT == 6:
             p.x_exp, p.g_exp, p.v_exp = pk.attn_exp[id(ca)]
@@ -490,6 +520,8 @@ class UnetEngine:
 
     def _emit_self_attn(self, ws, pk, at: Attention, x: Act, want_stats: bool) -> Act:
         """layers.py:52-104 + residual: LayerNorm tokens -> fold them as their own context -> chunked online-softmax attention"""
+        if ws.store16:
+            raise _Store16Unsupported()
         lib = L.lib()
         Cc, HW, batch = x.C, x.H * x.W, x.batch
         if Cc not in (8, 16, 32):
@@ -524,6 +556,8 @@ class UnetEngine:
 
     def _emit_transformer_block(self, ws, pk, tb: TransformerBlock, x: Act) -> Act:
         """layers.py:496-499: x = attn(x) + x ; x = ff(x) + x"""
+        if ws.store16:
+            raise _Store16Unsupported()
         lib = L.lib()
         y = self._emit_self_attn(ws, pk, tb.attn.fn, x, want_stats=False)
         if y.C not in (8, 16, 32):
@@ -592,6 +626,8 @@ class UnetEngine:
         assert cin == u.channels * (2 if u.lowres_cond else 1)
         cfg, nt = self._tile_cfg(H, W, B)
         ce_mfma = bool(pk.ce_mfma) and W % 4 == 0
+        if ws.store16 and not ce_mfma:
+            raise _Store16Unsupported()
         if ce_mfma:                       # its own tile shapes: 32 x 64 for large images, 16 x 32 below (enough workgroups at 64 x 64)
             cfg = 8 if H * W >= 128 * 128 else 9
             th, tw = C.c_int(), C.c_int()
@@ -613,6 +649,7 @@ class UnetEngine:
                 ce.w[i] = L.ptr(pk.ce_w[i]) + 4 * chan0 * k * k * co        # packed [Cin][k][k][co]: a channel offset is a pointer offset
                 ce.bias[i] = L.ptr(cv.bias) if with_bias else 0
             ce.out, ce.out_stats, ce.tile_cfg, ce.addend = L.ptr(out_t), L.ptr(out_stats), cfg, L.ptr(addend)
+            ce.out_st = 1 if ws.store16 else 0
             if ce_mfma:
                 tab, exps = pk.ce_mfma[chan0]
                 ce.w_mfma, ce.tile_cfg = L.ptr(tab), cfg | (0x400 if ws.half else 0)
@@ -622,7 +659,7 @@ class UnetEngine:
 
         ws.prog_pre = []
         if u.lowres_cond:
-            ws.ce_lr = torch.zeros(B, ctot, H, W, dtype=torch.float32, device=ws.dev)
+            ws.ce_lr = torch.zeros(B, ctot, H, W, dtype=torch.bfloat16 if ws.store16 else torch.float32, device=ws.dev)
             ws.prog_pre.append((lib.mi_crossembed_fwd, ce_params(ws.lowres, u.channels, False, ws.ce_lr, None, None), "crossembed_lowres"))
             ws.prog.append((lib.mi_crossembed_fwd, ce_params(ws.x, 0, True, cur.t, cur.stats, ws.ce_lr), "crossembed"))
         else:
@@ -659,7 +696,7 @@ class UnetEngine:
                 cur = self._emit_conv(ws, pk, cur, None, wpack=pk.conv[id(cv)], bias=cv.bias, Cout=cv.out_channels, up2=1)
         cur = self._emit_resnet(ws, pk, u.final_res_block, cur, None)
         out = self._emit_conv(ws, pk, cur, None, wpack=pk.conv[id(u.final_conv)], bias=u.final_conv.bias, Cout=u.channels_out,
-                              want_stats=False, conditioned=True)
+                              want_stats=False, conditioned=True, out_fp32=True)       # the prediction feeds the (fp32, bit-exact) sampler
         ws.pred = out.t
         if (out.H, out.W) != (H, W):
             raise L.MinImagenHipError(f"U-Net output is {out.H}x{out.W} for a {H}x{W} input (image size must be divisible by the down-sampling factor)")

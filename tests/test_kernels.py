@@ -26,11 +26,11 @@ def tile_nt(lib, cfg, H, W):
     return -(-H // th.value) * -(-W // tw.value)
 
 
-def check_stats(ost, ref):
+def check_stats(ost, ref, rtol=1e-5):
     dims = tuple(range(2, ref.dim()))
     es = (ost[..., 0].sum(-1) - ref.sum(dims)).abs().max().item() / max(ref.abs().sum(dims).max().item(), 1e-6)
     eq = (ost[..., 1].sum(-1) - (ref ** 2).sum(dims)).abs().max().item() / max((ref ** 2).sum(dims).max().item(), 1e-6)
-    assert es < 1e-5 and eq < 1e-5, (es, eq)
+    assert es < rtol and eq < rtol, (es, eq)
 
 
 CONV_CASES = [
@@ -197,6 +197,73 @@ def test_conv_row_paired_path(backend, case):
     print(f"rp conv {case}: max|d| = {err:.2e} (gate {2e-5 * scale:.2e}, |ref|max {ref.abs().max().item():.3g})")
     assert err < 2e-5 * scale
     check_stats(ost.cpu(), ref.float())
+
+
+BF16_CASES = [
+    # B, C0, C1, Cout, H, W, res, tile_cfg, output storage (1 = bf16, 0 = fp32: the final conv feeds the fp32 sampler)
+    (2, 8, 0, 8, 16, 64, 'id', 6, 1),
+    (1, 8, 8, 8, 24, 72, 'conv2', 6, 1),          # concat input + 1x1 residual over a concat, all stored as bf16
+    (2, 16, 0, 16, 16, 32, 'id', 7, 1),
+    (1, 8, 0, 3, 16, 64, 'none', 6, 0),
+]
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("case", BF16_CASES)
+def test_conv_row_paired_bf16_storage(backend, case):
+    """reduced-precision configuration (BASELINE configs 3-5): the single-term kernels (tile_cfg | 0x400) read and write activations stored
+    as bf16 (mi_act.st / out_st); statistics and accumulation stay fp32.  Against torch fp32 on the same bf16-rounded inputs: the error
+    budget is the single fp16 term (2^-11 per operand) plus the bf16 rounding of the output (2^-9)"""
+    dev = setup(backend)
+    lib = L.lib()
+    B, C0, C1, Cout, H, W, res, cfg, ost = case
+    g = torch.Generator().manual_seed(hash(case) & 0xffff)
+    rn = lambda *s_: torch.randn(*s_, generator=g)
+    bf = lambda t: t.to(torch.bfloat16)
+    x0 = bf(rn(B, C0, H, W) * 1.5 + 0.3)
+    x1 = bf(rn(B, C1, H, W)) if C1 else None
+    Cin = C0 + C1
+    w, bias = rn(Cout, Cin, 3, 3) * 0.2, rn(Cout)
+    gamma, beta = 1 + 0.2 * rn(Cin), 0.1 * rn(Cin)
+    sk = 2 ** -0.5
+    h = torch.cat((x0.float(), x1.float() * sk), 1) if C1 else x0.float()
+    h = F.silu(F.group_norm(h, 8, gamma, beta, 1e-5))
+    ref = F.conv2d(h.double(), w.double(), bias.double(), padding=1)
+    keep = {}
+    d = lambda name, t: keep.setdefault(name, t.to(dev).contiguous())
+    p = L.MiConvParams()
+    p.B, p.H, p.W = B, H, W
+    p.in0 = L.MiAct(d("x0", x0).data_ptr(), C0, d("s0", chan_stats(x0.float())).data_ptr(), 1, 1.0, 0, 1)
+    if C1:
+        p.in1 = L.MiAct(d("x1", x1).data_ptr(), C1, d("s1", chan_stats(x1.float())).data_ptr(), 1, sk, 0, 1)
+    p.Cout, p.ksize, p.stride, p.up2 = Cout, 3, 1, 0
+    wf, wexp = P.pack_conv_weight_rp(w)
+    p.w_rp, p.w_rp_exp, p.bias = d("wf", wf).data_ptr(), wexp, d("b", bias).data_ptr()
+    p.gn_groups, p.gn_gamma, p.gn_beta, p.gn_eps = 8, d("g", gamma).data_ptr(), d("be", beta).data_ptr(), 1e-5
+    if res != 'none':
+        r0 = bf(rn(B, Cout if res == 'id' else 8, H, W))
+        r1 = bf(rn(B, 16, H, W)) if res == 'conv2' else None
+        p.res0 = L.MiAct(d("r0", r0).data_ptr(), r0.shape[1], d("rs0", chan_stats(r0.float())).data_ptr(), 1, 1.0, 0, 1)
+        if res == 'id':
+            ref = ref + r0.double()
+        else:
+            rin = torch.cat((r0.float(), r1.float() * sk), 1)
+            rw, rb = rn(Cout, rin.shape[1], 1, 1) * 0.3, rn(Cout)
+            ref = ref + F.conv2d(rin.double(), rw.double(), rb.double())
+            p.res_w = 1
+            rwf, p.res_w_rp_exp = P.pack_conv_weight_rp(rw)
+            p.res_w_rp, p.res_b = d("rwf", rwf).data_ptr(), d("rb", rb).data_ptr()
+            p.res1 = L.MiAct(d("r1", r1).data_ptr(), 16, d("rs1", chan_stats(r1.float())).data_ptr(), 1, sk, 0, 1)
+    nt = tile_nt(lib, cfg, H, W)
+    out = torch.full((B, Cout, H, W), float('nan'), device=dev).to(torch.bfloat16 if ost else torch.float32)
+    ostat = torch.zeros(B, Cout, nt, 2, device=dev)
+    p.out, p.out_st, p.out_stats, p.tile_cfg = out.data_ptr(), ost, ostat.data_ptr(), cfg | 0x400
+    L.check(lib.mi_conv_fwd(C.byref(p), L.current_stream()), "conv rp (bf16 storage)")
+    err = (out.cpu().double() - ref).abs()
+    tol = 2e-3 * ref.abs().max().item() + (2.0 ** -8) * ref.abs() * ost            # single fp16 term + bf16 rounding of the stored result
+    print(f"rp conv bf16 storage {case}: max|d| = {err.max().item():.2e} (|ref|max {ref.abs().max().item():.3g})")
+    assert bool((err <= tol).all())
+    check_stats(ostat.cpu(), ref.float(), rtol=2e-3)
 
 
 RP_MODE_CASES = [
