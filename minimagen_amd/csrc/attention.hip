@@ -531,6 +531,7 @@ extern "C" int mi_cross_attn_fwd(const mi_cross_attn_params* pp, void* stream) {
     // without text (Unet.py:572: text is optional; 1 tile, fp16 kernel only)
     if (JT != 17 && !(JT == 1 && (p.variant == 6 || p.variant == 7))) { mi_set_error("mi_cross_attn_fwd: context of %d rows (%d tiles) not instantiated (MinImagen: 1 + time tokens [+ 256])", p.J, JT); return MI_ERR_UNSUPPORTED; }
     if (p.B2 <= 0 || p.HW <= 0) { mi_set_error("mi_cross_attn_fwd: empty problem"); return MI_ERR_INVALID; }
+    if ((p.x.st || p.out_st) && p.variant != 7) { mi_set_error("mi_cross_attn_fwd: bf16 activation storage is variant 7 only"); return MI_ERR_UNSUPPORTED; }
     // out_stats tiles are MI_ATTN_TOKENS_PER_WG tokens (NQ = 2); p.variant = 1 selects NQ = 1 (64-token tiles)
     if (p.variant == 6 || p.variant == 7) {      // fp16 MFMA (fragments from mi_attn_fold_rows with frag_f16 = 1): 6 = 3-term split (fp32-grade), 7 = single term
         // waves per workgroup (measured on MI355X): 8 for the SR bottleneck (4096 tokens: 0.53 -> 0.47 ms per pair of launches),

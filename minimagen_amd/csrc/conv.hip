@@ -448,6 +448,8 @@ extern "C" int mi_conv_fwd(const mi_conv_params* pp, void* stream) {
     const mi_conv_params& p = *pp;
     hipStream_t st = (hipStream_t)stream;
     const int Cin = p.in0.C + (p.in1.data ? p.in1.C : 0);
+    const bool any16 = p.in0.st || (p.in1.data && p.in1.st) || (p.res0.data && p.res0.st) || (p.res1.data && p.res1.st) || p.out_st;
+    if (any16 && !(p.w_rp && (p.tile_cfg & 0x400))) { mi_set_error("mi_conv_fwd: bf16 activation storage is read / written by the single-term row-paired kernels only (w_rp, tile_cfg | 0x400)"); return MI_ERR_UNSUPPORTED; }
     if (p.w_rp) {           // row-paired matrix-core family (narrow and wide regimes): its own limits
         if (p.gn_groups > MI_MAX_GROUPS || (p.gn_groups > 0 && (Cin % p.gn_groups) != 0)) { mi_set_error("mi_conv_fwd: Cin %d / groups %d", Cin, p.gn_groups); return MI_ERR_INVALID; }
         if (p.gn_groups > 0 && (!p.in0.stats || (p.in1.data && !p.in1.stats))) { mi_set_error("mi_conv_fwd: GroupNorm input without channel statistics"); return MI_ERR_INVALID; }

@@ -478,6 +478,7 @@ extern "C" int mi_crossembed_fwd(const mi_crossembed_params* pp, void* stream) {
     int th, tw;
     if (mi_conv_tile_shape(p.tile_cfg & 0xff, &th, &tw) != MI_OK) { mi_set_error("mi_crossembed_fwd: bad tile_cfg"); return MI_ERR_INVALID; }
     const int tiles = ((p.H + th - 1) / th) * ((p.W + tw - 1) / tw);
+    if (p.out_st && !(p.w_mfma && (p.tile_cfg & 0x400))) { mi_set_error("mi_crossembed_fwd: bf16 storage needs the matrix-core kernel with tile_cfg | 0x400"); return MI_ERR_UNSUPPORTED; }
     if (p.w_mfma) {             // matrix-core kernel: tile_cfg 8 (32 x 64) / 9 (16 x 32), | 0x400 = single fp16 term
         const int cfg = p.tile_cfg & 0xff;
         if (!fast || p.in1 || p.C0 < 1 || p.C0 > 4 || (p.W & 3) || (cfg != 8 && cfg != 9)) {

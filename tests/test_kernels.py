@@ -406,6 +406,8 @@ def test_conv_rejects_bad_arguments():
     assert lib.mi_conv_fwd(C.byref(p), None) == -1
     p.gn_groups, p.B = 0, 0              # empty batch
     assert lib.mi_conv_fwd(C.byref(p), None) == -1
+    p.B, p.out_st = 1, 1                 # bf16 storage outside the single-term row-paired kernels
+    assert lib.mi_conv_fwd(C.byref(p), None) == -3 and b"bf16" in lib.mi_last_error()
 
 
 CE_CASES = [(2, 3, 0, 64, 64, (3, 7, 15), (4, 2, 2), 0, 0), (2, 3, 3, 40, 72, (3, 7, 15), (4, 2, 2), 1, 0),
