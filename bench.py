@@ -200,11 +200,38 @@ def pmc_traffic(dom, rows, S):
     return {"traffic": None}
 
 
+def cpu_baseline_reference(ncores):
+    """Config 1 of BASELINE.json through the UNMODIFIED reference (oracle/ref_loader.py imports it from /root/reference; only where
+    that tree exists, i.e. never on the GPU box): Imagen.sample, base U-Net 64x64, B=4, cond_scale 3, a bounded number of timesteps."""
+    from oracle import ref_loader
+    ref = ref_loader.load_reference()
+    p = json.load(open(os.path.join(ROOT, "tests", "golden", "unet_params.json")))
+    T = 25                                     # bounded sample: 25 of the reference's timesteps (its loop has no early exit)
+    unet = ref.Unet(**p["unet0"])
+    im = ref.Imagen(unets=[unet], text_encoder_name="t5_small", image_sizes=(64,), timesteps=T, cond_drop_prob=0.15)
+    im.unets[0].load_state_dict(torch.load(os.path.join(ROOT, "tests", "golden", "unet0_sd.pt"), weights_only=False))
+    emb, mask = synthetic_text(4)
+    with torch.no_grad():
+        t0 = time.time()
+        im.sample(text_embeds=emb, text_masks=mask, cond_scale=3.)
+        dt = time.time() - t0
+    return dict(value=4 * T / dt, unit="denoising-steps/s", cores=ncores, kind="reference",
+                sample=f"the reference's own Imagen.sample (/root/reference, CPU, torch {torch.__version__}): base U-Net (unet_0 params) 64x64, B=4, "
+                       f"cond_scale=3 (BASELINE config 1), {T} timesteps in {dt:.1f}s on {ncores} host threads")
+
+
 def cpu_baseline():
-    """Config 1 of BASELINE.json on this host: base U-Net 64x64, B=4, T=100, cond_scale 3, oracle (CPU port)."""
+    """Config 1 of BASELINE.json on this host: base U-Net 64x64, B=4, T=100, cond_scale 3 -- the reference itself where its tree exists
+    (the build container), the oracle (a CPU port of its algorithm) on the GPU box."""
     from oracle import restated as R
     ncores = min(os.cpu_count(), 16)     # tiny-channel convs do not scale further; more threads only add sync cost
     torch.set_num_threads(ncores)
+    try:
+        from oracle import ref_loader
+        if ref_loader.reference_available():
+            return cpu_baseline_reference(ncores)
+    except Exception as e:                 # the port below is always available
+        print(f"bench: reference CPU baseline unavailable ({type(e).__name__}: {e}); timing the oracle port", file=sys.stderr)
     sd = torch.load(os.path.join(ROOT, "tests", "golden", "unet0_sd.pt"), weights_only=False)
     emb, mask = synthetic_text(4)
     B, T = 4, 100
@@ -232,26 +259,35 @@ def cpu_baseline():
                 sr_unet_forward_B4_ms=sr_ms)
 
 
+def timed_calls(im, emb, mask, cond_scale, precision, calls, warmup, pipelined, seed0=2):
+    """seconds per sample() call: `warmup` untimed calls, then `calls` timed ones (the main loop's method)"""
+    for k in range(warmup):
+        im.sample(text_embeds=emb, text_masks=mask, cond_scale=cond_scale, _seed=seed0 + k, _precision=precision, _async=pipelined)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(calls):
+        im.sample(text_embeds=emb, text_masks=mask, cond_scale=cond_scale, _seed=seed0 + warmup + k, _precision=precision, _async=pipelined)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / calls
+
+
 def secondary_lines(dev, timesteps, cond_scale):
-    """The other single-GPU BASELINE.json configurations, short runs (1 warm-up + 2 timed sample() calls each), as extra keys of the
-    driver line: config 2 (base 64^2, B=32, fp32), config 3's shape (cascade 64->256, B=16, half-precision matrix-core contractions) and
-    config 5's per-GPU shape (cascade 64->256->1024, B=8, half precision, noise augmentation on both SR stages).  Never the headline."""
+    """The other single-GPU BASELINE.json configurations as extra keys of the driver line, timed like the headline (3 warm-up calls, then
+    8 / 8 / 3 timed sample() calls, pipelined across calls and one at a time): config 2 (base 64^2, B=32, fp32), config 3's shape
+    (cascade 64->256, B=16, reduced precision) and config 5's per-GPU shape (cascade 64->256->1024, B=8, reduced precision, noise
+    augmentation on both SR stages).  Never the headline."""
     out = {}
-    for key, workload, B, precision in (("config2_base64_B32_fp32", "base64", 32, "fp32"),
-                                        ("config3_cascade64_256_B16_half", "cascade64_256", 16, "half"),
-                                        ("config5_cascade64_256_1024_B8_half", "cascade64_256_1024", 8, "half")):
+    for key, workload, B, precision, calls in (("config2_base64_B32_fp32", "base64", 32, "fp32", 8),
+                                               ("config3_cascade64_256_B16_half", "cascade64_256", 16, "half", 8),
+                                               ("config5_cascade64_256_1024_B8_half", "cascade64_256_1024", 8, "half", 3)):
         im, sizes = build_imagen(workload, timesteps, dev)
         emb, mask = synthetic_text(B)
         emb, mask = emb.to(dev), mask.to(dev)
-        im.sample(text_embeds=emb, text_masks=mask, cond_scale=cond_scale, _seed=1, _precision=precision)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for k in range(2):
-            im.sample(text_embeds=emb, text_masks=mask, cond_scale=cond_scale, _seed=2 + k, _precision=precision)
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / 2
+        dt_sync = timed_calls(im, emb, mask, cond_scale, precision, calls, 3 if calls > 3 else 1, False)
+        dt = timed_calls(im, emb, mask, cond_scale, precision, calls, 1, True)
         out[key] = {"denoising_steps_per_s": B * timesteps * len(sizes) / dt, "images_per_s": B / dt, "ms_per_sample_call": dt * 1e3,
-                    "per_gpu_batch": B, "precision": precision, "image_sizes": list(sizes)}
+                    "denoising_steps_per_s_no_pipeline": B * timesteps * len(sizes) / dt_sync, "ms_per_sample_call_no_pipeline": dt_sync * 1e3,
+                    "timed_calls": calls, "per_gpu_batch": B, "precision": precision, "image_sizes": list(sizes)}
         del im
         torch.cuda.empty_cache()
     return out
@@ -269,11 +305,14 @@ def main():
     ap.add_argument("--precision", default="fp32", choices=["fp32", "half"],
                     help="fp32 (default, the headline): every contraction fp32-grade; half: single-fp16-term matrix-core contractions "
                          "(BASELINE's reduced-precision configurations; parity gate 3e-2) -- reported as a secondary line, never the headline")
-    ap.add_argument("--t5", action="store_true", help="also time the T5 text-embedding pass (K16) for the batch")
+    ap.add_argument("--no-t5", action="store_true", help="skip the T5 text-embedding pass (K16) for the batch (timed by default, outside the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="make every sample() call wait for the previous one (no cross-call stage pipelining)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short runs of the other single-GPU BASELINE configurations")
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="STRONG scaling (BASELINE config 4: fixed total batch, e.g. 128, sharded over the ranks; overrides --batch). "
+                         "Default 0 = weak scaling with --batch rows per GPU")
     ap.add_argument("--breakdown-out", default="")
     args = ap.parse_args()
 
@@ -298,53 +337,105 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
 
     from minimagen_amd import _lib as L
-    from minimagen_amd.distributed import gather_samples
+    from minimagen_amd.distributed import gather_samples, shard_bounds
     L.use_library(L.DEFAULT_LIB)
     im, sizes = build_imagen(args.workload, args.timesteps, dev)
-    B = args.batch
-    gB = B * world
-    emb, mask = synthetic_text(B, row0=rank * B)
+    strong = args.global_batch > 0
+    if strong:
+        gB = args.global_batch
+        row0, row1 = shard_bounds(gB, world, rank)          # the partitioning of minimagen_amd.distributed.sample_distributed
+        B = row1 - row0
+        assert B > 0, "more ranks than samples"
+    else:
+        B = args.batch
+        gB, row0 = B * world, rank * B
+    emb, mask = synthetic_text(B, row0=row0)
     emb, mask = emb.to(dev), mask.to(dev)
 
     gstream = torch.cuda.Stream(device=dev) if (world > 1 and not one_gpu) else None
 
-    def one_step(k):
+    def one_step(k, pipelined=True, gather=True):
         # successive sample() calls are pipelined across the per-stage HIP streams (_async: the caller's stream is not made to wait; the
         # timed region ends with a device-wide synchronize, so every image is finished inside it)
-        out = im.sample(text_embeds=emb, text_masks=mask, cond_scale=args.cond_scale, _seed=1234 + k, _sample_offset=rank * B, _precision=args.precision,
-                        _async=not args.no_pipeline)
-        if world > 1 and one_gpu:
-            torch.cuda.current_stream().wait_event(im.last_sample_done)
+        out = im.sample(text_embeds=emb, text_masks=mask, cond_scale=args.cond_scale, _seed=1234 + k, _sample_offset=row0, _precision=args.precision,
+                        _async=pipelined)
+        if world > 1 and gather and one_gpu:
+            if pipelined:
+                torch.cuda.current_stream().wait_event(im.last_sample_done)
             host = out.cpu()
             pad = [torch.empty_like(host) for _ in range(world)]
             dist.all_gather(pad, host)
             out = torch.cat(pad, 0).to(dev)
-        elif world > 1:
+        elif world > 1 and gather:
             # RCCL over xGMI, the only collective of the path: one all_gather_into_tensor of the finished images, on its own stream behind
             # the last stage's event -- the caller's stream stays free, so the next call's base stage still starts under this call's SR stage
-            gstream.wait_event(im.last_sample_done)
+            if pipelined:
+                gstream.wait_event(im.last_sample_done)
+            else:
+                gstream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(gstream):
                 out.record_stream(gstream)
                 out = gather_samples(out, gB)
         return out
 
+    def timed(steps, pipelined):
+        """(max-over-ranks seconds, this rank's own seconds, last output): barrier + synchronize on both sides of exactly `steps` steps"""
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            out = one_step(100 + k, pipelined)
+        torch.cuda.synchronize()
+        mine = time.perf_counter() - t0
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], device="cpu" if one_gpu else dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt, mine, out
+
+    pipelined = not args.no_pipeline
     for k in range(args.warmup):
-        one_step(k)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        out = one_step(100 + k)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], device="cpu" if one_gpu else dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        one_step(k, pipelined)
+    # the benched mode is value-checked outside the timed region: the second of two back-to-back pipelined calls (its base stage ran
+    # under the first call's super-resolution stage) against the same call made synchronously
+    pipe_ok = None
+    if pipelined:
+        torch.cuda.synchronize()
+        ref_out = one_step(7, False, gather=False).clone()
+        torch.cuda.synchronize()
+        one_step(6, True, gather=False)
+        chk = one_step(7, True, gather=False)
+        torch.cuda.synchronize()
+        pipe_ok = bool(torch.equal(chk, ref_out))
+        assert pipe_ok, "pipelined sample() differs from the synchronous call"
+        del ref_out, chk
+    dt, mine, out = timed(args.steps, pipelined)
     assert torch.isfinite(out).all() and out.shape[0] == gB
+    dt_sync = None
+    if pipelined:                       # the reference's sample() is synchronous: report that mode beside the pipelined headline
+        dt_sync, _, _ = timed(max(2, min(args.steps, 8)), False)
+        dt_sync /= max(2, min(args.steps, 8))
+    per_rank = None
+    gather_ms = None
+    if world > 1:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, {"rank": rank, "rows": B, "seconds": mine})
+        if not one_gpu:                 # the collective alone, on its stream, with HIP events
+            loc = torch.zeros(B, 3, sizes[-1], sizes[-1], device=dev)
+            with torch.cuda.stream(gstream):
+                gather_samples(loc, gB)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(5):
+                    gather_samples(loc, gB)
+                e1.record()
+            e1.synchronize()
+            gather_ms = e0.elapsed_time(e1) / 5
 
     n_stages = len(sizes)
     steps_per_sample = args.timesteps * n_stages
@@ -353,14 +444,27 @@ def main():
         "metric": {1: "denoising-steps/sec (images/sec x T), base 64^2", 2: "denoising-steps/sec (images/sec x T), base 64^2 + SR 64->256 cascade",
                    3: "denoising-steps/sec (images/sec x T), base 64^2 + SR 64->256 + SR 256->1024 cascade"}[n_stages],
         "value": value, "unit": "denoising-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
         "dtype": "f32" if args.precision == "fp32" else "f16 operands on the matrix cores, f32 accumulate/softmax/statistics/storage", "data": "synthetic (random-init weights seed 0, randn text embeddings seed 7 with ragged masks, Philox noise)",
         "config": {"workload": f"{args.workload}: unet_0 params @64x64" + (" + unet_1 params (lowres_cond) @256x256" if n_stages >= 2 else "") + (" + unet_1 params (lowres_cond) @1024x1024" if n_stages == 3 else "")
                    + f", T={args.timesteps}/stage, cond_scale={args.cond_scale} (2 U-Net evals/step), dynamic thresholding 0.9, " + ("fp32 storage / accumulate / softmax / statistics, contractions as 3-term fp16-split (hi*hi + hi*lo + lo*hi) MFMA products"
                       if args.precision == "fp32" else "half-precision matrix-core contractions (single fp16 term)"),
-                   "per_gpu_batch": B, "global_batch": gB, "timesteps": args.timesteps, "parallelism": f"dp{world}"},
+                   "per_gpu_batch": B if not strong else f"{gB}/{world} (fixed global batch, contiguous shards)", "global_batch": gB,
+                   "timesteps": args.timesteps, "parallelism": f"dp{world}",
+                   "call_mode": ("successive sample() calls PIPELINED across the per-stage HIP streams (_async=True: the base stage of call k+1 runs under "
+                                 "the super-resolution stage of call k; outputs bit-identical to synchronous calls, checked in this run); "
+                                 "value_no_pipeline = the same calls one at a time, the reference's synchronous semantics") if pipelined
+                                else "synchronous sample() calls, one at a time (the reference's semantics)"},
         "images_per_s": gB * args.steps / dt,
+        "pipelined": pipelined,
     }
+    if pipelined:
+        res["pipelined_equals_synchronous"] = pipe_ok
+        res["value_no_pipeline"] = gB * steps_per_sample / dt_sync
+        res["ms_per_step_no_pipeline"] = dt_sync * 1e3
+    if world > 1:
+        res["per_rank"] = [dict(r, denoising_steps_per_s=r["rows"] * steps_per_sample * args.steps / r["seconds"]) for r in per_rank]
+        res["all_gather_ms"] = gather_ms
 
     if rank == 0 and not args.no_breakdown:
         stage = n_stages - 1
@@ -405,7 +509,7 @@ def main():
         if args.breakdown_out:
             with open(args.breakdown_out, "w") as f:
                 json.dump(rows, f, indent=1)
-    if rank == 0 and args.t5:
+    if rank == 0 and not args.no_t5:
         res["t5_encode"] = t5_leg(dev, B)
     if rank == 0 and world == 1 and not args.no_secondary and args.workload == "cascade64_256" and args.precision == "fp32":
         res["secondary"] = secondary_lines(dev, args.timesteps, args.cond_scale)

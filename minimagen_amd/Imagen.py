@@ -252,6 +252,10 @@ class Imagen(nn.Module):
                 if noise_dev is None:
                     while len(cached) >= 8:                      # bounded: one exec per (guidance, threshold, shard offset) combination
                         old = cached.pop(next(iter(cached)))
+                        # replays of the evicted exec may still be queued on a stage stream (sample() never host-syncs): drain the
+                        # device before the handle goes (rare: a 9th distinct (guidance, threshold, shard) combination)
+                        if L.backend() == "hip-gfx950":
+                            torch.cuda.synchronize(ws.dev)
                         lib.mi_graph_destroy(old["graph"])
                     cached[gkey] = entry
         if use_graph:
@@ -363,6 +367,13 @@ class Imagen(nn.Module):
                 streams[stage].wait_event(inputs_ready)
                 if prev_done is not None:
                     streams[stage].wait_event(prev_done)
+            if on_gpu:
+                # the stage streams read the caller's tensors after sample() has returned (_async) / after the caller may have dropped
+                # them: tell the caching allocator, or a block freed on the caller's stream could be handed out again while a stage's
+                # text_cond launch is still queued
+                for t_in in (text_embeds, text_masks):
+                    if t_in is not None and t_in.is_cuda:
+                        t_in.record_stream(streams[stage])
             with (torch.cuda.stream(streams[stage]) if on_gpu else null_context()):
                 eng = unet.engine()
                 # per call, never sticky engine state: a later Unet.forward stays on the engine's default precision
@@ -382,7 +393,11 @@ class Imagen(nn.Module):
             if _async:
                 # pipelined use: the result is ready when ``done`` is (the caller synchronises / waits on it before touching the images)
                 self.last_sample_done = prev_done
-                return img if not return_pil_images else _to_pil_images(img)
+                if not return_pil_images:
+                    return img
+                caller_stream.wait_event(prev_done)          # the device -> host copy below runs on the caller's stream
+                img.record_stream(caller_stream)
+                return _to_pil_images(img)
             caller_stream.wait_event(prev_done)
             img.record_stream(caller_stream)
         if not return_pil_images:

@@ -5,6 +5,8 @@ from __future__ import annotations
 from dataclasses import dataclass
 from typing import List, Union
 
+import warnings
+
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -62,6 +64,7 @@ class Unet(nn.Module):
     """Denoising U-Net (minimagen/Unet.py:25-472).  Parameters live in torch modules named exactly as in
     the reference so that ``load_state_dict`` of a reference checkpoint works; the forward pass is a
     sequence of HIP kernel launches built by :class:`minimagen_amd.engine.UnetEngine`."""
+    _warned_torch_path = False
 
     def __init__(
             self,
@@ -194,6 +197,10 @@ class Unet(nn.Module):
         assert not (self.lowres_cond and not exists(lowres_noise_times)), 'low resolution conditioning noise time must be present'
         if self.training and torch.is_grad_enabled():
             # training (Imagen.forward): the differentiable torch-op form of the same module tree; sampling / evaluation takes the HIP engine
+            if x.is_cuda and not Unet._warned_torch_path:          # once per process
+                Unet._warned_torch_path = True
+                warnings.warn("minimagen_amd.Unet.forward: module in train() mode with autograd enabled -> differentiable torch-op path; "
+                              "call .eval() or wrap the call in torch.no_grad() to run inference on the HIP engine", stacklevel=2)
             return self._forward_train(x, time, lowres_cond_img=lowres_cond_img, lowres_noise_times=lowres_noise_times,
                                        text_embeds=text_embeds, text_mask=text_mask, cond_drop_prob=cond_drop_prob)
         keep = prob_mask_like((x.shape[0],), 1 - cond_drop_prob, device='cpu')      # Unet.py:587
@@ -265,12 +272,14 @@ class Unet(nn.Module):
     def forward_with_cond_scale(self, *args, cond_scale: float = 1., **kwargs) -> torch.Tensor:
         """Unet.py:474-506: both guidance halves run as ONE batch of 2B rows through the engine."""
         x, time = args
-        if cond_scale == 1:         # the sampling API: always the HIP engine (no conditioning dropout), whatever the module's train flag
+        if cond_scale == 1:         # the sampling API: always the HIP engine, whatever the module's train flag
+            # Unet.py:482-485: the single forward still honours a caller's cond_drop_prob (default 0: keep every row's conditioning)
+            keep1 = prob_mask_like((x.shape[0],), 1 - kwargs.get('cond_drop_prob', 0.), device='cpu')
             with torch.no_grad():
                 return self.engine().forward_once(x, time, lowres_cond_img=kwargs.get('lowres_cond_img') if self.lowres_cond else None,
                                                   lowres_noise_times=kwargs.get('lowres_noise_times') if self.lowres_cond else None,
                                                   text_embeds=kwargs.get('text_embeds'), text_mask=kwargs.get('text_mask'),
-                                                  keep=torch.ones(x.shape[0], dtype=torch.bool))
+                                                  keep=keep1)
         assert not (self.lowres_cond and not exists(kwargs.get('lowres_cond_img'))), 'low resolution conditioning image must be present'
         assert not (self.lowres_cond and not exists(kwargs.get('lowres_noise_times'))), 'low resolution conditioning noise time must be present'
         with torch.no_grad():

@@ -76,6 +76,10 @@ def _close_workspace(ws):
     for st in getattr(ws, "sampler_state", {}).values():
         for entry in getattr(st, "graphs", {}).values():
             if entry.get("graph") is not None:
+                # sample() never host-syncs its stage streams: replays of this exec (and the workspace buffers it addresses, dropped
+                # together with it) may still be queued -- drain the device first (invalidations are rare: new weights / .to())
+                if L.backend() == "hip-gfx950" and torch.cuda.is_available():
+                    torch.cuda.synchronize(ws.dev)
                 lib.mi_graph_destroy(entry["graph"])
                 entry["graph"] = None
         if hasattr(st, "graphs"):

@@ -92,9 +92,39 @@ def test_bench_two_ranks_control_flow_on_one_gpu(tmp_path):
     port = str(29000 + os.getpid() % 1500)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", port,
            os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--batch", "2", "--timesteps", "25",
-           "--no-breakdown", "--no-cpu-baseline", "--no-secondary"]
+           "--no-breakdown", "--no-cpu-baseline", "--no-secondary", "--no-t5"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 4 and line["config"]["parallelism"] == "dp2"
     assert line["value"] > 0 and line["scaling"] == "weak" and line["steps"] == 1
+    assert line["pipelined"] and line["pipelined_equals_synchronous"] and line["value_no_pipeline"] > 0
+    assert [r["rows"] for r in line["per_rank"]] == [2, 2]
+    # strong scaling (BASELINE config 4): a fixed global batch sharded over the ranks
+    out = subprocess.run(cmd + ["--global-batch", "4"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["scaling"] == "strong" and line["config"]["global_batch"] == 4 and [r["rows"] for r in line["per_rank"]] == [2, 2]
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_over_rccl():
+    """the real multi-GPU branch (one rank per GPU, backend "nccl" = RCCL, all_gather_into_tensor of the finished images on its own
+    stream): runs only where two devices are visible (the single-GPU test tier skips it)"""
+    import json
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("MINIMAGEN_BENCH_ONE_GPU", None)
+    port = str(27000 + os.getpid() % 1500)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", port,
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2", "--timesteps", "25",
+           "--no-breakdown", "--no-cpu-baseline", "--no-secondary", "--no-t5"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["all_gather_ms"] > 0 and line["pipelined_equals_synchronous"]

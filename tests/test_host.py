@@ -37,6 +37,30 @@ def test_struct_layouts_match_the_library():
     L.use_library(L.DEFAULT_LIB)    # _bind() compares sizeof() of every parameter struct
 
 
+def test_integration_md_binding_example_matches_the_abi():
+    """INTEGRATION.md shows the ctypes binding a maintainer would write: the struct it spells out must have the library's layout (a
+    binder copying the document must pass mi_struct_size) and the ABI version it quotes must be the header's"""
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    m = re.search(r"class MiAct\(C\.Structure\):[^\n]*\n\s*_fields_ = (\[.*?\])\n", doc, re.S)
+    assert m, "INTEGRATION.md no longer shows the MiAct binding"
+    fields = eval(m.group(1), {"C": ctypes})
+    doc_act = type("DocMiAct", (ctypes.Structure,), {"_fields_": fields})
+    lib = ctypes.CDLL(L.DEFAULT_LIB)
+    lib.mi_struct_size.argtypes = [ctypes.c_int]
+    assert ctypes.sizeof(doc_act) == lib.mi_struct_size(0)
+    assert [(n, t) for n, t in fields] == [(n, t) for n, t in L.MiAct._fields_]
+    nargs = len(fields)
+    for call in re.findall(r"MiAct\(([^#\n]*?)\)\s", doc):
+        depth, count = 0, 1
+        for ch in call:
+            depth += ch in "([" 
+            depth -= ch in ")]"
+            count += (ch == "," and depth == 0)
+        assert count == nargs, f"MiAct({call}) in INTEGRATION.md has {count} arguments, the struct has {nargs} fields"
+    ver = int(re.search(r"#define MI_ABI_VERSION (\d+)", open(os.path.join(ROOT, "include", "minimagen_hip.h")).read()).group(1))
+    assert f"(currently {ver})" in doc and lib.mi_abi_version() == ver
+
+
 def test_cubic_taps_match_oracle_restatement():
     for in_sz, out_sz in ((64, 256), (64, 128), (256, 1024), (16, 64)):
         osz, idx, w = cubic_taps(in_sz, out_sz)

@@ -510,6 +510,50 @@ def test_crossembed_matrix_core(backend, case):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("case", [(2, 3, 3, 0, 64, 64, 9, False), (2, 3, 6, 3, 40, 72, 8, True), (1, 3, 3, 0, 72, 136, 8, True)])
+def test_crossembed_bf16_output(backend, case):
+    """reduced-precision configuration of CrossEmbed (tile_cfg | 0x400: single fp16 term; out_st = 1: the result is STORED as bf16, the
+    addend -- the hoisted low-res half -- is READ as bf16); statistics stay fp32 and are taken before the rounding.  Error budget vs
+    torch fp64 on the same inputs: single fp16 term (2^-11 per operand) + bf16 rounding of the stored result (2^-9 relative)"""
+    dev = setup(backend)
+    lib = L.lib()
+    B, Cin, Cw, c0, H, W, cfg, with_add = case
+    g = torch.Generator().manual_seed(hash(case) & 0xffff)
+    rn = lambda *s_: torch.randn(*s_, generator=g)
+    ks, cout = (3, 7, 15), (4, 2, 2)
+    x = rn(B, Cin, H, W)
+    ws = [rn(co, Cw, k, k) * 0.1 for k, co in zip(ks, cout)]
+    bs = [rn(co) for co in cout]
+    add = (rn(B, 8, H, W)).to(torch.bfloat16) if with_add else None
+    tab, exps = P.pack_crossembed_mfma(ws, c0, Cin)
+    ref = torch.cat([F.conv2d(x.double(), w[:, c0:c0 + Cin].double(), b.double(), padding=(k - 1) // 2) for w, b, k in zip(ws, bs, ks)], 1)
+    if with_add:
+        ref = ref + add.double()
+    p = L.MiCrossEmbedParams()
+    p.B, p.H, p.W = B, H, W
+    xd, tabd = x.to(dev), tab.to(dev)
+    p.in0, p.C0, p.in0_batch_mod = xd.data_ptr(), Cin, 0
+    p.n_kernels = 3
+    bd = [b.to(dev) for b in bs]
+    for i in range(3):
+        p.ksize[i], p.cout[i], p.bias[i], p.w_mfma_exp[i] = ks[i], cout[i], bd[i].data_ptr(), exps[i]
+    p.w_mfma = tabd.data_ptr()
+    addd = add.to(dev) if with_add else None
+    p.addend = addd.data_ptr() if with_add else 0
+    nt = tile_nt(lib, cfg, H, W)
+    out = torch.full(ref.shape, float('nan'), device=dev).to(torch.bfloat16)
+    ost = torch.zeros(B, 8, nt, 2, device=dev)
+    p.out, p.out_stats, p.out_st, p.tile_cfg = out.data_ptr(), ost.data_ptr(), 1, cfg | 0x400
+    L.check(lib.mi_crossembed_fwd(C.byref(p), L.current_stream()), "crossembed (bf16 storage)")
+    err = (out.cpu().double() - ref).abs()
+    tol = 2e-3 * ref.abs().max().item() + (2.0 ** -8) * ref.abs()
+    print(f"crossembed bf16 out {case}: max|d| = {err.max().item():.2e} (|ref|max {ref.abs().max().item():.3g})")
+    assert bool((err <= tol).all())
+    assert (out.cpu().float() - ref.float()).abs().max() > 1e-5          # the output really is bf16-rounded
+    check_stats(ost.cpu(), ref.float(), rtol=2e-3)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
 @pytest.mark.parametrize("case", [(2, 16, 256, 8, 2, 0), (1, 16, 200, 8, 4, 0), (1, 8, 128, 8, 2, 0), (1, 32, 128, 16, 2, 0),
                                   (8, 16, 200, 8, 4, 1), (1, 8, 128, 8, 2, 1), (2, 16, 256, 8, 4, 2), (2, 16, 256, 8, 4, 3), (1, 8, 200, 8, 2, 4), (1, 16, 256, 8, 4, 5),
                                   (2, 16, 200, 8, 4, 6), (1, 8, 128, 8, 2, 6), (1, 32, 128, 16, 2, 6),
@@ -567,6 +611,61 @@ def test_cross_attention_folded(backend, case):
     assert torch.isfinite(out).all()
     assert (out.cpu() - ref).abs().max().item() < 3e-5
     check_stats(ost.cpu(), ref)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("case", [(2, 16, 256, 8, 4), (1, 16, 200, 8, 2), (1, 8, 128, 8, 2), (1, 32, 128, 16, 2)])
+def test_cross_attention_bf16_io(backend, case):
+    """reduced-precision configuration of K9 (variant 7: single fp16 term) with the tokens READ as bf16 (x.st = 1) and the result
+    STORED as bf16 (out_st = 1) -- what the BASELINE U-Nets run under _precision="half".  Against the oracle's unfolded fp32
+    CrossAttention + residual on the same bf16-rounded tokens: single-term products (2^-11 per operand) + bf16 rounding of the output"""
+    dev = setup(backend)
+    lib = L.lib()
+    B2, Cc, HW, cd, ntok = case
+    heads, J = 8, 1 + ntok + 256
+    g = torch.Generator().manual_seed(3)
+    rn = lambda *s: torch.randn(*s, generator=g)
+    sd = {"a.norm.gamma": 1 + 0.2 * rn(Cc), "a.norm.beta": 0.1 * rn(Cc),
+          "a.to_q.weight": rn(heads * 64, Cc) * Cc ** -0.5, "a.to_kv.weight": rn(2 * heads * 64, cd) * cd ** -0.5,
+          "a.null_kv": rn(2, 64), "a.to_out.0.weight": rn(Cc, heads * 64) * (heads * 64) ** -0.5,
+          "a.to_out.1.gamma": 1 + 0.2 * rn(Cc), "a.to_out.1.beta": 0.1 * rn(Cc)}
+    x16 = (rn(B2, Cc, HW) * 1.3).to(torch.bfloat16)
+    x, c = x16.float(), rn(B2, J - 1, cd)
+    xt = x.permute(0, 2, 1)
+    ref = (R.cross_attention(xt, c, sd, "a") + xt).permute(0, 2, 1).contiguous()
+    mg, mv, g0, v0 = [t.to(dev) for t in P.fold_cross_attention(sd["a.to_q.weight"], sd["a.to_kv.weight"], sd["a.to_out.0.weight"], sd["a.null_kv"], heads)]
+    FR = lib.mi_attn_fragment_floats(Cc)
+    gv = torch.zeros(B2, heads, 18, 64, FR, device=dev)
+    fp = L.MiAttnFoldParams()
+    fp.B2, fp.C, fp.cd, fp.heads, fp.JT, fp.n_blocks, fp.frag_f16 = B2, Cc, cd, heads, 17, 1, 1
+    x_exp, g_exp, v_exp = P.attn_f16_exponents(mg, mv, g0, v0, cmax=float(c.abs().max()), xmax=P.layernorm_bound(sd["a.norm.gamma"], sd["a.norm.beta"], Cc))
+    fp.blk[0].g_exp, fp.blk[0].v_exp = g_exp, v_exp
+    fp.blk[0].mg, fp.blk[0].mv, fp.blk[0].g0, fp.blk[0].v0, fp.blk[0].gv = mg.data_ptr(), mv.data_ptr(), g0.data_ptr(), v0.data_ptr(), gv.data_ptr()
+    ct, cx = c[:, :ntok].contiguous().to(dev), c[:, ntok:].contiguous().to(dev)
+    fp.c_rows, fp.c_stride_b, fp.row0, fp.nrows, fp.write_null = cx.data_ptr(), 256 * cd, 1 + ntok, 256, 1
+    L.check(lib.mi_attn_fold_rows(C.byref(fp), L.current_stream()))
+    fp.c_rows, fp.c_stride_b, fp.row0, fp.nrows, fp.write_null = ct.data_ptr(), ntok * cd, 1, ntok, 0
+    L.check(lib.mi_attn_fold_rows(C.byref(fp), L.current_stream()))
+    ap = L.MiCrossAttnParams()
+    ap.B2, ap.C, ap.HW, ap.heads, ap.J = B2, Cc, HW, heads, J
+    xd = x16.to(dev)
+    sdd = {k: v.to(dev) for k, v in sd.items()}
+    ap.x, ap.gv = L.MiAct(xd.data_ptr(), Cc, 0, 0, 1.0, 0, 1), gv.data_ptr()
+    ap.n1_g, ap.n1_b = sdd["a.norm.gamma"].data_ptr(), sdd["a.norm.beta"].data_ptr()
+    ap.n2_g, ap.n2_b = sdd["a.to_out.1.gamma"].data_ptr(), sdd["a.to_out.1.beta"].data_ptr()
+    out = torch.full(x.shape, float('nan'), device=dev).to(torch.bfloat16)
+    ost = torch.zeros(B2, Cc, -(-HW // 64), 2, device=dev)
+    ap.out, ap.out_stats, ap.out_st, ap.variant = out.data_ptr(), ost.data_ptr(), 1, 7
+    ap.x_exp, ap.g_exp, ap.v_exp = x_exp, g_exp, v_exp
+    L.check(lib.mi_cross_attn_fwd(C.byref(ap), L.current_stream()))
+    o = out.cpu().float()
+    assert torch.isfinite(o).all()
+    err = (o - ref).abs()
+    tol = 4e-3 * ref.abs().max().item() + (2.0 ** -8) * ref.abs()
+    print(f"cross-attention bf16 I/O {case}: max|d| = {err.max().item():.2e} (|ref|max {ref.abs().max().item():.3g})")
+    assert bool((err <= tol).all())
+    assert err.max() > 1e-5                                              # reduced precision really ran
+    check_stats(ost.cpu(), ref, rtol=4e-3)
 
 
 @pytest.mark.parametrize("backend", BACKENDS)

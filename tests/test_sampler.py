@@ -159,6 +159,79 @@ def test_three_stage_cascade_properties(backend):
     assert torch.equal(e, a[1:])
 
 
+@pytest.mark.parametrize("backend", GPU_ONLY)
+def test_async_pipelined_calls_equal_synchronous_calls(backend):
+    """What bench.py times: back-to-back sample(_async=True) calls, each with DIFFERENT, FRESHLY ALLOCATED text embeddings and its own
+    seed, the caller dropping its inputs as soon as sample() returns and immediately reusing the memory (the caching allocator hands
+    the freed block to the next same-sized allocation on the caller's stream).  Every output must be bit-identical to the same call
+    made synchronously, one at a time."""
+    dev = setup(backend)
+    im = make_imagen([64, 256], 25, dev)
+    B, Ltxt, n_calls = 4, 64, 4
+    host = [R.synthetic_text(B, length=Ltxt, seed=30 + k) for k in range(n_calls)]
+    sync = []
+    for k, (emb, mask) in enumerate(host):
+        sync.append(im.sample(text_embeds=emb.to(dev), text_masks=mask.to(dev), cond_scale=3., _seed=100 + k).clone())
+    torch.cuda.synchronize()
+    outs, events = [], []
+    for k, (emb, mask) in enumerate(host):
+        e, m = emb.to(dev), mask.to(dev)
+        outs.append(im.sample(text_embeds=e, text_masks=m, cond_scale=3., _seed=100 + k, _async=True))
+        events.append(im.last_sample_done)
+        del e, m
+        # same-sized scratch allocations on the caller's stream, scribbled over at once: with the inputs' blocks back in the allocator's
+        # pool this would overwrite embeddings a stage stream has not consumed yet
+        junk_e = torch.full((B, Ltxt, 512), float('nan'), device=dev)
+        junk_m = torch.zeros(B, Ltxt, dtype=torch.bool, device=dev)
+        del junk_e, junk_m
+    for ev in events:
+        ev.synchronize()
+    torch.cuda.synchronize()
+    for k in range(n_calls):
+        assert torch.equal(outs[k], sync[k]), f"pipelined call {k} differs from the synchronous one"
+    assert not torch.equal(sync[0], sync[1])
+    # and return_pil_images on the pipelined path waits for the last stage before the device -> host copy
+    pil = im.sample(text_embeds=host[0][0].to(dev), text_masks=host[0][1].to(dev), cond_scale=3., _seed=100, _async=True, return_pil_images=True)
+    import numpy as np
+    want = sync[0].cpu().mul(255).to(torch.uint8).permute(0, 2, 3, 1).numpy()
+    assert all(np.array_equal(np.asarray(pil[i]), want[i]) for i in range(B))
+
+
+@pytest.mark.parametrize("backend", GPU_ONLY)
+def test_three_stage_cascade_values_vs_oracle(backend):
+    """BASELINE config 5's shape (64 -> 256 -> 1024, third U-Net = unet_1 params, noise augmentation on both SR stages) with VALUES:
+    B=1, T=25, cond_scale 1, injected noise, against the oracle; max|d| <= 1e-4, mean|d| <= 1e-5 on [0,1] images"""
+    dev = setup(backend)
+    im = make_imagen([64, 256, 1024], 25, dev)
+    emb, mask = R.synthetic_text(1, length=32, seed=13)
+    out = im.sample(text_embeds=emb.to(dev), text_masks=mask.to(dev), cond_scale=1., lowres_sample_noise_level=0.2, _noise=R.make_randn(77))
+    sd0, sd1 = I.load("unet0_sd.pt"), I.load("unet1_sd.pt")
+    ref = R.sample([sd0, sd1, sd1], [64, 256, 1024], 25, text_embeds=emb, text_masks=mask, cond_scale=1., randn=R.make_randn(77),
+                   lowres_sample_noise_level=0.2)
+    d = (out.cpu() - ref).abs()
+    print(f"cascade 64->256->1024 T=25 cs=1 B=1 vs oracle: max|d| = {d.max():.2e}, mean|d| = {d.mean():.2e}")
+    assert out.shape == (1, 3, 1024, 1024) and d.max() < 1e-4 and d.mean() < 1e-5, (d.max(), d.mean())
+
+
+@pytest.mark.parametrize("backend", GPU_ONLY)
+@pytest.mark.parametrize("sizes,B", [([64], 2), ([64, 256], 2)])
+def test_half_precision_uses_bf16_storage(backend, sizes, B):
+    """the reduced-precision configuration of the BASELINE U-Nets must really store its activations as bf16 (engine.workspace falls back
+    to fp32 storage silently when a layer has no bf16-reading kernel: that must not happen for unet_0 / unet_1)"""
+    dev = setup(backend)
+    im = make_imagen(sizes, 25, dev)
+    emb, mask = R.synthetic_text(B, length=16, seed=7)
+    im.sample(text_embeds=emb.to(dev), text_masks=mask.to(dev), cond_scale=3., _seed=3, _precision="half")
+    for unet, S in zip(im.unets, sizes):
+        ws = unet.engine().workspace(B, 2 * B, S, S, precision="half")
+        assert ws.half and ws.store16, f"stage {S}: fp32 storage fallback"
+        acts = [t for t in ws.tensors if t is not None and t.dim() == 4 and t.shape[-1] == S]
+        assert acts and all(t.dtype == torch.bfloat16 for t in acts if t is not ws.pred)
+        assert ws.pred.dtype == torch.float32                                   # the prediction feeds the fp32 sampler
+        ws32 = unet.engine().workspace(B, 2 * B, S, S, precision="fp32")
+        assert not ws32.store16
+
+
 _BASE = dict(dim=8, dim_mults=(1, 2), num_resnet_blocks=1, layer_attns=False, layer_cross_attns=False, memory_efficient=False)
 _SR = dict(dim=8, dim_mults=(1, 2), num_resnet_blocks=(1, 2), layer_attns=False, layer_cross_attns=False, memory_efficient=True)
 ARG_SWEEP = {   # Imagen kwargs, sample kwargs, image sizes, batch, caption length

@@ -44,6 +44,27 @@ def test_t5_encoder_matches_transformers(backend, case):
     assert d.max() < 2e-4 and d.mean() < 2e-5, (d.max(), d.mean(), ref.abs().max())
 
 
+@pytest.mark.gpu
+def test_t5_encoder_bench_shape():
+    """the shape bench.py's t5_encode leg runs: T5Config() = t5-small, 6 layers, B=32, L=64, ragged masks"""
+    from transformers import T5Config, T5EncoderModel
+    from minimagen_amd.t5 import T5EncoderHIP
+    dev = setup("gpu")
+    torch.manual_seed(0)
+    m = T5EncoderModel(T5Config()).eval()
+    B, Lq = 32, 64
+    ids = torch.randint(0, 32128, (B, Lq), generator=torch.Generator().manual_seed(1))
+    keep = torch.tensor([max(1, Lq - (r % 24)) for r in range(B)])
+    mask = torch.arange(Lq)[None, :] < keep[:, None]
+    with torch.no_grad():
+        ref = m(input_ids=ids, attention_mask=mask.long()).last_hidden_state
+    ref = ref.masked_fill(~mask[:, :, None], 0.)
+    out, mk = T5EncoderHIP.from_hf(m, device=dev).encode(ids.to(dev), mask.to(dev))
+    d = (out.cpu() - ref).abs()
+    print(f"T5 6 layers B=32 L=64: max|d| = {d.max():.2e}, mean|d| = {d.mean():.2e}, |ref|max = {ref.abs().max():.3g}")
+    assert torch.equal(mk.cpu(), mask) and d.max() < 2e-4 * max(1.0, ref.abs().max().item()) and d.mean() < 2e-5
+
+
 def test_relative_position_bucket_matches_transformers():
     from transformers.models.t5.modeling_t5 import T5Attention
     from minimagen_amd.t5 import relative_position_bucket
