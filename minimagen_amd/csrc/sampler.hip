@@ -271,7 +271,10 @@ __global__ __launch_bounds__(256) void posterior_kernel(const mi_posterior_param
 // ------------------------------------------------------------------ K11 epilogue + K12 + K13 in one launch (small images)
 // One workgroup of 1024 work-items per image; every work-item keeps its quads of x0 in registers, the three radix passes run on
 // histograms in LDS.  Operation order per element as in cfg_x0_kernel / quantile_*_kernel / posterior_kernel: bit-identical results.
-constexpr int SS_NT = 1024, SS_MAXQ = MI_SAMPLER_SMALL_N / 4 / SS_NT;      // quads per work-item
+#ifndef SS_THREADS
+#define SS_THREADS 1024
+#endif
+constexpr int SS_NT = SS_THREADS, SS_MAXQ = MI_SAMPLER_SMALL_N / 4 / SS_NT;      // quads per work-item
 __global__ __launch_bounds__(SS_NT) void sampler_small_kernel(const mi_cfg_x0_params c, const mi_quantile_params q, const mi_posterior_params pp) {
     __shared__ unsigned lh[2][MI_Q_BINS];
     __shared__ int scratch[8];
@@ -285,6 +288,9 @@ __global__ __launch_bounds__(SS_NT) void sampler_small_kernel(const mi_cfg_x0_pa
     float x0v[SS_MAXQ][4], xtv[SS_MAXQ][4];
     for (int i = tid; i < 2 * MI_Q_BINS; i += SS_NT) (&lh[0][0])[i] = 0u;
     if (tid == 0) nan_sh = 0u;
+#if defined(SS_FENCE) && (SS_FENCE & 1)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < SS_MAXQ; ++u) {
@@ -387,6 +393,9 @@ __global__ __launch_bounds__(SS_NT) void sampler_small_kernel(const mi_cfg_x0_pa
             for (int e = 0; e < 4; ++e) if (4 * qd + e < n) pp.x[ob + 4 * qd + e] = r[e];
         }
     }
+#if defined(SS_FENCE) && (SS_FENCE & 2)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#endif
 }
 
 __global__ void step_advance_kernel(int* t_state, long long* times, int B, int set, int value) {

@@ -166,8 +166,8 @@ def test_async_pipelined_calls_equal_synchronous_calls(backend):
     the freed block to the next same-sized allocation on the caller's stream).  Every output must be bit-identical to the same call
     made synchronously, one at a time."""
     dev = setup(backend)
-    im = make_imagen([64, 256], 25, dev)
-    B, Ltxt, n_calls = 4, 64, 4
+    im = make_imagen([64, 256], 50, dev)
+    B, Ltxt, n_calls = 16, 64, 4          # large enough that the two stages really overlap for most of a call
     host = [R.synthetic_text(B, length=Ltxt, seed=30 + k) for k in range(n_calls)]
     sync = []
     for k, (emb, mask) in enumerate(host):
@@ -195,6 +195,93 @@ def test_async_pipelined_calls_equal_synchronous_calls(backend):
     import numpy as np
     want = sync[0].cpu().mul(255).to(torch.uint8).permute(0, 2, 3, 1).numpy()
     assert all(np.array_equal(np.asarray(pil[i]), want[i]) for i in range(B))
+
+
+@pytest.mark.parametrize("backend", GPU_ONLY)
+def test_kernels_of_two_streams_side_by_side_stay_bit_exact(backend):
+    """The stage-pipelined sampler runs the base stage of call k+1 NEXT TO the super-resolution stage of call k.  Round 3 found the fused
+    small-image sampler tail returning wrong pixels in that situation only (a compiler-generated packed-fp32 instruction with an SGPR
+    operand misbehaves next to another kernel's matrix-core waves: profiles/r03_pk_f32_hazard.txt).  Here: (1) the tail kernel on fixed
+    inputs under a CrossEmbed load on a second stream, (2) a whole base-stage U-Net evaluation under the SR U-Net's kernels -- both
+    must reproduce their idle-GPU results bit for bit."""
+    import ctypes as C
+    from minimagen_amd import _lib as L
+    from minimagen_amd.helpers import quantile_rank
+    dev = setup(backend)
+    lib = L.lib()
+    im = make_imagen([64, 256], 100, dev)
+    B, n, T = 16, 3 * 64 * 64, 100
+    emb, mask = R.synthetic_text(B, length=32, seed=7)
+    emb, mask = emb.to(dev), mask.to(dev)
+    keep = torch.cat((torch.ones(B, dtype=torch.bool), torch.zeros(B, dtype=torch.bool)))
+    engs, wss = [], []
+    for stage, S in enumerate((64, 256)):
+        eng = im.unets[stage].engine(); eng.pack()
+        ws = eng.workspace(B, 2 * B, S, S)
+        g = torch.Generator().manual_seed(stage)
+        ws.x.copy_(torch.randn(ws.x.shape, generator=g)); ws.times.fill_(37)
+        if ws.lowres is not None:
+            ws.lowres.copy_(torch.randn(ws.lowres.shape, generator=g)); ws.lowres_times.fill_(20)
+            eng.prepare_lowres(ws)
+        eng.set_text(ws, emb, mask, keep)
+        engs.append(eng); wss.append(ws)
+    main, side = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    ce = [(fn, p_) for fn, p_, name in wss[1].prog if name == "crossembed"]
+
+    def load(reps):
+        with torch.cuda.stream(side):
+            for _ in range(reps):
+                for fn, p_ in ce:
+                    fn(C.byref(p_), side.cuda_stream)
+
+    # (1) the fused tail of a base-stage step
+    g = torch.Generator().manual_seed(0)
+    pred, x_in = torch.randn(2 * B, n, generator=g).to(dev), torch.randn(B, n, generator=g).to(dev)
+    coef = im.noise_schedulers[0].sampler_coef_table().to(dev).contiguous()
+    t_state = torch.full((1,), 37, dtype=torch.int32, device=dev)
+    k_lo, k_hi, w = quantile_rank(n, 0.9)
+    x = torch.empty_like(x_in)
+    s_q, v_q = torch.zeros(B, device=dev), torch.zeros(B, 2, device=dev)
+    seed_dev = torch.full((1,), 1234, dtype=torch.int64, device=dev)
+    cp = L.MiCfgX0Params(B, n, L.ptr(pred), 1, 3.0, L.ptr(x), L.ptr(coef), L.ptr(t_state), 0, 0, 0)
+    qp = L.MiQuantileParams(B, n, 0, k_lo, k_hi, w, 0, L.ptr(s_q), L.ptr(v_q), 1, 1)
+    pp = L.MiPosteriorParams(B, n, T, 0, L.ptr(s_q), L.ptr(x), L.ptr(coef), L.ptr(t_state), 0, 1234, 0, 0, L.ptr(seed_dev))
+
+    def tail():
+        with torch.cuda.stream(main):
+            x.copy_(x_in)
+            L.check(lib.mi_sampler_step_small_fwd(C.byref(cp), C.byref(qp), C.byref(pp), main.cuda_stream), "small")
+            return x.clone()
+    torch.cuda.synchronize()
+    ref = tail()
+    torch.cuda.synchronize()
+    wrong = 0
+    for rep in range(4):
+        load(150)
+        outs = [tail() for _ in range(100)]
+        torch.cuda.synchronize()
+        wrong += sum(0 if torch.equal(o, ref) else 1 for o in outs)
+    assert wrong == 0, f"{wrong} of 400 tail launches differ from the idle-GPU result"
+
+    # (2) every kernel of the base-stage U-Net evaluation
+    def outputs(ws):
+        return [t for t in ws.tensors if t is not None and t.is_floating_point()] + [ws.pred]
+    with torch.cuda.stream(main):
+        engs[0].run(wss[0])
+        ref0 = [t.clone() for t in outputs(wss[0])]
+    torch.cuda.synchronize()
+    for rep in range(6):
+        with torch.cuda.stream(side):
+            for _ in range(6):
+                engs[1].run(wss[1])
+        with torch.cuda.stream(main):
+            got = []
+            for _ in range(4):
+                engs[0].run(wss[0])
+                got.append([t.clone() for t in outputs(wss[0])])
+        torch.cuda.synchronize()
+        for gset in got:
+            assert all(torch.equal(a, b) for a, b in zip(ref0, gset)), "base-stage U-Net evaluation differs under a concurrent SR load"
 
 
 @pytest.mark.parametrize("backend", GPU_ONLY)
