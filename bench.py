@@ -88,14 +88,14 @@ def entry_cost(name, p, cond_dim=8):
     return 0.0, 0.0, "hbm"
 
 
-def op_breakdown(im, stage, B, cond_scale, reps=20):
+def op_breakdown(im, stage, B, cond_scale, reps=20, precision="fp32"):
     """Time every kernel launch of one U-Net evaluation of `stage` with HIP events on the launch stream, IN PROGRAM ORDER (each
     launch sees the cache state its predecessor leaves behind, as inside the captured graph), averaged over `reps` evaluations."""
     from minimagen_amd import _lib as L
     unet = im.unets[stage]
     S = im.image_sizes[stage]
     eng = unet.engine()
-    ws = eng.workspace(B, 2 * B if cond_scale != 1 else B, S, S)
+    ws = eng.workspace(B, 2 * B if cond_scale != 1 else B, S, S, precision=precision)
     stream = L.current_stream()
     prog = [(fn, p, name) for fn, p, name in ws.prog if p is not None]
     for _ in range(2):
@@ -134,14 +134,14 @@ def op_breakdown(im, stage, B, cond_scale, reps=20):
     return rows
 
 
-def graph_step_ms(im, stage, B, cond_scale, T, reps=40):
+def graph_step_ms(im, stage, B, cond_scale, T, reps=40, precision="fp32"):
     """Per-step time of the stage's captured HIP graph (U-Net evaluation of both guidance halves + CFG/x0 + quantile + posterior draw),
     replayed back to back exactly as sample() does -- the figure the end-to-end throughput is made of (no per-launch event overhead)."""
     from minimagen_amd import _lib as L
     lib = L.lib()
     unet = im.unets[stage]
     S = im.image_sizes[stage]
-    ws = unet.engine().workspace(B, 2 * B if cond_scale != 1 else B, S, S)
+    ws = unet.engine().workspace(B, 2 * B if cond_scale != 1 else B, S, S, precision=precision)
     states = getattr(ws, "sampler_state", {})
     entries = [(st, e) for st in states.values() for e in getattr(st, "graphs", {}).values() if e.get("graph")]
     if not entries:
@@ -271,25 +271,34 @@ def timed_calls(im, emb, mask, cond_scale, precision, calls, warmup, pipelined, 
     return (time.perf_counter() - t0) / calls
 
 
-def secondary_lines(dev, timesteps, cond_scale):
-    """The other single-GPU BASELINE.json configurations as extra keys of the driver line, timed like the headline (3 warm-up calls, then
-    8 / 8 / 3 timed sample() calls, pipelined across calls and one at a time): config 2 (base 64^2, B=32, fp32), config 3's shape
-    (cascade 64->256, B=16, reduced precision) and config 5's per-GPU shape (cascade 64->256->1024, B=8, reduced precision, noise
-    augmentation on both SR stages).  Never the headline."""
+def secondary_lines(timesteps, cond_scale):
+    """The other single-GPU BASELINE.json configurations as extra keys of the driver line, each timed by the main loop of THIS script in a
+    fresh process (3 warm-up calls, then 8 / 8 / 3 timed sample() calls, pipelined; plus the same calls one at a time): config 2 (base 64^2,
+    B=32, fp32), config 3's shape (cascade 64->256, B=16, reduced precision) and config 5's per-GPU shape (cascade 64->256->1024, B=8,
+    reduced precision, noise augmentation on both SR stages).  Never the headline.
+    (A fresh process per configuration: device memory that a process has freed and allocated again can be markedly slower -- the second
+    Imagen built in one process ran its SR stage 1.75x slower, the third at full speed again, profiles/r03_config3_timing.json -- which is
+    what made round 2's in-process secondary lines read 228 ms per call for config 3.)"""
+    import subprocess
     out = {}
     for key, workload, B, precision, calls in (("config2_base64_B32_fp32", "base64", 32, "fp32", 8),
                                                ("config3_cascade64_256_B16_half", "cascade64_256", 16, "half", 8),
                                                ("config5_cascade64_256_1024_B8_half", "cascade64_256_1024", 8, "half", 3)):
-        im, sizes = build_imagen(workload, timesteps, dev)
-        emb, mask = synthetic_text(B)
-        emb, mask = emb.to(dev), mask.to(dev)
-        dt_sync = timed_calls(im, emb, mask, cond_scale, precision, calls, 3 if calls > 3 else 1, False)
-        dt = timed_calls(im, emb, mask, cond_scale, precision, calls, 1, True)
-        out[key] = {"denoising_steps_per_s": B * timesteps * len(sizes) / dt, "images_per_s": B / dt, "ms_per_sample_call": dt * 1e3,
-                    "denoising_steps_per_s_no_pipeline": B * timesteps * len(sizes) / dt_sync, "ms_per_sample_call_no_pipeline": dt_sync * 1e3,
-                    "timed_calls": calls, "per_gpu_batch": B, "precision": precision, "image_sizes": list(sizes)}
-        del im
-        torch.cuda.empty_cache()
+        cmd = [sys.executable, os.path.abspath(__file__), "--workload", workload, "--batch", str(B), "--precision", precision, "--steps", str(calls),
+               "--warmup", "3" if calls > 3 else "1", "--timesteps", str(timesteps), "--cond-scale", str(cond_scale),
+               "--no-secondary", "--no-breakdown", "--no-cpu-baseline", "--no-t5"]
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+        r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not lines:
+            out[key] = {"error": (r.stderr or r.stdout)[-400:]}
+            continue
+        j = json.loads(lines[-1])
+        n_img = B
+        out[key] = {"denoising_steps_per_s": j["value"], "images_per_s": j["images_per_s"], "ms_per_sample_call": j["ms_per_step"],
+                    "denoising_steps_per_s_no_pipeline": j.get("value_no_pipeline"), "ms_per_sample_call_no_pipeline": j.get("ms_per_step_no_pipeline"),
+                    "pipelined_equals_synchronous": j.get("pipelined_equals_synchronous"), "timed_calls": calls, "per_gpu_batch": n_img,
+                    "precision": precision, "image_sizes": {"base64": [64], "cascade64_256": [64, 256], "cascade64_256_1024": [64, 256, 1024]}[workload]}
     return out
 
 
@@ -468,7 +477,7 @@ def main():
 
     if rank == 0 and not args.no_breakdown:
         stage = n_stages - 1
-        rows = op_breakdown(im, stage, B, args.cond_scale)
+        rows = op_breakdown(im, stage, B, args.cond_scale, precision=args.precision)
         total_ms = sum(r["ms"] for r in rows)
         dom = max(rows, key=lambda r: r["ms"])
         attn_f16 = int(os.environ.get("MINIMAGEN_ATTN_VARIANT", "6")) == 6     # engine default: fp16x3-split matrix-core attention
@@ -498,7 +507,7 @@ def main():
                             "hbm_frac_whole_forward": (alg_fwd_mb * 1e6 * B * nfwd / (total_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if alg_fwd_mb else None,
                             "by_kernel_ms": {k: sum(r["ms"] for r in rows if r["kernel"] == k) for k in sorted({r["kernel"] for r in rows})}}
         with torch.cuda.stream(im._stream):          # the stream sample() captured and replays on
-            gs = graph_step_ms(im, stage, B, args.cond_scale, args.timesteps)
+            gs = graph_step_ms(im, stage, B, args.cond_scale, args.timesteps, precision=args.precision)
         torch.cuda.synchronize()
         if gs is not None and alg_fwd_mb:
             epi_mb = 6 * 3 * sizes[stage] ** 2 * 4 / 1e6                 # sampler epilogue bytes per image per step
@@ -512,7 +521,7 @@ def main():
     if rank == 0 and not args.no_t5:
         res["t5_encode"] = t5_leg(dev, B)
     if rank == 0 and world == 1 and not args.no_secondary and args.workload == "cascade64_256" and args.precision == "fp32":
-        res["secondary"] = secondary_lines(dev, args.timesteps, args.cond_scale)
+        res["secondary"] = secondary_lines(args.timesteps, args.cond_scale)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline()
     if rank == 0:
