@@ -2,6 +2,7 @@
 // T5LayerNorm (RMS), fp32 MFMA GEMM with fused ReLU / gated-GELU / residual epilogues, and the self-attention core
 // (unscaled q.k^T + bucketed relative position bias + key mask, softmax, .v) on v_mfma_f32_16x16x4_f32.
 #include "common.hip.h"
+#include <cstdlib>
 
 namespace {
 
@@ -57,6 +58,129 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
         }
     }
     // D layout: column (n) = lane & 15, row (m) = 4 * (lane >> 4) + r
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm * 32 + i * 16 + 4 * (lane >> 4) + r, n = n0 + wn * 32 + j * 16 + (lane & 15);
+                if (m < M && n < N) {
+                    float v = acc[i][j][r];
+                    if (act == 1) v = fmaxf(v, 0.0f);
+                    else if (act == 2) v = gelu_new(v);
+                    else if (act == 3) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+                    if (GATED) v *= accg[i][j][r];
+                    if (R) v += R[(size_t)m * N + n];
+                    Cout[(size_t)m * N + n] = v;
+                }
+            }
+}
+
+// ---- the same GEMM on the f16 matrix-core instruction (16x the fp32 MFMA rate) at fp32 accuracy: every operand is split x = hi + lo (two
+// fp16) and multiplied as lo*hi + hi*lo + hi*hi with fp32 accumulation (2^-22 per product, as in the conv / attention kernels).  Range
+// safety without any knowledge about the tensors: BLOCK scaling per K slice -- the 64 x 32 tile of A, of W (and of G) is scaled by the power
+// of two that brings its largest magnitude into [128, 256) before the split (exact), the slice's products are accumulated in a zeroed
+// accumulator and added to the running fp32 sum with the inverse scale (one FMA per accumulator register and slice).  An element 2^-22
+// below its tile's maximum still has a normal fp16 hi half; what a smaller element loses is below fp32 rounding of the tile's products.
+typedef _Float16 t5_f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ int t5_scale_exp(float m) {           // k with m * 2^k in [128, 256); 0 for zero / non-finite input
+    const int be = (int)((__float_as_uint(m) & 0x7fffffffu) >> 23);
+    return (be == 0 || be == 255) ? 0 : 134 - be;
+}
+__device__ __forceinline__ void t5_split8(const float4& u, const float4& v, float sc, uint4& hi, uint4& lo) {
+    const float x[8] = {u.x * sc, u.y * sc, u.z * sc, u.w * sc, v.x * sc, v.y * sc, v.z * sc, v.w * sc};
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const mi_f16x2 h2 = {(_Float16)x[2 * e], (_Float16)x[2 * e + 1]};
+        h[e] = __builtin_bit_cast(unsigned, h2);
+        l[e] = mi_split_lo2(h[e], x[2 * e], x[2 * e + 1]);
+    }
+    hi = make_uint4(h[0], h[1], h[2], h[3]);
+    lo = make_uint4(l[0], l[1], l[2], l[3]);
+}
+template <bool GATED>
+__global__ __launch_bounds__(256) void gemm_f16x3_kernel(const float* __restrict__ A, const float* __restrict__ W, const float* __restrict__ G,
+                                                         const float* __restrict__ R, float* __restrict__ Cout, int M, int N, int K, int act) {
+    constexpr int BM = 64, BN = 64, BK = 32, PITCH = 5;      // rows of 4 16-byte chunks (8 halves each) + 1 pad chunk: conflict-free ds_read_b128
+    __shared__ __attribute__((aligned(16))) uint4 Ah[BM * PITCH], Al[BM * PITCH], Wh[BN * PITCH], Wl[BN * PITCH];
+    __shared__ __attribute__((aligned(16))) uint4 Gh[GATED ? BN * PITCH : 1], Gl[GATED ? BN * PITCH : 1];
+    __shared__ float smax[3][4];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int lr = tid >> 2, lc = tid & 3;                    // staging: row, 8-float chunk
+    f32x4 acc[2][2], accg[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; accg[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto amax8 = [](const float4& u, const float4& v) {
+        return fmaxf(fmaxf(fmaxf(fabsf(u.x), fabsf(u.y)), fmaxf(fabsf(u.z), fabsf(u.w))), fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    };
+    // the next slice's global loads are issued right after this slice's values have been split into LDS: they fly under the MFMA section
+    // (and under the other resident workgroups) instead of in front of every slice
+    float4 a0 = z4, a1 = z4, w0 = z4, w1 = z4, g0 = z4, g1 = z4;
+    auto load_slice = [&](int k0) {
+        if (m0 + lr < M) { const float4* pa = reinterpret_cast<const float4*>(A + (size_t)(m0 + lr) * K + k0 + 8 * lc); a0 = pa[0]; a1 = pa[1]; }
+        if (n0 + lr < N) {
+            const float4* pw = reinterpret_cast<const float4*>(W + (size_t)(n0 + lr) * K + k0 + 8 * lc); w0 = pw[0]; w1 = pw[1];
+            if (GATED) { const float4* pg = reinterpret_cast<const float4*>(G + (size_t)(n0 + lr) * K + k0 + 8 * lc); g0 = pg[0]; g1 = pg[1]; }
+        }
+    };
+    load_slice(0);
+    for (int k0 = 0; k0 < K; k0 += BK) {
+        const float ma = mi_wave_max(amax8(a0, a1)), mw = mi_wave_max(amax8(w0, w1)), mg = GATED ? mi_wave_max(amax8(g0, g1)) : 0.0f;
+        __syncthreads();                                      // the previous slice's fragments and maxima are consumed
+        if (lane == 0) { smax[0][wave] = ma; smax[1][wave] = mw; smax[2][wave] = mg; }
+        __syncthreads();
+        const int ea = t5_scale_exp(fmaxf(fmaxf(smax[0][0], smax[0][1]), fmaxf(smax[0][2], smax[0][3])));
+        const int ew = t5_scale_exp(fmaxf(fmaxf(smax[1][0], smax[1][1]), fmaxf(smax[1][2], smax[1][3])));
+        const int eg = GATED ? t5_scale_exp(fmaxf(fmaxf(smax[2][0], smax[2][1]), fmaxf(smax[2][2], smax[2][3]))) : 0;
+        uint4 hi, lo;
+        t5_split8(a0, a1, ldexpf(1.0f, ea), hi, lo); Ah[lr * PITCH + lc] = hi; Al[lr * PITCH + lc] = lo;
+        t5_split8(w0, w1, ldexpf(1.0f, ew), hi, lo); Wh[lr * PITCH + lc] = hi; Wl[lr * PITCH + lc] = lo;
+        if (GATED) { t5_split8(g0, g1, ldexpf(1.0f, eg), hi, lo); Gh[lr * PITCH + lc] = hi; Gl[lr * PITCH + lc] = lo; }
+        if (k0 + BK < K) load_slice(k0 + BK);
+        __syncthreads();
+        t5_f16x8 ah[2], al[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int o = (wm * 32 + i * 16 + (lane & 15)) * PITCH + (lane >> 4);
+            ah[i] = __builtin_bit_cast(t5_f16x8, Ah[o]);
+            al[i] = __builtin_bit_cast(t5_f16x8, Al[o]);
+        }
+        const float un = ldexpf(1.0f, -(ea + ew)), ung = ldexpf(1.0f, -(ea + eg));
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int o = (wn * 32 + j * 16 + (lane & 15)) * PITCH + (lane >> 4);
+            const t5_f16x8 bh = __builtin_bit_cast(t5_f16x8, Wh[o]), bl = __builtin_bit_cast(t5_f16x8, Wl[o]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                f32x4 sl = (f32x4){0.f, 0.f, 0.f, 0.f};
+                sl = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh, sl, 0, 0, 0);
+                sl = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl, sl, 0, 0, 0);
+                sl = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh, sl, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] = fmaf(sl[r], un, acc[i][j][r]);
+            }
+            if (GATED) {
+                const t5_f16x8 gh = __builtin_bit_cast(t5_f16x8, Gh[o]), gl = __builtin_bit_cast(t5_f16x8, Gl[o]);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    f32x4 sl = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    sl = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], gh, sl, 0, 0, 0);
+                    sl = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], gl, sl, 0, 0, 0);
+                    sl = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], gh, sl, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) accg[i][j][r] = fmaf(sl[r], ung, accg[i][j][r]);
+                }
+            }
+        }
+    }
+    // D layout as in the fp32 kernel above: row (m) = 4 * (lane >> 4) + r, column (n) = lane & 15
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -177,6 +301,14 @@ __global__ __launch_bounds__(256) void t5_attention_kernel(const float* __restri
 extern "C" int mi_gemm_f32(const float* A, const float* W, const float* gate, const float* R, float* Cout, int M, int N, int K, int act, void* stream) {
     if (M <= 0 || N <= 0 || (gate && (N % 64) != 0) || (K % 16) != 0) { mi_set_error("mi_gemm_f32: need M>0, K%%16==0 (and N%%64==0 when gated) (got %d,%d,%d)", M, N, K); return MI_ERR_INVALID; }
     const dim3 grid((N + 63) / 64, (M + 63) / 64);
+    // K in multiples of 32 (every T5 / attention projection): 3-term fp16 products on the f16 matrix-core instruction, block-scaled per K slice;
+    // otherwise (and with MI_GEMM_EXACT_F32 set in the environment, for A/B measurements) the exact-fp32 MFMA kernel
+    static const bool exact = getenv("MI_GEMM_EXACT_F32") != nullptr;
+    if ((K % 32) == 0 && !exact) {
+        if (gate) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_f16x3_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, A, W, gate, R, Cout, M, N, K, act);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_f16x3_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, A, W, gate, R, Cout, M, N, K, act);
+        return mi_check_launch("gemm_f16x3_kernel");
+    }
     if (gate) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_f32_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, A, W, gate, R, Cout, M, N, K, act);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_f32_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, A, W, gate, R, Cout, M, N, K, act);
     return mi_check_launch("gemm_f32_kernel");

@@ -44,6 +44,43 @@ def test_t5_encoder_matches_transformers(backend, case):
     assert d.max() < 2e-4 and d.mean() < 2e-5, (d.max(), d.mean(), ref.abs().max())
 
 
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("case", [(100, 96, 64, False, 0, 1.0, 1.0), (70, 128, 96, True, 2, 1.0, 1.0), (64, 64, 256, False, 1, 2.0 ** 12, 2.0 ** -14),
+                                  (33, 64, 64, False, 3, 2.0 ** -18, 2.0 ** 9)])
+def test_gemm_f16x3_block_scaled(backend, case):
+    """mi_gemm_f32 on the f16 matrix-core instruction (3-term fp16 splits, per-K-slice block scaling) against fp64: C = act(A W^T) [* A G^T] + R,
+    ragged M / N, operands far from unit scale and rows / columns whose magnitudes differ by 2^20 inside one tile -- the error budget is a few
+    fp32 roundings of sum_k |a||w| (what an fp32 GEMM itself is allowed)"""
+    import ctypes as C
+    from minimagen_amd import _lib as L
+    dev = setup(backend)
+    lib = L.lib()
+    M, N, K, gated, act, sa, sw = case
+    g = torch.Generator().manual_seed(5)
+    A = torch.randn(M, K, generator=g) * sa
+    W = torch.randn(N, K, generator=g) * sw
+    A[::7] *= 2.0 ** -20                       # tiny rows next to large ones in the same 64 x 32 tile
+    W[1::5] *= 2.0 ** -12
+    A[3, 5] = 0.0
+    G = torch.randn(N, K, generator=g) if gated else None
+    Rm = torch.randn(M, N, generator=g) * sa * sw
+    pre = A.double() @ W.double().t()
+    ref = pre.clamp(min=0) if act == 1 else (torch.nn.functional.gelu(pre, approximate="tanh") if act == 2 else (torch.nn.functional.gelu(pre) if act == 3 else pre))
+    bound = A.abs().double() @ W.abs().double().t()
+    if gated:
+        gate = A.double() @ G.double().t()
+        bound = bound * gate.abs() + ref.abs() * (A.abs().double() @ G.abs().double().t())
+        ref = ref * gate
+    ref = ref + Rm.double()
+    Ad, Wd, Rd = A.to(dev), W.to(dev), Rm.to(dev)
+    Gd = G.to(dev) if gated else None
+    out = torch.full((M, N), float("nan"), device=dev)
+    L.check(lib.mi_gemm_f32(L.ptr(Ad), L.ptr(Wd), L.ptr(Gd), L.ptr(Rd), L.ptr(out), M, N, K, act, L.current_stream()), "mi_gemm_f32")
+    err = (out.cpu().double() - ref).abs()
+    tol = 4e-6 * bound + 1e-6 * ref.abs() + 1e-30
+    assert torch.isfinite(out).all() and bool((err <= tol).all()), (err / tol).max()
+
+
 @pytest.mark.gpu
 def test_t5_encoder_bench_shape():
     """the shape bench.py's t5_encode leg runs: T5Config() = t5-small, 6 layers, B=32, L=64, ragged masks"""
