@@ -5,9 +5,10 @@ ROOTDIR=$(pwd); OUT=$ROOTDIR/gpurun_out; mkdir -p $OUT
 timeout 1500 python -m pytest tests -m gpu -q --timeout 900 > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -4 $OUT/pytest_gpu.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke rc=$?"; tail -1 $OUT/smoke.log
 timeout 600 python bench.py --breakdown-out $OUT/bd_cascade.json > $OUT/bench_cascade.log 2>&1; echo "bench rc=$?"; tail -1 $OUT/bench_cascade.log
-timeout 300 python bench.py --precision half --no-cpu-baseline --no-secondary --breakdown-out $OUT/bd_half.json > $OUT/bench_half.log 2>&1; tail -1 $OUT/bench_half.log | cut -c1-200
-timeout 300 python bench.py --workload base64 --no-cpu-baseline --no-secondary --breakdown-out $OUT/bd_base.json > $OUT/bench_base.log 2>&1; tail -1 $OUT/bench_base.log | cut -c1-400
-CMD="python $ROOTDIR/bench.py --steps 1 --warmup 0 --timesteps 25 --no-cpu-baseline --no-secondary --no-breakdown"
+timeout 300 python bench.py --precision half --no-cpu-baseline --no-secondary --no-t5 --breakdown-out $OUT/bd_half.json > $OUT/bench_half.log 2>&1; tail -1 $OUT/bench_half.log | cut -c1-200
+timeout 300 python bench.py --workload base64 --no-cpu-baseline --no-secondary --no-t5 --breakdown-out $OUT/bd_base.json > $OUT/bench_base.log 2>&1; tail -1 $OUT/bench_base.log | cut -c1-400
+timeout 600 python tools/gpu_full_parity.py > $OUT/full_parity.txt 2>&1; tail -3 $OUT/full_parity.txt
+CMD="python $ROOTDIR/bench.py --steps 1 --warmup 0 --timesteps 25 --no-cpu-baseline --no-secondary --no-breakdown --no-t5 --no-pipeline"
 cd /tmp; export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_trace -o cascade -- $CMD > $OUT/rocprof_trace.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAVE_CYCLES -d $OUT/prof_sq -o cascade -- $CMD > $OUT/rocprof_sq.log 2>&1

@@ -28,7 +28,8 @@ emb, mask = R.synthetic_text(B, length=64, seed=7)
 for prec in ("fp32", "half"):
     t0 = time.time()
     out = im.sample(text_embeds=emb.to(dev), text_masks=mask.to(dev), cond_scale=3., _noise=R.make_randn(1234), _precision=prec).cpu()
-    print(f"HIP {prec}: {time.time() - t0:.1f}s", flush=True)
+    st16 = [u.engine().workspace(B, 2 * B, S, S, precision=prec).store16 for u, S in zip(im.unets, (64, 256))]
+    print(f"HIP {prec}: {time.time() - t0:.1f}s; bf16 activation storage per stage: {st16}", flush=True)
     if prec == "fp32":
         t0 = time.time()
         torch.set_num_threads(min(os.cpu_count(), 32))
