@@ -126,6 +126,11 @@ RP_CASES = [
     (2, 16, 8, 16, 32, 64, True, True, 'none', 6 | (2 << 12), 1.0, 1.0),     # 16 + 8 skip channels -> 16 (base U-Net up path, Unet.py:166-178)
     (2, 16, 0, 16, 32, 32, True, True, 'conv2', 7, 1.0, 1.0),                # ... and its second conv with the 1x1 residual over the 24
     (1, 16, 0, 16, 16, 64, True, False, 'conv2', 6, 1.0 / 256, 1.0),
+    # more 8x64-tile shapes of the 8-channel layers
+    (8, 8, 0, 8, 24, 200, True, True, 'id', 6, 1.0, 1.0),                    # B % 8 == 0, ragged tile edges in both directions
+    (1, 8, 0, 3, 24, 136, False, False, 'none', 6, 1.0, 1.0),                # the final conv: no GroupNorm, 3 output channels
+    (2, 8, 0, 8, 16, 64, True, True, 'none', 6 | (1 << 12), 1.0, 1.0),       # one-tile strips
+    (1, 8, 0, 8, 72, 64, True, False, 'id', 6 | (5 << 12), 1.0 / 64, 30.0),  # odd strip length, ragged last strip, scaled operands
 ]
 
 
