@@ -213,6 +213,7 @@ def cpu_baseline_reference(ncores):
     im.unets[0].load_state_dict(torch.load(os.path.join(ROOT, "tests", "golden", "unet0_sd.pt"), weights_only=False))
     emb, mask = synthetic_text(4)
     with torch.no_grad():
+        im.sample(text_embeds=emb, text_masks=mask, cond_scale=3.)          # warm-up (thread pools, oneDNN primitives)
         t0 = time.time()
         im.sample(text_embeds=emb, text_masks=mask, cond_scale=3.)
         dt = time.time() - t0
