@@ -214,10 +214,12 @@ typedef struct mi_attn_fold_params {
          mode 0: fold c_rows and write the fragments (one step; Unet.forward)
          mode 1: fold c_rows of B2 = steps * rows virtual batch rows into blk[].table (no fragments written)
          mode 2: scatter the rows of step *t_state from blk[].table into the fragments of the B2 real batch rows, and copy that
-                 step's ss_n scale/shift values per row from ss_all to ss (the ResnetBlocks' time_mlp outputs) */
+                 step's ss_n scale/shift values per row from ss_all to ss (the ResnetBlocks' time_mlp outputs)
+         mode 3: as mode 2 with a table of ONE row per timestep shared by all batch rows (the time tokens depend on the timestep only; built by a
+                 mode-1 call over T pseudo-rows); the scale/shift table ss_all stays per (timestep, batch row) */
     int mode;
     const int* t_state;
-    int t_off;              /* mode 2: the step is *t_state - t_off */
+    int t_off;              /* modes 2 / 3: the step is *t_state - t_off */
     const float* ss_all; float* ss; int ss_n;
 } mi_attn_fold_params;
 int mi_attn_fold_rows(const mi_attn_fold_params* p, void* stream);

@@ -136,12 +136,14 @@ __global__ __launch_bounds__(256) void cond_step_kernel(const mi_cond_step_param
         float q = 0.0f;
         for (int k = 0; k < p.cd; ++k) { const float d = row[k] - m; q = fmaf(d, d, q); }
         const float rs = 1.0f / sqrtf(q / (float)p.cd + 1e-5f);
-        for (int k = 0; k < p.cd; ++k)
-            p.c_time[((size_t)bb * ntot + r) * p.cd + k] = (row[k] - m) * rs * p.norm_w[k] + p.norm_b[k];
+        if (p.c_time)
+            for (int k = 0; k < p.cd; ++k)
+                p.c_time[((size_t)bb * ntot + r) * p.cd + k] = (row[k] - m) * rs * p.norm_w[k] + p.norm_b[k];
     }
     __syncthreads();
-    for (int r = tid; r < p.time_mlps.out; r += NT)
-        p.ss[(size_t)bb * p.time_mlps.out + r] = dot_row(p.time_mlps.w + (size_t)r * p.tcd, hid, p.tcd) + p.time_mlps.b[r];
+    if (p.ss)
+        for (int r = tid; r < p.time_mlps.out; r += NT)
+            p.ss[(size_t)bb * p.time_mlps.out + r] = dot_row(p.time_mlps.w + (size_t)r * p.tcd, hid, p.tcd) + p.time_mlps.b[r];
 }
 
 // context rows -> MFMA A-operand fragments of the folded cross-attention (see minimagen_hip.h).  Modes 1 / 2 split the work into
@@ -159,7 +161,9 @@ __global__ __launch_bounds__(256) void attn_fold_rows_kernel(const mi_attn_fold_
     float* gv = p.blk[blk].gv + (size_t)bb * p.heads * p.JT * 64 * FR;
     const int first = p.write_null ? -1 : 0;
     const int total = (p.nrows - first) * p.heads * C;
-    const size_t trow = p.mode == 2 ? (size_t)(*p.t_state - p.t_off) * gridDim.x + bb : (size_t)bb;      // row of the compact table
+    // row of the compact table: mode 2 -- one row per (timestep, batch row); mode 3 -- one row per timestep, shared by every batch row (the
+    // time tokens depend on the timestep only); mode 1 -- the row being built
+    const size_t trow = p.mode == 2 ? (size_t)(*p.t_state - p.t_off) * gridDim.x + bb : (p.mode == 3 ? (size_t)(*p.t_state - p.t_off) : (size_t)bb);
     for (int idx = threadIdx.x; idx < total; idx += 256) {
         const int a = idx % C, h = (idx / C) % p.heads, r = idx / (C * p.heads) + first;
         float g, v;
@@ -171,7 +175,7 @@ __global__ __launch_bounds__(256) void attn_fold_rows_kernel(const mi_attn_fold_
         } else {
             j = p.row0 + r;
             float* tab = p.mode ? p.blk[blk].table + (((trow * p.nrows + r) * p.heads + h) * C + a) * 2 : nullptr;
-            if (p.mode == 2) {
+            if (p.mode >= 2) {
                 g = tab[0];
                 v = tab[1];
             } else {
@@ -228,10 +232,10 @@ extern "C" int mi_cond_step_fwd(const mi_cond_step_params* p, void* stream) {
 }
 
 extern "C" int mi_attn_fold_rows(const mi_attn_fold_params* p, void* stream) {
-    const bool stage = p->mode == 2;
+    const bool stage = p->mode == 2 || p->mode == 3;
     if (p->n_blocks < (stage ? 0 : 1) || p->n_blocks > MI_ATTN_MAX_BLOCKS || (p->n_blocks && (p->C % 4) != 0) || p->B2 <= 0) { mi_set_error("mi_attn_fold_rows: bad n_blocks / C"); return MI_ERR_INVALID; }
     if (p->n_blocks && p->mode != 1 && p->row0 + p->nrows > p->JT * 16) { mi_set_error("mi_attn_fold_rows: rows beyond the padded context"); return MI_ERR_INVALID; }
-    if (p->mode < 0 || p->mode > 2 || (p->mode && p->write_null) || (stage && (!p->t_state || (p->ss_n > 0 && (!p->ss_all || !p->ss))))) { mi_set_error("mi_attn_fold_rows: bad mode / table arguments"); return MI_ERR_INVALID; }
+    if (p->mode < 0 || p->mode > 3 || (p->mode && p->write_null) || (stage && (!p->t_state || (p->ss_n > 0 && (!p->ss_all || !p->ss))))) { mi_set_error("mi_attn_fold_rows: bad mode / table arguments"); return MI_ERR_INVALID; }
     for (int k = 0; k < p->n_blocks; ++k) if (p->mode && !p->blk[k].table) { mi_set_error("mi_attn_fold_rows: mode %d needs blk[].table", p->mode); return MI_ERR_INVALID; }
     hipLaunchKernelGGL(attn_fold_rows_kernel, dim3(p->B2, p->n_blocks + ((stage && p->ss_n > 0) ? 1 : 0)), dim3(256), 0, (hipStream_t)stream, *p);
     return mi_check_launch("attn_fold_rows_kernel");

@@ -770,32 +770,41 @@ class UnetEngine:
         if tb is None:
             tb = Workspace()
             n = T * B2
+            # per (timestep, batch row): the scale/shift rows (they see the sample's pooled text through t).  Per timestep only: the time
+            # tokens of the cross-attention context and their folded (g, v) rows -- identical for every sample, so one row per t.
             tb.times = torch.arange(T, dtype=torch.int64, device=dev).repeat_interleave(B2).contiguous()
             tb.lowres_times = torch.zeros(n, dtype=torch.int64, device=dev) if u.lowres_cond else None
             tb.text_hiddens = torch.empty(n, u.time_cond_dim, dtype=torch.float32, device=dev)
             tb.ss = torch.empty(n, max(pk.R, 1), dtype=torch.float32, device=dev)
-            tb.c_time = torch.empty(n, ws.ntot, u.cond_dim, dtype=torch.float32, device=dev)
             cp = L.MiCondStepParams.from_buffer_copy(ws.cond_params)
             cp.B2 = cp.B = n
             cp.time, cp.lowres_time = L.ptr(tb.times), L.ptr(tb.lowres_times)
-            cp.text_hiddens, cp.ss, cp.c_time, cp.t_out = (L.ptr(tb.text_hiddens) if ws.has_text else 0), L.ptr(tb.ss), L.ptr(tb.c_time), 0
+            cp.text_hiddens, cp.ss, cp.c_time, cp.t_out = (L.ptr(tb.text_hiddens) if ws.has_text else 0), L.ptr(tb.ss), 0, 0
             tb.cond = cp
+            tb.times_t = torch.arange(T, dtype=torch.int64, device=dev)
+            tb.lowres_t = torch.zeros(T, dtype=torch.int64, device=dev) if u.lowres_cond else None
+            tb.c_time_t = torch.empty(T, ws.ntot, u.cond_dim, dtype=torch.float32, device=dev)
+            ct = L.MiCondStepParams.from_buffer_copy(ws.cond_params)
+            ct.B2 = ct.B = T
+            ct.time, ct.lowres_time = L.ptr(tb.times_t), L.ptr(tb.lowres_t)
+            ct.text_hiddens, ct.ss, ct.c_time, ct.t_out = 0, 0, L.ptr(tb.c_time_t), 0
+            tb.cond_t = ct
             tb.fold, tb.tables = [], []
             stage_blocks = []
-            for fn, fp, name in self._fold_params(ws, pk, tb.c_time, ws.ntot * u.cond_dim, 1, ws.ntot, 0):
+            for fn, fp, name in self._fold_params(ws, pk, tb.c_time_t, ws.ntot * u.cond_dim, 1, ws.ntot, 0):
                 f1 = L.MiAttnFoldParams.from_buffer_copy(fp)
-                f1.B2, f1.mode = n, 1
+                f1.B2, f1.mode = T, 1
                 for k in range(fp.n_blocks):
-                    t = torch.empty(n, ws.ntot, fp.heads, fp.C, 2, dtype=torch.float32, device=dev)
+                    t = torch.empty(T, ws.ntot, fp.heads, fp.C, 2, dtype=torch.float32, device=dev)
                     tb.tables.append(t)
                     f1.blk[k].table = L.ptr(t)
                 tb.fold.append(f1)
-                f2 = L.MiAttnFoldParams.from_buffer_copy(f1)            # per-step scatter of the same blocks
-                f2.B2, f2.mode, f2.t_state = B2, 2, L.ptr(t_state)
+                f2 = L.MiAttnFoldParams.from_buffer_copy(f1)            # per-step scatter of the same blocks into the B2 real rows
+                f2.B2, f2.mode, f2.t_state = B2, 3, L.ptr(t_state)
                 stage_blocks.append(f2)
             if not stage_blocks:                                       # no cross-attention anywhere: the scale/shift rows only
                 f2 = L.MiAttnFoldParams()
-                f2.B2, f2.mode, f2.t_state, f2.n_blocks = B2, 2, L.ptr(t_state), 0
+                f2.B2, f2.mode, f2.t_state, f2.n_blocks = B2, 3, L.ptr(t_state), 0
                 stage_blocks.append(f2)
             stage_blocks[0].ss_all, stage_blocks[0].ss, stage_blocks[0].ss_n = L.ptr(tb.ss), L.ptr(ws.ss), ws.ss.shape[1]
             tb.stage = [(lib.mi_attn_fold_rows, f2, "stage_step") for f2 in stage_blocks]
@@ -806,7 +815,9 @@ class UnetEngine:
             tb.lowres_times.view(T, B2)[:, :ws.B].copy_(ws.lowres_times.unsqueeze(0).expand(T, -1))
             if B2 != ws.B:
                 tb.lowres_times.view(T, B2)[:, ws.B:].copy_(ws.lowres_times.unsqueeze(0).expand(T, -1))
-        L.check(lib.mi_cond_step_fwd(C.byref(tb.cond), st), "mi_cond_step_fwd (all steps)")
+            tb.lowres_t.copy_(ws.lowres_times[:1].expand(T))           # the augmentation level is one scalar per sample() (Imagen.py:479-485)
+        L.check(lib.mi_cond_step_fwd(C.byref(tb.cond), st), "mi_cond_step_fwd (all steps: scale/shift rows)")
+        L.check(lib.mi_cond_step_fwd(C.byref(tb.cond_t), st), "mi_cond_step_fwd (all steps: time tokens)")
         for f1 in tb.fold:
             L.check(lib.mi_attn_fold_rows(C.byref(f1), st), "mi_attn_fold_rows (all steps)")
         ws.prog_stage = tb.stage
