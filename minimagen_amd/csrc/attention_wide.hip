@@ -4,6 +4,7 @@
 // The folded kernels of attention.hip pay K = C per score, which only wins while C <= 32; from 64 channels up the reference's own
 // factorisation (dim_head 64) is the cheaper one.  Everything here is exact fp32 on v_mfma_f32_16x16x4_f32 (no operand splits).
 #include "common.hip.h"
+#include <cstdlib>
 
 namespace {
 
@@ -99,6 +100,194 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const mi_flash_attn_par
     }
 }
 
+// ---- the same attention on the f16 matrix-core instruction (v_mfma_f32_16x16x32_f16, 16x the fp32 MFMA rate) at fp32 accuracy: Q, K, V and P are
+// split x = hi + lo (two fp16) and multiplied as lo*hi + hi*lo + hi*hi with fp32 accumulation (2^-22 per product).  Range safety as in
+// gemm_f16x3_kernel (t5.hip): per 64-row chunk K and V are scaled by the power of two that brings their largest magnitude into [128, 256)
+// before the split (exact), Q once per wave; the scores are unscaled in fp32 before the softmax, a chunk's P.V goes through a zeroed
+// accumulator and is added to the running output with the inverse scale.  K = 32 per instruction: QK^T contracts 32 of the 64 head dims,
+// P.V a PAIR of score tiles -- the lane that holds S[j = 16t + 4lg + r][query lq] (t = 2hf, 2hf + 1) in the C/D layout supplies exactly
+// those eight P values as its B operand, and V^T is staged in LDS with the context rows of a 32-row half permuted to that order
+// (position 8lg + 4t' + r), so that a lane's A operand is one aligned 16-byte read.
+typedef _Float16 fw_f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ int fw_scale_exp(float m) {           // k with m * 2^k in [128, 256); 0 for zero / non-finite input
+    const int be = (int)((__float_as_uint(m) & 0x7fffffffu) >> 23);
+    return (be == 0 || be == 255) ? 0 : 134 - be;
+}
+__device__ __forceinline__ void fw_split8(const float (&x)[8], uint4& hi, uint4& lo) {
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const mi_f16x2 h2 = {(_Float16)x[2 * e], (_Float16)x[2 * e + 1]};
+        h[e] = __builtin_bit_cast(unsigned, h2);
+        l[e] = mi_split_lo2(h[e], x[2 * e], x[2 * e + 1]);
+    }
+    hi = make_uint4(h[0], h[1], h[2], h[3]);
+    lo = make_uint4(l[0], l[1], l[2], l[3]);
+}
+__global__ __launch_bounds__(256) void flash_attn_f16x3_kernel(const mi_flash_attn_params p) {
+    constexpr int D = 64, CP = 9;                        // LDS rows of 8 16-byte chunks (64 halves) + 1 pad chunk: conflict-free ds_read_b128
+    __shared__ __attribute__((aligned(16))) uint4 KsH[64 * CP], KsL[64 * CP];      // [context row j][head dim d]
+    __shared__ __attribute__((aligned(16))) uint4 VtH[64 * CP], VtL[64 * CP];      // [head dim d][permuted context row]
+    __shared__ float smax[2][4];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lq = lane & 15, lg = lane >> 4;
+    const int h = blockIdx.y, b = blockIdx.z, kvh = p.kv_heads == 1 ? 0 : h;
+    const int inner = p.heads * D;
+    const int tok = (blockIdx.x * 4 + wave) * 16 + lq;
+    const int tokc = tok < p.HW ? tok : p.HW - 1;
+    const int nnull = p.null_k ? 1 : 0, J = nnull + p.n0 + p.n1;
+    // Q as the B operand: this lane supplies dims 32hf + 8lg + e of query lq, pre-scaled by q_scale (scores in log2 units) and by 2^eq
+    fw_f16x8 qh[2], ql[2];
+    int eq;
+    {
+        const float* qr = p.q + ((size_t)b * p.HW + tokc) * inner + h * D;
+        float qv[2][8];
+        float mq = 0.0f;
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const float4 a = *reinterpret_cast<const float4*>(qr + 32 * hf + 8 * lg), c = *reinterpret_cast<const float4*>(qr + 32 * hf + 8 * lg + 4);
+            const float t[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { qv[hf][e] = t[e] * p.q_scale; mq = fmaxf(mq, fabsf(qv[hf][e])); }
+        }
+        eq = fw_scale_exp(mi_wave_max(mq));
+        const float sq = ldexpf(1.0f, eq);
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            float t[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t[e] = qv[hf][e] * sq;
+            uint4 hi, lo;
+            fw_split8(t, hi, lo);
+            qh[hf] = __builtin_bit_cast(fw_f16x8, hi);
+            ql[hf] = __builtin_bit_cast(fw_f16x8, lo);
+        }
+    }
+    float m = -INFINITY, l = 0.0f;
+    f32x4 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // staging role: work-item -> (context row, 16-dim quarter); the row's position in the permuted order of V^T
+    const int srow = tid >> 2, sd0 = (tid & 3) * 16;
+    const int spos = (srow & 32) | (((srow >> 2) & 3) << 3) | (((srow >> 4) & 1) << 2) | (srow & 3);
+
+    for (int j0 = 0; j0 < J; j0 += 64) {
+        const int jj = j0 + srow;
+        const float* ksrc = nullptr;
+        const float* vsrc = nullptr;
+        if (jj < J) {
+            if (jj < nnull) { ksrc = p.null_k; vsrc = p.null_v; }
+            else if (jj - nnull < p.n0) { const size_t o_ = (size_t)b * p.bs0 + (size_t)(jj - nnull) * p.ld0 + kvh * D; ksrc = p.k0 + o_; vsrc = p.v0 + o_; }
+            else { const size_t o_ = (size_t)b * p.bs1 + (size_t)(jj - nnull - p.n0) * p.ld1 + kvh * D; ksrc = p.k1 + o_; vsrc = p.v1 + o_; }
+        }
+        float kf[16], vf[16];
+        float mk = 0.0f, mv = 0.0f;
+#pragma unroll
+        for (int e = 0; e < 16; e += 4) {
+            float4 k4 = make_float4(0.f, 0.f, 0.f, 0.f), v4 = k4;
+            if (ksrc) { k4 = *reinterpret_cast<const float4*>(ksrc + sd0 + e); v4 = *reinterpret_cast<const float4*>(vsrc + sd0 + e); }
+            kf[e] = k4.x; kf[e + 1] = k4.y; kf[e + 2] = k4.z; kf[e + 3] = k4.w;
+            vf[e] = v4.x; vf[e + 1] = v4.y; vf[e + 2] = v4.z; vf[e + 3] = v4.w;
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { mk = fmaxf(mk, fabsf(kf[e])); mv = fmaxf(mv, fabsf(vf[e])); }
+        mk = mi_wave_max(mk); mv = mi_wave_max(mv);
+        __syncthreads();                          // the previous chunk's fragments and maxima are no longer read
+        if (lane == 0) { smax[0][wave] = mk; smax[1][wave] = mv; }
+        __syncthreads();
+        const int ek = fw_scale_exp(fmaxf(fmaxf(smax[0][0], smax[0][1]), fmaxf(smax[0][2], smax[0][3])));
+        const int ev = fw_scale_exp(fmaxf(fmaxf(smax[1][0], smax[1][1]), fmaxf(smax[1][2], smax[1][3])));
+        {
+            const float sk = ldexpf(1.0f, ek), sv = ldexpf(1.0f, ev);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                float t[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) t[e] = kf[8 * c + e] * sk;
+                uint4 hi, lo;
+                fw_split8(t, hi, lo);
+                KsH[srow * CP + (sd0 >> 3) + c] = hi;
+                KsL[srow * CP + (sd0 >> 3) + c] = lo;
+            }
+            _Float16* vth = reinterpret_cast<_Float16*>(VtH);
+            _Float16* vtl = reinterpret_cast<_Float16*>(VtL);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float x = vf[e] * sv;
+                const _Float16 hi = (_Float16)x, lo = (_Float16)(x - (float)hi);
+                vth[(sd0 + e) * (8 * CP) + spos] = hi;
+                vtl[(sd0 + e) * (8 * CP) + spos] = lo;
+            }
+        }
+        __syncthreads();
+        const float us = ldexpf(1.0f, -(ek + eq)), uv = ldexpf(1.0f, -ev);
+        f32x4 s[4];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+            f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const fw_f16x8 kh = __builtin_bit_cast(fw_f16x8, KsH[(16 * jt + lq) * CP + 4 * hf + lg]), kl = __builtin_bit_cast(fw_f16x8, KsL[(16 * jt + lq) * CP + 4 * hf + lg]);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl, qh[hf], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, ql[hf], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, qh[hf], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                acc[r] *= us;
+                if (j0 + 16 * jt + 4 * lg + r >= J) acc[r] = -INFINITY;
+                mx = fmaxf(mx, acc[r]);
+            }
+            s[jt] = acc;
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float mn = fmaxf(m, mx);                      // finite: every chunk holds at least one live row
+        const float alpha = __builtin_amdgcn_exp2f(m - mn);  // m = -inf on the first chunk -> 0
+        m = mn;
+        l *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[dt][r] *= alpha;
+        fw_f16x8 ph[2], pl[2];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            float pe[8];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { pe[4 * t + r] = __builtin_amdgcn_exp2f(s[2 * hf + t][r] - mn); l += pe[4 * t + r]; }
+            uint4 hi, lo;
+            fw_split8(pe, hi, lo);
+            ph[hf] = __builtin_bit_cast(fw_f16x8, hi);
+            pl[hf] = __builtin_bit_cast(fw_f16x8, lo);
+        }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            f32x4 sl = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const fw_f16x8 vh = __builtin_bit_cast(fw_f16x8, VtH[(16 * dt + lq) * CP + 4 * hf + lg]), vl = __builtin_bit_cast(fw_f16x8, VtL[(16 * dt + lq) * CP + 4 * hf + lg]);
+                sl = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl, ph[hf], sl, 0, 0, 0);
+                sl = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, pl[hf], sl, 0, 0, 0);
+                sl = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, ph[hf], sl, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[dt][r] = fmaf(sl[r], uv, o[dt][r]);
+        }
+    }
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+    const float linv = 1.0f / l;
+    if (tok < p.HW) {
+        float* orow = p.out + ((size_t)b * p.HW + tok) * inner + h * D;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+            *reinterpret_cast<float4*>(orow + 16 * dt + 4 * lg) = make_float4(o[dt][0] * linv, o[dt][1] * linv, o[dt][2] * linv, o[dt][3] * linv);
+    }
+}
+
 // ---- tokens [B][HW][C] -> NCHW, with an optional LayerNorm over C (gamma, beta) in front, a residual NCHW tensor added and the next
 // GroupNorm's partial statistics (64-token tiles) emitted: to_out.1 + residual of both attentions, and the tail of ChanFeedForward
 __global__ __launch_bounds__(256) void tokens_to_nchw_kernel(const mi_tokens_to_nchw_params p) {
@@ -174,7 +363,11 @@ extern "C" int mi_flash_attn_fwd(const mi_flash_attn_params* p, void* stream) {
     if (p->B <= 0 || p->HW <= 0 || p->heads <= 0 || (p->kv_heads != 1 && p->kv_heads != p->heads)) { mi_set_error("mi_flash_attn_fwd: bad shape"); return MI_ERR_INVALID; }
     if (p->n0 + p->n1 + (p->null_k ? 1 : 0) <= 0 || (p->null_k && !p->null_v)) { mi_set_error("mi_flash_attn_fwd: empty context"); return MI_ERR_INVALID; }
     if ((p->ld0 & 3) || (p->n1 && (p->ld1 & 3))) { mi_set_error("mi_flash_attn_fwd: row strides must be multiples of 4 floats"); return MI_ERR_INVALID; }
-    hipLaunchKernelGGL(flash_attn_kernel, dim3((p->HW + 63) / 64, p->heads, p->B), dim3(256), 0, (hipStream_t)stream, *p);
+    // 3-term fp16 products on the f16 matrix-core instruction (block-scaled per chunk); MI_FLASH_EXACT_F32 in the environment selects the
+    // exact-fp32 MFMA kernel (A/B measurements)
+    static const bool exact = getenv("MI_FLASH_EXACT_F32") != nullptr;
+    if (exact) hipLaunchKernelGGL(flash_attn_kernel, dim3((p->HW + 63) / 64, p->heads, p->B), dim3(256), 0, (hipStream_t)stream, *p);
+    else hipLaunchKernelGGL(flash_attn_f16x3_kernel, dim3((p->HW + 63) / 64, p->heads, p->B), dim3(256), 0, (hipStream_t)stream, *p);
     return mi_check_launch("flash_attn_kernel");
 }
 

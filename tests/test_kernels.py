@@ -673,6 +673,61 @@ def test_cross_attention_bf16_io(backend, case):
     check_stats(ost.cpu(), ref, rtol=4e-3)
 
 
+FLASH_CASES = [
+    # B, HW, heads, kv_heads, n0 (first segment), n1 (second segment), null row, q scale, k scale, v scale
+    (2, 100, 2, 2, 4, 40, True, 1.0, 1.0, 1.0),            # CrossAttention: null + time tokens + text rows, per-head k / v, ragged HW and J
+    (1, 64, 3, 1, 64, 0, True, 1.0, 1.0, 1.0),             # multi-query self-attention: one shared k / v head, context = the tokens themselves
+    (1, 80, 2, 2, 130, 0, False, 30.0, 1.0 / 64, 300.0),   # three chunks, no null row, operands far from unit scale
+    (1, 16, 1, 1, 3, 0, True, 1.0 / 256, 256.0, 1.0 / 512),
+]
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("case", FLASH_CASES)
+def test_flash_attention_unfolded(backend, case):
+    """mi_flash_attn_fwd (dim_head 64, online softmax over 64-row chunks, null k / v + two context segments, per-head or multi-query k / v)
+    against softmax(q k^T * scale) v in fp64"""
+    dev = setup(backend)
+    lib = L.lib()
+    B, HW, heads, kvh, n0, n1, has_null, qs, ks, vs = case
+    g = torch.Generator().manual_seed(11)
+    rn = lambda *s_: torch.randn(*s_, generator=g)
+    inner, kin = heads * 64, kvh * 64
+    q = rn(B, HW, inner) * qs
+    kv0 = rn(B, n0, 2 * kin); kv0[..., :kin] *= ks; kv0[..., kin:] *= vs
+    kv1 = rn(B, max(n1, 1), 2 * kin); kv1[..., :kin] *= ks; kv1[..., kin:] *= vs
+    null = rn(2, 64); null[0] *= ks; null[1] *= vs
+    scale = 64 ** -0.5 / (qs * ks)                          # keeps the logits O(1) whatever the operand scales: the test is about range, not about saturation
+    ref = torch.zeros(B, HW, inner, dtype=torch.float64)
+    for b in range(B):
+        for h in range(heads):
+            kh = h if kvh > 1 else 0
+            ksegs, vsegs = [], []
+            if has_null:
+                ksegs.append(null[0:1]); vsegs.append(null[1:2])
+            ksegs.append(kv0[b, :, kh * 64:(kh + 1) * 64]); vsegs.append(kv0[b, :, kin + kh * 64:kin + (kh + 1) * 64])
+            if n1:
+                ksegs.append(kv1[b, :, kh * 64:(kh + 1) * 64]); vsegs.append(kv1[b, :, kin + kh * 64:kin + (kh + 1) * 64])
+            K_, V_ = torch.cat(ksegs).double(), torch.cat(vsegs).double()
+            sim = q[b, :, h * 64:(h + 1) * 64].double() @ K_.t() * scale
+            ref[b, :, h * 64:(h + 1) * 64] = torch.softmax(sim, -1) @ V_
+    qd, kv0d, kv1d, nulld = q.to(dev), kv0.to(dev), kv1.to(dev), null.to(dev)
+    out = torch.full((B, HW, inner), float('nan'), device=dev)
+    p = L.MiFlashAttnParams()
+    p.B, p.HW, p.heads, p.kv_heads, p.q, p.q_scale = B, HW, heads, kvh, L.ptr(qd), scale * P.LOG2E
+    if has_null:
+        p.null_k, p.null_v = L.ptr(nulld), L.ptr(nulld) + 4 * 64
+    p.k0, p.v0, p.n0, p.ld0, p.bs0 = L.ptr(kv0d), L.ptr(kv0d) + 4 * kin, n0, 2 * kin, n0 * 2 * kin
+    if n1:
+        p.k1, p.v1, p.n1, p.ld1, p.bs1 = L.ptr(kv1d), L.ptr(kv1d) + 4 * kin, n1, 2 * kin, n1 * 2 * kin
+    p.out = L.ptr(out)
+    L.check(lib.mi_flash_attn_fwd(C.byref(p), L.current_stream()), "flash")
+    err = (out.cpu().double() - ref).abs().max().item()
+    gate = 2e-5 * max(1.0, ref.abs().max().item())
+    print(f"flash attention {case}: max|d| = {err:.2e} (gate {gate:.2e})")
+    assert torch.isfinite(out).all() and err < gate
+
+
 @pytest.mark.parametrize("backend", BACKENDS)
 def test_quantile_bit_exact(backend):
     """K12: exact order statistics + torch's fp32 rank arithmetic + fused lerp == torch.quantile, incl. ties and n = 3*256^2."""
