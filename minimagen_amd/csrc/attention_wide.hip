@@ -124,15 +124,19 @@ __device__ __forceinline__ void fw_split8(const float (&x)[8], uint4& hi, uint4&
     hi = make_uint4(h[0], h[1], h[2], h[3]);
     lo = make_uint4(l[0], l[1], l[2], l[3]);
 }
-__global__ __launch_bounds__(256) void flash_attn_f16x3_kernel(const mi_flash_attn_params p) {
+// NW waves per workgroup: waves 0-3 are the four 16-query groups of one head, every further group of four waves another head of the SAME 64
+// queries -- for the multi-query Attention (one shared k / v head) a staged, split and transposed K / V chunk then serves NW / 4 heads.
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void flash_attn_f16x3_kernel(const mi_flash_attn_params p) {
     constexpr int D = 64, CP = 9;                        // LDS rows of 8 16-byte chunks (64 halves) + 1 pad chunk: conflict-free ds_read_b128
+    constexpr int NH = NW / 4, EPT = 64 / NW, PPR = NW;  // heads per workgroup; head dims per work-item and pieces per row when staging
     __shared__ __attribute__((aligned(16))) uint4 KsH[64 * CP], KsL[64 * CP];      // [context row j][head dim d]
     __shared__ __attribute__((aligned(16))) uint4 VtH[64 * CP], VtL[64 * CP];      // [head dim d][permuted context row]
-    __shared__ float smax[2][4];
+    __shared__ float smax[2][NW];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lq = lane & 15, lg = lane >> 4;
-    const int h = blockIdx.y, b = blockIdx.z, kvh = p.kv_heads == 1 ? 0 : h;
+    const int h = blockIdx.y * NH + (wave >> 2), b = blockIdx.z, kvh = p.kv_heads == 1 ? 0 : h;
     const int inner = p.heads * D;
-    const int tok = (blockIdx.x * 4 + wave) * 16 + lq;
+    const int tok = (blockIdx.x * 4 + (wave & 3)) * 16 + lq;
     const int tokc = tok < p.HW ? tok : p.HW - 1;
     const int nnull = p.null_k ? 1 : 0, J = nnull + p.n0 + p.n1;
     // Q as the B operand: this lane supplies dims 32hf + 8lg + e of query lq, pre-scaled by q_scale (scores in log2 units) and by 2^eq
@@ -166,8 +170,8 @@ __global__ __launch_bounds__(256) void flash_attn_f16x3_kernel(const mi_flash_at
     f32x4 o[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // staging role: work-item -> (context row, 16-dim quarter); the row's position in the permuted order of V^T
-    const int srow = tid >> 2, sd0 = (tid & 3) * 16;
+    // staging role: work-item -> (context row, EPT head dims); the row's position in the permuted order of V^T
+    const int srow = tid / PPR, sd0 = (tid % PPR) * EPT;
     const int spos = (srow & 32) | (((srow >> 2) & 3) << 3) | (((srow >> 4) & 1) << 2) | (srow & 3);
 
     for (int j0 = 0; j0 < J; j0 += 64) {
@@ -179,39 +183,46 @@ __global__ __launch_bounds__(256) void flash_attn_f16x3_kernel(const mi_flash_at
             else if (jj - nnull < p.n0) { const size_t o_ = (size_t)b * p.bs0 + (size_t)(jj - nnull) * p.ld0 + kvh * D; ksrc = p.k0 + o_; vsrc = p.v0 + o_; }
             else { const size_t o_ = (size_t)b * p.bs1 + (size_t)(jj - nnull - p.n0) * p.ld1 + kvh * D; ksrc = p.k1 + o_; vsrc = p.v1 + o_; }
         }
-        float kf[16], vf[16];
+        float kf[EPT], vf[EPT];
         float mk = 0.0f, mv = 0.0f;
 #pragma unroll
-        for (int e = 0; e < 16; e += 4) {
+        for (int e = 0; e < EPT; e += 4) {
             float4 k4 = make_float4(0.f, 0.f, 0.f, 0.f), v4 = k4;
             if (ksrc) { k4 = *reinterpret_cast<const float4*>(ksrc + sd0 + e); v4 = *reinterpret_cast<const float4*>(vsrc + sd0 + e); }
             kf[e] = k4.x; kf[e + 1] = k4.y; kf[e + 2] = k4.z; kf[e + 3] = k4.w;
             vf[e] = v4.x; vf[e + 1] = v4.y; vf[e + 2] = v4.z; vf[e + 3] = v4.w;
         }
 #pragma unroll
-        for (int e = 0; e < 16; ++e) { mk = fmaxf(mk, fabsf(kf[e])); mv = fmaxf(mv, fabsf(vf[e])); }
+        for (int e = 0; e < EPT; ++e) { mk = fmaxf(mk, fabsf(kf[e])); mv = fmaxf(mv, fabsf(vf[e])); }
         mk = mi_wave_max(mk); mv = mi_wave_max(mv);
         __syncthreads();                          // the previous chunk's fragments and maxima are no longer read
         if (lane == 0) { smax[0][wave] = mk; smax[1][wave] = mv; }
         __syncthreads();
-        const int ek = fw_scale_exp(fmaxf(fmaxf(smax[0][0], smax[0][1]), fmaxf(smax[0][2], smax[0][3])));
-        const int ev = fw_scale_exp(fmaxf(fmaxf(smax[1][0], smax[1][1]), fmaxf(smax[1][2], smax[1][3])));
+        float mka = 0.0f, mva = 0.0f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { mka = fmaxf(mka, smax[0][w]); mva = fmaxf(mva, smax[1][w]); }
+        const int ek = fw_scale_exp(mka), ev = fw_scale_exp(mva);
         {
             const float sk = ldexpf(1.0f, ek), sv = ldexpf(1.0f, ev);
+            _Float16* ksh = reinterpret_cast<_Float16*>(KsH);
+            _Float16* ksl = reinterpret_cast<_Float16*>(KsL);
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                float t[8];
+            for (int e = 0; e < EPT; e += 4) {        // K row-major: 4 halves (8 bytes) of hi and of lo per step
+                unsigned hb[2], lb[2];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) t[e] = kf[8 * c + e] * sk;
-                uint4 hi, lo;
-                fw_split8(t, hi, lo);
-                KsH[srow * CP + (sd0 >> 3) + c] = hi;
-                KsL[srow * CP + (sd0 >> 3) + c] = lo;
+                for (int q = 0; q < 2; ++q) {
+                    const float x0 = kf[e + 2 * q] * sk, x1 = kf[e + 2 * q + 1] * sk;
+                    const mi_f16x2 h2 = {(_Float16)x0, (_Float16)x1};
+                    hb[q] = __builtin_bit_cast(unsigned, h2);
+                    lb[q] = mi_split_lo2(hb[q], x0, x1);
+                }
+                *reinterpret_cast<uint2*>(ksh + srow * (8 * CP) + sd0 + e) = make_uint2(hb[0], hb[1]);
+                *reinterpret_cast<uint2*>(ksl + srow * (8 * CP) + sd0 + e) = make_uint2(lb[0], lb[1]);
             }
             _Float16* vth = reinterpret_cast<_Float16*>(VtH);
             _Float16* vtl = reinterpret_cast<_Float16*>(VtL);
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
+            for (int e = 0; e < EPT; ++e) {
                 const float x = vf[e] * sv;
                 const _Float16 hi = (_Float16)x, lo = (_Float16)(x - (float)hi);
                 vth[(sd0 + e) * (8 * CP) + spos] = hi;
@@ -366,8 +377,11 @@ extern "C" int mi_flash_attn_fwd(const mi_flash_attn_params* p, void* stream) {
     // 3-term fp16 products on the f16 matrix-core instruction (block-scaled per chunk); MI_FLASH_EXACT_F32 in the environment selects the
     // exact-fp32 MFMA kernel (A/B measurements)
     static const bool exact = getenv("MI_FLASH_EXACT_F32") != nullptr;
+    static const bool one_head = getenv("MI_FLASH_ONE_HEAD") != nullptr;
     if (exact) hipLaunchKernelGGL(flash_attn_kernel, dim3((p->HW + 63) / 64, p->heads, p->B), dim3(256), 0, (hipStream_t)stream, *p);
-    else hipLaunchKernelGGL(flash_attn_f16x3_kernel, dim3((p->HW + 63) / 64, p->heads, p->B), dim3(256), 0, (hipStream_t)stream, *p);
+    else if (p->kv_heads == 1 && (p->heads & 3) == 0 && !one_head)      // multi-query: four heads of the same 64 queries share every staged K / V chunk
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(flash_attn_f16x3_kernel<16>), dim3((p->HW + 63) / 64, p->heads / 4, p->B), dim3(1024), 0, (hipStream_t)stream, *p);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(flash_attn_f16x3_kernel<4>), dim3((p->HW + 63) / 64, p->heads, p->B), dim3(256), 0, (hipStream_t)stream, *p);
     return mi_check_launch("flash_attn_kernel");
 }
 

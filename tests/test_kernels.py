@@ -677,6 +677,7 @@ FLASH_CASES = [
     # B, HW, heads, kv_heads, n0 (first segment), n1 (second segment), null row, q scale, k scale, v scale
     (2, 100, 2, 2, 4, 40, True, 1.0, 1.0, 1.0),            # CrossAttention: null + time tokens + text rows, per-head k / v, ragged HW and J
     (1, 64, 3, 1, 64, 0, True, 1.0, 1.0, 1.0),             # multi-query self-attention: one shared k / v head, context = the tokens themselves
+    (2, 150, 8, 1, 150, 0, True, 1.0, 1.0, 1.0),           # multi-query with heads % 4 == 0: four heads per workgroup share the staged chunks
     (1, 80, 2, 2, 130, 0, False, 30.0, 1.0 / 64, 300.0),   # three chunks, no null row, operands far from unit scale
     (1, 16, 1, 1, 3, 0, True, 1.0 / 256, 256.0, 1.0 / 512),
 ]
