@@ -253,9 +253,14 @@ __global__ __launch_bounds__(256, WPS) void cross_attn_folded_kernel(const mi_cr
 // lo*lo term is 2^-22 relative, so the result stays inside the fp32 parity tolerance.
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-// ATTN_QK32=1: QK^T as {G hi | G lo}.{x hi | x hi} (K = 32) + G hi . x lo (K = 16).  Correct on the SIMT emulator, WRONG on the MI355X
-// (round 1 and round 2, every ordering; the same pair is correct in isolation, tools/ubench/mfma32_layout.hip) and worth only 2 % of the
-// kernel (measured 0.413 vs 0.421 ms per pair of launches): off.
+// ATTN_QK32=1: QK^T as {G hi | G lo}.{x hi | x hi} (K = 32) + G hi . x lo (K = 16): two instructions per tile instead of three.  Correct on the
+// SIMT emulator, WRONG on the MI355X as compiled -- root cause (round 3, profiles/r03_attention_qk32_root_cause.txt): hipcc emits
+//     v_mfma_f32_16x16x16_f16 v[14:17], ...            (4 passes)
+//     v_mfma_f32_16x16x32_f16 v[70:73], ..., v[14:17]  (8 passes; SrcC = the previous result, a DIFFERENT vDst)
+// back to back with no wait state, and the hardware does not interlock a dependent SrcC read across the two instruction shapes: the second
+// instruction reads the accumulator before it is written.  Either order fails; separate accumulators added on the VALU pass all 16 device cases, and
+// so does the same-accumulator form with s_nop states between the two instructions (inline asm).  With the wait states the form is no faster than
+// three K = 16 instructions (same 24 pipe cycles), so it stays off: this kernel chains only instructions of ONE shape per accumulator.
 #ifndef ATTN_QPF
 #define ATTN_QPF 1          // prefetch the next QK^T fragment (one tile ahead) in the 3-term kernel
 #endif
