@@ -399,6 +399,52 @@ int mi_embed_rows(const int64_t* ids, const float* table, float* out, int rows, 
  * + bias_tab[heads][2L-1] (relative position bias indexed by (j - i) + L-1) + key mask, softmax, .v -> ctx [B*L][inner] */
 int mi_t5_attention(const float* qkv, const float* bias_tab, const uint8_t* key_mask, float* ctx, int B, int L, int heads, void* stream);
 
+/* ---- training path: parameter gradients of the 3x3 stride-1 convolutions -------
+ * The backward of Block.project (layers.py:126,145; Imagen.forward -> loss.backward(), Imagen.py:512-573).  The data gradient of a
+ * 3x3 stride-1 conv is mi_conv_fwd itself on the transposed, flipped kernel; this entry computes
+ *   dw[co][ci][ky][kx] = sum_{b,y,x} dy[b][co][y][x] * a[b][ci][y+ky-1][x+kx-1]   and   db[co] = sum dy[b][co][y][x]
+ * (a = the conv's input, i.e. the activated tensor) as a split-K matrix-core GEMM; partial sums go through `partial`
+ * (mi_conv_wgrad_workspace(Cin, Cout, nwg) floats) and are added in a fixed order: deterministic. */
+typedef struct mi_conv_wgrad_params {
+    int B, Cin, Cout, H, W;
+    const float* a;                 /* [B][Cin][H][W] */
+    const float* dy;                /* [B][Cout][H][W] */
+    float* dw;                      /* [Cout][Cin][3][3] */
+    float* db;                      /* [Cout] or NULL */
+    float* partial; int nwg;        /* workspace and the number of workgroups walking the pixel tiles (e.g. 512) */
+    /* a_stats != NULL: `a` is the RAW input of a Block and the kernel applies SiLU(GroupNorm(a) * (scale + 1) + shift) while it stages
+       the tiles (the activated tensor is never materialised): statistics [B][Cin][a_nt][2], affine, scale|shift table as in mi_conv_params */
+    const float* a_stats; int a_nt;
+    const float* gamma; const float* beta; int groups; float eps;
+    const float* ss; int ss_stride, ss_off;
+} mi_conv_wgrad_params;
+long long mi_conv_wgrad_workspace(int Cin, int Cout, int nwg);
+int mi_conv_wgrad(const mi_conv_wgrad_params* p, void* stream);
+
+/* the pointwise half of Block's backward, fused (the normalised / activated tensors are recomputed in registers): with
+ * y1 = gamma * xhat + beta, y2 = y1 * (scale + 1) + shift, a = silu(y2) and da = dL/da (the data gradient of the conv):
+ * dx (GroupNorm backward included), dgamma, dbeta, d(scale | shift).  Three launches: row sums, apply, parameter gradients. */
+typedef struct mi_block_bwd_params {
+    int B, C, HW, groups, nt, nchunk;   /* nchunk: row chunks per (image, channel) (grid.y of the two streaming kernels) */
+    float eps;
+    const float* x; const float* da;    /* [B][C][HW] */
+    const float* x_stats;               /* [B][C][nt][2] */
+    const float* gamma; const float* beta;
+    const float* ss; int ss_stride, ss_off;   /* [B][ss_stride]: scale at ss_off + c, shift at ss_off + C + c; or NULL */
+    float* uv;                          /* workspace [B][C][nchunk][2] */
+    float* dx;                          /* [B][C][HW] */
+    float* dgamma; float* dbeta;        /* [C] */
+    float* dss;                         /* [B][2C] (d scale | d shift), required when ss != NULL */
+} mi_block_bwd_params;
+int mi_block_bwd(const mi_block_bwd_params* p, void* stream);
+/* per-(image, channel) sum and sum of squares of x [rows][HW] -> stats [rows][2] (a tensor no HIP producer left statistics for) */
+int mi_chan_stats_fwd(const float* x, float* stats, int rows, int HW, void* stream);
+/* a [Cout][Cin][3][3] weight (adjoint != 0: its adjoint W'[ci][co][ky][kx] = W[co][ci][2-ky][2-kx]) times 2^exp -> the row-paired fp16 hi|lo
+ * fragments of mi_conv_params.w_rp and the direct-conv layout [Cin'][3][3][cout_pad] of mi_conv_params.w, in one launch on the device
+ * (the training path re-packs after every optimiser step).  mi_pack_conv3_floats(…, which): element counts (0: fp16 fragments, 1: fp32). */
+long long mi_pack_conv3_floats(int Cout, int Cin, int adjoint, int cout_pad, int which);
+int mi_pack_conv3(const float* w, int Cout, int Cin, int adjoint, int exp, void* frag, float* generic, int cout_pad, void* stream);
+
 /* ---- HIP graphs: capture a sequence of the calls above once, replay it per timestep ------- */
 int mi_graph_begin(void* stream);
 int mi_graph_end(void* stream, void** graph_exec);

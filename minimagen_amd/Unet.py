@@ -11,6 +11,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from . import train_ops
 from .helpers import default, exists, cast_tuple, prob_mask_like
 from .layers import (Attention, CrossEmbedLayer, Downsample, EinopsToAndFrom, Identity, Parallel, Residual, ResnetBlock,
                      SinusoidalPosEmb, TransformerBlock, Upsample)
@@ -197,10 +198,10 @@ class Unet(nn.Module):
         assert not (self.lowres_cond and not exists(lowres_noise_times)), 'low resolution conditioning noise time must be present'
         if self.training and torch.is_grad_enabled():
             # training (Imagen.forward): the differentiable torch-op form of the same module tree; sampling / evaluation takes the HIP engine
-            if x.is_cuda and not Unet._warned_torch_path:          # once per process
+            if x.is_cuda and not train_ops.active(x) and not Unet._warned_torch_path:          # once per process
                 Unet._warned_torch_path = True
-                warnings.warn("minimagen_amd.Unet.forward: module in train() mode with autograd enabled -> differentiable torch-op path; "
-                              "call .eval() or wrap the call in torch.no_grad() to run inference on the HIP engine", stacklevel=2)
+                warnings.warn("minimagen_amd.Unet.forward: module in train() mode with autograd enabled and MINIMAGEN_TRAIN_HIP=0 -> torch ops "
+                              "only; call .eval() or wrap the call in torch.no_grad() to run inference on the HIP engine", stacklevel=2)
             return self._forward_train(x, time, lowres_cond_img=lowres_cond_img, lowres_noise_times=lowres_noise_times,
                                        text_embeds=text_embeds, text_mask=text_mask, cond_drop_prob=cond_drop_prob)
         keep = prob_mask_like((x.shape[0],), 1 - cond_drop_prob, device='cpu')      # Unet.py:587
@@ -214,6 +215,10 @@ class Unet(nn.Module):
         """Unet.py:355-472 as differentiable torch ops over the layers' own ``forward`` methods (minimagen_amd/layers.py): the training
         path.  Same order of operations as the reference; per-sample conditioning dropout with probability ``cond_drop_prob``."""
         b = x.shape[0]
+        dev_path = train_ops.active(x)      # the 3x3 convolutions (Blocks, Upsample, final_conv) forward and backward on the HIP kernels
+        if dev_path:
+            train_ops.begin_step(self)
+        conv3 = lambda m, v: train_ops.conv3x3_forward(m, v) if (dev_path and train_ops.is_plain_conv3x3(m)) else m(v)
         # ---- conditioning (Unet.py:508-634)
         hid = self.to_time_hiddens(time)
         t, tokens = self.to_time_cond(hid), self.to_time_tokens[0](hid).reshape(b, self.num_time_tokens, self.cond_dim)
@@ -265,9 +270,9 @@ class Unet(nn.Module):
             for blk in blocks:
                 x = blk(with_skip(x), t)
             x = attn(x)
-            x = up(x)
+            x = conv3(up[1], up[0](x)) if isinstance(up, nn.Sequential) else up(x)
         x = self.final_res_block(x, t)
-        return self.final_conv(x)
+        return conv3(self.final_conv, x)
 
     def forward_with_cond_scale(self, *args, cond_scale: float = 1., **kwargs) -> torch.Tensor:
         """Unet.py:474-506: both guidance halves run as ONE batch of 2B rows through the engine."""

@@ -139,9 +139,23 @@ class MiResizeParams(C.Structure):
                 ("in_", C.c_void_p), ("out", C.c_void_p), ("idx_h", C.c_void_p), ("w_h", C.c_void_p), ("idx_w", C.c_void_p), ("w_w", C.c_void_p)]
 
 
+class MiConvWgradParams(C.Structure):
+    _fields_ = [("B", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int), ("H", C.c_int), ("W", C.c_int), ("a", C.c_void_p), ("dy", C.c_void_p),
+                ("dw", C.c_void_p), ("db", C.c_void_p), ("partial", C.c_void_p), ("nwg", C.c_int),
+                ("a_stats", C.c_void_p), ("a_nt", C.c_int), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("groups", C.c_int), ("eps", C.c_float),
+                ("ss", C.c_void_p), ("ss_stride", C.c_int), ("ss_off", C.c_int)]
+
+
+class MiBlockBwdParams(C.Structure):
+    _fields_ = [("B", C.c_int), ("C", C.c_int), ("HW", C.c_int), ("groups", C.c_int), ("nt", C.c_int), ("nchunk", C.c_int), ("eps", C.c_float),
+                ("x", C.c_void_p), ("da", C.c_void_p), ("x_stats", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p),
+                ("ss", C.c_void_p), ("ss_stride", C.c_int), ("ss_off", C.c_int), ("uv", C.c_void_p), ("dx", C.c_void_p),
+                ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("dss", C.c_void_p)]
+
+
 _STRUCTS = {0: MiAct, 1: MiConvParams, 2: MiCrossEmbedParams, 3: MiLinear, 4: MiTextCondParams, 5: MiCondStepParams,
             6: MiAttnFoldParams, 7: MiCrossAttnParams, 8: MiCfgX0Params, 9: MiQuantileParams, 10: MiPosteriorParams,
-            11: MiResizeParams, 12: MiSelfAttnParams, 13: MiChanFFParams, 14: MiFlashAttnParams, 15: MiTokensToNchwParams}
+            11: MiResizeParams, 12: MiSelfAttnParams, 13: MiChanFFParams, 14: MiFlashAttnParams, 15: MiTokensToNchwParams, 16: MiConvWgradParams, 17: MiBlockBwdParams}
 
 _lib = None
 _backend = None
@@ -159,7 +173,7 @@ def _bind(lib):
     vp, i32, i64, u64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float
     for name in ("mi_conv_fwd", "mi_gn_coef_fwd", "mi_crossembed_fwd", "mi_text_cond_fwd", "mi_cond_step_fwd", "mi_attn_fold_rows", "mi_cross_attn_fwd",
                  "mi_cfg_x0_fwd", "mi_quantile_fwd", "mi_posterior_fwd", "mi_resize_fwd", "mi_self_attn_fwd", "mi_chan_ff_fwd",
-                 "mi_flash_attn_fwd", "mi_tokens_to_nchw_fwd"):
+                 "mi_flash_attn_fwd", "mi_tokens_to_nchw_fwd", "mi_conv_wgrad", "mi_block_bwd"):
         getattr(lib, name).argtypes = [vp, vp]
         getattr(lib, name).restype = i32
     lib.mi_step_advance.argtypes = [vp, vp, i32, vp]
@@ -182,6 +196,12 @@ def _bind(lib):
     lib.mi_graph_destroy.argtypes = [vp]
     lib.mi_conv_tile_shape.argtypes = [i32, C.POINTER(i32), C.POINTER(i32)]
     lib.mi_conv_cout_tile.argtypes = [i32]
+    lib.mi_conv_wgrad_workspace.argtypes = [i32, i32, i32]
+    lib.mi_conv_wgrad_workspace.restype = C.c_longlong
+    lib.mi_chan_stats_fwd.argtypes = [vp, vp, i32, i32, vp]
+    lib.mi_pack_conv3_floats.argtypes = [i32, i32, i32, i32, i32]
+    lib.mi_pack_conv3_floats.restype = C.c_longlong
+    lib.mi_pack_conv3.argtypes = [vp, i32, i32, i32, i32, vp, vp, i32, vp]
     lib.mi_attn_fragment_floats.argtypes = [i32]
     for which, st in _STRUCTS.items():
         n = lib.mi_struct_size(which)

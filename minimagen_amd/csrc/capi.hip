@@ -42,6 +42,8 @@ extern "C" int mi_struct_size(int which) {
         case 13: return (int)sizeof(mi_chan_ff_params);
         case 14: return (int)sizeof(mi_flash_attn_params);
         case 15: return (int)sizeof(mi_tokens_to_nchw_params);
+        case 16: return (int)sizeof(mi_conv_wgrad_params);
+        case 17: return (int)sizeof(mi_block_bwd_params);
     }
     return -1;
 }

@@ -30,6 +30,29 @@ __device__ __forceinline__ float mi_silu(float v) {
     return v * __builtin_amdgcn_rcpf(1.0f + expf(-v));
 }
 
+// ---- training path helpers (train_bwd.hip, conv_wgrad.hip)
+// mean / rstd of the group of channel c of image b from the per-channel statistics [B][C][nt][2]; executed by one wave, result in all lanes
+__device__ __forceinline__ void mi_group_moments(const float* stats, int nt, int C, int groups, int HW, float eps, int b, int c, float& mu, float& r) {
+    const int lane = threadIdx.x & 63;
+    const int cpg = C / groups, g = c / cpg;
+    const float* base = stats + ((size_t)b * C + (size_t)g * cpg) * nt * 2;
+    double s = 0.0, q = 0.0;
+    for (int i = lane; i < cpg * nt; i += 64) { s += (double)base[2 * i]; q += (double)base[2 * i + 1]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
+    const double n = (double)cpg * (double)HW;
+    const double m = s / n;
+    double var = q / n - m * m;
+    if (var < 0.0) var = 0.0;
+    mu = (float)m;
+    r = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+__device__ __forceinline__ float mi_silu_grad(float v) {          // d/dv (v * sigmoid(v))
+    const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.44269504088896340736f));
+    return sg * (1.0f + v * (1.0f - sg));
+}
+
 // fp16 hi/lo split of four fp32 values for the 3-term MFMA products: hi = fp16(x), lo = fp16(x - hi) (22 mantissa bits kept).
 // (A mask + v_cvt_pkrtz formulation was measured 16 % slower on MI355X than plain conversions.  -DMI_SPLIT_PLAIN builds the plain form
 //  on the device too.)

@@ -63,3 +63,43 @@ def sample_distributed(imagen, *, text_embeds: torch.Tensor, text_masks: Optiona
     if not gather or ws == 1:
         return local
     return gather_samples(local, batch, group)
+
+
+def allreduce_gradients(params, *, bucket_mb: float = 64.0, group=None, average: bool = True):
+    """Data-parallel training (the reference trains on one device, train.py:99-103): sum the ranks' parameter
+    gradients after ``loss.backward()``.  Gradients are copied into flat fp32 buckets of ``bucket_mb`` MiB (xGMI is point-to-point: a ring
+    all-reduce is bound per link, so few large collectives, not one per tensor), every bucket's ``all_reduce`` (RCCL) is issued
+    asynchronously and the results are scattered back after the last one was enqueued.  Parameters without a gradient on this rank
+    contribute zeros (every rank must issue the same collectives).  Returns the number of collectives."""
+    ws = dist.get_world_size(group) if dist.is_initialized() else 1
+    params = [p for p in params if p.requires_grad]
+    if ws == 1 or not params:
+        return 0
+    limit = max(1, int(bucket_mb * (1 << 20) / 4))
+    buckets, cur, n = [], [], 0
+    for p in params:
+        if cur and n + p.numel() > limit:
+            buckets.append(cur)
+            cur, n = [], 0
+        cur.append(p)
+        n += p.numel()
+    buckets.append(cur)
+    work = []
+    for bucket in buckets:
+        dev = bucket[0].device
+        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).float() for p in bucket])
+        assert flat.device == dev
+        work.append((bucket, flat, dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True)))
+    for bucket, flat, handle in work:
+        handle.wait()
+        if average:
+            flat.div_(ws)
+        off = 0
+        for p in bucket:
+            g = flat[off:off + p.numel()].view_as(p)
+            if p.grad is None:
+                p.grad = g.clone()
+            else:
+                p.grad.copy_(g)
+            off += p.numel()
+    return len(buckets)

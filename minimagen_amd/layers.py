@@ -16,6 +16,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from . import train_ops
 from .helpers import default, exists
 
 
@@ -162,6 +163,8 @@ class Block(_Container):
         self.project = nn.Conv2d(dim, dim_out, 3, padding=1)
 
     def forward(self, x, scale_shift=None):
+        if torch.is_grad_enabled() and train_ops.active(x):        # training on the device: fused HIP forward, HIP dgrad / wgrad
+            return train_ops.block_forward(self, x, scale_shift)
         x = self.groupnorm(x)
         if exists(scale_shift):
             scale, shift = scale_shift

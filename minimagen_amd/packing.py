@@ -64,7 +64,13 @@ def sinusoid_freq(dim: int, device) -> torch.Tensor:
 RP_PERM = (0, 2, 1, 3)      # lane group -> input row of the row-paired matrix-core conv (csrc/conv_rp.hip)
 
 
-def pack_conv_weight_rp(w: torch.Tensor):
+def rp_weight_exponent(mx: float) -> int:
+    """power of two that brings a weight tensor's maximum magnitude into [128, 256)"""
+    exp = 0 if (mx == 0.0 or not math.isfinite(mx)) else 7 - math.floor(math.log2(mx))
+    return max(-100, min(100, exp))
+
+
+def pack_conv_weight_rp(w: torch.Tensor, exp=None):
     """[Cout][Cin][3][3] (or [Cout][Cres][1][1]) fp32 -> (fragments, exponent) for csrc/conv_rp.hip.
 
     B operand of v_mfma_f32_16x16x32_f16 with N = (output-row parity dy, 8 output channels), K = (4 input rows, 8 input channels)
@@ -74,41 +80,43 @@ def pack_conv_weight_rp(w: torch.Tensor):
     lo = fp16(w' - hi) then keeps ~22 bits whatever the magnitude of the checkpoint's weights; the kernel undoes the scale."""
     cout, cin, kh, kw = w.shape
     assert (kh, kw) in ((3, 3), (1, 1), (4, 4))
-    wd = w.detach().double().cpu()
-    mx = float(wd.abs().max())
-    exp = 0 if (mx == 0.0 or not math.isfinite(mx)) else 7 - math.floor(math.log2(mx))
-    exp = max(-100, min(100, exp))
+    if exp is None:
+        wd = w.detach().double().cpu()
+        exp = rp_weight_exponent(float(wd.abs().max()))
+    else:                       # the training path packs on the device, exponents of all layers fetched with one host round trip
+        wd = w.detach().double()
+    dev = wd.device
     ws = wd * (2.0 ** exp)
     if kh == 4:
         # k4 s2 (Downsample): N = 16 output channels of ONE output row, K = (4 vertical taps <-> lane group, 8 input channels), one
         # step per horizontal tap: lane (lq, lg) holds W[co = 16jt + lq][ci = 8k + e][ky = lg][kx = step]
         nj, ko = -(-cout // 16), -(-cin // 8)
-        wp = torch.zeros(nj * 16, ko * 8, 4, 4, dtype=torch.float64)
+        wp = torch.zeros(nj * 16, ko * 8, 4, 4, dtype=torch.float64, device=dev)
         wp[:cout, :cin] = ws
-        lane = torch.arange(64)
+        lane = torch.arange(64, device=dev)
         lq, lg = lane & 15, lane >> 4
-        co = 16 * torch.arange(nj)[:, None] + lq[None, :]
-        ci = 8 * torch.arange(ko)[:, None] + torch.arange(8)[None, :]
-        out = wp[co[None, None, :, :, None], ci[:, None, None, None, :], lg[None, None, None, :, None], torch.arange(4)[None, :, None, None, None]]
+        co = 16 * torch.arange(nj, device=dev)[:, None] + lq[None, :]
+        ci = 8 * torch.arange(ko, device=dev)[:, None] + torch.arange(8, device=dev)[None, :]
+        out = wp[co[None, None, :, :, None], ci[:, None, None, None, :], lg[None, None, None, :, None], torch.arange(4, device=dev)[None, :, None, None, None]]
         hi = out.float().half()
         lo = (out - hi.double()).float().half()
         return torch.cat((hi, lo), dim=-1).contiguous().to(w.device), exp
     nj, ko, steps = -(-cout // 8), -(-cin // 8), kw
-    wp = torch.zeros(nj * 8, ko * 8, 3, kw, dtype=torch.float64)
+    wp = torch.zeros(nj * 8, ko * 8, 3, kw, dtype=torch.float64, device=dev)
     if kh == 3:
         wp[:cout, :cin] = ws
     else:
         wp[:cout, :cin, 1, :] = ws[:, :, 0, :]          # centre row; its single "step" is the centre column
-    lane = torch.arange(64)
+    lane = torch.arange(64, device=dev)
     lq, lg = lane & 15, lane >> 4
-    r = torch.tensor(RP_PERM)[lg]
+    r = torch.tensor(RP_PERM, device=dev)[lg]
     ky = r - (lq >> 3)
     live = ((ky >= 0) & (ky <= 2)).double()
     kyc = ky.clamp(0, 2)
-    co = (8 * torch.arange(nj)[:, None] + (lq & 7)[None, :])                 # [nj][64]
-    ci = (8 * torch.arange(ko)[:, None] + torch.arange(8)[None, :])         # [ko][8]
+    co = (8 * torch.arange(nj, device=dev)[:, None] + (lq & 7)[None, :])                 # [nj][64]
+    ci = (8 * torch.arange(ko, device=dev)[:, None] + torch.arange(8, device=dev)[None, :])         # [ko][8]
     # out[k, s, jt, lane, e] = wp[co[jt, lane], ci[k, e], ky[lane], s]  (one gather, no Python loop over the channel tiles)
-    out = wp[co[None, None, :, :, None], ci[:, None, None, None, :], kyc[None, None, None, :, None], torch.arange(steps)[None, :, None, None, None]]
+    out = wp[co[None, None, :, :, None], ci[:, None, None, None, :], kyc[None, None, None, :, None], torch.arange(steps, device=dev)[None, :, None, None, None]]
     out = out * live[None, None, None, :, None]
     hi = out.float().half()
     lo = (out - hi.double()).float().half()

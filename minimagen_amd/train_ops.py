@@ -1,0 +1,278 @@
+"""Training on the device: the convolutions of ``Imagen.forward`` -> ``Unet.forward`` in train mode
+(minimagen/Imagen.py:512-573, Unet.py:355-472) on the HIP kernels, forward AND backward.
+
+``Block`` (GroupNorm -> [scale / shift] -> SiLU -> Conv3x3, layers.py:107-145) and the plain 3x3 convolutions (``final_conv``, the conv of
+``Upsample``) become ``torch.autograd.Function``s:
+
+* forward: ONE ``mi_conv_fwd`` launch -- the fused inference kernel (GroupNorm-apply + scale/shift + SiLU + conv, conv_rp.hip); only the
+  block's INPUT is kept for the backward (the normalised / activated tensors are never stored: a third of the activation memory of the
+  torch-op graph);
+* backward, data gradient: the same kernel on the transposed, flipped weights (a 3x3 stride-1 convolution's adjoint is a 3x3 stride-1
+  convolution), range-scaled by the gradient's own channel statistics;
+* backward, weight / bias gradient: ``mi_conv_wgrad`` (conv_wgrad.hip: split-K fp32 matrix-core GEMM, deterministic);
+* backward, pointwise part: ``mi_block_bwd`` (train_bwd.hip) -- GroupNorm / scale-shift / SiLU backward with the activation recomputed in
+  registers from the saved input (row sums, apply, parameter gradients: three launches); the weight-gradient kernel applies the same
+  activation while it stages its operand tiles, so the activated tensor is never written to memory in either direction.
+
+Weights are re-packed into matrix-core fragments (``mi_pack_conv3``: one launch per weight and direction) when their version counter changes,
+i.e. once per optimiser step; the exponents of all layers come back with one host round trip (``begin_step``).  Everything else of the training graph (attention, conditioning, 1x1 / k4s2
+convs, CrossEmbed) stays on torch ops.  ``gradient all-reduce``: minimagen_amd/distributed.py::allreduce_gradients.
+MINIMAGEN_TRAIN_HIP=0 switches the whole thing off (torch ops only)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib as L
+from . import packing as P
+
+ENABLED = os.environ.get("MINIMAGEN_TRAIN_HIP", "1") != "0"
+FORCE = False                   # tests: take the HIP path for host tensors too (emulator build of the kernels)
+WGRAD_NWG = int(os.environ.get("MINIMAGEN_WGRAD_NWG", "1024"))
+
+
+def active(x: torch.Tensor) -> bool:
+    """the HIP training path runs for fp32 GPU tensors under autograd (and for host tensors when a test forces the emulator)"""
+    return ENABLED and x.dtype == torch.float32 and x.dim() == 4 and (x.is_cuda or FORCE)
+
+
+class _Pack:
+    """one conv weight (or its adjoint) in the layouts mi_conv_fwd reads: [Cin][3][3][Cout_pad] fp32 (direct-conv family) and the row-paired
+    fp16 hi|lo fragments + their exponent -- written by ONE launch of mi_pack_conv3 on the device"""
+    __slots__ = ("generic", "frag", "exp", "cout", "cin", "rp")
+
+    def __init__(self, w: torch.Tensor, exp: int, adjoint: bool):
+        lib = L.lib()
+        Cout, Cin = w.shape[0], w.shape[1]
+        self.cout, self.cin = (Cin, Cout) if adjoint else (Cout, Cin)
+        ct = lib.mi_conv_cout_tile(self.cout)
+        pad = -(-self.cout // ct) * ct
+        self.generic = torch.empty(lib.mi_pack_conv3_floats(Cout, Cin, int(adjoint), pad, 1), dtype=torch.float32, device=w.device)
+        self.frag = torch.empty(lib.mi_pack_conv3_floats(Cout, Cin, int(adjoint), pad, 0), dtype=torch.float16, device=w.device)
+        self.exp, self.rp = exp, self.cin % 8 == 0
+        L.check(lib.mi_pack_conv3(w.data_ptr(), Cout, Cin, int(adjoint), exp, self.frag.data_ptr(), self.generic.data_ptr(), pad, L.current_stream()),
+                "mi_pack_conv3")
+
+
+def _packs(weight: torch.Tensor, exp=None):
+    """(forward pack, data-gradient pack) of a [Cout][Cin][3][3] parameter, cached on the parameter until it is updated in place"""
+    cached = getattr(weight, "_mi_train_packs", None)
+    if cached is not None and cached[0] == weight._version and cached[1].generic.device == weight.device:
+        return cached[1], cached[2]
+    w = weight.detach()
+    if exp is None:
+        exp = P.rp_weight_exponent(float(w.abs().max()))
+    w = w.contiguous()
+    L.require_device(w)
+    fwd = _Pack(w, exp, False)
+    bwd = _Pack(w, exp, True)             # adjoint: W'[ci][co][ky][kx] = W[co][ci][2-ky][2-kx]
+    weight._mi_train_packs = (weight._version, fwd, bwd)
+    return fwd, bwd
+
+
+def begin_step(module: torch.nn.Module):
+    """re-pack every 3x3 stride-1 conv weight under ``module`` whose version changed; the exponents of all of them with ONE device->host copy"""
+    stale = [m.weight for m in module.modules() if isinstance(m, torch.nn.Conv2d) and m.kernel_size == (3, 3) and m.stride == (1, 1)
+             and (getattr(m.weight, "_mi_train_packs", None) is None or m.weight._mi_train_packs[0] != m.weight._version
+                  or m.weight._mi_train_packs[1].generic.device != m.weight.device)]
+    if not stale:
+        return
+    with torch.no_grad():
+        mx = torch.stack([w.abs().max() for w in stale]).tolist()
+        for w, m in zip(stale, mx):
+            _packs(w, P.rp_weight_exponent(m))
+
+
+def _chan_stats(x: torch.Tensor) -> torch.Tensor:
+    """per-(image, channel) sum and sum of squares, [B][C][1][2] (one statistics tile): what a producing kernel's epilogue would have left"""
+    B, Cc, H, W = x.shape
+    st = torch.empty(B, Cc, 1, 2, dtype=torch.float32, device=x.device)
+    L.check(L.lib().mi_chan_stats_fwd(x.data_ptr(), st.data_ptr(), B * Cc, H * W, L.current_stream()), "mi_chan_stats_fwd")
+    return st
+
+
+_ZEROS = {}
+
+
+def _zero_bias(n: int, dev) -> torch.Tensor:
+    key = (n, str(dev))
+    if key not in _ZEROS:
+        _ZEROS[key] = torch.zeros(n, dtype=torch.float32, device=dev)
+    return _ZEROS[key]
+
+
+def _conv3x3(x: torch.Tensor, pack: _Pack, bias, gn=None, ss=None, stats=None) -> torch.Tensor:
+    """one mi_conv_fwd launch: out = conv3x3(act(x)) + bias with act = SiLU(GroupNorm(x) * (scale + 1) + shift) when ``gn`` is given"""
+    lib = L.lib()
+    B, Cin, H, W = x.shape
+    Cout = pack.cout
+    assert Cin == pack.cin
+    L.require_device(x)
+    out = torch.empty(B, Cout, H, W, dtype=torch.float32, device=x.device)
+    if stats is None:
+        stats = _chan_stats(x)
+    if bias is None:
+        bias = _zero_bias(Cout, x.device)
+    keep = [stats, bias, out]
+    p = L.MiConvParams()
+    p.B, p.H, p.W = B, H, W
+    p.in0 = L.MiAct(x.data_ptr(), Cin, stats.data_ptr(), 1, 1.0, 0, 0)
+    p.Cout, p.ksize, p.stride, p.up2 = Cout, 3, 1, 0
+    p.w, p.bias, p.out = pack.generic.data_ptr(), bias.data_ptr(), out.data_ptr()
+    if gn is not None:
+        gamma, beta, groups, eps = gn
+        p.gn_groups, p.gn_gamma, p.gn_beta, p.gn_eps = groups, gamma.data_ptr(), beta.data_ptr(), eps
+        if ss is not None:
+            p.scale_shift, p.ss_stride, p.ss_off = ss.data_ptr(), ss.shape[1], 0
+    rp = pack.rp and W % 4 == 0
+    if rp:
+        wide = not (Cin <= 64 and Cout <= 32)
+        cfg = 6
+        if wide or Cout > 16 or (H * W <= 64 * 64 and (W <= 32 or Cout <= 8)):
+            cfg = 7
+        p.w_rp, p.w_rp_exp = pack.frag.data_ptr(), pack.exp
+        if wide:
+            coef = torch.empty(B, Cin, 4, dtype=torch.float32, device=x.device)
+            exps = torch.empty(B, 2, dtype=torch.int32, device=x.device)
+            keep += [coef, exps]
+            p.gn_coef, p.gn_exps = coef.data_ptr(), exps.data_ptr()
+        p.tile_cfg = cfg
+        if wide:
+            L.check(lib.mi_gn_coef_fwd(C.byref(p), L.current_stream()), "mi_gn_coef_fwd (training)")
+    else:
+        p.tile_cfg = 0 if (W >= 64 and H * W > 64 * 64) else 2
+    L.check(lib.mi_conv_fwd(C.byref(p), L.current_stream()), "mi_conv_fwd (training)")
+    return out
+
+
+def _wgrad(a: torch.Tensor, dy: torch.Tensor, want_bias: bool, act=None):
+    """dW, db of a 3x3 conv from its input ``a`` and the output gradient; ``act`` = (stats, gamma, beta, groups, eps, ss): ``a`` is the raw
+    Block input and the kernel applies GroupNorm -> scale/shift -> SiLU while staging the tiles"""
+    lib = L.lib()
+    B, Cin, H, W = a.shape
+    Cout = dy.shape[1]
+    tiles = B * (-(-H // 8)) * (-(-W // 32))
+    nblk = (-(-Cin // 16)) * (-(-Cout // 16))
+    nwg = max(1, min(tiles, max(64, WGRAD_NWG // nblk)))
+    part = torch.empty(lib.mi_conv_wgrad_workspace(Cin, Cout, nwg), dtype=torch.float32, device=a.device)
+    dw = torch.empty(Cout, Cin, 3, 3, dtype=torch.float32, device=a.device)
+    db = torch.empty(Cout, dtype=torch.float32, device=a.device) if want_bias else None
+    p = L.MiConvWgradParams()
+    p.B, p.Cin, p.Cout, p.H, p.W = B, Cin, Cout, H, W
+    p.a, p.dy, p.dw, p.db, p.partial, p.nwg = a.data_ptr(), dy.data_ptr(), dw.data_ptr(), L.ptr(db), part.data_ptr(), nwg
+    if act is not None:
+        stats, gamma, beta, groups, eps, ss = act
+        p.a_stats, p.a_nt, p.gamma, p.beta, p.groups, p.eps = stats.data_ptr(), 1, gamma.data_ptr(), beta.data_ptr(), groups, eps
+        if ss is not None:
+            p.ss, p.ss_stride, p.ss_off = ss.data_ptr(), ss.shape[1], 0
+    L.check(lib.mi_conv_wgrad(C.byref(p), L.current_stream()), "mi_conv_wgrad")
+    return dw, db
+
+
+def _block_bwd(x, da, stats, gamma, beta, groups, eps, ss):
+    """dx, dgamma, dbeta, d(scale|shift) of GroupNorm -> scale/shift -> SiLU from the activation's gradient (mi_block_bwd: three launches)"""
+    lib = L.lib()
+    B, Cc, H, W = x.shape
+    HW = H * W
+    nchunk = max(1, min(HW // 1024, -(-2048 // (B * Cc))))
+    uv = torch.empty(B, Cc, nchunk, 2, dtype=torch.float32, device=x.device)
+    dx = torch.empty_like(x)
+    dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(beta)
+    dss = torch.empty(B, 2 * Cc, dtype=torch.float32, device=x.device) if ss is not None else None
+    p = L.MiBlockBwdParams()
+    p.B, p.C, p.HW, p.groups, p.nt, p.nchunk, p.eps = B, Cc, HW, groups, 1, nchunk, eps
+    p.x, p.da, p.x_stats, p.gamma, p.beta = x.data_ptr(), da.data_ptr(), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr()
+    if ss is not None:
+        p.ss, p.ss_stride, p.ss_off = ss.data_ptr(), ss.shape[1], 0
+    p.uv, p.dx, p.dgamma, p.dbeta, p.dss = uv.data_ptr(), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), L.ptr(dss)
+    L.check(lib.mi_block_bwd(C.byref(p), L.current_stream()), "mi_block_bwd")
+    return dx, dgamma, dbeta, dss
+
+
+class _BlockFn(torch.autograd.Function):
+    """layers.py:131-145: fused HIP forward; backward = data-gradient conv (the forward kernel on the adjoint weights) -> mi_block_bwd
+    (GroupNorm / scale-shift / SiLU backward, recomputing the activation in registers) + mi_conv_wgrad with the activation fused into its
+    operand staging.  Saved for the backward: the block's input, its channel statistics and the scale|shift table -- nothing else."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, scale, shift, weight, bias, groups, eps):
+        x = x.contiguous()
+        fwd, _ = _packs(weight)
+        g, b = gamma.detach().contiguous(), beta.detach().contiguous()
+        ss = None
+        if scale is not None:
+            B = x.shape[0]
+            ss = torch.cat((scale.detach().reshape(B, -1), shift.detach().reshape(B, -1)), 1).contiguous()
+        stats = _chan_stats(x)
+        out = _conv3x3(x, fwd, None if bias is None else bias.detach(), gn=(g, b, groups, eps), ss=ss, stats=stats)
+        ctx.save_for_backward(x, g, b, ss, stats, weight)
+        ctx.groups, ctx.eps, ctx.has_bias, ctx.ss_shape = groups, eps, bias is not None, (None if scale is None else scale.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, ss, stats, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        _, bwd = _packs(weight)
+        need = ctx.needs_input_grad
+        dx = dgamma = dbeta = dscale = dshift = dw = db = None
+        if any(need[:5]):
+            da = _conv3x3(dy, bwd, None)
+            dx, dgamma, dbeta, dss = _block_bwd(x, da, stats, gamma, beta, ctx.groups, ctx.eps, ss)
+            if dss is not None:
+                Cc = x.shape[1]
+                dscale, dshift = dss[:, :Cc].reshape(ctx.ss_shape), dss[:, Cc:].reshape(ctx.ss_shape)
+        if need[5] or (ctx.has_bias and need[6]):
+            dw, db = _wgrad(x, dy, ctx.has_bias and need[6], act=(stats, gamma, beta, ctx.groups, ctx.eps, ss))
+        pick = lambda g, n: g if n else None
+        return (pick(dx, need[0]), pick(dgamma, need[1]), pick(dbeta, need[2]), pick(dscale, need[3]), pick(dshift, need[4]),
+                pick(dw, need[5]), db, None, None)
+
+
+class _ConvFn(torch.autograd.Function):
+    """a plain 3x3 stride-1 convolution (Unet.py final_conv, layers.py:512-515 after the nearest x2): forward, data gradient and
+    parameter gradients on the HIP kernels"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x = x.contiguous()
+        fwd, _ = _packs(weight)
+        out = _conv3x3(x, fwd, None if bias is None else bias.detach())
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        _, bwd = _packs(weight)
+        need = ctx.needs_input_grad
+        dx = _conv3x3(dy, bwd, None) if need[0] else None
+        dw = db = None
+        if need[1] or (ctx.has_bias and need[2]):
+            dw, db = _wgrad(x, dy, ctx.has_bias and need[2])
+        return dx, (dw if need[1] else None), db
+
+
+def block_forward(block, x: torch.Tensor, scale_shift=None) -> torch.Tensor:
+    """``Block.forward`` (layers.py:131-145) through _BlockFn"""
+    gnm = block.groupnorm
+    conv = block.project
+    scale, shift = scale_shift if scale_shift is not None else (None, None)
+    if not isinstance(gnm, torch.nn.GroupNorm):             # Block(norm=False): not a layer of the reference's U-Nets; keep the semantics
+        h = x if scale is None else x * (scale + 1) + shift
+        return _ConvFn.apply(F.silu(h), conv.weight, conv.bias)
+    return _BlockFn.apply(x, gnm.weight, gnm.bias, scale, shift, conv.weight, conv.bias, gnm.num_groups, gnm.eps)
+
+
+def conv3x3_forward(conv: torch.nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
+    return _ConvFn.apply(x, conv.weight, conv.bias)
+
+
+def is_plain_conv3x3(m) -> bool:
+    return isinstance(m, torch.nn.Conv2d) and m.kernel_size == (3, 3) and m.stride == (1, 1) and m.padding == (1, 1) and m.groups == 1 \
+        and m.dilation == (1, 1) and m.padding_mode == "zeros"

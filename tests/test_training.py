@@ -9,7 +9,7 @@ import torch
 from minimagen_amd.Imagen import Imagen
 from minimagen_amd.Unet import Unet
 from oracle import restated as R
-from tests._backend import GPU_ONLY, setup
+from tests._backend import BACKENDS, GPU_ONLY, setup
 
 NARROW_ATTN = dict(dim=8, dim_mults=(1, 2), num_resnet_blocks=1, layer_attns=(False, True), layer_cross_attns=(False, True), attend_at_middle=True)
 BASE = dict(dim=8, dim_mults=(1, 2), num_resnet_blocks=1, layer_attns=False, layer_cross_attns=False, memory_efficient=False)
@@ -107,3 +107,184 @@ def test_training_path_on_the_gpu_agrees_with_the_hip_engine(backend):
     c = u.eval()(x, tm, text_embeds=emb, text_mask=mask)
     d = u.train()(x, tm, text_embeds=emb, text_mask=mask)
     assert (c - b).abs().max() > 1e-4 and (c - d).abs().max() < 2e-5 * max(1.0, float(c.abs().max()))
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# training on the device (minimagen_amd/train_ops.py): HIP forward + HIP data / weight gradients for the 3x3 convolutions
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("case", [(2, 8, 8, 16, 32, 3), (1, 16, 24, 13, 40, 5), (3, 3, 5, 9, 7, 2), (1, 40, 8, 8, 32, 1), (2, 8, 8, 64, 64, 64)])
+def test_conv_wgrad_kernel(backend, case):
+    """mi_conv_wgrad (split-K fp32 matrix-core GEMM over pixel tiles, partials added in a fixed order) against torch autograd in fp64: ragged
+    tiles, channel counts off the 16-blocks, fewer workgroups than tiles, and run-to-run bit equality"""
+    import ctypes as C
+    import torch.nn.functional as F
+    from minimagen_amd import _lib as L
+    B, Cin, Cout, H, W, nwg = case
+    if backend == "emu" and H * W > 1024:
+        pytest.skip("emulator time")
+    dev = setup(backend)
+    lib = L.lib()
+    g = torch.Generator().manual_seed(1)
+    a, dy = torch.randn(B, Cin, H, W, generator=g), torch.randn(B, Cout, H, W, generator=g)
+    w = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    b = torch.zeros(Cout, dtype=torch.float64, requires_grad=True)
+    F.conv2d(a.double(), w, b, padding=1).backward(dy.double())
+    ad, dyd = a.to(dev), dy.to(dev)
+    outs = []
+    for rep in range(2):
+        part = torch.full((lib.mi_conv_wgrad_workspace(Cin, Cout, nwg),), float('nan'), device=dev)
+        dw, db = torch.full((Cout, Cin, 3, 3), float('nan'), device=dev), torch.full((Cout,), float('nan'), device=dev)
+        p = L.MiConvWgradParams(B, Cin, Cout, H, W, ad.data_ptr(), dyd.data_ptr(), dw.data_ptr(), db.data_ptr(), part.data_ptr(), nwg)
+        L.check(lib.mi_conv_wgrad(C.byref(p), L.current_stream()), "mi_conv_wgrad")
+        outs.append((dw.cpu(), db.cpu()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    tol = 2e-6 * (B * H * W) ** 0.5 * 4          # fp32 accumulation over B*H*W products of unit-variance factors
+    assert (outs[0][0].double() - w.grad).abs().max() < tol and (outs[0][1].double() - b.grad).abs().max() < tol
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("shape", [(16, 8), (8, 24), (3, 8), (40, 16)])
+def test_pack_conv3_on_the_device_matches_the_host_packing(backend, shape):
+    """mi_pack_conv3 (the training path re-packs every weight after every optimiser step) writes the values packing.pack_conv_weight_rp /
+    pack_conv_weight write on the host, for a weight and for its adjoint"""
+    from minimagen_amd import _lib as L, packing as P, train_ops
+    dev = setup(backend)
+    lib = L.lib()
+    Cout, Cin = shape
+    w = (torch.randn(Cout, Cin, 3, 3, generator=torch.Generator().manual_seed(3)) * 0.07).to(dev)
+    exp = P.rp_weight_exponent(float(w.abs().max()))
+    for adjoint in (False, True):
+        pk = train_ops._Pack(w, exp, adjoint)
+        wl = w.flip(2, 3).transpose(0, 1).contiguous() if adjoint else w
+        assert torch.equal(pk.generic.cpu().reshape(-1), P.pack_conv_weight(wl.cpu(), lib.mi_conv_cout_tile(wl.shape[0])).reshape(-1))
+        if wl.shape[1] % 8 == 0:
+            frag, e = P.pack_conv_weight_rp(wl.cpu())
+            assert e == exp and torch.equal(pk.frag.cpu().reshape(-1), frag.reshape(-1))        # values (the host form writes -0 for dead taps)
+
+
+def _block_grads(blk, x, ss, gy, hip):
+    from minimagen_amd import train_ops
+    train_ops.FORCE, train_ops.ENABLED = hip, hip
+    try:
+        for t in list(blk.parameters()) + [x] + list(ss or ()):
+            t.grad = None
+        y = blk(x, ss)
+        y.backward(gy)
+        return [y.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in blk.parameters()] + [t.grad.clone() for t in (ss or ())]
+    finally:
+        train_ops.FORCE, train_ops.ENABLED = False, True
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("case", [(8, 16, 16, 32, True), (16, 8, 9, 12, False), (24, 3, 8, 8, True), (3, 8, 8, 16, False), (8, 8, 64, 64, True),
+                                  (128, 64, 16, 16, True)])
+def test_block_function_gradients(backend, case):
+    """Block (layers.py:131-145) through train_ops._BlockFn -- fused HIP forward, HIP data gradient (the forward kernel on the adjoint
+    weights), mi_conv_wgrad, recomputed pointwise part -- against the same module on torch ops: output and the gradients of the input,
+    GroupNorm affine, conv weight / bias and the scale / shift, on the row-paired kernels (narrow and wide) and the direct-conv family"""
+    from minimagen_amd.layers import Block
+    Cin, Cout, H, W, with_ss = case
+    if backend == "emu" and (H * W > 1024 or Cin > 64):
+        pytest.skip("emulator time")
+    dev = setup(backend)
+    torch.manual_seed(0)
+    blk = Block(Cin, Cout, groups=8 if Cin % 8 == 0 else 3).train().to(dev)
+    with torch.no_grad():
+        blk.groupnorm.weight.add_(0.3 * torch.randn(Cin, device=dev))
+        blk.groupnorm.bias.add_(0.2 * torch.randn(Cin, device=dev))
+    x = (torch.randn(2, Cin, H, W, device=dev) * 1.5 + 0.2).requires_grad_()
+    ss = tuple((torch.randn(2, Cin, 1, 1, device=dev) * 0.3).requires_grad_() for _ in range(2)) if with_ss else None
+    gy = torch.randn(2, Cout, H, W, device=dev) * 1e-3                # loss gradients are small: the data-gradient conv range-scales them
+    ref = _block_grads(blk, x, ss, gy, False)
+    got = _block_grads(blk, x, ss, gy, True)
+    for a, b in zip(got, ref):
+        assert (a - b).abs().max() <= 2e-5 * max(1e-6, float(b.abs().max())), (case, float((a - b).abs().max()), float(b.abs().max()))
+
+
+def _unet_loss_grads(im, imgs, emb, mask, hip, unet_number):
+    from minimagen_amd import train_ops
+    train_ops.FORCE, train_ops.ENABLED = hip, hip
+    try:
+        im.zero_grad(set_to_none=True)
+        torch.manual_seed(11)                                           # the same timesteps / noise / dropout mask on both paths
+        loss = im(imgs, text_embeds=emb, text_masks=mask, unet_number=unet_number)
+        loss.backward()
+        return loss.item(), {n: p.grad.clone() for n, p in im.unets[unet_number - 1].named_parameters()}
+    finally:
+        train_ops.FORCE, train_ops.ENABLED = False, True
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_training_step_on_the_device_path_equals_the_torch_op_path(backend):
+    """Imagen.forward -> loss.backward() with every Block / Upsample conv / final_conv of the U-Net on the HIP kernels (forward, data
+    gradient, weight gradient) against the torch-op graph whose loss and gradients test_imagen_forward_matches_the_reference_loss pins
+    on the unmodified reference: base U-Net and the lowres-conditioned SR U-Net of a cascade"""
+    dev = setup(backend)
+    torch.manual_seed(7)
+    size = (16, 32) if backend == "emu" else (32, 64)
+    im = Imagen((Unet(**BASE), Unet(**SR)), text_encoder_name="t5_small", image_sizes=size, timesteps=60).train().to(dev)
+    imgs = torch.rand(2, 3, size[1] + 8, size[1] + 8, device=dev)
+    emb, mask = R.synthetic_text(2, length=11, seed=5)
+    emb, mask = emb.to(dev), mask.to(dev)
+    for n in (1, 2):
+        la, ga = _unet_loss_grads(im, imgs, emb, mask, False, n)
+        lb, gb = _unet_loss_grads(im, imgs, emb, mask, True, n)
+        assert abs(la - lb) < 1e-5 * max(1.0, abs(la)), (la, lb)
+        for name, g in ga.items():
+            assert (gb[name] - g).abs().max() < 1e-4 * max(1e-3, float(g.abs().max())), (n, name, float((gb[name] - g).abs().max()), float(g.abs().max()))
+
+
+_GRAD_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from minimagen_amd.Imagen import Imagen
+from minimagen_amd.Unet import Unet
+from minimagen_amd.distributed import allreduce_gradients, shard_bounds
+from oracle import restated as R
+rank = int(sys.argv[3])
+dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{sys.argv[2]}", rank=rank, world_size=2)
+torch.manual_seed(3)
+im = Imagen((Unet(dim=8, dim_mults=(1, 2), num_resnet_blocks=1, layer_attns=False, layer_cross_attns=False),), text_encoder_name="t5_small",
+            image_sizes=(16,), timesteps=40, cond_drop_prob=0.).train()
+B = 4
+imgs = torch.rand(B, 3, 16, 16)
+emb, mask = R.synthetic_text(B, length=7, seed=2)
+t_all = torch.randint(0, 40, (B,), generator=torch.Generator().manual_seed(5))
+noise = torch.randn(B, 3, 16, 16, generator=torch.Generator().manual_seed(6))
+def loss_of(rows):
+    # the per-sample objective of Imagen._p_losses with fixed timesteps / noise (so that shards and the whole batch see the same draws)
+    x0 = imgs[rows] * 2 - 1
+    nd = im.noise_schedulers[0]
+    xt = nd.q_sample(x0, t_all[rows], noise[rows])
+    pred = im.unets[0](xt, t_all[rows], text_embeds=emb[rows], text_mask=mask[rows], cond_drop_prob=0.)
+    return ((pred - noise[rows]) ** 2).mean(dim=(1, 2, 3))
+lo, hi = shard_bounds(B, 2, rank)
+im.zero_grad(set_to_none=True)
+(loss_of(slice(lo, hi)).sum() / (hi - lo)).backward()
+n = allreduce_gradients(im.unets[0].parameters(), bucket_mb=0.01)          # several buckets
+assert n > 1
+mine = [p.grad.clone() for p in im.unets[0].parameters()]
+im.zero_grad(set_to_none=True)
+loss_of(slice(0, B)).mean().backward()
+for g, p in zip(mine, im.unets[0].parameters()):
+    assert (g - p.grad).abs().max() < 1e-6 * max(1.0, float(p.grad.abs().max())), "averaged shard gradients differ from the full-batch gradient"
+dist.barrier()
+dist.destroy_process_group()
+print("ok")
+'''
+
+
+def test_allreduce_gradients_world_size_2_gloo(tmp_path):
+    """data-parallel training step on two ranks: each differentiates its contiguous shard, allreduce_gradients (bucketed, averaged) leaves
+    every rank with the gradient of the whole batch"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "g.py"
+    script.write_text(_GRAD_WORKER)
+    port = str(33500 + os.getpid() % 2000)
+    procs = [subprocess.Popen([sys.executable, str(script), root, port, str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
