@@ -133,29 +133,36 @@ __global__ __launch_bounds__(256) void conv_wgrad_partial_kernel(WgradArgs p) {
     }
 }
 
+// 16 output elements x 16 slices of the partials per workgroup: every thread adds its slice in a fixed order, then a fixed-order LDS tree
 __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* partial, const float* partial_db, float* dw, float* db, int Cin, int Cout,
                                                                 int nciB, int ncoB, int nwg) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
+    __shared__ float red[16][17];
+    const int e16 = threadIdx.x & 15, slice = threadIdx.x >> 4;
+    const int idx = blockIdx.x * 16 + e16;
     const int nw = Cout * Cin * 9;
+    float s = 0.f;
     if (idx < nw) {
         const int tap = idx % 9, ci = (idx / 9) % Cin, co = idx / (9 * Cin);
         const long long blk = (long long)(co / 16) * nciB + ci / 16, e = tap * 256 + (co % 16) * 16 + ci % 16;
         const long long stride = (long long)ncoB * nciB * WG_BLK;
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        int w = 0;
-        for (; w + 4 <= nwg; w += 4) {
-            s0 += partial[(w + 0) * stride + blk * WG_BLK + e];
-            s1 += partial[(w + 1) * stride + blk * WG_BLK + e];
-            s2 += partial[(w + 2) * stride + blk * WG_BLK + e];
-            s3 += partial[(w + 3) * stride + blk * WG_BLK + e];
-        }
-        for (; w < nwg; ++w) s0 += partial[w * stride + blk * WG_BLK + e];
-        dw[idx] = (s0 + s1) + (s2 + s3);
+        const float* src = partial + blk * WG_BLK + e;
+        float s0 = 0.f, s1 = 0.f;
+        int w = slice;
+        for (; w + 16 < nwg; w += 32) { s0 += src[w * stride]; s1 += src[(w + 16) * stride]; }
+        if (w < nwg) s0 += src[w * stride];
+        s = s0 + s1;
     } else if (db != nullptr && idx < nw + Cout) {
         const int co = idx - nw;
-        float s = 0.f;
-        for (int w = 0; w < nwg; ++w) s += partial_db[((long long)w * ncoB + co / 16) * 16 + co % 16];
-        db[co] = s;
+        for (int w = slice; w < nwg; w += 16) s += partial_db[((long long)w * ncoB + co / 16) * 16 + co % 16];
+    }
+    red[slice][e16] = s;
+    __syncthreads();
+    if (slice == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][e16];
+        if (idx < nw) dw[idx] = t;
+        else if (db != nullptr && idx < nw + Cout) db[idx - nw] = t;
     }
 }
 
@@ -188,7 +195,7 @@ extern "C" int mi_conv_wgrad(const mi_conv_wgrad_params* q, void* stream) {
     int rc = mi_check_launch("conv_wgrad_partial_kernel");
     if (rc) return rc;
     const int n = q->Cout * q->Cin * 9 + (q->db ? q->Cout : 0);
-    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)q->partial, (const float*)p.partial_db, q->dw, q->db,
+    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((n + 15) / 16), dim3(256), 0, st, (const float*)q->partial, (const float*)p.partial_db, q->dw, q->db,
                        q->Cin, q->Cout, p.nciB, p.ncoB, q->nwg);
     return mi_check_launch("conv_wgrad_reduce_kernel");
 }

@@ -3,7 +3,7 @@
 //   channel_stats_kernel      per-(image, channel) sum and sum of squares of a tensor no HIP producer left statistics for
 //   block_bwd_sums_kernel     U = sum g * xhat, V = sum g over a (image, channel) row chunk, g = dA * silu'(y2)          (reads x, dA)
 //   block_bwd_apply_kernel    dx = rstd * (k * g - mean_g(dxhat) - xhat * mean_g(dxhat * xhat))                      (reads x, dA)
-//   block_bwd_params_kernel   dgamma, dbeta, dscale, dshift from U, V
+//   block_bwd_params_kernel   dgamma, dbeta, dscale, dshift from U, V (one wave per channel)
 //   pack_conv3_kernel         a 3x3 conv weight (or its adjoint) -> row-paired fp16 hi|lo fragments + the direct-conv layout, on the device
 // with y1 = gamma * xhat + beta, y2 = y1 * (scale + 1) + shift, a = silu(y2), k = gamma * (scale + 1).
 #include "common.hip.h"
@@ -117,13 +117,13 @@ __global__ __launch_bounds__(256) void block_bwd_apply_kernel(mi_block_bwd_param
     }
 }
 
-// one thread per channel
+// one wave per channel: lanes stride over the (image, chunk) pairs, fixed-order shuffle tree
 __global__ __launch_bounds__(256) void block_bwd_params_kernel(mi_block_bwd_params p) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c >= p.C) return;
     const float ga = p.gamma[c], be = p.beta[c];
     double dg = 0.0, db = 0.0;
-    for (int b = 0; b < p.B; ++b) {
+    for (int b = lane; b < p.B; b += 64) {
         double U = 0.0, V = 0.0;
         const float* uv = p.uv + ((size_t)b * p.C + c) * p.nchunk * 2;
         for (int j = 0; j < p.nchunk; ++j) { U += (double)uv[2 * j]; V += (double)uv[2 * j + 1]; }
@@ -136,8 +136,9 @@ __global__ __launch_bounds__(256) void block_bwd_params_kernel(mi_block_bwd_para
         dg += (double)sc1 * U;
         db += (double)sc1 * V;
     }
-    p.dgamma[c] = (float)dg;
-    p.dbeta[c] = (float)db;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { dg += __shfl_xor(dg, o); db += __shfl_xor(db, o); }
+    if (lane == 0) { p.dgamma[c] = (float)dg; p.dbeta[c] = (float)db; }
 }
 
 constexpr int PK_PERM[4] = {0, 2, 1, 3};        // packing.RP_PERM
@@ -200,7 +201,7 @@ extern "C" int mi_block_bwd(const mi_block_bwd_params* q, void* stream) {
     hipLaunchKernelGGL(block_bwd_apply_kernel, grid, dim3(256), 0, st, p);
     rc = mi_check_launch("block_bwd_apply_kernel");
     if (rc) return rc;
-    hipLaunchKernelGGL(block_bwd_params_kernel, dim3((p.C + 255) / 256), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(block_bwd_params_kernel, dim3((p.C + 3) / 4), dim3(256), 0, st, p);
     return mi_check_launch("block_bwd_params_kernel");
 }
 
