@@ -273,43 +273,6 @@ def timed_calls(im, emb, mask, cond_scale, precision, calls, warmup, pipelined, 
     return (time.perf_counter() - t0) / calls
 
 
-def lanes_leg(args, dev):
-    """`--lanes L`: L independent sample() calls of --batch rows each kept in flight on one GPU (L Imagen instances sharing one set of
-    weights: separate stage streams, workspaces and captured graphs), every lane pipelined across its own calls.  The kernels of two lanes'
-    super-resolution stages fill each other's launch floors and tails.  Value-checked: lane i's output must equal the
-    same call made alone.  Prints its own JSON line; a serving-side figure, never the headline."""
-    Ln, B, T = args.lanes, args.batch, args.timesteps
-    ims = []
-    for i in range(Ln):
-        im, sizes = build_imagen(args.workload, T, dev)
-        if ims:
-            im.load_state_dict(ims[0].state_dict())
-        ims.append(im)
-    parts = []
-    for i in range(Ln):
-        e, m = synthetic_text(B, row0=i * B)
-        parts.append((e.to(dev), m.to(dev)))
-    kw = dict(cond_scale=args.cond_scale, _precision=args.precision)
-
-    def run(seed, pipelined=True):
-        return [ims[i].sample(text_embeds=parts[i][0], text_masks=parts[i][1], _seed=seed, _sample_offset=i * B, _async=pipelined, **kw) for i in range(Ln)]
-    alone = [o.clone() for o in run(7, False)]
-    torch.cuda.synchronize()
-    for k in range(args.warmup):
-        run(k)
-    got = run(7)
-    torch.cuda.synchronize()
-    same = all(bool(torch.equal(a, b)) for a, b in zip(alone, got))
-    assert same, "calls in flight side by side differ from the same calls made alone"
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        run(100 + k)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / args.steps
-    print(json.dumps({"lanes": Ln, "per_call_batch": B, "value": Ln * B * T * len(sizes) / dt, "unit": "denoising-steps/s", "ms_per_round_of_calls": dt * 1e3,
-                      "images_per_s": Ln * B / dt, "equals_calls_made_alone": same, "steps": args.steps, "warmup": args.warmup}))
-
-
 def secondary_lines(timesteps, cond_scale):
     """The other single-GPU BASELINE.json configurations as extra keys of the driver line, each timed by the main loop of THIS script in a
     fresh process (3 warm-up calls, then 8 / 8 / 3 timed sample() calls, pipelined; plus the same calls one at a time): config 2 (base 64^2,
@@ -338,11 +301,6 @@ def secondary_lines(timesteps, cond_scale):
                     "denoising_steps_per_s_no_pipeline": j.get("value_no_pipeline"), "ms_per_sample_call_no_pipeline": j.get("ms_per_step_no_pipeline"),
                     "pipelined_equals_synchronous": j.get("pipelined_equals_synchronous"), "timed_calls": calls, "per_gpu_batch": n_img,
                     "precision": precision, "image_sizes": {"base64": [64], "cascade64_256": [64, 256], "cascade64_256_1024": [64, 256, 1024]}[workload]}
-    # the headline workload with TWO independent calls kept in flight (a serving-side figure: same B=32 calls, two lanes)
-    cmd = [sys.executable, os.path.abspath(__file__), "--lanes", "2", "--steps", "6", "--warmup", "2", "--timesteps", str(timesteps), "--cond-scale", str(cond_scale)]
-    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    out["headline_workload_two_calls_in_flight"] = json.loads(lines[-1]) if (r.returncode == 0 and lines) else {"error": (r.stderr or r.stdout)[-400:]}
     return out
 
 
@@ -367,7 +325,8 @@ def main():
                     help="STRONG scaling (BASELINE config 4: fixed total batch, e.g. 128, sharded over the ranks; overrides --batch). "
                          "Default 0 = weak scaling with --batch rows per GPU")
     ap.add_argument("--breakdown-out", default="")
-    ap.add_argument("--lanes", type=int, default=1, help="N=1 only: keep this many independent sample() calls of --batch rows in flight (lanes_leg); prints its own line")
+    ap.add_argument("--lanes", type=int, default=0, help="independent call lanes of the pipelined mode (sets of stage streams / workspaces / graphs that "
+                    "sample(_async=True) alternates between; 0 = the library default MINIMAGEN_SAMPLE_LANES = 2, 1 = one lane: only the stages of successive calls overlap)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -393,9 +352,9 @@ def main():
     from minimagen_amd import _lib as L
     from minimagen_amd.distributed import gather_samples, shard_bounds
     L.use_library(L.DEFAULT_LIB)
-    if args.lanes > 1:
-        assert world == 1, "--lanes is a single-GPU leg"
-        return lanes_leg(args, dev)
+    import minimagen_amd.Imagen as MI
+    if args.lanes > 0:
+        MI.SAMPLE_LANES = args.lanes
     im, sizes = build_imagen(args.workload, args.timesteps, dev)
     strong = args.global_batch > 0
     if strong:
@@ -473,10 +432,17 @@ def main():
         del ref_out, chk
     dt, mine, out = timed(args.steps, pipelined)
     assert torch.isfinite(out).all() and out.shape[0] == gB
-    dt_sync = None
+    dt_sync = dt_one = None
     if pipelined:                       # the reference's sample() is synchronous: report that mode beside the pipelined headline
         dt_sync, _, _ = timed(max(2, min(args.steps, 8)), False)
         dt_sync /= max(2, min(args.steps, 8))
+        if MI.SAMPLE_LANES > 1:         # ... and the pipelined mode with ONE lane (stage overlap of successive calls only)
+            lanes = MI.SAMPLE_LANES
+            MI.SAMPLE_LANES = 1
+            one_step(90, True); one_step(91, True)
+            dt_one, _, _ = timed(max(2, min(args.steps, 8)), True)
+            dt_one /= max(2, min(args.steps, 8))
+            MI.SAMPLE_LANES = lanes
     per_rank = None
     gather_ms = None
     if world > 1:
@@ -508,9 +474,10 @@ def main():
                       if args.precision == "fp32" else "half-precision matrix-core contractions (single fp16 term)"),
                    "per_gpu_batch": B if not strong else f"{gB}/{world} (fixed global batch, contiguous shards)", "global_batch": gB,
                    "timesteps": args.timesteps, "parallelism": f"dp{world}",
-                   "call_mode": ("successive sample() calls PIPELINED across the per-stage HIP streams (_async=True: the base stage of call k+1 runs under "
-                                 "the super-resolution stage of call k; outputs bit-identical to synchronous calls, checked in this run); "
-                                 "value_no_pipeline = the same calls one at a time, the reference's synchronous semantics") if pipelined
+                   "call_mode": (f"successive sample() calls PIPELINED (_async=True) over {MI.SAMPLE_LANES} call lane(s) of per-stage HIP streams: "
+                                 "two calls are in flight side by side and the base stage of a call runs under the super-resolution stage of the one "
+                                 "before it; outputs bit-identical to synchronous calls, checked in this run; value_one_lane = stage overlap of "
+                                 "successive calls only (round 2's mode), value_no_pipeline = the same calls one at a time, the reference's synchronous semantics") if pipelined
                                 else "synchronous sample() calls, one at a time (the reference's semantics)"},
         "images_per_s": gB * args.steps / dt,
         "pipelined": pipelined,
@@ -519,6 +486,10 @@ def main():
         res["pipelined_equals_synchronous"] = pipe_ok
         res["value_no_pipeline"] = gB * steps_per_sample / dt_sync
         res["ms_per_step_no_pipeline"] = dt_sync * 1e3
+        res["lanes"] = MI.SAMPLE_LANES
+        if dt_one is not None:
+            res["value_one_lane"] = gB * steps_per_sample / dt_one
+            res["ms_per_step_one_lane"] = dt_one * 1e3
     if world > 1:
         res["per_rank"] = [dict(r, denoising_steps_per_s=r["rows"] * steps_per_sample * args.steps / r["seconds"]) for r in per_rank]
         res["all_gather_ms"] = gather_ms

@@ -18,6 +18,8 @@ from .helpers import (cast_tuple, cubic_taps, default, eval_decorator, exists, m
                       resize_image_to)
 from .t5 import get_encoded_dim, t5_encode_text
 
+SAMPLE_LANES = max(1, int(os.environ.get("MINIMAGEN_SAMPLE_LANES", "2")))     # independent call lanes of sample(_async=True)
+
 
 class Imagen(nn.Module):
     """minimagen/Imagen.py:22-131."""
@@ -348,15 +350,23 @@ class Imagen(nn.Module):
         on_gpu = L.backend() == "hip-gfx950"
         for unet in self.unets:
             unet.engine().pack()                         # validate / refresh the packed weights once per call, on the caller's stream
+        # LANES: asynchronous calls alternate between SAMPLE_LANES independent sets of (stage streams, workspaces, graphs), so that two
+        # calls are in flight side by side -- the kernels of one call's stages fill the launch floors and tails of the other's (measured:
+        # 42.8 K vs 37.7 K steps/s for the B = 32 cascade).  Calls on one lane stay ordered by its streams; lanes share
+        # only read-only state (weights, tables).  Synchronous calls use lane 0.
+        lane = 0
+        if _async and on_gpu and SAMPLE_LANES > 1:
+            lane = self._lane_rr = (getattr(self, "_lane_rr", -1) + 1) % SAMPLE_LANES
         if on_gpu:
-            streams = getattr(self, "_stage_streams", None)
-            if streams is None or len(streams) != len(self.unets) or streams[0].device != device:
+            all_streams = getattr(self, "_stage_streams", None)
+            if all_streams is None or len(all_streams[0]) != len(self.unets) or all_streams[0][0].device != device or len(all_streams) != max(1, SAMPLE_LANES):
                 # earlier (smaller-image, latency-bound) stages get the higher stream priority: their short kernels then slot in between the
                 # workgroups of the later stages' large ones instead of queueing behind them
                 prio = int(os.environ.get("MINIMAGEN_STAGE_PRIORITY", "1"))
-                streams = self._stage_streams = [torch.cuda.Stream(device=device, priority=(-1 if (prio and k + 1 < len(self.unets)) else 0))
-                                                 for k in range(len(self.unets))]
-            self._stream = streams[-1]                   # (benchmarks time the last stage's captured graph on its own stream)
+                all_streams = self._stage_streams = [[torch.cuda.Stream(device=device, priority=(-1 if (prio and k + 1 < len(self.unets)) else 0))
+                                                      for k in range(len(self.unets))] for _ in range(max(1, SAMPLE_LANES))]
+            streams = all_streams[lane]
+            self._stream = all_streams[0][-1]            # (benchmarks time the last stage's captured graph on its own stream)
             caller_stream = torch.cuda.current_stream(device)
             inputs_ready = caller_stream.record_event()
         from .helpers import null_context
@@ -378,7 +388,7 @@ class Imagen(nn.Module):
                 eng = unet.engine()
                 # per call, never sticky engine state: a later Unet.forward stays on the engine's default precision
                 ws = eng.workspace(batch_size, B2, image_size, image_size,
-                                   precision=_precision if _precision is not None else os.environ.get("MINIMAGEN_PRECISION", "fp32"))
+                                   precision=_precision if _precision is not None else os.environ.get("MINIMAGEN_PRECISION", "fp32"), lane=lane)
                 eng.set_text(ws, text_embeds, text_masks, keep)
                 if unet.lowres_cond:
                     if on_gpu:

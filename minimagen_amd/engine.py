@@ -244,12 +244,14 @@ class UnetEngine:
         host behind that stage's queued work)."""
         return self._pack if self._pack is not None else self.pack()
 
-    def workspace(self, B: int, B2: int, H: int, W: int, precision: Optional[str] = None, has_text: bool = True) -> Workspace:
+    def workspace(self, B: int, B2: int, H: int, W: int, precision: Optional[str] = None, has_text: bool = True, lane: int = 0) -> Workspace:
+        """``lane``: independent workspaces (buffers, step tables, captured graphs) of one shape, so that two sample() calls can be in
+        flight side by side (Imagen.sample(_async=True) alternates lanes)"""
         pk = self.packed()
         dev = next(self.unet.parameters()).device
         precision = self.precision if precision is None else precision
         assert precision in ("fp32", "half"), precision
-        key = (B, B2, H, W, str(dev), precision, has_text)
+        key = (B, B2, H, W, str(dev), precision, has_text) + ((lane,) if lane else ())
         ws = self._ws.get(key)
         if ws is not None:
             return ws
