@@ -445,6 +445,21 @@ int mi_chan_stats_fwd(const float* x, float* stats, int rows, int HW, void* stre
 long long mi_pack_conv3_floats(int Cout, int Cin, int adjoint, int cout_pad, int which);
 int mi_pack_conv3(const float* w, int Cout, int Cin, int adjoint, int exp, void* frag, float* generic, int cout_pad, void* stream);
 
+/* weight / bias gradients of CrossEmbedLayer (layers.py:254-305; the first layer: no data gradient is needed): one correlation over the
+ * largest member's taps serves every member (a smaller member's gradient is the centre window of its channels), split-K on the fp32
+ * matrix-core instruction, partials added in a fixed order.  Kernel sizes odd and <= 15, <= 16 output channels in all, Cin * kmax <= 96. */
+typedef struct mi_crossembed_wgrad_params {
+    int B, Cin, H, W;
+    const float* x;                 /* [B][Cin][H][W]: the layer's input (image | low-res conditioning image) */
+    const float* dy;                /* [B][sum cout][H][W] */
+    int n_kernels; int ksize[3]; int cout[3];
+    float* dw[3];                   /* [cout_i][Cin][k_i][k_i] */
+    float* db[3];                   /* [cout_i] or NULL */
+    float* partial; int nwg;        /* mi_crossembed_wgrad_workspace(Cin, kmax, nwg) floats; workgroups walking the pixel tiles (e.g. 256) */
+} mi_crossembed_wgrad_params;
+long long mi_crossembed_wgrad_workspace(int Cin, int kmax, int nwg);
+int mi_crossembed_wgrad(const mi_crossembed_wgrad_params* p, void* stream);
+
 /* ---- HIP graphs: capture a sequence of the calls above once, replay it per timestep ------- */
 int mi_graph_begin(void* stream);
 int mi_graph_end(void* stream, void** graph_exec);

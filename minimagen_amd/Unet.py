@@ -245,9 +245,11 @@ class Unet(nn.Module):
             c = torch.cat((tokens, text_tokens), dim=-2)
         c = self.norm_cond(c)
         # ---- trunk (Unet.py:396-472)
-        if self.lowres_cond:
-            x = torch.cat((x, lowres_cond_img), dim=1)
-        x = self.init_conv(x)
+        lowres = lowres_cond_img if self.lowres_cond else None
+        if dev_path and train_ops.crossembed_supported(self.init_conv, x, lowres):
+            x = train_ops.crossembed_forward(self.init_conv, x, lowres)       # matrix-core forward, shared-correlation weight gradient
+        else:
+            x = self.init_conv(torch.cat((x, lowres), dim=1) if self.lowres_cond else x)
         hiddens = []
         for pre, first, blocks, attn, post in self.downs:
             if exists(pre):

@@ -153,9 +153,15 @@ class MiBlockBwdParams(C.Structure):
                 ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("dss", C.c_void_p)]
 
 
+class MiCrossEmbedWgradParams(C.Structure):
+    _fields_ = [("B", C.c_int), ("Cin", C.c_int), ("H", C.c_int), ("W", C.c_int), ("x", C.c_void_p), ("dy", C.c_void_p),
+                ("n_kernels", C.c_int), ("ksize", C.c_int * 3), ("cout", C.c_int * 3), ("dw", C.c_void_p * 3), ("db", C.c_void_p * 3),
+                ("partial", C.c_void_p), ("nwg", C.c_int)]
+
+
 _STRUCTS = {0: MiAct, 1: MiConvParams, 2: MiCrossEmbedParams, 3: MiLinear, 4: MiTextCondParams, 5: MiCondStepParams,
             6: MiAttnFoldParams, 7: MiCrossAttnParams, 8: MiCfgX0Params, 9: MiQuantileParams, 10: MiPosteriorParams,
-            11: MiResizeParams, 12: MiSelfAttnParams, 13: MiChanFFParams, 14: MiFlashAttnParams, 15: MiTokensToNchwParams, 16: MiConvWgradParams, 17: MiBlockBwdParams}
+            11: MiResizeParams, 12: MiSelfAttnParams, 13: MiChanFFParams, 14: MiFlashAttnParams, 15: MiTokensToNchwParams, 16: MiConvWgradParams, 17: MiBlockBwdParams, 18: MiCrossEmbedWgradParams}
 
 _lib = None
 _backend = None
@@ -173,7 +179,7 @@ def _bind(lib):
     vp, i32, i64, u64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float
     for name in ("mi_conv_fwd", "mi_gn_coef_fwd", "mi_crossembed_fwd", "mi_text_cond_fwd", "mi_cond_step_fwd", "mi_attn_fold_rows", "mi_cross_attn_fwd",
                  "mi_cfg_x0_fwd", "mi_quantile_fwd", "mi_posterior_fwd", "mi_resize_fwd", "mi_self_attn_fwd", "mi_chan_ff_fwd",
-                 "mi_flash_attn_fwd", "mi_tokens_to_nchw_fwd", "mi_conv_wgrad", "mi_block_bwd"):
+                 "mi_flash_attn_fwd", "mi_tokens_to_nchw_fwd", "mi_conv_wgrad", "mi_block_bwd", "mi_crossembed_wgrad"):
         getattr(lib, name).argtypes = [vp, vp]
         getattr(lib, name).restype = i32
     lib.mi_step_advance.argtypes = [vp, vp, i32, vp]
@@ -198,6 +204,8 @@ def _bind(lib):
     lib.mi_conv_cout_tile.argtypes = [i32]
     lib.mi_conv_wgrad_workspace.argtypes = [i32, i32, i32]
     lib.mi_conv_wgrad_workspace.restype = C.c_longlong
+    lib.mi_crossembed_wgrad_workspace.argtypes = [i32, i32, i32]
+    lib.mi_crossembed_wgrad_workspace.restype = C.c_longlong
     lib.mi_chan_stats_fwd.argtypes = [vp, vp, i32, i32, vp]
     lib.mi_pack_conv3_floats.argtypes = [i32, i32, i32, i32, i32]
     lib.mi_pack_conv3_floats.restype = C.c_longlong

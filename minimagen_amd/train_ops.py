@@ -32,6 +32,7 @@ from . import packing as P
 ENABLED = os.environ.get("MINIMAGEN_TRAIN_HIP", "1") != "0"
 FORCE = False                   # tests: take the HIP path for host tensors too (emulator build of the kernels)
 WGRAD_NWG = int(os.environ.get("MINIMAGEN_WGRAD_NWG", "1024"))
+CE_WGRAD_NWG = int(os.environ.get("MINIMAGEN_CE_WGRAD_NWG", "512"))
 
 
 def active(x: torch.Tensor) -> bool:
@@ -256,6 +257,92 @@ class _ConvFn(torch.autograd.Function):
         if need[1] or (ctx.has_bias and need[2]):
             dw, db = _wgrad(x, dy, ctx.has_bias and need[2])
         return dx, (dw if need[1] else None), db
+
+
+def _ce_tables(convs, channels: int):
+    """Toeplitz fragment tables of the matrix-core CrossEmbed kernel (packing.pack_crossembed_mfma), one per input half, cached on the first
+    member's weight until any member is updated; ONE device->host copy of the (small) weights per optimiser step"""
+    key = tuple(c.weight._version for c in convs) + (str(convs[0].weight.device),)
+    cached = getattr(convs[0].weight, "_mi_ce_tables", None)
+    if cached is not None and cached[0] == key:
+        return cached[1]
+    dev = convs[0].weight.device
+    with torch.no_grad():
+        flat = torch.cat([c.weight.detach().reshape(-1) for c in convs]).cpu()
+    ws, off = [], 0
+    for c in convs:
+        n = c.weight.numel()
+        ws.append(flat[off:off + n].reshape(c.weight.shape))
+        off += n
+    tabs = {}
+    for chan0 in range(0, convs[0].in_channels, channels):
+        tab, exps = P.pack_crossembed_mfma(ws, chan0, channels)
+        tabs[chan0] = (tab.to(dev, non_blocking=True), exps)
+    convs[0].weight._mi_ce_tables = (key, tabs)
+    return tabs
+
+
+def crossembed_supported(layer, x: torch.Tensor, lowres) -> bool:
+    """the matrix-core forward + the shared-correlation weight gradient cover the reference's configuration: kernel sizes (3, 7, 15),
+    dim_scales (4, 2, 2), stride 1, <= 4 image channels per half, W % 4 == 0; the input must not need a gradient (it is the first layer)"""
+    cv = layer.convs
+    return (active(x) and layer.stride == 1 and [c.kernel_size[0] for c in cv] == [3, 7, 15] and [c.out_channels for c in cv] == [4, 2, 2]
+            and x.shape[1] <= 4 and x.shape[3] % 4 == 0 and not x.requires_grad and (lowres is None or (not lowres.requires_grad and lowres.shape == x.shape))
+            and cv[0].in_channels == x.shape[1] * (2 if lowres is not None else 1) and all(c.bias is not None for c in cv))
+
+
+class _CrossEmbedFn(torch.autograd.Function):
+    """CrossEmbedLayer (layers.py:298-305) of the image (| low-res conditioning image): forward on the matrix-core Toeplitz kernel (one launch
+    per input half, the second as addend of the first), weight / bias gradients by mi_crossembed_wgrad"""
+
+    @staticmethod
+    def forward(ctx, x, lowres, tabs, w0, b0, w1, b1, w2, b2):
+        lib = L.lib()
+        x = x.contiguous()
+        B, Cc, H, W = x.shape
+        ws_, bs_ = (w0, w1, w2), (b0, b1, b2)
+        cfg = 8 if H * W >= 128 * 128 else 9
+        out = torch.empty(B, 8, H, W, dtype=torch.float32, device=x.device)
+        halves = [(x, 0)] + ([(lowres.contiguous(), Cc)] if lowres is not None else [])
+        addend = None
+        for src, chan0 in reversed(halves):             # the low-res half first (no bias), then the image half adds it and the biases
+            dst = out if chan0 == 0 else torch.empty_like(out)
+            p = L.MiCrossEmbedParams()
+            p.B, p.H, p.W, p.in0, p.C0, p.n_kernels = B, H, W, src.data_ptr(), Cc, 3
+            tab, exps = tabs[chan0]
+            for i in range(3):
+                p.ksize[i], p.cout[i], p.w_mfma_exp[i] = ws_[i].shape[-1], ws_[i].shape[0], exps[i]
+                p.bias[i] = bs_[i].data_ptr() if chan0 == 0 else 0
+            p.w_mfma, p.out, p.tile_cfg, p.addend = tab.data_ptr(), dst.data_ptr(), cfg, L.ptr(addend)
+            L.check(lib.mi_crossembed_fwd(C.byref(p), L.current_stream()), "mi_crossembed_fwd (training)")
+            addend = dst
+        ctx.save_for_backward(x if lowres is None else torch.cat((x, lowres), 1))
+        ctx.shapes = [w.shape for w in ws_]
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = L.lib()
+        (xin,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        B, Cin, H, W = xin.shape
+        tiles = B * (-(-H // 8)) * (-(-W // 32))
+        nwg = max(1, min(tiles, CE_WGRAD_NWG))
+        part = torch.empty(lib.mi_crossembed_wgrad_workspace(Cin, 15, nwg), dtype=torch.float32, device=xin.device)
+        dws = [torch.empty(sh, dtype=torch.float32, device=xin.device) for sh in ctx.shapes]
+        dbs = [torch.empty(sh[0], dtype=torch.float32, device=xin.device) for sh in ctx.shapes]
+        p = L.MiCrossEmbedWgradParams()
+        p.B, p.Cin, p.H, p.W, p.x, p.dy, p.n_kernels, p.partial, p.nwg = B, Cin, H, W, xin.data_ptr(), dy.data_ptr(), 3, part.data_ptr(), nwg
+        for i in range(3):
+            p.ksize[i], p.cout[i], p.dw[i], p.db[i] = ctx.shapes[i][-1], ctx.shapes[i][0], dws[i].data_ptr(), dbs[i].data_ptr()
+        L.check(lib.mi_crossembed_wgrad(C.byref(p), L.current_stream()), "mi_crossembed_wgrad")
+        return None, None, None, dws[0], dbs[0], dws[1], dbs[1], dws[2], dbs[2]
+
+
+def crossembed_forward(layer, x: torch.Tensor, lowres) -> torch.Tensor:
+    cv = layer.convs
+    tabs = _ce_tables(cv, x.shape[1])
+    return _CrossEmbedFn.apply(x, lowres, tabs, cv[0].weight, cv[0].bias, cv[1].weight, cv[1].bias, cv[2].weight, cv[2].bias)
 
 
 def block_forward(block, x: torch.Tensor, scale_shift=None) -> torch.Tensor:

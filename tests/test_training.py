@@ -164,6 +164,45 @@ def test_pack_conv3_on_the_device_matches_the_host_packing(backend, shape):
             assert e == exp and torch.equal(pk.frag.cpu().reshape(-1), frag.reshape(-1))        # values (the host form writes -0 for dead taps)
 
 
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("case", [(2, 6, 16, 32, (3, 7, 15), (4, 2, 2), 3), (1, 3, 11, 40, (3, 7, 15), (4, 2, 2), 2), (1, 4, 9, 9, (3, 5), (6, 2), 1),
+                                  (2, 6, 64, 64, (3, 7, 15), (4, 2, 2), 64)])
+def test_crossembed_wgrad_kernel(backend, case):
+    """mi_crossembed_wgrad: one K x K correlation for all members of a CrossEmbedLayer (the smaller kernels' gradients are centre windows)
+    against torch autograd in fp64; ragged tiles, fewer workgroups than tiles, other member sets, run-to-run bit equality"""
+    import ctypes as C
+    import torch.nn.functional as F
+    from minimagen_amd import _lib as L
+    B, Cin, H, W, ks, cs, nwg = case
+    if backend == "emu" and H * W > 1024:
+        pytest.skip("emulator time")
+    dev = setup(backend)
+    lib = L.lib()
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    ws = [torch.zeros(c, Cin, k, k, dtype=torch.float64, requires_grad=True) for k, c in zip(ks, cs)]
+    bs = [torch.zeros(c, dtype=torch.float64, requires_grad=True) for c in cs]
+    y = torch.cat([F.conv2d(x.double(), w, b, padding=k // 2) for w, b, k in zip(ws, bs, ks)], 1)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy.double())
+    xd, dyd = x.to(dev), dy.to(dev)
+    runs = []
+    for rep in range(2):
+        part = torch.full((lib.mi_crossembed_wgrad_workspace(Cin, max(ks), nwg),), float('nan'), device=dev)
+        dws = [torch.full(w.shape, float('nan'), device=dev) for w in ws]
+        dbs = [torch.full(b.shape, float('nan'), device=dev) for b in bs]
+        p = L.MiCrossEmbedWgradParams()
+        p.B, p.Cin, p.H, p.W, p.x, p.dy, p.n_kernels, p.partial, p.nwg = B, Cin, H, W, xd.data_ptr(), dyd.data_ptr(), len(ks), part.data_ptr(), nwg
+        for i in range(len(ks)):
+            p.ksize[i], p.cout[i], p.dw[i], p.db[i] = ks[i], cs[i], dws[i].data_ptr(), dbs[i].data_ptr()
+        L.check(lib.mi_crossembed_wgrad(C.byref(p), L.current_stream()), "mi_crossembed_wgrad")
+        runs.append([t.cpu() for t in dws + dbs])
+    assert all(torch.equal(a, b) for a, b in zip(*runs))
+    tol = 2e-6 * (B * H * W) ** 0.5 * 4
+    for got, ref in zip(runs[0], [w.grad for w in ws] + [b.grad for b in bs]):
+        assert (got.double() - ref).abs().max() < tol
+
+
 def _block_grads(blk, x, ss, gy, hip):
     from minimagen_amd import train_ops
     train_ops.FORCE, train_ops.ENABLED = hip, hip
