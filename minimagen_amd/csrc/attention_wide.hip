@@ -174,7 +174,10 @@ __global__ __launch_bounds__(64 * NW) void flash_attn_f16x3_kernel(const mi_flas
     const int srow = tid / PPR, sd0 = (tid % PPR) * EPT;
     const int spos = (srow & 32) | (((srow >> 2) & 3) << 3) | (((srow >> 4) & 1) << 2) | (srow & 3);
 
-    for (int j0 = 0; j0 < J; j0 += 64) {
+    // this work-item's piece of the K / V chunk starting at context row j0, straight from the fp32 tensors; the NEXT chunk's loads are issued
+    // right after the current one has been staged, so that they fly under the chunk's matrix-core work instead of in front of it
+    float kf[EPT], vf[EPT];
+    auto load_chunk = [&](int j0) {
         const int jj = j0 + srow;
         const float* ksrc = nullptr;
         const float* vsrc = nullptr;
@@ -183,8 +186,6 @@ __global__ __launch_bounds__(64 * NW) void flash_attn_f16x3_kernel(const mi_flas
             else if (jj - nnull < p.n0) { const size_t o_ = (size_t)b * p.bs0 + (size_t)(jj - nnull) * p.ld0 + kvh * D; ksrc = p.k0 + o_; vsrc = p.v0 + o_; }
             else { const size_t o_ = (size_t)b * p.bs1 + (size_t)(jj - nnull - p.n0) * p.ld1 + kvh * D; ksrc = p.k1 + o_; vsrc = p.v1 + o_; }
         }
-        float kf[EPT], vf[EPT];
-        float mk = 0.0f, mv = 0.0f;
 #pragma unroll
         for (int e = 0; e < EPT; e += 4) {
             float4 k4 = make_float4(0.f, 0.f, 0.f, 0.f), v4 = k4;
@@ -192,6 +193,10 @@ __global__ __launch_bounds__(64 * NW) void flash_attn_f16x3_kernel(const mi_flas
             kf[e] = k4.x; kf[e + 1] = k4.y; kf[e + 2] = k4.z; kf[e + 3] = k4.w;
             vf[e] = v4.x; vf[e + 1] = v4.y; vf[e + 2] = v4.z; vf[e + 3] = v4.w;
         }
+    };
+    load_chunk(0);
+    for (int j0 = 0; j0 < J; j0 += 64) {
+        float mk = 0.0f, mv = 0.0f;
 #pragma unroll
         for (int e = 0; e < EPT; ++e) { mk = fmaxf(mk, fabsf(kf[e])); mv = fmaxf(mv, fabsf(vf[e])); }
         mk = mi_wave_max(mk); mv = mi_wave_max(mv);
@@ -230,6 +235,7 @@ __global__ __launch_bounds__(64 * NW) void flash_attn_f16x3_kernel(const mi_flas
             }
         }
         __syncthreads();
+        if (j0 + 64 < J) load_chunk(j0 + 64);
         const float us = ldexpf(1.0f, -(ek + eq)), uv = ldexpf(1.0f, -ev);
         f32x4 s[4];
         float mx = -INFINITY;
