@@ -385,8 +385,11 @@ extern "C" int mi_flash_attn_fwd(const mi_flash_attn_params* p, void* stream) {
     static const bool exact = getenv("MI_FLASH_EXACT_F32") != nullptr;
     static const bool one_head = getenv("MI_FLASH_ONE_HEAD") != nullptr;
     if (exact) hipLaunchKernelGGL(flash_attn_kernel, dim3((p->HW + 63) / 64, p->heads, p->B), dim3(256), 0, (hipStream_t)stream, *p);
-    else if (p->kv_heads == 1 && (p->heads & 3) == 0 && !one_head)      // multi-query: four heads of the same 64 queries share every staged K / V chunk
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(flash_attn_f16x3_kernel<16>), dim3((p->HW + 63) / 64, p->heads / 4, p->B), dim3(1024), 0, (hipStream_t)stream, *p);
+    else if (p->kv_heads == 1 && (p->heads & 3) == 0 && !one_head) {    // multi-query: heads of the same 64 queries share every staged K / V chunk
+        static const int two_heads = getenv("MI_FLASH_TWO_HEADS") ? atoi(getenv("MI_FLASH_TWO_HEADS")) : 0;
+        if (two_heads) hipLaunchKernelGGL(HIP_KERNEL_NAME(flash_attn_f16x3_kernel<8>), dim3((p->HW + 63) / 64, p->heads / 2, p->B), dim3(512), 0, (hipStream_t)stream, *p);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(flash_attn_f16x3_kernel<16>), dim3((p->HW + 63) / 64, p->heads / 4, p->B), dim3(1024), 0, (hipStream_t)stream, *p);
+    }
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(flash_attn_f16x3_kernel<4>), dim3((p->HW + 63) / 64, p->heads, p->B), dim3(256), 0, (hipStream_t)stream, *p);
     return mi_check_launch("flash_attn_kernel");
 }
