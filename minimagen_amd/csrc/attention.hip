@@ -541,7 +541,8 @@ extern "C" int mi_cross_attn_fwd(const mi_cross_attn_params* pp, void* stream) {
     if (p.variant == 6 || p.variant == 7) {      // fp16 MFMA (fragments from mi_attn_fold_rows with frag_f16 = 1): 6 = 3-term split (fp32-grade), 7 = single term
         // waves per workgroup (measured on MI355X): 8 for the SR bottleneck (4096 tokens: 0.53 -> 0.47 ms per pair of launches),
         // 16 for up to 1024 tokens (base U-Net)
-        const int nwv = p.HW <= 1024 ? 16 : 8;
+        static const int force_nwv = getenv("MI_ATTN_WAVES") ? atoi(getenv("MI_ATTN_WAVES")) : 0;      // A/B knob: 8 or 16
+        const int nwv = (force_nwv == 8 || force_nwv == 16) ? force_nwv : (p.HW <= 1024 ? 16 : 8);
         const dim3 g6(((p.HW + 16 * nwv - 1) / (16 * nwv)) * p.B2);
 #define MI_ATTN16_LAUNCH(CC) \
         if (JT == 1) { \
