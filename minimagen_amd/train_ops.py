@@ -58,10 +58,16 @@ class _Pack:
                 "mi_pack_conv3")
 
 
+def _pack_key(weight: torch.Tensor):
+    """identity of the values a pack was made from: in-place updates bump the version counter (every torch optimiser), ``p.data = t`` and
+    ``.to()`` change the storage pointer / device"""
+    return (weight._version, weight.data_ptr(), str(weight.device))
+
+
 def _packs(weight: torch.Tensor, exp=None):
     """(forward pack, data-gradient pack) of a [Cout][Cin][3][3] parameter, cached on the parameter until it is updated in place"""
     cached = getattr(weight, "_mi_train_packs", None)
-    if cached is not None and cached[0] == weight._version and cached[1].generic.device == weight.device:
+    if cached is not None and cached[0] == _pack_key(weight):
         return cached[1], cached[2]
     w = weight.detach()
     if exp is None:
@@ -70,15 +76,14 @@ def _packs(weight: torch.Tensor, exp=None):
     L.require_device(w)
     fwd = _Pack(w, exp, False)
     bwd = _Pack(w, exp, True)             # adjoint: W'[ci][co][ky][kx] = W[co][ci][2-ky][2-kx]
-    weight._mi_train_packs = (weight._version, fwd, bwd)
+    weight._mi_train_packs = (_pack_key(weight), fwd, bwd)
     return fwd, bwd
 
 
 def begin_step(module: torch.nn.Module):
     """re-pack every 3x3 stride-1 conv weight under ``module`` whose version changed; the exponents of all of them with ONE device->host copy"""
     stale = [m.weight for m in module.modules() if isinstance(m, torch.nn.Conv2d) and m.kernel_size == (3, 3) and m.stride == (1, 1)
-             and (getattr(m.weight, "_mi_train_packs", None) is None or m.weight._mi_train_packs[0] != m.weight._version
-                  or m.weight._mi_train_packs[1].generic.device != m.weight.device)]
+             and (getattr(m.weight, "_mi_train_packs", None) is None or m.weight._mi_train_packs[0] != _pack_key(m.weight))]
     if not stale:
         return
     with torch.no_grad():
@@ -262,7 +267,7 @@ class _ConvFn(torch.autograd.Function):
 def _ce_tables(convs, channels: int):
     """Toeplitz fragment tables of the matrix-core CrossEmbed kernel (packing.pack_crossembed_mfma), one per input half, cached on the first
     member's weight until any member is updated; ONE device->host copy of the (small) weights per optimiser step"""
-    key = tuple(c.weight._version for c in convs) + (str(convs[0].weight.device),)
+    key = tuple(_pack_key(c.weight) for c in convs)
     cached = getattr(convs[0].weight, "_mi_ce_tables", None)
     if cached is not None and cached[0] == key:
         return cached[1]

@@ -327,3 +327,19 @@ def test_allreduce_gradients_world_size_2_gloo(tmp_path):
     procs = [subprocess.Popen([sys.executable, str(script), root, port, str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
     outs = [p.communicate(timeout=300)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
+
+
+def test_training_packs_follow_the_weights():
+    """the fragment packs cached on a conv weight are rebuilt after an in-place optimiser update, after ``p.data = ...`` and stay put otherwise"""
+    from minimagen_amd import train_ops
+    setup("emu")
+    w = torch.nn.Parameter(torch.randn(8, 8, 3, 3) * 0.1)
+    a, _ = train_ops._packs(w)
+    assert train_ops._packs(w)[0] is a
+    with torch.no_grad():
+        w.add_(0.5)
+    b, _ = train_ops._packs(w)
+    assert b is not a and not torch.equal(b.generic, a.generic)
+    w.data = torch.randn(8, 8, 3, 3)
+    c, _ = train_ops._packs(w)
+    assert c is not b and torch.equal(c.generic.reshape(8, 3, 3, 8), w.detach().permute(1, 2, 3, 0))
