@@ -307,46 +307,57 @@ __global__ __launch_bounds__(64 * NW) void flash_attn_f16x3_kernel(const mi_flas
 
 // ---- tokens [B][HW][C] -> NCHW, with an optional LayerNorm over C (gamma, beta) in front, a residual NCHW tensor added and the next
 // GroupNorm's partial statistics (64-token tiles) emitted: to_out.1 + residual of both attentions, and the tail of ChanFeedForward
+// A workgroup = 64 tokens.  Token rows are read channel-contiguous (a wave per token row: coalesced), the 64 x 64 (token, channel) blocks go
+// through an LDS transpose (pitch 65) and leave token-contiguous per channel (a wave per channel: coalesced NCHW stores, wave-level statistics).
 __global__ __launch_bounds__(256) void tokens_to_nchw_kernel(const mi_tokens_to_nchw_params p) {
     __shared__ float sMean[64], sRstd[64];
-    const int tid = threadIdx.x, tok_l = tid & 63, cq = tid >> 6;
+    __shared__ float tileS[64][65];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tile = blockIdx.x, b = blockIdx.y;
-    const int tok = tile * 64 + tok_l;
-    const bool ok = tok < p.HW;
-    const float* trow = p.tokens + ((size_t)b * p.HW + (ok ? tok : p.HW - 1)) * p.C;
+    const int tok0 = tile * 64;
+    const float* base = p.tokens + (size_t)b * p.HW * p.C;
     if (p.gamma) {
-        // per-token moments: the four work-items of a token each take a quarter of the channels
-        float s = 0.f, q = 0.f;
-        for (int c = cq; c < p.C; c += 4) { const float v = trow[c]; s += v; q = fmaf(v, v, q); }
-        __shared__ float ps[4][64], pq[4][64];
-        ps[cq][tok_l] = s; pq[cq][tok_l] = q;
-        __syncthreads();
-        if (cq == 0) {
-            const float S = (ps[0][tok_l] + ps[1][tok_l]) + (ps[2][tok_l] + ps[3][tok_l]);
-            const float mean = S / (float)p.C;
-            // two-pass variance (the reference's torch.var over the centred values, layers.py:341-343)
+        // per-token moments, a wave per token: mean, then the variance of the centred values (the reference's torch.var, layers.py:341-343)
+        for (int t = wave; t < 64; t += 4) {
+            const int tk = tok0 + t < p.HW ? tok0 + t : p.HW - 1;
+            const float* row = base + (size_t)tk * p.C;
+            float sm = 0.f;
+            for (int c = lane; c < p.C; c += 64) sm += row[c];
+            const float mean = mi_wave_sum(sm) / (float)p.C;
             float v = 0.f;
-            for (int c = 0; c < p.C; ++c) { const float d = trow[c] - mean; v = fmaf(d, d, v); }
-            sMean[tok_l] = mean;
-            sRstd[tok_l] = 1.0f / sqrtf(v / (float)p.C + p.eps);
+            for (int c = lane; c < p.C; c += 64) { const float d = row[c] - mean; v = fmaf(d, d, v); }
+            v = mi_wave_sum(v);
+            if (lane == 0) { sMean[t] = mean; sRstd[t] = 1.0f / sqrtf(v / (float)p.C + p.eps); }
         }
-        __syncthreads();
     }
     const int nt = (p.HW + 63) / 64;
     const int br = p.res.data ? mi_row_of(b, p.res.bmod) : 0;
-    for (int c = cq; c < p.C; c += 4) {              // a wave = the 64 tokens of one channel: coalesced NCHW writes, wave-level statistics
-        float y = 0.f;
-        if (ok) {
-            y = trow[c];
-            if (p.gamma) y = (y - sMean[tok_l]) * sRstd[tok_l] * p.gamma[c] + (p.beta ? p.beta[c] : 0.0f);
-            if (p.res.data) y += p.res.data[((size_t)br * p.C + c) * p.HW + tok] * p.res.scale;
-            p.out[((size_t)b * p.C + c) * p.HW + tok] = y;
+    const int tok = tok0 + lane;
+    const bool ok = tok < p.HW;
+    for (int c0 = 0; c0 < p.C; c0 += 64) {
+        __syncthreads();                                  // moments published / the previous block's reads are done
+#pragma unroll 4
+        for (int i = 0; i < 16; ++i) {
+            const int t = wave * 16 + i;
+            tileS[t][lane] = (tok0 + t < p.HW && c0 + lane < p.C) ? base[(size_t)(tok0 + t) * p.C + c0 + lane] : 0.f;
         }
-        if (p.out_stats) {
-            const float s = mi_wave_sum(y), q = mi_wave_sum(y * y);
-            if (tok_l == 0) {
-                p.out_stats[((size_t)(b * p.C + c) * nt + tile) * 2] = s;
-                p.out_stats[((size_t)(b * p.C + c) * nt + tile) * 2 + 1] = q;
+        __syncthreads();
+        for (int i = 0; i < 16; ++i) {
+            const int c = c0 + wave * 16 + i;
+            if (c >= p.C) break;                          // wave-uniform
+            float y = 0.f;
+            if (ok) {
+                y = tileS[lane][wave * 16 + i];
+                if (p.gamma) y = (y - sMean[lane]) * sRstd[lane] * p.gamma[c] + (p.beta ? p.beta[c] : 0.0f);
+                if (p.res.data) y += p.res.data[((size_t)br * p.C + c) * p.HW + tok] * p.res.scale;
+                p.out[((size_t)b * p.C + c) * p.HW + tok] = y;
+            }
+            if (p.out_stats) {
+                const float s_ = mi_wave_sum(y), q_ = mi_wave_sum(y * y);
+                if (lane == 0) {
+                    p.out_stats[((size_t)(b * p.C + c) * nt + tile) * 2] = s_;
+                    p.out_stats[((size_t)(b * p.C + c) * nt + tile) * 2 + 1] = q_;
+                }
             }
         }
     }

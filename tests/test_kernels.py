@@ -905,3 +905,39 @@ def test_resize_and_lowres_augment(backend):
     a, b = float(sched.sqrt_alphas_cumprod[20]), float(sched.sqrt_one_minus_alphas_cumprod[20])
     lib.mi_lowres_augment(up.data_ptr(), noise.to(dev).data_ptr(), out.data_ptr(), up.numel(), a, b, 1, L.current_stream())
     assert torch.equal(out.cpu(), sched.q_sample(ref, 20, noise) * 2 - 1)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("case", [(2, 100, 96, True, True), (1, 64, 128, True, False), (3, 37, 40, False, True), (1, 256, 512, True, True)])
+def test_tokens_to_nchw(backend, case):
+    """mi_tokens_to_nchw_fwd (to_out.1 LayerNorm + residual + NCHW + statistics of the wide attention blocks, layers.py:14-104): token rows read
+    channel-contiguous, transposed through LDS; ragged token / channel counts, with and without LayerNorm and residual, against torch fp64"""
+    dev = setup(backend)
+    lib = L.lib()
+    B, HW, Cc, ln, res = case
+    g = torch.Generator().manual_seed(11)
+    tok = torch.randn(B, HW, Cc, generator=g) * 1.3 + 0.4
+    gamma, beta = 1 + 0.2 * torch.randn(Cc, generator=g), 0.1 * torch.randn(Cc, generator=g)
+    r = torch.randn(B, Cc, HW, generator=g)
+    ref = tok.double()
+    if ln:
+        mu = ref.mean(-1, keepdim=True)
+        ref = (ref - mu) / torch.sqrt(((ref - mu) ** 2).mean(-1, keepdim=True) + 1e-5) * gamma.double() + beta.double()
+    ref = ref.transpose(1, 2)
+    if res:
+        ref = ref + 0.5 * r.double()
+    keep = [t.to(dev).contiguous() for t in (tok, gamma, beta, r)]
+    nt = -(-HW // 64)
+    out = torch.full((B, Cc, HW), float('nan'), device=dev)
+    ost = torch.full((B, Cc, nt, 2), float('nan'), device=dev)
+    p = L.MiTokensToNchwParams()
+    p.B, p.HW, p.C, p.tokens = B, HW, Cc, keep[0].data_ptr()
+    if ln:
+        p.gamma, p.beta, p.eps = keep[1].data_ptr(), keep[2].data_ptr(), 1e-5
+    if res:
+        p.res = L.MiAct(keep[3].data_ptr(), Cc, 0, 0, 0.5, 0, 0)
+    p.out, p.out_stats = out.data_ptr(), ost.data_ptr()
+    L.check(lib.mi_tokens_to_nchw_fwd(C.byref(p), L.current_stream()), "mi_tokens_to_nchw_fwd")
+    assert (out.cpu().double() - ref).abs().max() < 2e-5
+    st = ost.cpu().double()
+    assert (st[..., 0].sum(-1) - ref.sum(-1)).abs().max() < 1e-3 and (st[..., 1].sum(-1) - (ref ** 2).sum(-1)).abs().max() < 1e-2
