@@ -201,9 +201,33 @@ class CrossAttention(_Container):
         self.to_kv = nn.Linear(context_dim, inner_dim * 2, bias=False)
         self.to_out = nn.Sequential(nn.Linear(inner_dim, dim, bias=False), LayerNorm(dim))
 
+    def _forward_folded(self, x, context, mask=None):
+        """The sampler's fold (packing.fold_cross_attention) as differentiable torch ops, for the training graph on the
+        GPU when the token side is narrower than a head (C < dim_head: the BASELINE U-Nets, C = 16 against 64): the token side never
+        leaves its C channels -- sim_h = x . (s Wq_h^T k_h^T), out = sum_h softmax(sim_h) . (v_h Wo_h^T) -- so the [tokens x heads*dim_head]
+        query and pre-projection tensors (268 MB each at 64 x 64, B = 32) and three quarters of the multiply-adds disappear.  Equal to
+        ``forward`` in real arithmetic; rounding differs at the 1e-6 level."""
+        b, n, Cc = x.shape
+        H, D = self.heads, self.dim_head
+        x, context = self.norm(x), self.norm_context(context)
+        k, v = (t.reshape(b, -1, H, D).transpose(1, 2) for t in self.to_kv(context).chunk(2, dim=-1))          # [b, H, J0, D]
+        nk, nv = (t.expand(b, H, 1, -1) for t in self.null_kv.unbind(dim=-2))
+        k, v = torch.cat((nk, k), dim=-2), torch.cat((nv, v), dim=-2)                                           # [b, H, J, D]
+        J = k.shape[2]
+        kf = torch.einsum('bhjd,hdc->bhjc', k, self.to_q.weight.reshape(H, D, Cc)) * self.scale                 # keys in token-channel space
+        vf = torch.einsum('bhjd,chd->bhjc', v, self.to_out[0].weight.reshape(Cc, H, D))                         # values through to_out.0
+        sim = torch.bmm(x, kf.reshape(b, H * J, Cc).transpose(1, 2)).reshape(b, n, H, J)
+        if exists(mask):
+            sim = sim.masked_fill(~F.pad(mask, (1, 0), value=True)[:, None, None, :], -torch.finfo(sim.dtype).max)
+        attn = sim.softmax(dim=-1, dtype=torch.float32)
+        out = torch.bmm(attn.reshape(b, n, H * J), vf.reshape(b, H * J, Cc))
+        return self.to_out[1](out)
+
     def forward(self, x, context, mask=None):
         """layers.py:220-251"""
         b, n, _ = x.shape
+        if torch.is_grad_enabled() and train_ops.ENABLED and (x.is_cuda or train_ops.FORCE) and x.shape[-1] < self.dim_head:
+            return self._forward_folded(x, context, mask)
         x, context = self.norm(x), self.norm_context(context)
         heads = lambda t: t.reshape(b, t.shape[1], self.heads, -1).transpose(1, 2)
         q = heads(self.to_q(x)) * self.scale

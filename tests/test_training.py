@@ -273,6 +273,14 @@ def test_training_step_on_the_device_path_equals_the_torch_op_path(backend):
         assert abs(la - lb) < 1e-5 * max(1.0, abs(la)), (la, lb)
         for name, g in ga.items():
             assert (gb[name] - g).abs().max() < 1e-4 * max(1e-3, float(g.abs().max())), (n, name, float((gb[name] - g).abs().max()), float(g.abs().max()))
+    # a U-Net with self- and cross-attention: the cross-attention takes the folded training form next to the HIP convolutions
+    torch.manual_seed(8)
+    im2 = Imagen((Unet(**NARROW_ATTN),), text_encoder_name="t5_small", image_sizes=(size[0],), timesteps=60).train().to(dev)
+    la, ga = _unet_loss_grads(im2, imgs, emb, mask, False, 1)
+    lb, gb = _unet_loss_grads(im2, imgs, emb, mask, True, 1)
+    assert abs(la - lb) < 1e-5 * max(1.0, abs(la)), (la, lb)
+    for name, g in ga.items():
+        assert (gb[name] - g).abs().max() < 1e-4 * max(1e-3, float(g.abs().max())), (name, float((gb[name] - g).abs().max()), float(g.abs().max()))
 
 
 _GRAD_WORKER = r'''
@@ -343,3 +351,32 @@ def test_training_packs_follow_the_weights():
     w.data = torch.randn(8, 8, 3, 3)
     c, _ = train_ops._packs(w)
     assert c is not b and torch.equal(c.generic.reshape(8, 3, 3, 8), w.detach().permute(1, 2, 3, 0))
+
+
+def test_cross_attention_folded_training_form_equals_the_reference_form():
+    """CrossAttention._forward_folded (the sampler's fold as differentiable torch ops, taken by the training graph on the GPU for C < dim_head)
+    against the layer's reference-order forward: output and every gradient (token input, context, null_kv, to_q, to_kv, to_out, both norms)"""
+    from minimagen_amd import train_ops
+    from minimagen_amd.layers import CrossAttention
+    torch.manual_seed(4)
+    ca = CrossAttention(dim=16, context_dim=24, norm_context=True).train()
+    with torch.no_grad():
+        for p_ in ca.parameters():
+            p_.add_(0.1 * torch.randn_like(p_))
+    x = torch.randn(2, 50, 16, requires_grad=True)
+    ctx = torch.randn(2, 9, 24, requires_grad=True)
+    mask = torch.arange(9)[None, :] < torch.tensor([9, 4])[:, None]
+    gy = torch.randn(2, 50, 16)
+    res = {}
+    for folded in (False, True):
+        train_ops.FORCE = folded
+        try:
+            for t in list(ca.parameters()) + [x, ctx]:
+                t.grad = None
+            y = ca(x, ctx, mask=mask)
+            y.backward(gy)
+            res[folded] = [y.detach().clone(), x.grad.clone(), ctx.grad.clone()] + [p_.grad.clone() for p_ in ca.parameters()]
+        finally:
+            train_ops.FORCE = False
+    for a, b in zip(res[True], res[False]):
+        assert (a - b).abs().max() <= 2e-5 * max(1e-3, float(b.abs().max())), (float((a - b).abs().max()), float(b.abs().max()))

@@ -3,7 +3,7 @@
 # aggregated by kernel -> gpurun_out/train_tail_hip<0|1>.txt (the trace itself is dropped: library auto-tuning pollutes its head)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-for mode in 1 0; do
+for mode in ${MODES:-1 0}; do
   rm -rf /tmp/train_prof
   PROFILE_ONLY=$mode B1=${B1:-32} B2=${B2:-32} timeout 240 rocprofv3 --kernel-trace --output-format csv -d /tmp/train_prof -o train -- python $R/tools/gpu_train_step.py > $R/gpurun_out/train_prof_$mode.log 2>&1
   f=$(find /tmp/train_prof -name "*kernel_trace.csv" | head -1)
