@@ -117,7 +117,8 @@ class Imagen(nn.Module):
 
     def forward(self, images, texts: List[str] = None, text_embeds: torch.Tensor = None, text_masks: torch.Tensor = None, unet_number: int = None):
         """Imagen.py:575-650: the training loss of ONE U-Net of the cascade on a batch of images + captions.  The U-Net runs through its
-        differentiable torch-op form when it is in train mode with autograd on (Unet._forward_train) and through the HIP engine otherwise
+        differentiable training graph when it is in train mode with autograd on (Unet._forward_train: HIP kernels for the convolution stack,
+        forward and backward, torch ops for the rest -- minimagen_amd/train_ops.py) and through the HIP inference engine otherwise
         (evaluation of the loss)."""
         assert not (len(self.unets) > 1 and not exists(unet_number)), \
             f'you must specify which unet you want trained, from a range of 1 to {len(self.unets)}, if you are training cascading DDPM (multiple unets)'

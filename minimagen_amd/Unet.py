@@ -197,7 +197,8 @@ class Unet(nn.Module):
         assert not (self.lowres_cond and not exists(lowres_cond_img)), 'low resolution conditioning image must be present'
         assert not (self.lowres_cond and not exists(lowres_noise_times)), 'low resolution conditioning noise time must be present'
         if self.training and torch.is_grad_enabled():
-            # training (Imagen.forward): the differentiable torch-op form of the same module tree; sampling / evaluation takes the HIP engine
+            # training (Imagen.forward): the differentiable training graph of the same module tree (HIP convolutions forward + backward on the GPU,
+            # torch ops for the rest); sampling / evaluation takes the HIP inference engine
             if x.is_cuda and not train_ops.active(x) and not Unet._warned_torch_path:          # once per process
                 Unet._warned_torch_path = True
                 warnings.warn("minimagen_amd.Unet.forward: module in train() mode with autograd enabled and MINIMAGEN_TRAIN_HIP=0 -> torch ops "
@@ -212,8 +213,8 @@ class Unet(nn.Module):
 
     def _forward_train(self, x, time, *, lowres_cond_img=None, lowres_noise_times=None, text_embeds=None, text_mask=None,
                        cond_drop_prob: float = 0.) -> torch.Tensor:
-        """Unet.py:355-472 as differentiable torch ops over the layers' own ``forward`` methods (minimagen_amd/layers.py): the training
-        path.  Same order of operations as the reference; per-sample conditioning dropout with probability ``cond_drop_prob``."""
+        """Unet.py:355-472 over the layers' own differentiable ``forward`` methods (minimagen_amd/layers.py): the training path -- on the GPU
+        with the 3x3 convolutions, the Blocks and CrossEmbed on the HIP kernels in both directions (minimagen_amd/train_ops.py).  Same order of operations as the reference; per-sample conditioning dropout with probability ``cond_drop_prob``."""
         b = x.shape[0]
         dev_path = train_ops.active(x)      # the 3x3 convolutions (Blocks, Upsample, final_conv) forward and backward on the HIP kernels
         if dev_path:

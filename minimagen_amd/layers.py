@@ -4,9 +4,10 @@ Two execution paths share these modules' parameters:
 
 * **sampling / inference** (the hot path): ``Unet.forward`` hands the whole module tree to ``minimagen_amd.engine``, which runs every
   layer as hand-written HIP kernels -- the ``forward`` methods below are NOT on that path;
-* **training** (``Imagen.forward`` -> ``Unet.forward`` in train mode with autograd on): the ``forward`` methods below, plain
-  differentiable torch ops on whatever device the parameters live on.  They state each layer's arithmetic once more in the
-  reference's own order of operations, so the two paths can be tested against each other.
+* **training** (``Imagen.forward`` -> ``Unet.forward`` in train mode with autograd on): the ``forward`` methods below, differentiable
+  torch ops on whatever device the parameters live on -- they state each layer's arithmetic once more in the reference's own order of
+  operations, so the paths can be tested against each other.  On the GPU ``Block`` (and the plain 3x3 convs / CrossEmbedLayer, see
+  ``Unet._forward_train``) switch to ``minimagen_amd.train_ops``: HIP kernels forward AND backward; ``CrossAttention`` to its folded form.
 """
 from __future__ import annotations
 

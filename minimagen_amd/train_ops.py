@@ -15,8 +15,9 @@
   activation while it stages its operand tiles, so the activated tensor is never written to memory in either direction.
 
 Weights are re-packed into matrix-core fragments (``mi_pack_conv3``: one launch per weight and direction) when their version counter changes,
-i.e. once per optimiser step; the exponents of all layers come back with one host round trip (``begin_step``).  Everything else of the training graph (attention, conditioning, 1x1 / k4s2
-convs, CrossEmbed) stays on torch ops.  ``gradient all-reduce``: minimagen_amd/distributed.py::allreduce_gradients.
+i.e. once per optimiser step; the exponents of all layers come back with one host round trip (``begin_step``).  ``CrossEmbedLayer``: matrix-core forward + ``mi_crossembed_wgrad``.
+Everything else of the training graph (attention -- cross-attention in the sampler's folded form, layers.CrossAttention._forward_folded --,
+conditioning, 1x1 / k4s2 convs) stays on torch ops.  ``gradient all-reduce``: minimagen_amd/distributed.py::allreduce_gradients.
 MINIMAGEN_TRAIN_HIP=0 switches the whole thing off (torch ops only)."""
 from __future__ import annotations
 
