@@ -460,6 +460,25 @@ typedef struct mi_crossembed_wgrad_params {
 long long mi_crossembed_wgrad_workspace(int Cin, int kmax, int nwg);
 int mi_crossembed_wgrad(const mi_crossembed_wgrad_params* p, void* stream);
 
+/* the core of the folded cross-attention of the training graph (layers.py:220-251 with keys / values mapped into the token's channel space):
+ *   out[b][i][:] = sum_h sum_j softmax_j(q[b][i] . kf[b][h][j]) vf[b][h][j]        (mask[b][j] == 0: row j takes no part)
+ * forward (saves the per-(token, head) logsumexp) and backward (dq, and per-token-chunk partials of dkf / dvf that the caller adds) without the
+ * [tokens x heads x context] score tensor.  fp32 VALU kernels; C in {8, 16, 32}, J * C <= 6144. */
+typedef struct mi_folded_attn_params {
+    int B, n, H, J, C, nchunk;
+    const float* q;                 /* [B][n][C] */
+    const float* kf; const float* vf;   /* [B][H][J][C] */
+    const uint8_t* mask;            /* [B][J] or NULL */
+    float* out;                     /* [B][n][C] (forward) */
+    float* lse;                     /* [B][n][H]: written by the forward, read by the backward (log2 domain) */
+    const float* dout;              /* [B][n][C] (backward) */
+    float* dsum;                    /* [B][n][H] workspace of the backward */
+    float* dq;                      /* [B][n][C] */
+    float* dkf; float* dvf;         /* [nchunk][B][H][J][C] partials over token chunks */
+} mi_folded_attn_params;
+int mi_folded_attn_fwd(const mi_folded_attn_params* p, void* stream);
+int mi_folded_attn_bwd(const mi_folded_attn_params* p, void* stream);
+
 /* ---- HIP graphs: capture a sequence of the calls above once, replay it per timestep ------- */
 int mi_graph_begin(void* stream);
 int mi_graph_end(void* stream, void** graph_exec);

@@ -45,6 +45,7 @@ extern "C" int mi_struct_size(int which) {
         case 16: return (int)sizeof(mi_conv_wgrad_params);
         case 17: return (int)sizeof(mi_block_bwd_params);
         case 18: return (int)sizeof(mi_crossembed_wgrad_params);
+        case 19: return (int)sizeof(mi_folded_attn_params);
     }
     return -1;
 }

@@ -217,6 +217,9 @@ class CrossAttention(_Container):
         J = k.shape[2]
         kf = torch.einsum('bhjd,hdc->bhjc', k, self.to_q.weight.reshape(H, D, Cc)) * self.scale                 # keys in token-channel space
         vf = torch.einsum('bhjd,chd->bhjc', v, self.to_out[0].weight.reshape(Cc, H, D))                         # values through to_out.0
+        if train_ops.folded_attention_supported(x, kf):            # HIP forward + backward, no [tokens x heads x context] tensor at all
+            full = F.pad(mask, (1, 0), value=True) if exists(mask) else None
+            return self.to_out[1](train_ops.folded_attention(x, kf, vf, full))
         sim = torch.bmm(x, kf.reshape(b, H * J, Cc).transpose(1, 2)).reshape(b, n, H, J)
         if exists(mask):
             sim = sim.masked_fill(~F.pad(mask, (1, 0), value=True)[:, None, None, :], -torch.finfo(sim.dtype).max)

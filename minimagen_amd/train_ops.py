@@ -351,6 +351,58 @@ def crossembed_forward(layer, x: torch.Tensor, lowres) -> torch.Tensor:
     return _CrossEmbedFn.apply(x, lowres, tabs, cv[0].weight, cv[0].bias, cv[1].weight, cv[1].bias, cv[2].weight, cv[2].bias)
 
 
+def folded_attention_supported(q: torch.Tensor, kf: torch.Tensor) -> bool:
+    """mi_folded_attn_fwd / _bwd: fp32, C in {8, 16, 32}, J * C <= 6144 (the BASELINE U-Nets: C = 16, J = 259 / 261)"""
+    return (ENABLED and q.dtype == torch.float32 and (q.is_cuda or FORCE) and q.shape[-1] in (8, 16, 32) and kf.shape[2] * kf.shape[3] <= 6144
+            and kf.shape[2] <= 1024)
+
+
+class _FoldedAttnFn(torch.autograd.Function):
+    """out[b, i] = sum_h sum_j softmax_j(q[b, i] . kf[b, h, j]) vf[b, h, j] (the core of layers.CrossAttention._forward_folded) on the HIP
+    kernels of attn_train.hip: the [tokens x heads x context] score tensor is never materialised, forward or backward; saved for the
+    backward: q, kf, vf and the per-(token, head) logsumexp"""
+
+    @staticmethod
+    def forward(ctx, q, kf, vf, mask):
+        lib = L.lib()
+        q, kf, vf = q.contiguous(), kf.contiguous(), vf.contiguous()
+        L.require_device(q, kf, vf)
+        B, n, Cc = q.shape
+        H, J = kf.shape[1], kf.shape[2]
+        m8 = None if mask is None else mask.to(torch.uint8).contiguous()
+        out = torch.empty_like(q)
+        lse = torch.empty(B, n, H, dtype=torch.float32, device=q.device)
+        p = L.MiFoldedAttnParams()
+        p.B, p.n, p.H, p.J, p.C, p.nchunk = B, n, H, J, Cc, 1
+        p.q, p.kf, p.vf, p.mask, p.out, p.lse = q.data_ptr(), kf.data_ptr(), vf.data_ptr(), L.ptr(m8), out.data_ptr(), lse.data_ptr()
+        L.check(lib.mi_folded_attn_fwd(C.byref(p), L.current_stream()), "mi_folded_attn_fwd")
+        ctx.save_for_backward(q, kf, vf, m8, lse)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = L.lib()
+        q, kf, vf, m8, lse = ctx.saved_tensors
+        dout = dout.contiguous()
+        B, n, Cc = q.shape
+        H, J = kf.shape[1], kf.shape[2]
+        nchunk = max(1, min(n // 128, -(-2048 // (B * H))))
+        dq = torch.empty_like(q)
+        dsum = torch.empty_like(lse)
+        dkf = torch.empty(nchunk, B, H, J, Cc, dtype=torch.float32, device=q.device)
+        dvf = torch.empty_like(dkf)
+        p = L.MiFoldedAttnParams()
+        p.B, p.n, p.H, p.J, p.C, p.nchunk = B, n, H, J, Cc, nchunk
+        p.q, p.kf, p.vf, p.mask, p.lse = q.data_ptr(), kf.data_ptr(), vf.data_ptr(), L.ptr(m8), lse.data_ptr()
+        p.dout, p.dsum, p.dq, p.dkf, p.dvf = dout.data_ptr(), dsum.data_ptr(), dq.data_ptr(), dkf.data_ptr(), dvf.data_ptr()
+        L.check(lib.mi_folded_attn_bwd(C.byref(p), L.current_stream()), "mi_folded_attn_bwd")
+        return dq, (dkf[0] if nchunk == 1 else dkf.sum(0)), (dvf[0] if nchunk == 1 else dvf.sum(0)), None
+
+
+def folded_attention(q: torch.Tensor, kf: torch.Tensor, vf: torch.Tensor, mask) -> torch.Tensor:
+    return _FoldedAttnFn.apply(q, kf, vf, mask)
+
+
 def block_forward(block, x: torch.Tensor, scale_shift=None) -> torch.Tensor:
     """``Block.forward`` (layers.py:131-145) through _BlockFn"""
     gnm = block.groupnorm

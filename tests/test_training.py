@@ -358,6 +358,7 @@ def test_cross_attention_folded_training_form_equals_the_reference_form():
     against the layer's reference-order forward: output and every gradient (token input, context, null_kv, to_q, to_kv, to_out, both norms)"""
     from minimagen_amd import train_ops
     from minimagen_amd.layers import CrossAttention
+    setup("emu")                                  # the folded form's core runs on the HIP kernels (emulator build here)
     torch.manual_seed(4)
     ca = CrossAttention(dim=16, context_dim=24, norm_context=True).train()
     with torch.no_grad():
@@ -380,3 +381,36 @@ def test_cross_attention_folded_training_form_equals_the_reference_form():
             train_ops.FORCE = False
     for a, b in zip(res[True], res[False]):
         assert (a - b).abs().max() <= 2e-5 * max(1e-3, float(b.abs().max())), (float((a - b).abs().max()), float(b.abs().max()))
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("case", [(2, 300, 8, 16, 37, True), (1, 70, 2, 8, 261, False), (3, 129, 4, 32, 20, True), (2, 4096, 8, 16, 261, True)])
+def test_folded_attention_kernels(backend, case):
+    """mi_folded_attn_fwd / _bwd (out = sum_h softmax(q kf_h^T) vf_h without the score tensor; dq, dkf, dvf with per-chunk partials) against
+    torch autograd in fp64: ragged token counts, masked context rows, every instantiated channel count, several token chunks"""
+    from minimagen_amd import train_ops
+    B, n, H, Cc, J, with_mask = case
+    if backend == "emu" and n > 1024:
+        pytest.skip("emulator time")
+    dev = setup(backend)
+    g = torch.Generator().manual_seed(3)
+    q = torch.randn(B, n, Cc, generator=g)
+    kf = torch.randn(B, H, J, Cc, generator=g) * 0.5
+    vf = torch.randn(B, H, J, Cc, generator=g)
+    mask = (torch.arange(J)[None, :] < torch.tensor([J - (5 * r) % J for r in range(B)])[:, None]) if with_mask else None
+    gy = torch.randn(B, n, Cc, generator=g)
+    qd, kd, vd = (t.double().requires_grad_() for t in (q, kf, vf))
+    sim = torch.einsum('bnc,bhjc->bhnj', qd, kd)
+    if mask is not None:
+        sim = sim.masked_fill(~mask[:, None, None, :], -torch.finfo(torch.float32).max)
+    ref = torch.einsum('bhnj,bhjc->bnc', sim.softmax(-1), vd)
+    ref.backward(gy.double())
+    train_ops.FORCE = True
+    try:
+        qh, kh, vh = (t.to(dev).requires_grad_() for t in (q, kf, vf))
+        out = train_ops.folded_attention(qh, kh, vh, None if mask is None else mask.to(dev))
+        out.backward(gy.to(dev))
+    finally:
+        train_ops.FORCE = False
+    for got, want in ((out, ref), (qh.grad, qd.grad), (kh.grad, kd.grad), (vh.grad, vd.grad)):
+        assert (got.detach().cpu().double() - want.detach()).abs().max() < 3e-5 * max(1.0, float(want.abs().max())), (case, float((got.detach().cpu().double() - want.detach()).abs().max()))
