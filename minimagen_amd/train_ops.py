@@ -16,8 +16,9 @@
 
 Weights are re-packed into matrix-core fragments (``mi_pack_conv3``: one launch per weight and direction) when their version counter changes,
 i.e. once per optimiser step; the exponents of all layers come back with one host round trip (``begin_step``).  ``CrossEmbedLayer``: matrix-core forward + ``mi_crossembed_wgrad``.
-Everything else of the training graph (attention -- cross-attention in the sampler's folded form, layers.CrossAttention._forward_folded --,
-conditioning, 1x1 / k4s2 convs) stays on torch ops.  ``gradient all-reduce``: minimagen_amd/distributed.py::allreduce_gradients.
+``CrossAttention`` (C < dim_head): the sampler's fold with the core on ``mi_folded_attn_fwd`` /
+``mi_folded_attn_bwd`` (no score tensor, layers.CrossAttention._forward_folded).  Everything else of the training graph (self-attention,
+conditioning, 1x1 / k4s2 convs, LayerNorms) stays on torch ops.  ``gradient all-reduce``: minimagen_amd/distributed.py::allreduce_gradients.
 MINIMAGEN_TRAIN_HIP=0 switches the whole thing off (torch ops only)."""
 from __future__ import annotations
 
