@@ -134,6 +134,19 @@ def unnormalize_zero_to_one(img):
     return (img + 1) * 0.5
 
 
+_TAPS_DEV = {}
+
+
+def _taps_on(in_sz: int, out_sz: int, pad_mode: str, device, dtype):
+    """the tap tables of one (size pair, padding) resident on ``device`` (no host -> device copy per call: the training step stays capturable
+    in a HIP graph and the eager loop loses two copies per resize)"""
+    key = (in_sz, out_sz, pad_mode, str(device), dtype)
+    if key not in _TAPS_DEV:
+        _, idx, w = cubic_taps(in_sz, out_sz, pad_mode)
+        _TAPS_DEV[key] = (idx.long().to(device), w.to(device, dtype))
+    return _TAPS_DEV[key]
+
+
 def resize_image_to(image: torch.Tensor, target_image_size: int, clamp_range: tuple = None, pad_mode: str = 'reflect') -> torch.Tensor:
     """helpers.py:138-164 as tensor ops (training path; the sampling path runs mi_resize_fwd on the same tap tables): resize_right's
     cubic resampling, H pass then W pass, antialiased when shrinking; identity when the size already matches."""
@@ -142,8 +155,7 @@ def resize_image_to(image: torch.Tensor, target_image_size: int, clamp_range: tu
         return image
     out = image
     for dim, in_sz in ((-2, image.shape[-2]), (-1, image.shape[-1])):
-        _, idx, w = cubic_taps(in_sz, int(round(target_image_size * in_sz / orig)), pad_mode)
-        idx, w = idx.long().to(out.device), w.to(out.device, out.dtype)
+        idx, w = _taps_on(in_sz, int(round(target_image_size * in_sz / orig)), pad_mode, out.device, out.dtype)
         g = out.index_select(dim, idx.reshape(-1))
         if dim == -2:
             g = g.reshape(*out.shape[:-2], idx.shape[0], idx.shape[1], out.shape[-1])
