@@ -440,3 +440,41 @@ def test_allreduce_gradients_over_rccl(tmp_path):
     procs = [subprocess.Popen([sys.executable, str(script), root, port, str(r), "nccl"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env) for r in range(2)]
     outs = [p.communicate(timeout=600)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_optimiser_steps_on_the_device_path_track_the_torch_op_path(backend):
+    """four Adam steps from the same initial weights: the device path (weights re-packed after every in-place update, CrossEmbed tables rebuilt,
+    folded attention) and the torch-op path end at the same parameters and losses"""
+    import copy
+    from minimagen_amd import train_ops
+    dev = setup(backend)
+    torch.manual_seed(12)
+    im0 = Imagen((Unet(**NARROW_ATTN),), text_encoder_name="t5_small", image_sizes=(16,), timesteps=50, cond_drop_prob=0.1).train().to(dev)
+    imgs = torch.rand(2, 3, 16, 16, device=dev)
+    emb, mask = R.synthetic_text(2, length=9, seed=4)
+    emb, mask = emb.to(dev), mask.to(dev)
+    runs = {}
+    for hip in (False, True):
+        im = copy.deepcopy(im0)
+        opt = torch.optim.Adam(im.parameters(), lr=2e-3)
+        train_ops.FORCE, train_ops.ENABLED = hip, hip
+        try:
+            losses = []
+            for k in range(4):
+                torch.manual_seed(100 + k)
+                loss = im(imgs, text_embeds=emb, text_masks=mask)
+                opt.zero_grad(set_to_none=True)
+                loss.backward()
+                opt.step()
+                losses.append(loss.item())
+        finally:
+            train_ops.FORCE, train_ops.ENABLED = False, True
+        runs[hip] = (losses, [p.detach().clone() for p in im.parameters()])
+    for a, b in zip(*[runs[h][0] for h in (True, False)]):
+        assert abs(a - b) < 2e-4 * max(1.0, abs(b)), (runs[True][0], runs[False][0])
+    # Adam normalises the update: a parameter whose gradient is tiny can move by lr in either direction -- compare where the update is well defined
+    worst = max(float((a - b).abs().max()) for a, b in zip(runs[True][1], runs[False][1]))
+    assert worst < 4 * 2e-3, worst
+    close = sum(int(((a - b).abs() < 2e-4).sum()) for a, b in zip(runs[True][1], runs[False][1])) / sum(a.numel() for a in runs[True][1])
+    assert close > 0.97, close
