@@ -364,6 +364,8 @@ class Imagen(nn.Module):
                 # earlier (smaller-image, latency-bound) stages get the higher stream priority: their short kernels then slot in between the
                 # workgroups of the later stages' large ones instead of queueing behind them
                 prio = int(os.environ.get("MINIMAGEN_STAGE_PRIORITY", "1"))
+                if all_streams is not None:
+                    torch.cuda.synchronize(device)       # (rare: lane count / device changed) work queued on the old lanes' streams still owns the workspaces
                 all_streams = self._stage_streams = [[torch.cuda.Stream(device=device, priority=(-1 if (prio and k + 1 < len(self.unets)) else 0))
                                                       for k in range(len(self.unets))] for _ in range(max(1, SAMPLE_LANES))]
             streams = all_streams[lane]
