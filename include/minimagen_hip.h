@@ -475,6 +475,7 @@ typedef struct mi_folded_attn_params {
     float* dsum;                    /* [B][n][H] workspace of the backward */
     float* dq;                      /* [B][n][C] */
     float* dkf; float* dvf;         /* [nchunk][B][H][J][C] partials over token chunks */
+    float* oh;                      /* [B][n][H][C] per-head outputs: written by the forward, read by the backward; or NULL (one more pass) */
 } mi_folded_attn_params;
 int mi_folded_attn_fwd(const mi_folded_attn_params* p, void* stream);
 int mi_folded_attn_bwd(const mi_folded_attn_params* p, void* stream);

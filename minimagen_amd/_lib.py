@@ -162,7 +162,7 @@ class MiCrossEmbedWgradParams(C.Structure):
 class MiFoldedAttnParams(C.Structure):
     _fields_ = [("B", C.c_int), ("n", C.c_int), ("H", C.c_int), ("J", C.c_int), ("C", C.c_int), ("nchunk", C.c_int), ("q", C.c_void_p),
                 ("kf", C.c_void_p), ("vf", C.c_void_p), ("mask", C.c_void_p), ("out", C.c_void_p), ("lse", C.c_void_p), ("dout", C.c_void_p),
-                ("dsum", C.c_void_p), ("dq", C.c_void_p), ("dkf", C.c_void_p), ("dvf", C.c_void_p)]
+                ("dsum", C.c_void_p), ("dq", C.c_void_p), ("dkf", C.c_void_p), ("dvf", C.c_void_p), ("oh", C.c_void_p)]
 
 
 _STRUCTS = {0: MiAct, 1: MiConvParams, 2: MiCrossEmbedParams, 3: MiLinear, 4: MiTextCondParams, 5: MiCondStepParams,

@@ -2,8 +2,9 @@
 // channel space, layers.CrossAttention._forward_folded) forward and backward without ever materialising the [tokens x heads x context] score
 // tensor:      out_i = sum_h sum_j softmax_j(q_i . kf_hj) vf_hj ,          q [B][n][C], kf / vf [B][H][J][C] (C = 8 / 16 / 32), mask [B][J].
 // The problem is tiny per score (C multiply-adds) and has no reuse the matrix cores could exploit at C = 16, so these are fp32 VALU kernels:
-//   folded_attn_fwd_kernel    a work-item per token, kf / vf of one (row, head) in LDS read as broadcasts; saves logsumexp per (token, head)
-//   folded_attn_dq_kernel     a work-item per token: recomputes the probabilities, D = sum_j p dP, dq = sum_h sum_j p (dP - D) kf_hj; saves D
+//   folded_attn_fwd_kernel    a work-item per token, kf / vf of one (row, head) in LDS read as broadcasts, online softmax over blocks of 8
+//                             context rows; saves the logsumexp and the head's own output per (token, head)
+//   folded_attn_dq_kernel     a work-item per token: recomputes the probabilities, D = dO . O_h, dq = sum_h sum_j p (dP - D) kf_hj; saves D
 //   folded_attn_dkv_kernel    a work-item per context row j of one (row, head, token chunk): dkf_j = sum_i dS_ij q_i, dvf_j = sum_i p_ij dO_i
 //                             over the chunk's tokens (staged in LDS, broadcast reads); chunk partials are added by the caller (fixed order)
 // exp through the hardware exp2 on log2(e)-scaled scores (fp32 throughout).
@@ -38,22 +39,41 @@ __global__ __launch_bounds__(256) void folded_attn_fwd_kernel(mi_folded_attn_par
         const size_t base = ((size_t)b * p.H + h) * p.J * CC;
         for (int i = threadIdx.x; i < p.J * CC; i += 256) { ks[i] = p.kf[base + i]; vs[i] = p.vf[base + i]; }
         __syncthreads();
-        float m = -INFINITY;
-        for (int j = 0; j < p.J; ++j)
-            if (live[j] != 0.f) m = fmaxf(m, dotc<CC>(q, ks + j * CC));
-        float l = 0.f, acc[CC];
+        // online softmax over blocks of 8 context rows: every score is computed once; the running sums are rescaled once per block
+        float m = -INFINITY, l = 0.f, acc[CC];
 #pragma unroll
         for (int c = 0; c < CC; ++c) acc[c] = 0.f;
-        for (int j = 0; j < p.J; ++j) {
-            if (live[j] == 0.f) continue;
-            const float pj = __builtin_amdgcn_exp2f(dotc<CC>(q, ks + j * CC) - m);
-            l += pj;
+        for (int j0 = 0; j0 < p.J; j0 += 8) {
+            float sc[8];
+            float mb = m;
 #pragma unroll
-            for (int c = 0; c < CC; ++c) acc[c] = fmaf(pj, vs[j * CC + c], acc[c]);
+            for (int t = 0; t < 8; ++t) {
+                const int j = j0 + t;
+                sc[t] = (j < p.J && live[j] != 0.f) ? dotc<CC>(q, ks + j * CC) : -INFINITY;
+                mb = fmaxf(mb, sc[t]);
+            }
+            if (mb == -INFINITY) continue;              // nothing live so far (wave-uniform: the mask is per image)
+            const float alpha = __builtin_amdgcn_exp2f(m - mb);      // m = -inf -> 0
+            m = mb;
+            l *= alpha;
+#pragma unroll
+            for (int c = 0; c < CC; ++c) acc[c] *= alpha;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int j = (j0 + t < p.J) ? j0 + t : p.J - 1;
+                const float pj = __builtin_amdgcn_exp2f(sc[t] - m);          // exp2(-inf) = 0 for masked / out-of-range rows
+                l += pj;
+#pragma unroll
+                for (int c = 0; c < CC; ++c) acc[c] = fmaf(pj, vs[j * CC + c], acc[c]);
+            }
         }
         const float inv = 1.0f / l;
 #pragma unroll
-        for (int c = 0; c < CC; ++c) o[c] = fmaf(acc[c], inv, o[c]);
+        for (int c = 0; c < CC; ++c) { acc[c] *= inv; o[c] += acc[c]; }
+        if (ok && p.oh) {                                  // the head's own output: the backward's D = dO . O_h needs no extra pass
+#pragma unroll
+            for (int c = 0; c < CC; ++c) p.oh[(((size_t)b * p.n + tok) * p.H + h) * CC + c] = acc[c];
+        }
         if (ok) p.lse[((size_t)b * p.n + tok) * p.H + h] = m + log2f(l);       // log2 domain: p = exp2(s * log2e - lse)
     }
     if (ok) {
@@ -80,10 +100,14 @@ __global__ __launch_bounds__(256) void folded_attn_dq_kernel(mi_folded_attn_para
         __syncthreads();
         const float lse = p.lse[row * p.H + h];
         float D = 0.f;
-        for (int j = 0; j < p.J; ++j) {
-            if (live[j] == 0.f) continue;
-            const float pj = __builtin_amdgcn_exp2f(dotc<CC>(q, ks + j * CC) - lse);
-            D = fmaf(pj, dotc<CC>(g, vs + j * CC), D);
+        if (p.oh) {                                        // D = sum_j p_j dP_j = dO . (sum_j p_j vf_j) = dO . O_h
+            D = dotc<CC>(g, p.oh + (row * p.H + h) * CC);
+        } else {
+            for (int j = 0; j < p.J; ++j) {
+                if (live[j] == 0.f) continue;
+                const float pj = __builtin_amdgcn_exp2f(dotc<CC>(q, ks + j * CC) - lse);
+                D = fmaf(pj, dotc<CC>(g, vs + j * CC), D);
+            }
         }
         for (int j = 0; j < p.J; ++j) {
             if (live[j] == 0.f) continue;

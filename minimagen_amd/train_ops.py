@@ -373,17 +373,18 @@ class _FoldedAttnFn(torch.autograd.Function):
         m8 = None if mask is None else mask.to(torch.uint8).contiguous()
         out = torch.empty_like(q)
         lse = torch.empty(B, n, H, dtype=torch.float32, device=q.device)
+        oh = torch.empty(B, n, H, Cc, dtype=torch.float32, device=q.device)       # per-head outputs (8 x the output: 67 MB at 64 x 64, B = 32)
         p = L.MiFoldedAttnParams()
         p.B, p.n, p.H, p.J, p.C, p.nchunk = B, n, H, J, Cc, 1
-        p.q, p.kf, p.vf, p.mask, p.out, p.lse = q.data_ptr(), kf.data_ptr(), vf.data_ptr(), L.ptr(m8), out.data_ptr(), lse.data_ptr()
+        p.q, p.kf, p.vf, p.mask, p.out, p.lse, p.oh = q.data_ptr(), kf.data_ptr(), vf.data_ptr(), L.ptr(m8), out.data_ptr(), lse.data_ptr(), oh.data_ptr()
         L.check(lib.mi_folded_attn_fwd(C.byref(p), L.current_stream()), "mi_folded_attn_fwd")
-        ctx.save_for_backward(q, kf, vf, m8, lse)
+        ctx.save_for_backward(q, kf, vf, m8, lse, oh)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         lib = L.lib()
-        q, kf, vf, m8, lse = ctx.saved_tensors
+        q, kf, vf, m8, lse, oh = ctx.saved_tensors
         dout = dout.contiguous()
         B, n, Cc = q.shape
         H, J = kf.shape[1], kf.shape[2]
@@ -395,7 +396,7 @@ class _FoldedAttnFn(torch.autograd.Function):
         p = L.MiFoldedAttnParams()
         p.B, p.n, p.H, p.J, p.C, p.nchunk = B, n, H, J, Cc, nchunk
         p.q, p.kf, p.vf, p.mask, p.lse = q.data_ptr(), kf.data_ptr(), vf.data_ptr(), L.ptr(m8), lse.data_ptr()
-        p.dout, p.dsum, p.dq, p.dkf, p.dvf = dout.data_ptr(), dsum.data_ptr(), dq.data_ptr(), dkf.data_ptr(), dvf.data_ptr()
+        p.dout, p.dsum, p.dq, p.dkf, p.dvf, p.oh = dout.data_ptr(), dsum.data_ptr(), dq.data_ptr(), dkf.data_ptr(), dvf.data_ptr(), oh.data_ptr()
         L.check(lib.mi_folded_attn_bwd(C.byref(p), L.current_stream()), "mi_folded_attn_bwd")
         return dq, (dkf[0] if nchunk == 1 else dkf.sum(0)), (dvf[0] if nchunk == 1 else dvf.sum(0)), None
 
