@@ -435,6 +435,7 @@ typedef struct mi_block_bwd_params {
     float* dx;                          /* [B][C][HW] */
     float* dgamma; float* dbeta;        /* [C] */
     float* dss;                         /* [B][2C] (d scale | d shift), required when ss != NULL */
+    float* dx_stats;                    /* [B][C][nchunk][2] (sum, sum of squares) of dx per row chunk, or NULL */
 } mi_block_bwd_params;
 int mi_block_bwd(const mi_block_bwd_params* p, void* stream);
 /* per-(image, channel) sum and sum of squares of x [rows][HW] -> stats [rows][2] (a tensor no HIP producer left statistics for) */

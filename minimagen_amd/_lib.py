@@ -150,7 +150,7 @@ class MiBlockBwdParams(C.Structure):
     _fields_ = [("B", C.c_int), ("C", C.c_int), ("HW", C.c_int), ("groups", C.c_int), ("nt", C.c_int), ("nchunk", C.c_int), ("eps", C.c_float),
                 ("x", C.c_void_p), ("da", C.c_void_p), ("x_stats", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p),
                 ("ss", C.c_void_p), ("ss_stride", C.c_int), ("ss_off", C.c_int), ("uv", C.c_void_p), ("dx", C.c_void_p),
-                ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("dss", C.c_void_p)]
+                ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("dss", C.c_void_p), ("dx_stats", C.c_void_p)]
 
 
 class MiCrossEmbedWgradParams(C.Structure):

@@ -23,6 +23,9 @@ struct WgradArgs {
     const float* a_stats; int a_nt; const float* gamma; const float* beta; int groups; float eps; const float* ss; int ss_stride, ss_off;
 };
 
+// PACK (Cin <= 8): the N dimension holds TWO taps x 8 input channels (lanes 0-7 of a column group: tap 2m, lanes 8-15: tap 2m + 1), so the nine taps
+// take five MFMAs per 4-pixel step instead of nine; the partial block is then [m][co][half * 8 + ci]
+template <bool PACK>
 __global__ __launch_bounds__(256) void conv_wgrad_partial_kernel(WgradArgs p) {
     __shared__ float lds[WG_DY_FLOATS + WG_A_FLOATS];             // 40.5 KB; reused for the cross-wave reduction (4 x 2304 floats)
     __shared__ float aff[16][2];                                  // y2 = x * aff[c][0] + aff[c][1] of the current image's 16 input channels
@@ -45,6 +48,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_partial_kernel(WgradArgs p) {
 #pragma unroll
     for (int c = 0; c < 16; ++c) sdb[c] = 0.f;
 
+    int poff[5];                                                  // PACK: window offset (ky * AW + kx) of this lane's tap in each of the five MFMAs
+#pragma unroll
+    for (int m = 0; m < 5; ++m) {
+        const int tap = 2 * m + (lc >> 3);
+        poff[m] = tap < 9 ? (tap / 3) * WG_AW + tap % 3 : 0;
+    }
     const int ntiles = p.B * p.tiles_y * p.tiles_x;
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
         const int b = t / (p.tiles_y * p.tiles_x);
@@ -96,13 +105,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_partial_kernel(WgradArgs p) {
             for (int s = 0; s < WG_TW / 4; ++s) {
                 const int px = 4 * s + kk;
                 const float av = dy_s[(r * WG_TW + px) * WG_PITCH + lc];
+                if constexpr (PACK) {
 #pragma unroll
-                for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) {
-                        const float bv = a_s[((r + ky) * WG_AW + px + kx) * WG_PITCH + lc];
-                        acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[ky * 3 + kx], 0, 0, 0);
+                    for (int m = 0; m < 5; ++m) {
+                        const float bv = a_s[(r * WG_AW + px + poff[m]) * WG_PITCH + (lc & 7)];
+                        acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[m], 0, 0, 0);
                     }
+                } else {
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx) {
+                            const float bv = a_s[((r + ky) * WG_AW + px + kx) * WG_PITCH + lc];
+                            acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[ky * 3 + kx], 0, 0, 0);
+                        }
+                }
             }
         }
     }
@@ -135,7 +152,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_partial_kernel(WgradArgs p) {
 
 // 16 output elements x 16 slices of the partials per workgroup: every thread adds its slice in a fixed order, then a fixed-order LDS tree
 __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* partial, const float* partial_db, float* dw, float* db, int Cin, int Cout,
-                                                                int nciB, int ncoB, int nwg) {
+                                                                int nciB, int ncoB, int nwg, int pack) {
     __shared__ float red[16][17];
     const int e16 = threadIdx.x & 15, slice = threadIdx.x >> 4;
     const int idx = blockIdx.x * 16 + e16;
@@ -143,7 +160,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* par
     float s = 0.f;
     if (idx < nw) {
         const int tap = idx % 9, ci = (idx / 9) % Cin, co = idx / (9 * Cin);
-        const long long blk = (long long)(co / 16) * nciB + ci / 16, e = tap * 256 + (co % 16) * 16 + ci % 16;
+        const long long blk = (long long)(co / 16) * nciB + ci / 16;
+        const long long e = pack ? (tap >> 1) * 256 + (co % 16) * 16 + (tap & 1) * 8 + ci : tap * 256 + (co % 16) * 16 + ci % 16;
         const long long stride = (long long)ncoB * nciB * WG_BLK;
         const float* src = partial + blk * WG_BLK + e;
         float s0 = 0.f, s1 = 0.f;
@@ -191,11 +209,13 @@ extern "C" int mi_conv_wgrad(const mi_conv_wgrad_params* q, void* stream) {
     const long long ntiles = (long long)p.B * p.tiles_x * p.tiles_y;
     if (ntiles > 0x7fffffffLL || (long long)p.nciB * p.ncoB > 65535) { mi_set_error("mi_conv_wgrad: problem too large"); return MI_ERR_INVALID; }
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(conv_wgrad_partial_kernel, dim3(q->nwg, p.nciB * p.ncoB), dim3(256), 0, st, p);
+    const int pack = q->Cin <= 8 ? 1 : 0;
+    if (pack) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_partial_kernel<true>), dim3(q->nwg, p.nciB * p.ncoB), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_partial_kernel<false>), dim3(q->nwg, p.nciB * p.ncoB), dim3(256), 0, st, p);
     int rc = mi_check_launch("conv_wgrad_partial_kernel");
     if (rc) return rc;
     const int n = q->Cout * q->Cin * 9 + (q->db ? q->Cout : 0);
     hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((n + 15) / 16), dim3(256), 0, st, (const float*)q->partial, (const float*)p.partial_db, q->dw, q->db,
-                       q->Cin, q->Cout, p.nciB, p.ncoB, q->nwg);
+                       q->Cin, q->Cout, p.nciB, p.ncoB, q->nwg, pack);
     return mi_check_launch("conv_wgrad_reduce_kernel");
 }

@@ -109,11 +109,32 @@ __global__ __launch_bounds__(256) void block_bwd_apply_kernel(mi_block_bwd_param
     const mi_gptr<const float> x = mi_global(p.x) + (size_t)row * p.HW;
     const mi_gptr<const float> da = mi_global(p.da) + (size_t)row * p.HW;
     float* dx = p.dx + (size_t)row * p.HW;
+    float s = 0.f, q = 0.f;
+    double S = 0.0, Q = 0.0;
+    int n = 0;
     for (int i = i0 + threadIdx.x; i < i1; i += 256) {
         const float xv = x[i];
         const float g = da[i] * mi_silu_grad(fmaf(xv, k.A, k.Bc));
         const float xh = (xv - k.mu) * k.r;
-        dx[i] = k.r * (k.k * g - M1 - xh * M2);
+        const float d = k.r * (k.k * g - M1 - xh * M2);
+        dx[i] = d;
+        s += d; q = fmaf(d, d, q);
+        if (++n == 64) { S += (double)s; Q += (double)q; s = q = 0.f; n = 0; }
+    }
+    if (p.dx_stats) {               // (sum, sum of squares) of this chunk of dx: the statistics the NEXT backward's data-gradient conv scales by
+        __shared__ double red[8];
+        S += (double)s; Q += (double)q;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { S += __shfl_xor(S, o); Q += __shfl_xor(Q, o); }
+        const int wave = threadIdx.x >> 6;
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) { red[2 * wave] = S; red[2 * wave + 1] = Q; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float* o = p.dx_stats + ((size_t)row * gridDim.y + blockIdx.y) * 2;
+            o[0] = (float)((red[0] + red[2]) + (red[4] + red[6]));
+            o[1] = (float)((red[1] + red[3]) + (red[5] + red[7]));
+        }
     }
 }
 

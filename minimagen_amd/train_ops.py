@@ -112,7 +112,7 @@ def _zero_bias(n: int, dev) -> torch.Tensor:
     return _ZEROS[key]
 
 
-def _conv3x3(x: torch.Tensor, pack: _Pack, bias, gn=None, ss=None, stats=None) -> torch.Tensor:
+def _conv3x3(x: torch.Tensor, pack: _Pack, bias, gn=None, ss=None, stats=None, want_stats: bool = False):
     """one mi_conv_fwd launch: out = conv3x3(act(x)) + bias with act = SiLU(GroupNorm(x) * (scale + 1) + shift) when ``gn`` is given"""
     lib = L.lib()
     B, Cin, H, W = x.shape
@@ -127,7 +127,7 @@ def _conv3x3(x: torch.Tensor, pack: _Pack, bias, gn=None, ss=None, stats=None) -
     keep = [stats, bias, out]
     p = L.MiConvParams()
     p.B, p.H, p.W = B, H, W
-    p.in0 = L.MiAct(x.data_ptr(), Cin, stats.data_ptr(), 1, 1.0, 0, 0)
+    p.in0 = L.MiAct(x.data_ptr(), Cin, stats.data_ptr(), stats.shape[2], 1.0, 0, 0)
     p.Cout, p.ksize, p.stride, p.up2 = Cout, 3, 1, 0
     p.w, p.bias, p.out = pack.generic.data_ptr(), bias.data_ptr(), out.data_ptr()
     if gn is not None:
@@ -152,8 +152,14 @@ def _conv3x3(x: torch.Tensor, pack: _Pack, bias, gn=None, ss=None, stats=None) -
             L.check(lib.mi_gn_coef_fwd(C.byref(p), L.current_stream()), "mi_gn_coef_fwd (training)")
     else:
         p.tile_cfg = 0 if (W >= 64 and H * W > 64 * 64) else 2
+    out_stats = None
+    if want_stats:                  # the epilogue's per-tile partial statistics of the OUTPUT: the next Block reads them instead of a statistics pass
+        th, tw = C.c_int(), C.c_int()
+        lib.mi_conv_tile_shape(p.tile_cfg & 0xff, C.byref(th), C.byref(tw))
+        out_stats = torch.empty(B, Cout, (-(-H // th.value)) * (-(-W // tw.value)), 2, dtype=torch.float32, device=x.device)
+        p.out_stats = out_stats.data_ptr()
     L.check(lib.mi_conv_fwd(C.byref(p), L.current_stream()), "mi_conv_fwd (training)")
-    return out
+    return (out, out_stats) if want_stats else out
 
 
 def _wgrad(a: torch.Tensor, dy: torch.Tensor, want_bias: bool, act=None):
@@ -173,7 +179,7 @@ def _wgrad(a: torch.Tensor, dy: torch.Tensor, want_bias: bool, act=None):
     p.a, p.dy, p.dw, p.db, p.partial, p.nwg = a.data_ptr(), dy.data_ptr(), dw.data_ptr(), L.ptr(db), part.data_ptr(), nwg
     if act is not None:
         stats, gamma, beta, groups, eps, ss = act
-        p.a_stats, p.a_nt, p.gamma, p.beta, p.groups, p.eps = stats.data_ptr(), 1, gamma.data_ptr(), beta.data_ptr(), groups, eps
+        p.a_stats, p.a_nt, p.gamma, p.beta, p.groups, p.eps = stats.data_ptr(), stats.shape[2], gamma.data_ptr(), beta.data_ptr(), groups, eps
         if ss is not None:
             p.ss, p.ss_stride, p.ss_off = ss.data_ptr(), ss.shape[1], 0
     L.check(lib.mi_conv_wgrad(C.byref(p), L.current_stream()), "mi_conv_wgrad")
@@ -191,12 +197,14 @@ def _block_bwd(x, da, stats, gamma, beta, groups, eps, ss):
     dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(beta)
     dss = torch.empty(B, 2 * Cc, dtype=torch.float32, device=x.device) if ss is not None else None
     p = L.MiBlockBwdParams()
-    p.B, p.C, p.HW, p.groups, p.nt, p.nchunk, p.eps = B, Cc, HW, groups, 1, nchunk, eps
+    p.B, p.C, p.HW, p.groups, p.nt, p.nchunk, p.eps = B, Cc, HW, groups, stats.shape[2], nchunk, eps
     p.x, p.da, p.x_stats, p.gamma, p.beta = x.data_ptr(), da.data_ptr(), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr()
     if ss is not None:
         p.ss, p.ss_stride, p.ss_off = ss.data_ptr(), ss.shape[1], 0
-    p.uv, p.dx, p.dgamma, p.dbeta, p.dss = uv.data_ptr(), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), L.ptr(dss)
+    dx_stats = torch.empty(B, Cc, nchunk, 2, dtype=torch.float32, device=x.device)
+    p.uv, p.dx, p.dgamma, p.dbeta, p.dss, p.dx_stats = uv.data_ptr(), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), L.ptr(dss), dx_stats.data_ptr()
     L.check(lib.mi_block_bwd(C.byref(p), L.current_stream()), "mi_block_bwd")
+    dx._mi_stats = (dx_stats, dx._version)        # the previous Block's backward receives this very tensor as its output gradient
     return dx, dgamma, dbeta, dss
 
 
@@ -206,7 +214,7 @@ class _BlockFn(torch.autograd.Function):
     operand staging.  Saved for the backward: the block's input, its channel statistics and the scale|shift table -- nothing else."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, scale, shift, weight, bias, groups, eps):
+    def forward(ctx, x, gamma, beta, scale, shift, weight, bias, groups, eps, x_stats):
         x = x.contiguous()
         fwd, _ = _packs(weight)
         g, b = gamma.detach().contiguous(), beta.detach().contiguous()
@@ -214,21 +222,24 @@ class _BlockFn(torch.autograd.Function):
         if scale is not None:
             B = x.shape[0]
             ss = torch.cat((scale.detach().reshape(B, -1), shift.detach().reshape(B, -1)), 1).contiguous()
-        stats = _chan_stats(x)
-        out = _conv3x3(x, fwd, None if bias is None else bias.detach(), gn=(g, b, groups, eps), ss=ss, stats=stats)
+        stats = x_stats if x_stats is not None else _chan_stats(x)        # left by the producing Block's epilogue, or one statistics pass
+        out, out_stats = _conv3x3(x, fwd, None if bias is None else bias.detach(), gn=(g, b, groups, eps), ss=ss, stats=stats, want_stats=True)
         ctx.save_for_backward(x, g, b, ss, stats, weight)
         ctx.groups, ctx.eps, ctx.has_bias, ctx.ss_shape = groups, eps, bias is not None, (None if scale is None else scale.shape)
-        return out
+        ctx.mark_non_differentiable(out_stats)
+        return out, out_stats
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dstats=None):
         x, gamma, beta, ss, stats, weight = ctx.saved_tensors
         dy = dy.contiguous()
         _, bwd = _packs(weight)
         need = ctx.needs_input_grad
         dx = dgamma = dbeta = dscale = dshift = dw = db = None
         if any(need[:5]):
-            da = _conv3x3(dy, bwd, None)
+            tag = getattr(dy, "_mi_stats", None)          # left by the consumer Block's backward when dy is its dx, unmodified
+            dy_stats = tag[0] if (tag is not None and tag[1] == dy._version and tag[0].shape[:2] == dy.shape[:2]) else None
+            da = _conv3x3(dy, bwd, None, stats=dy_stats)
             dx, dgamma, dbeta, dss = _block_bwd(x, da, stats, gamma, beta, ctx.groups, ctx.eps, ss)
             if dss is not None:
                 Cc = x.shape[1]
@@ -237,7 +248,7 @@ class _BlockFn(torch.autograd.Function):
             dw, db = _wgrad(x, dy, ctx.has_bias and need[6], act=(stats, gamma, beta, ctx.groups, ctx.eps, ss))
         pick = lambda g, n: g if n else None
         return (pick(dx, need[0]), pick(dgamma, need[1]), pick(dbeta, need[2]), pick(dscale, need[3]), pick(dshift, need[4]),
-                pick(dw, need[5]), db, None, None)
+                pick(dw, need[5]), db, None, None, None)
 
 
 class _ConvFn(torch.autograd.Function):
@@ -413,7 +424,13 @@ def block_forward(block, x: torch.Tensor, scale_shift=None) -> torch.Tensor:
     if not isinstance(gnm, torch.nn.GroupNorm):             # Block(norm=False): not a layer of the reference's U-Nets; keep the semantics
         h = x if scale is None else x * (scale + 1) + shift
         return _ConvFn.apply(F.silu(h), conv.weight, conv.bias)
-    return _BlockFn.apply(x, gnm.weight, gnm.bias, scale, shift, conv.weight, conv.bias, gnm.num_groups, gnm.eps)
+    # statistics handed over by the Block that produced x (block1 -> block2 of a ResnetBlock without cross-attention): valid for this very tensor
+    # object while it has not been written since
+    tag = getattr(x, "_mi_stats", None)
+    x_stats = tag[0] if (tag is not None and tag[1] == x._version and x.is_contiguous() and tag[0].shape[:2] == x.shape[:2]) else None
+    out, out_stats = _BlockFn.apply(x, gnm.weight, gnm.bias, scale, shift, conv.weight, conv.bias, gnm.num_groups, gnm.eps, x_stats)
+    out._mi_stats = (out_stats, out._version)
+    return out
 
 
 def conv3x3_forward(conv: torch.nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
