@@ -69,6 +69,12 @@ def entry_cost(name, p, cond_dim=8):
             elems += p.B * cres * p.H * p.W + p.B * p.Cout * p.H * p.W + p.Cout * cres + p.Cout
             flops += 2.0 * p.B * p.H * p.W * p.Cout * cres
         return elems * 4.0, flops, "hbm"
+    if name == "resident":            # a run of convs in one launch: the sum of its layers (the definition counts every Conv2d call)
+        by = fl = 0.0
+        for q in p._fused:
+            b_, f_, _ = entry_cost("conv", q, cond_dim)
+            by, fl = by + b_, fl + f_
+        return by, fl, "hbm"
     if name == "crossembed":
         cin = p.C0 + (p.C1 if p.in1 else 0)
         elems, flops = 0, 0.0
@@ -120,6 +126,9 @@ def op_breakdown(im, stage, B, cond_scale, reps=20, precision="fp32"):
         if name == "conv":
             cin = p.in0.C + (p.in1.C if p.in1.data else 0)
             desc = f"conv k{p.ksize}s{p.stride}{'u' if p.up2 else ''} {cin}->{p.Cout} @{p.H}x{p.W} B{p.B}{' gn' if p.gn_groups else ''}{' res' if p.res0.data else ''}"
+        elif name == "resident":
+            desc = f"resident chain of {p.n_layers} convs @{p.H}x{p.W} B{p.B} (" + ", ".join(
+                f"{q.in0.C + (q.in1.C if q.in1.data else 0)}->{q.Cout}{'+res' if q.res0.data else ''}" for q in p._fused) + ")"
         elif name == "cross_attn":
             desc = f"cross_attn C{p.C} tokens{p.HW} ctx{p.J} B{p.B2}"
         elif name == "crossembed":

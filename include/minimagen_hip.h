@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MI_ABI_VERSION 5
+#define MI_ABI_VERSION 6
 
 enum mi_status {
     MI_OK = 0,
@@ -480,6 +480,52 @@ typedef struct mi_folded_attn_params {
 } mi_folded_attn_params;
 int mi_folded_attn_fwd(const mi_folded_attn_params* p, void* stream);
 int mi_folded_attn_bwd(const mi_folded_attn_params* p, void* stream);
+
+/* ---- resident conv chain (conv_resident.hip) -----------------------------------------------
+ * A run of consecutive Block / ResnetBlock convolutions at ONE resolution (layers.py:131-145, 417-439; the <= 64 x 64 levels of
+ * Unet.forward, Unet.py:419-465) in ONE launch: every image is cut into horizontal slabs (16 rows of a 64-wide image, 8 rows of a
+ * 32-wide one), one 512-thread workgroup per slab keeps its slab of the running activation in registers from layer to layer, stages
+ * the fp16 operand planes in LDS and multiplies on the matrix cores exactly like the row-paired kernel of mi_conv_fwd.  Between two
+ * layers the workgroups of an image exchange only (a) their per-channel partial (sum, sum of squares) -- the next GroupNorm needs
+ * whole-image moments -- and (b) their first and last row (the 3x3 halo), through write-through (sc1) stores and one flag per slab
+ * (agent-scope, placement independent).  Slabs are claimed with a ticket counter by workgroups that are already resident, so the
+ * workgroups of one image are co-resident by construction whatever else runs on the GPU (no cooperative launch needed, no deadlock
+ * between concurrent launches of different streams).  Layer i computes
+ *     y_i = conv3x3(act_i(concat(src_i, in1 * scale))) + bias [+ residual_i]
+ * with act_i = GroupNorm -> [scale/shift] -> SiLU when gn_groups > 0, else the identity; y_i stays resident and is ALSO stored to
+ * `out` (with its per-slab statistics in `out_stats`, nt = slabs per image) when another launch consumes it. */
+#define MI_RES_MAX_LAYERS 8
+#define MI_RES_MAXC 16          /* channels of the resident tensor (every layer's Cout) */
+typedef struct mi_res_layer {
+    int src;                /* first part of the conv input: 0 = the resident tensor (the previous layer's y), 1 = in0 (global memory) */
+    mi_act in0;             /* src == 1 */
+    mi_act in1;             /* optional second part (skip connection, Unet.py:445), global memory; data == NULL: none */
+    int gn_groups;          /* over the concatenated input; 0 = no GroupNorm / activation */
+    const float* gn_gamma; const float* gn_beta; float gn_eps;
+    int ss_off;             /* scale at scale_shift[b][ss_off + c], shift at [ss_off + Cin + c]; < 0: none */
+    const void* w_rp; int w_rp_exp;   /* fragments as mi_conv_params.w_rp */
+    const float* bias;
+    int Cout;               /* 8 or 16 */
+    int res;                /* 0 none | 1 identity: the saved resident tensor X | 2 identity: res0 (global) |
+                               3 1x1 conv over concat(X, res1 * scale) | 4 1x1 conv over concat(res0, res1 * scale) */
+    mi_act res0, res1;
+    const void* res_w_rp; int res_w_rp_exp; const float* res_b;
+    int save_x;             /* keep y_i as X (a later layer's residual input: the ResnetBlock input) */
+    float* out; int out_st; float* out_stats;   /* NULL: y_i is not needed outside the launch */
+    int out_nt;             /* partial-statistics slots per channel of out_stats (>= slabs per image; slot = slab index, the others stay as they are) */
+} mi_res_layer;
+typedef struct mi_resident_params {
+    int B, H, W, n_layers;
+    const float* scale_shift; int ss_stride;    /* [B][ss_stride] */
+    void* sync;             /* mi_resident_sync_bytes(B, H, W) bytes, zero-filled ONCE when allocated; private to one stream's launches */
+    int half;               /* single fp16 term per product (reduced-precision configuration), tensors with st = 1 are bf16 */
+    mi_res_layer layer[MI_RES_MAX_LAYERS];
+} mi_resident_params;
+int mi_resident_slabs(int H, int W);                      /* workgroups per image (= nt of every out_stats); 0: shape not supported */
+long long mi_resident_sync_bytes(int B, int H, int W);
+int mi_resident_convs_fwd(const mi_resident_params* p, void* stream);
+/* error word of the last launches on `sync` (0 = fine; non-zero: a workgroup gave up waiting for its neighbours -- results invalid) */
+int mi_resident_error_offset(void);                       /* byte offset of the 32-bit error word inside `sync` */
 
 /* ---- HIP graphs: capture a sequence of the calls above once, replay it per timestep ------- */
 int mi_graph_begin(void* stream);

@@ -284,6 +284,53 @@ __device__ __forceinline__ float mi_wave_max(float v) {
     return v;
 }
 
+// ---- inter-workgroup hand-off inside one launch (conv_resident.hip).  Per-XCD L2s are not coherent with each other and a CU's
+// vector L1 is never refreshed by another CU's stores, so everything one workgroup hands to another goes through WRITE-THROUGH (sc1)
+// stores and L1-bypassing (sc1) loads -- placement independent -- and one agent-scope flag per producer: payload stores -> every storing
+// wave drains (s_waitcnt vmcnt(0)) -> __syncthreads() -> ONE lane stores the flag; the consumer polls the flag relaxed, then reads the
+// payload with sc1 loads (valid because the producer stored sc1).
+typedef unsigned long long mi_u64;
+// an optimisation barrier on one integer: the compiler must treat the value as unknown from here on (no code is emitted)
+#if defined(HIPEMU)
+#define MI_OPAQUE(x) asm volatile("" : "+r"(x))
+#else
+#define MI_OPAQUE(x) asm volatile("" : "+v"(x))
+#endif
+#if defined(HIPEMU)
+#include <sched.h>
+static inline mi_u64 mi_agent_load_u64(const mi_u64* p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
+static inline void mi_agent_store_u64(mi_u64* p, mi_u64 v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
+static inline mi_u64 mi_agent_add_u64(mi_u64* p, mi_u64 v) { return __atomic_fetch_add(p, v, __ATOMIC_ACQ_REL); }
+static inline void mi_agent_store_u32(unsigned* p, unsigned v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
+// 16 bytes = two 8-byte {tag, value} granules: each half is one atomic access (what the hardware was observed to do for sc1 dwordx4)
+static inline f32x4 mi_buf_load_f32x4_sc1(const mi_buf& r, unsigned voff) {
+    mi_u64 h[2] = {__atomic_load_n(reinterpret_cast<const mi_u64*>(r.base + voff), __ATOMIC_ACQUIRE), __atomic_load_n(reinterpret_cast<const mi_u64*>(r.base + voff + 8), __ATOMIC_ACQUIRE)};
+    f32x4 v; memcpy(&v, h, 16); return v;
+}
+static inline void mi_buf_store_f32x4_sc1(const mi_buf& r, unsigned voff, f32x4 v) {
+    mi_u64 h[2]; memcpy(h, &v, 16);
+    __atomic_store_n(reinterpret_cast<mi_u64*>(r.base + voff), h[0], __ATOMIC_RELEASE);
+    __atomic_store_n(reinterpret_cast<mi_u64*>(r.base + voff + 8), h[1], __ATOMIC_RELEASE);
+}
+static inline void mi_drain_vmem() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+static inline void mi_sleep() { sched_yield(); }
+#else
+__device__ __forceinline__ mi_u64 mi_agent_load_u64(const mi_u64* p) { return __hip_atomic_load(mi_global(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void mi_agent_store_u64(mi_u64* p, mi_u64 v) { __hip_atomic_store(mi_global(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ mi_u64 mi_agent_add_u64(mi_u64* p, mi_u64 v) { return __hip_atomic_fetch_add(mi_global(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void mi_agent_store_u32(unsigned* p, unsigned v) { __hip_atomic_store(mi_global(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// aux / cache-policy bit 4 = sc1 on gfx940+ (bit 0 = sc0, bit 1 = nt)
+__device__ __forceinline__ f32x4 mi_buf_load_f32x4_sc1(const mi_buf& r, unsigned voff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, 0, 16));
+}
+__device__ __forceinline__ void mi_buf_store_f32x4_sc1(const mi_buf& r, unsigned voff, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(mi_u32x4, v), r, (int)voff, 0, 16);
+}
+// inline asm: the compiler cannot drop or move it (it does drop builtin waits it believes redundant)
+__device__ __forceinline__ void mi_drain_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void mi_sleep() { __builtin_amdgcn_s_sleep(2); }
+#endif
+
 int mi_conv_rp_launch(const mi_conv_params& p, hipStream_t st);     // conv_rp.hip
 
 // host-side error plumbing (capi.hip)
