@@ -323,7 +323,7 @@ class Imagen(nn.Module):
         host noise stream in the reference's draw order (parity runs); otherwise noise is Philox keyed by
         (``_seed``, ``_sample_offset`` + row, stage, step, element) so a sharded batch reproduces the unsharded one;
         ``_precision`` = "fp32" (default) or "half" (single-fp16-term matrix-core contractions, see engine.UnetEngine.precision);
-        ``_async=True`` returns without making the caller's stream wait (``self.last_sample_done`` is the completion event): successive
+        ``_async=True`` returns without making the caller's stream wait (``self.last_sample_done`` / the returned tensor's ``sample_done`` is THIS call's completion event; ``wait_pending_samples()`` covers every lane): successive
         calls then pipeline across the per-stage streams (the base stage of the next batch under the super-resolution stage of this one)."""
         device = default(device, self.device)
         self._reset_unets_all_one_device(device=device)
@@ -405,8 +405,12 @@ class Imagen(nn.Module):
         if on_gpu:
             if _async:
                 # pipelined use: the result is ready when ``done`` is (the caller synchronises / waits on it before touching the images)
+                # per CALL: the event of this very call.  A later call on the OTHER lane does not wait for it -- capture it right after
+                # the call that produced the tensor (it also travels on the tensor), or use wait_pending_samples() to cover every lane
                 self.last_sample_done = prev_done
+                self.__dict__.setdefault("_lane_done", {})[lane] = prev_done
                 if not return_pil_images:
+                    img.sample_done = prev_done
                     return img
                 caller_stream.wait_event(prev_done)          # the device -> host copy below runs on the caller's stream
                 img.record_stream(caller_stream)
@@ -416,6 +420,15 @@ class Imagen(nn.Module):
         if not return_pil_images:
             return img
         return _to_pil_images(img)
+
+
+def _wait_pending_samples(self, stream=None):
+    """Make ``stream`` (default: the caller's current stream) wait for the latest ``sample(_async=True)`` call of EVERY call lane."""
+    for ev in self.__dict__.get("_lane_done", {}).values():
+        (stream if stream is not None else torch.cuda.current_stream()).wait_event(ev)
+
+
+Imagen.wait_pending_samples = _wait_pending_samples
 
 
 def _to_pil_images(img: torch.Tensor):

@@ -166,13 +166,16 @@ class Unet(nn.Module):
         out = super().load_state_dict(*args, **kwargs)
         if self._engine is not None:
             self._engine.invalidate()
+        train_ops.invalidate(self)
         return out
 
     def _apply(self, fn, *args, **kwargs):
         before = [t.data_ptr() for t in self.parameters()]
         out = super()._apply(fn, *args, **kwargs)           # .to() / .cuda() / .float(): the packed copies point at the old storage ...
-        if getattr(self, '_engine', None) is not None and before != [t.data_ptr() for t in self.parameters()]:
-            self._engine.invalidate()                       # ... but a no-op move (Imagen.sample re-homes the U-Nets on every call) keeps them
+        if before != [t.data_ptr() for t in self.parameters()]:
+            if getattr(self, '_engine', None) is not None:
+                self._engine.invalidate()                   # ... but a no-op move (Imagen.sample re-homes the U-Nets on every call) keeps them
+            train_ops.invalidate(self)
         return out
 
     # ------------------------------------------------------------------ reference API
@@ -219,7 +222,7 @@ class Unet(nn.Module):
         dev_path = train_ops.active(x)      # the 3x3 convolutions (Blocks, Upsample, final_conv) forward and backward on the HIP kernels
         if dev_path:
             train_ops.begin_step(self)
-        conv3 = lambda m, v: train_ops.conv3x3_forward(m, v) if (dev_path and train_ops.is_plain_conv3x3(m)) else m(v)
+        conv3 = lambda m, v: train_ops.conv3x3_forward(m, v) if (dev_path and train_ops.is_plain_conv3x3(m, v)) else m(v)
         # ---- conditioning (Unet.py:508-634)
         hid = self.to_time_hiddens(time)
         t, tokens = self.to_time_cond(hid), self.to_time_tokens[0](hid).reshape(b, self.num_time_tokens, self.cond_dim)

@@ -164,7 +164,7 @@ class Block(_Container):
         self.project = nn.Conv2d(dim, dim_out, 3, padding=1)
 
     def forward(self, x, scale_shift=None):
-        if torch.is_grad_enabled() and train_ops.active(x):        # training on the device: fused HIP forward, HIP dgrad / wgrad
+        if torch.is_grad_enabled() and train_ops.active(x) and train_ops.block_supported(self, x):        # training on the device: fused HIP forward, HIP dgrad / wgrad
             return train_ops.block_forward(self, x, scale_shift)
         x = self.groupnorm(x)
         if exists(scale_shift):

@@ -139,8 +139,12 @@ def attn_f16_exponents(mg, mv, g0, v0, cmax: float, xmax: float):
 
 def layernorm_bound(weight, bias, n: int) -> float:
     """max |LayerNorm(x)_i| over any input: a normalised element is at most sqrt(n - 1) in magnitude"""
-    b = float(bias.abs().max()) if bias is not None else 0.0
-    return float(weight.abs().max()) * math.sqrt(max(n - 1, 1)) + b
+    with torch.no_grad():           # ONE device -> host copy for both maxima
+        if bias is not None:
+            w, b = torch.stack((weight.detach().abs().max(), bias.detach().abs().max())).tolist()
+        else:
+            w, b = float(weight.detach().abs().max()), 0.0
+    return w * math.sqrt(max(n - 1, 1)) + b
 
 
 CE_TILES = ((0, 0), (0, 2), (1, 0), (2, 0))       # N tiles of the matrix-core CrossEmbed: (conv index, first output channel)

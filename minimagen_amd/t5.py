@@ -91,21 +91,31 @@ class T5EncoderHIP:
         b = relative_position_bucket(rel, self.cfg["nb"], self.cfg["md"])
         return self.rel_emb_cpu[b].t().contiguous().to(self.dev)
 
-    @torch.no_grad()
-    def encode(self, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor] = None):
-        """-> (last_hidden_state with masked rows zeroed (t5.py:82), bool mask)"""
-        lib, st, c = L.lib(), L.current_stream(), self.cfg
-        B, Lq = input_ids.shape
-        if Lq > MAX_LENGTH:
-            raise ValueError(f"sequence length {Lq} exceeds MAX_LENGTH {MAX_LENGTH} (t5.py:5)")
+    def _plan(self, B: int, Lq: int):
+        """static buffers + (later) the captured HIP graph of one (batch, length) shape: 42 launches become one replay"""
+        plans = self.__dict__.setdefault("_plans", {})
+        pl = plans.get((B, Lq))
+        if pl is None:
+            c = self.cfg
+            M, d, inner = B * Lq, c["d_model"], c["heads"] * c["d_kv"]
+            e = lambda *s: torch.empty(*s, dtype=torch.float32, device=self.dev)
+            pl = dict(ids=torch.zeros(B, Lq, dtype=torch.int64, device=self.dev), mask=torch.ones(B, Lq, dtype=torch.uint8, device=self.dev),
+                      h=e(M, d), x=e(M, d), qkv=e(M, 3 * inner), ctx=e(M, inner), ff=e(M, c["d_ff"]), h2=e(M, d), out=e(M, d),
+                      bias=self.bias_table(Lq), graph=None)
+            while len(plans) >= 8:                         # bounded: one plan per shape
+                old = plans.pop(next(iter(plans)))
+                if old["graph"] is not None:
+                    if L.backend() == "hip-gfx950":
+                        torch.cuda.synchronize(self.dev)
+                    L.lib().mi_graph_destroy(old["graph"])
+            plans[(B, Lq)] = pl
+        return pl
+
+    def _launch(self, pl, B: int, Lq: int, st):
+        lib, c = L.lib(), self.cfg
         M, d, inner = B * Lq, c["d_model"], c["heads"] * c["d_kv"]
-        ids = input_ids.to(self.dev, torch.int64).contiguous()
-        mask = torch.ones(B, Lq, dtype=torch.uint8, device=self.dev) if attention_mask is None else attention_mask.to(self.dev).to(torch.uint8).contiguous()
-        L.require_device(ids, mask)
-        e = lambda *s: torch.empty(*s, dtype=torch.float32, device=self.dev)
-        h, x, qkv, ctx, ff, h2 = e(M, d), e(M, d), e(M, 3 * inner), e(M, inner), e(M, c["d_ff"]), e(M, d)
-        bias = self.bias_table(Lq)
-        L.check(lib.mi_embed_rows(L.ptr(ids), L.ptr(self.emb), L.ptr(h), M, d, st), "mi_embed_rows")
+        h, x, qkv, ctx, ff, h2, bias, mask = pl["h"], pl["x"], pl["qkv"], pl["ctx"], pl["ff"], pl["h2"], pl["bias"], pl["mask"]
+        L.check(lib.mi_embed_rows(L.ptr(pl["ids"]), L.ptr(self.emb), L.ptr(h), M, d, st), "mi_embed_rows")
         for ly in self.layers:
             L.check(lib.mi_rmsnorm(L.ptr(h), L.ptr(ly["ln0"]), L.ptr(x), M, d, c["eps"], None, st), "mi_rmsnorm")
             L.check(lib.mi_gemm_f32(L.ptr(x), L.ptr(ly["wqkv"]), None, None, L.ptr(qkv), M, 3 * inner, d, 0, st), "mi_gemm_f32 qkv")
@@ -114,9 +124,47 @@ class T5EncoderHIP:
             L.check(lib.mi_rmsnorm(L.ptr(h2), L.ptr(ly["ln1"]), L.ptr(x), M, d, c["eps"], None, st), "mi_rmsnorm")
             L.check(lib.mi_gemm_f32(L.ptr(x), L.ptr(ly["wi"]), L.ptr(ly["wg"]), None, L.ptr(ff), M, c["d_ff"], d, self.act, st), "mi_gemm_f32 wi")
             L.check(lib.mi_gemm_f32(L.ptr(ff), L.ptr(ly["wo2"]), None, L.ptr(h2), L.ptr(h), M, d, c["d_ff"], 0, st), "mi_gemm_f32 wo")
-        out = e(M, d)
-        L.check(lib.mi_rmsnorm(L.ptr(h), L.ptr(self.final_ln), L.ptr(out), M, d, c["eps"], L.ptr(mask), st), "mi_rmsnorm final")
-        return out.reshape(B, Lq, d), mask.bool()
+        L.check(lib.mi_rmsnorm(L.ptr(h), L.ptr(self.final_ln), L.ptr(pl["out"]), M, d, c["eps"], L.ptr(mask), st), "mi_rmsnorm final")
+
+    @torch.no_grad()
+    def encode(self, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor] = None, _use_graph: bool = True):
+        """-> (last_hidden_state with masked rows zeroed (t5.py:82), bool mask).  The launches of one (batch, length) shape are captured in a
+        HIP graph on first use and replayed afterwards (static buffers; the result is copied out)."""
+        lib = L.lib()
+        B, Lq = input_ids.shape
+        if Lq > MAX_LENGTH:
+            raise ValueError(f"sequence length {Lq} exceeds MAX_LENGTH {MAX_LENGTH} (t5.py:5)")
+        ids = input_ids.to(self.dev, torch.int64).contiguous()
+        mask = None if attention_mask is None else attention_mask.to(self.dev).to(torch.uint8).contiguous()
+        L.require_device(ids, mask)
+        pl = self._plan(B, Lq)
+        pl["ids"].copy_(ids)
+        if mask is None:
+            pl["mask"].fill_(1)
+        else:
+            pl["mask"].copy_(mask)
+        if _use_graph and L.backend() == "hip-gfx950":
+            cur = torch.cuda.current_stream(self.dev)
+            side = self.__dict__.get("_stream")
+            if side is None:
+                side = self._stream = torch.cuda.Stream(device=self.dev)     # (graphs cannot be captured on the legacy default stream)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                st = side.cuda_stream
+                if pl["graph"] is None:
+                    L.check(lib.mi_graph_begin(st), "mi_graph_begin")
+                    try:
+                        self._launch(pl, B, Lq, st)
+                    finally:
+                        g = C.c_void_p()
+                        rc = lib.mi_graph_end(st, C.byref(g))
+                    L.check(rc, "mi_graph_end")
+                    pl["graph"] = g
+                L.check(lib.mi_graph_launch(pl["graph"], st), "mi_graph_launch")
+            cur.wait_stream(side)
+        else:
+            self._launch(pl, B, Lq, L.current_stream())
+        return pl["out"].clone().reshape(B, Lq, self.cfg["d_model"]), pl["mask"].bool()
 
 
 def _check_downloads(name):

@@ -83,15 +83,39 @@ def _packs(weight: torch.Tensor, exp=None):
 
 
 def begin_step(module: torch.nn.Module):
-    """re-pack every 3x3 stride-1 conv weight under ``module`` whose version changed; the exponents of all of them with ONE device->host copy"""
-    stale = [m.weight for m in module.modules() if isinstance(m, torch.nn.Conv2d) and m.kernel_size == (3, 3) and m.stride == (1, 1)
-             and (getattr(m.weight, "_mi_train_packs", None) is None or m.weight._mi_train_packs[0] != _pack_key(m.weight))]
-    if not stale:
+    """Once per training step: re-pack every conv weight under ``module`` whose VALUES changed.  The version counter and the storage pointer
+    (``_pack_key``) miss updates made through ``p.data`` (EMA copy-in, ``.data.mul_`` / ``.data.copy_``, hand-written SGD, an optimiser step
+    replayed from a captured graph), so every weight also carries a content fingerprint (max |w|, ||w||_2): two fused multi-tensor launches
+    and ONE device -> host copy for all layers -- the same copy that brings the exponents of the weights that need a new pack."""
+    convs = [m for m in module.modules() if isinstance(m, torch.nn.Conv2d) and m.weight.is_floating_point()]
+    if not convs:
         return
+    ws = [m.weight for m in convs]
     with torch.no_grad():
-        mx = torch.stack([w.abs().max() for w in stale]).tolist()
-        for w, m in zip(stale, mx):
-            _packs(w, P.rp_weight_exponent(m))
+        det = [w.detach() for w in ws]
+        fp = torch.stack(torch._foreach_norm(det, float("inf")) + torch._foreach_norm(det, 2)).tolist()
+    n = len(ws)
+    for k, (m, w) in enumerate(zip(convs, ws)):
+        mark = (fp[k], fp[n + k])
+        if getattr(w, "_mi_fingerprint", None) != mark:           # values changed behind the version counter: drop everything derived from them
+            w._mi_fingerprint = mark
+            for attr in ("_mi_train_packs", "_mi_ce_tables"):
+                if hasattr(w, attr):
+                    delattr(w, attr)
+        if m.kernel_size == (3, 3) and m.stride == (1, 1):
+            cached = getattr(w, "_mi_train_packs", None)
+            if cached is None or cached[0] != _pack_key(w):
+                with torch.no_grad():
+                    _packs(w, P.rp_weight_exponent(fp[k]))
+
+
+def invalidate(module: torch.nn.Module):
+    """Drop every pack / table derived from the parameters under ``module`` (they are rebuilt on the next use).  ``begin_step`` notices
+    changed values by itself; this is for callers that replace parameters outside a training step (``load_state_dict``, ``_apply``)."""
+    for prm in module.parameters():
+        for attr in ("_mi_train_packs", "_mi_ce_tables", "_mi_fingerprint"):
+            if hasattr(prm, attr):
+                delattr(prm, attr)
 
 
 def _chan_stats(x: torch.Tensor) -> torch.Tensor:
@@ -280,7 +304,7 @@ class _ConvFn(torch.autograd.Function):
 def _ce_tables(convs, channels: int):
     """Toeplitz fragment tables of the matrix-core CrossEmbed kernel (packing.pack_crossembed_mfma), one per input half, cached on the first
     member's weight until any member is updated; ONE device->host copy of the (small) weights per optimiser step"""
-    key = tuple(_pack_key(c.weight) for c in convs)
+    key = tuple((_pack_key(c.weight), getattr(c.weight, "_mi_fingerprint", None)) for c in convs)
     cached = getattr(convs[0].weight, "_mi_ce_tables", None)
     if cached is not None and cached[0] == key:
         return cached[1]
@@ -302,10 +326,10 @@ def _ce_tables(convs, channels: int):
 
 def crossembed_supported(layer, x: torch.Tensor, lowres) -> bool:
     """the matrix-core forward + the shared-correlation weight gradient cover the reference's configuration: kernel sizes (3, 7, 15),
-    dim_scales (4, 2, 2), stride 1, <= 4 image channels per half, W % 4 == 0; the input must not need a gradient (it is the first layer)"""
+    dim_scales (4, 2, 2), stride 1, <= 4 image channels per half and <= 6 in total (mi_crossembed_wgrad), W % 4 == 0; the input must not need a gradient (it is the first layer)"""
     cv = layer.convs
     return (active(x) and layer.stride == 1 and [c.kernel_size[0] for c in cv] == [3, 7, 15] and [c.out_channels for c in cv] == [4, 2, 2]
-            and x.shape[1] <= 4 and x.shape[3] % 4 == 0 and not x.requires_grad and (lowres is None or (not lowres.requires_grad and lowres.shape == x.shape))
+            and x.shape[1] <= 4 and cv[0].in_channels <= 6 and x.shape[3] % 4 == 0 and not x.requires_grad and (lowres is None or (not lowres.requires_grad and lowres.shape == x.shape))
             and cv[0].in_channels == x.shape[1] * (2 if lowres is not None else 1) and all(c.bias is not None for c in cv))
 
 
@@ -437,6 +461,25 @@ def conv3x3_forward(conv: torch.nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
     return _ConvFn.apply(x, conv.weight, conv.bias)
 
 
-def is_plain_conv3x3(m) -> bool:
-    return isinstance(m, torch.nn.Conv2d) and m.kernel_size == (3, 3) and m.stride == (1, 1) and m.padding == (1, 1) and m.groups == 1 \
+def conv_shape_supported(cin: int, cout: int, W: int, groups: int = 0) -> bool:
+    """the limits of mi_conv_fwd / mi_conv_wgrad as the kernels check them: the row-paired matrix-core family needs channel octets and
+    W % 4 == 0 and goes up to 4096 input channels (wide regime); everything else runs the direct-conv family (<= 256 input channels);
+    GroupNorm with at most 32 groups.  Both directions must fit (the data gradient is the same conv with the channel counts swapped)."""
+    def one(ci, co):
+        rp = ci % 8 == 0 and W % 4 == 0
+        return ci <= (4096 if rp else 256)
+    return one(cin, cout) and one(cout, cin) and groups <= 32
+
+
+def is_plain_conv3x3(m, x=None) -> bool:
+    ok = isinstance(m, torch.nn.Conv2d) and m.kernel_size == (3, 3) and m.stride == (1, 1) and m.padding == (1, 1) and m.groups == 1 \
         and m.dilation == (1, 1) and m.padding_mode == "zeros"
+    if ok and x is not None:
+        ok = conv_shape_supported(m.in_channels, m.out_channels, x.shape[-1])
+    return ok
+
+
+def block_supported(block, x: torch.Tensor) -> bool:
+    gnm = block.groupnorm
+    groups = gnm.num_groups if isinstance(gnm, torch.nn.GroupNorm) else 0
+    return conv_shape_supported(block.project.in_channels, block.project.out_channels, x.shape[-1], groups)

@@ -62,27 +62,25 @@ def test_integration_md_binding_example_matches_the_abi():
 
 
 def test_no_packed_fp32_with_scalar_operands_in_the_code_objects(tmp_path):
-    """Round 3 (profiles/r03_pk_f32_hazard.txt): a packed-fp32 VALU instruction with an SGPR operand returns wrong products for a 16-lane
-    pass while matrix-core waves of ANOTHER stream's kernel share its SIMD -- and the stage-pipelined sampler runs two streams side by
-    side.  The library is built with -fno-slp-vectorize; the hand-placed packed operations (attention softmax) use VGPR operands only.
-    Disassemble every gfx950 code object of the built library and check."""
-    import shutil
-    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
-    if not os.path.exists(objdump):
+    """Round 3 (profiles/r03_pk_f32_hazard.txt; stand-alone reproducer: tools/ubench/pk_f32_hazard.hip, profiles/r04_pk_f32_hazard_ubench.txt):
+    a packed-fp32 VALU instruction with an SGPR operand returns wrong products for a 16-lane pass while matrix-core waves of ANOTHER
+    stream's kernel share its SIMD -- and the stage-pipelined sampler runs two streams side by side.  The library is built with
+    -fno-slp-vectorize; the hand-placed packed operations (attention softmax) use VGPR operands only.  Disassemble every gfx950 code
+    object of the built library and check (the same check runs inside __graft_entry__.build() and, below, in the GPU tier)."""
+    from tools.check_code_objects import check_library, OBJDUMP
+    if not os.path.exists(OBJDUMP):
         pytest.skip("llvm-objdump not available")
-    so = tmp_path / "lib.so"
-    shutil.copy(L.DEFAULT_LIB, so)
-    subprocess.run([objdump, "--offloading", str(so)], cwd=tmp_path, check=True, capture_output=True)
-    bundles = sorted(f for f in os.listdir(tmp_path) if "gfx950" in f)
-    assert len(bundles) >= 6, bundles
-    n_pk = 0
-    for f in bundles:
-        asm = subprocess.run([objdump, "-d", str(tmp_path / f)], capture_output=True, text=True, check=True).stdout
-        pk = [l for l in asm.splitlines() if re.search(r"\bv_pk_(mul|add|fma)_f32\b", l)]
-        n_pk += len(pk)
-        bad = [l for l in pk if re.search(r"\bs\[\d+:\d+\]|\bs\d+\b", l.split("//")[0])]
-        assert not bad, f"{f}: packed fp32 instruction with a scalar operand: {bad[0].strip()}"
-    assert n_pk < 2000          # only the attention kernels' hand-placed ones remain (a vectoriser turned back on adds tens of thousands)
+    n_objects, n_pk = check_library(L.DEFAULT_LIB, str(tmp_path))
+    assert n_objects >= 6 and n_pk < 2000
+
+
+@pytest.mark.gpu
+def test_no_packed_fp32_with_scalar_operands_in_the_library_the_gpu_tests_load(tmp_path):
+    """the same disassembly check on the GPU box, on the very .so the -m gpu tests load"""
+    from tools.check_code_objects import check_library, OBJDUMP
+    assert os.path.exists(OBJDUMP), "the ROCm image ships llvm-objdump"
+    n_objects, n_pk = check_library(L.DEFAULT_LIB, str(tmp_path))
+    assert n_objects >= 6 and n_pk < 2000
 
 
 def test_cubic_taps_match_oracle_restatement():

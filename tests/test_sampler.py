@@ -283,6 +283,38 @@ def test_kernels_of_two_streams_side_by_side_stay_bit_exact(backend):
         for gset in got:
             assert all(torch.equal(a, b) for a, b in zip(ref0, gset)), "base-stage U-Net evaluation differs under a concurrent SR load"
 
+    # (3) the super-resolution U-Net evaluation as the VICTIM: under the base stage's kernels (one call lane's stage pipeline), and next to
+    # a second SR evaluation on another stream (two call lanes: SR next to SR is the common case of the pipelined mode)
+    ws1b = engs[1].workspace(B, 2 * B, 256, 256, lane=1)
+    ws1b.x.copy_(wss[1].x); ws1b.times.copy_(wss[1].times)
+    ws1b.lowres.copy_(wss[1].lowres); ws1b.lowres_times.copy_(wss[1].lowres_times)
+    engs[1].prepare_lowres(ws1b)
+    engs[1].set_text(ws1b, emb, mask, keep)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(main):
+        engs[1].run(wss[1])
+        ref1 = [t.clone() for t in outputs(wss[1])]
+    torch.cuda.synchronize()
+    for aggressor in ("base", "sr"):
+        for rep in range(4):
+            with torch.cuda.stream(side):
+                if aggressor == "base":
+                    for _ in range(12):
+                        engs[0].run(wss[0])
+                else:
+                    for _ in range(3):
+                        engs[1].run(ws1b)
+            with torch.cuda.stream(main):
+                got = []
+                for _ in range(2):
+                    engs[1].run(wss[1])
+                    got.append([t.clone() for t in outputs(wss[1])])
+            torch.cuda.synchronize()
+            for gset in got:
+                assert all(torch.equal(a, b) for a, b in zip(ref1, gset)), f"SR U-Net evaluation differs next to a concurrent {aggressor}-stage evaluation"
+        if aggressor == "sr":
+            assert all(torch.equal(a, b) for a, b in zip(ref1, outputs(ws1b))), "the second lane's SR evaluation differs from the first lane's"
+
 
 @pytest.mark.parametrize("backend", GPU_ONLY)
 def test_three_stage_cascade_values_vs_oracle(backend):

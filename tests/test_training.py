@@ -361,6 +361,28 @@ def test_training_packs_follow_the_weights():
     assert c is not b and torch.equal(c.generic.reshape(8, 3, 3, 8), w.detach().permute(1, 2, 3, 0))
 
 
+def test_training_packs_notice_updates_made_through_data():
+    """``p.data.mul_()`` / ``.data.copy_()`` (EMA copy-in, hand-written SGD) bump neither the version counter nor the storage pointer: the
+    content fingerprint taken by ``begin_step`` must still drop the stale packs (forward and data-gradient convs otherwise keep
+    the old weights while the weight-gradient kernel and the torch ops see the new ones)"""
+    from minimagen_amd import train_ops
+    setup("emu")
+    conv = torch.nn.Conv2d(8, 8, 3, padding=1)
+    train_ops.begin_step(conv)
+    a, _ = train_ops._packs(conv.weight)
+    train_ops.begin_step(conv)
+    assert train_ops._packs(conv.weight)[0] is a                       # untouched weights keep their packs
+    v, ptr = conv.weight._version, conv.weight.data_ptr()
+    conv.weight.data.mul_(2.0)
+    assert (conv.weight._version, conv.weight.data_ptr()) == (v, ptr)   # invisible to the identity key ...
+    train_ops.begin_step(conv)
+    b, _ = train_ops._packs(conv.weight)
+    assert b is not a                                                  # ... but not to the fingerprint
+    assert torch.equal(b.generic.reshape(8, 3, 3, -1)[..., :8], conv.weight.detach().permute(1, 2, 3, 0))
+    train_ops.invalidate(conv)
+    assert not hasattr(conv.weight, "_mi_train_packs")
+
+
 def test_cross_attention_folded_training_form_equals_the_reference_form():
     """CrossAttention._forward_folded (the sampler's fold as differentiable torch ops, taken by the training graph on the GPU for C < dim_head)
     against the layer's reference-order forward: output and every gradient (token input, context, null_kv, to_q, to_kv, to_out, both norms)"""
