@@ -108,3 +108,14 @@ for rep in range(6):
                   f"equals x_in there: {bool(torch.equal(vals, x_in[r][idx]))}; |value| max {vals.abs().max().item():.3e} (sentinel-driven if ~1e5+)", flush=True)
             print(f"  row {r}: s {as_[r].item():.6f} vs {rs[r].item():.6f}; v {av[r].tolist()} vs {rv[r].tolist()}; x mismatching elements {(ax[r] != rx[r]).sum().item()} of {n}, max|d| {(ax[r]-rx[r]).abs().max().item():.3e}", flush=True)
 print(f"under load: of {6*150*B} image-steps: x wrong {bad_x}, s wrong {bad_s}, order statistics wrong {bad_v}", flush=True)
+
+# in-kernel self-check of the packed product (library built with -DSS_PKCHECK, profiles/r04_pk_f32_hazard_bisect.txt)
+if hasattr(lib, "mi_debug_read_ss"):
+    import numpy as np
+    rec = np.zeros(256 * 8, dtype=np.float32)
+    cnt = C.c_uint(0)
+    lib.mi_debug_read_ss.argtypes = [C.c_void_p, C.POINTER(C.c_uint)]
+    lib.mi_debug_read_ss(rec.ctypes.data, C.byref(cnt))
+    print(f"in-kernel check: {cnt.value} packed products differ from the scalar product of the same registers", flush=True)
+    for r in rec.reshape(256, 8)[:min(cnt.value, 24)]:
+        print(f"   image {int(r[0])} work-item {int(r[1])} (lane {int(r[1]) & 63}, wave {int(r[1]) >> 6}) element {int(r[2])}: " + " ".join(f"{v:+.6f}" for v in r[3:]), flush=True)
