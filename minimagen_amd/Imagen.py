@@ -19,6 +19,7 @@ from .helpers import (cast_tuple, cubic_taps, default, eval_decorator, exists, m
 from .t5 import get_encoded_dim, t5_encode_text
 
 SAMPLE_LANES = max(1, int(os.environ.get("MINIMAGEN_SAMPLE_LANES", "2")))     # independent call lanes of sample(_async=True)
+_STAGE_STREAMS = {}          # (device, lanes, stages, priority mode) -> [lane][stage] HIP streams, process-wide (see sample())
 
 
 class Imagen(nn.Module):
@@ -366,8 +367,18 @@ class Imagen(nn.Module):
                 prio = int(os.environ.get("MINIMAGEN_STAGE_PRIORITY", "1"))
                 if all_streams is not None:
                     torch.cuda.synchronize(device)       # (rare: lane count / device changed) work queued on the old lanes' streams still owns the workspaces
-                all_streams = self._stage_streams = [[torch.cuda.Stream(device=device, priority=(-1 if (prio and k + 1 < len(self.unets)) else 0))
-                                                      for k in range(len(self.unets))] for _ in range(max(1, SAMPLE_LANES))]
+                # ONE set of stage streams per process and shape, shared by every Imagen instance.  HIP multiplexes its streams onto
+                # GPU_MAX_HW_QUEUES (default 4) hardware queues, and torch hands out pool streams round robin: a second Imagen built in the
+                # same process got streams whose hardware queue was shared with the stream feeding them, and every node of a graph launched
+                # there paid ~16 us (2.7 ms per 170-node launch: a 150 ms sample() took 261 ms; tools/gpu_realloc_slowdown.py,
+                # profiles/r04_second_instance_slowdown.txt -- the device buffers had nothing to do with it).  The first set a process creates
+                # has never shown the sharing; keeping it for all instances makes the mapping a constant.
+                key = (str(device), max(1, SAMPLE_LANES), len(self.unets), prio)
+                all_streams = _STAGE_STREAMS.get(key)
+                if all_streams is None:
+                    all_streams = _STAGE_STREAMS[key] = [[torch.cuda.Stream(device=device, priority=(-1 if (prio and k + 1 < len(self.unets)) else 0))
+                                                          for k in range(len(self.unets))] for _ in range(max(1, SAMPLE_LANES))]
+                self._stage_streams = all_streams
             streams = all_streams[lane]
             self._stream = all_streams[0][-1]            # (benchmarks time the last stage's captured graph on its own stream)
             caller_stream = torch.cuda.current_stream(device)
