@@ -287,9 +287,10 @@ def secondary_lines(timesteps, cond_scale):
     fresh process (3 warm-up calls, then 8 / 8 / 3 timed sample() calls, pipelined; plus the same calls one at a time): config 2 (base 64^2,
     B=32, fp32), config 3's shape (cascade 64->256, B=16, reduced precision) and config 5's per-GPU shape (cascade 64->256->1024, B=8,
     reduced precision, noise augmentation on both SR stages).  Never the headline.
-    (A fresh process per configuration: device memory that a process has freed and allocated again can be markedly slower -- the second
-    Imagen built in one process ran its SR stage 1.75x slower, the third at full speed again, profiles/r03_config3_timing.json -- which is
-    what made round 2's in-process secondary lines read 228 ms per call for config 3.)"""
+    (A fresh process per configuration keeps each measurement independent of what ran before.  The slowdown of a second Imagen built in
+    one process that motivated it in round 3 -- 261 instead of 150 ms per call -- is root-caused and fixed: HIP streams sharing a hardware
+    queue, profiles/r04_second_instance_slowdown.txt.)  Config 5's entry also carries the per-launch breakdown summary of its 1024^2 stage
+    (`unet_eval`, `roofline`) measured in that process."""
     import subprocess
     out = {}
     for key, workload, B, precision, calls in (("config2_base64_B32_fp32", "base64", 32, "fp32", 8),
@@ -297,7 +298,7 @@ def secondary_lines(timesteps, cond_scale):
                                                ("config5_cascade64_256_1024_B8_half", "cascade64_256_1024", 8, "half", 3)):
         cmd = [sys.executable, os.path.abspath(__file__), "--workload", workload, "--batch", str(B), "--precision", precision, "--steps", str(calls),
                "--warmup", "3" if calls > 3 else "1", "--timesteps", str(timesteps), "--cond-scale", str(cond_scale),
-               "--no-secondary", "--no-breakdown", "--no-cpu-baseline", "--no-t5"]
+               "--no-secondary", "--no-cpu-baseline", "--no-t5"] + ([] if workload == "cascade64_256_1024" else ["--no-breakdown"])
         env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
         r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
         lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -310,6 +311,9 @@ def secondary_lines(timesteps, cond_scale):
                     "denoising_steps_per_s_no_pipeline": j.get("value_no_pipeline"), "ms_per_sample_call_no_pipeline": j.get("ms_per_step_no_pipeline"),
                     "pipelined_equals_synchronous": j.get("pipelined_equals_synchronous"), "timed_calls": calls, "per_gpu_batch": n_img,
                     "precision": precision, "image_sizes": {"base64": [64], "cascade64_256": [64, 256], "cascade64_256_1024": [64, 256, 1024]}[workload]}
+        for extra in ("unet_eval", "roofline"):          # (config 5: the last stage's per-launch summary, measured in the same process)
+            if extra in j:
+                out[key][extra] = j[extra]
     return out
 
 

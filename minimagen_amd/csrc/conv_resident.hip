@@ -521,25 +521,32 @@ __global__ __launch_bounds__(64 * NW, (TW == 64 && R == 8) ? 4 : 2) void residen
                     bh[jt] = __builtin_bit_cast(rs_f16x8, wl[f]);
                     if constexpr (!HALF) bl[jt] = __builtin_bit_cast(rs_f16x8, wl[f + 1]);
                 }
+                // all A chunks of the tap first, then the products TERM-major: consecutive matrix-core instructions never share an
+                // accumulator (a dependent one waits for its predecessor's passes: GPW x NJ independent ones lie between two on the same tile)
+                rs_f16x8 ah[GPW], al[GPW];
 #pragma unroll
                 for (int g = 0; g < GPW; ++g) {
                     const int idx = slot * PLANE + (2 * gyy[g] + perm) * PW + 16 * gxx[g] + lq + sx;
-                    const rs_f16x8 ah = __builtin_bit_cast(rs_f16x8, actH[idx]);
-                    if constexpr (!HALF) {
-                        const rs_f16x8 al = __builtin_bit_cast(rs_f16x8, actL[idx]);
-#pragma unroll
-                        for (int jt = 0; jt < NJ; ++jt) {
-                            if (!NJX && jt >= njl) continue;
-                            acc[g][jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[jt], al, acc[g][jt], 0, 0, 0);
-                            acc[g][jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[jt], ah, acc[g][jt], 0, 0, 0);
-                        }
-                    }
-#pragma unroll
-                    for (int jt = 0; jt < NJ; ++jt) {
-                        if (!NJX && jt >= njl) continue;
-                        acc[g][jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[jt], ah, acc[g][jt], 0, 0, 0);
-                    }
+                    ah[g] = __builtin_bit_cast(rs_f16x8, actH[idx]);
+                    if constexpr (!HALF) al[g] = __builtin_bit_cast(rs_f16x8, actL[idx]);
                 }
+                if constexpr (!HALF) {
+#pragma unroll
+                    for (int g = 0; g < GPW; ++g)
+#pragma unroll
+                        for (int jt = 0; jt < NJ; ++jt)
+                            if (NJX || jt < njl) acc[g][jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[jt], al[g], acc[g][jt], 0, 0, 0);
+#pragma unroll
+                    for (int g = 0; g < GPW; ++g)
+#pragma unroll
+                        for (int jt = 0; jt < NJ; ++jt)
+                            if (NJX || jt < njl) acc[g][jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[jt], ah[g], acc[g][jt], 0, 0, 0);
+                }
+#pragma unroll
+                for (int g = 0; g < GPW; ++g)
+#pragma unroll
+                    for (int jt = 0; jt < NJ; ++jt)
+                        if (NJX || jt < njl) acc[g][jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[jt], ah[g], acc[g][jt], 0, 0, 0);
             }
         };
         for (int q0 = 0; q0 < nq; q0 += 2) {

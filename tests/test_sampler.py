@@ -317,6 +317,27 @@ def test_kernels_of_two_streams_side_by_side_stay_bit_exact(backend):
 
 
 @pytest.mark.parametrize("backend", GPU_ONLY)
+def test_three_stage_cascade_reduced_precision_values_vs_oracle(backend):
+    """BASELINE config 5 names bf16: the three-stage cascade 64 -> 256 -> 1024 in the reduced-precision configuration (single fp16 term on
+    the matrix cores, bf16 activation storage in all three U-Nets, noise augmentation on both SR stages) WITH VALUES against the fp32
+    oracle: the half-precision gate of SURVEY.md 8(c), max|d| <= 3e-2 and mean|d| <= 3e-3 on [0,1] images"""
+    dev = setup(backend)
+    im = make_imagen([64, 256, 1024], 25, dev)
+    emb, mask = R.synthetic_text(1, length=32, seed=13)
+    out = im.sample(text_embeds=emb.to(dev), text_masks=mask.to(dev), cond_scale=1., lowres_sample_noise_level=0.2, _noise=R.make_randn(77),
+                    _precision="half")
+    for u, S in zip(im.unets, (64, 256, 1024)):
+        ws = u.engine().workspace(1, 1, S, S, precision="half")
+        assert ws.half and ws.store16, f"stage {S}: the reduced-precision plan fell back to fp32 storage"
+    sd0, sd1 = I.load("unet0_sd.pt"), I.load("unet1_sd.pt")
+    ref = R.sample([sd0, sd1, sd1], [64, 256, 1024], 25, text_embeds=emb, text_masks=mask, cond_scale=1., randn=R.make_randn(77),
+                   lowres_sample_noise_level=0.2)
+    d = (out.cpu() - ref).abs()
+    print(f"cascade 64->256->1024 T=25 cs=1 B=1, reduced precision, vs the fp32 oracle: max|d| = {d.max():.2e}, mean|d| = {d.mean():.2e}")
+    assert out.shape == (1, 3, 1024, 1024) and d.max() < 3e-2 and d.mean() < 3e-3, (d.max(), d.mean())
+
+
+@pytest.mark.parametrize("backend", GPU_ONLY)
 def test_three_stage_cascade_values_vs_oracle(backend):
     """BASELINE config 5's shape (64 -> 256 -> 1024, third U-Net = unet_1 params, noise augmentation on both SR stages) with VALUES:
     B=1, T=25, cond_scale 1, injected noise, against the oracle; max|d| <= 1e-4, mean|d| <= 1e-5 on [0,1] images"""
