@@ -317,7 +317,59 @@ def secondary_lines(timesteps, cond_scale):
     return out
 
 
+def train_step_leg():
+    """SURVEY 8(f) rank 3 (not the headline): one training step (Imagen.forward -> loss.backward(), no optimiser) of the SR U-Net (unet_1
+    parameters, lowres_cond, 256^2) at B = 32 on the device path (conv stack, CrossEmbed and the folded cross-attention core forward and
+    backward on the HIP kernels, minimagen_amd/train_ops.py) with the same step on torch ops / MIOpen beside it: ms per step and peak
+    allocator memory.  Runs in a fresh process (`--train-step-only`)."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--train-step-only"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        return json.loads(lines[-1]) if (r.returncode == 0 and lines) else {"error": (r.stderr or r.stdout)[-400:]}
+    except Exception as exc:                      # never let the secondary leg take the driver line down
+        return {"error": repr(exc)[:400]}
+
+
+def train_step_only():
+    from minimagen_amd import train_ops
+    dev = torch.device("cuda:0")
+    im, sizes = build_imagen("cascade64_256", 1000, dev)
+    im.train()
+    B, S, unet_number = 32, sizes[-1], 2
+    imgs = torch.rand(B, 3, S, S, device=dev)
+    emb, mask = synthetic_text(B)
+    emb, mask = emb.to(dev), mask.to(dev)
+    out = {"config": f"unet_1 params (lowres_cond) @{S}x{S}, B={B}, fp32: Imagen.forward (random timestep, q_sample, low-res augmentation, MSE on the noise) + loss.backward(); "
+                     "no optimiser step; 3 warm-up + 10 timed steps per path"}
+    for hip in (False, True):
+        train_ops.ENABLED = hip
+        def step(seed):
+            torch.manual_seed(seed)
+            loss = im(imgs, text_embeds=emb, text_masks=mask, unet_number=unet_number)
+            for prm in im.unets[unet_number - 1].parameters():
+                prm.grad = None
+            loss.backward()
+            return loss
+        for k in range(3):
+            step(6 + k)
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        t0 = time.perf_counter()
+        for k in range(10):
+            loss = step(20 + k)
+        torch.cuda.synchronize()
+        key = "hip_kernels" if hip else "torch_ops_miopen"
+        out[key] = {"ms_per_fwd_bwd": (time.perf_counter() - t0) / 10 * 1e3, "peak_mem_MB": torch.cuda.max_memory_allocated() / 2 ** 20, "loss": float(loss)}
+    out["speedup_vs_torch_ops"] = out["torch_ops_miopen"]["ms_per_fwd_bwd"] / out["hip_kernels"]["ms_per_fwd_bwd"]
+    print(json.dumps(out))
+
+
 def main():
+    if "--train-step-only" in sys.argv:
+        return train_step_only()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=16)
@@ -554,6 +606,7 @@ def main():
         res["t5_encode"] = t5_leg(dev, B)
     if rank == 0 and world == 1 and not args.no_secondary and args.workload == "cascade64_256" and args.precision == "fp32":
         res["secondary"] = secondary_lines(args.timesteps, args.cond_scale)
+        res["secondary"]["train_step_sr_unet_B32"] = train_step_leg()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline()
     if rank == 0:

@@ -329,6 +329,24 @@ WIDE_CASES = [
 ]
 
 
+# the level shapes of the `Super` preset (dim 128, memory_efficient: Unet.py:637-692) at their REAL sizes for a 256^2 input -- GPU only (the
+# emulator would take minutes): first level 128 channels @128^2 (ResnetBlock conv with identity residual; the skip-concat conv of the up
+# path 256 -> 128 with its 1x1 residual), second level 256 channels @64^2, the k4 s2 Downsample 128 -> 256, nearest x2 + conv 256 -> 128
+WIDE_REAL_CASES = [
+    (1, 128, 0, 128, 128, 128, 3, 1, 0, True, True, 'id'),
+    (1, 128, 128, 128, 128, 128, 3, 1, 0, True, True, 'conv'),
+    (1, 256, 0, 256, 64, 64, 3, 1, 0, True, True, 'id'),
+    (1, 128, 0, 256, 64, 64, 4, 2, 0, False, False, 'none'),
+    (1, 256, 0, 128, 128, 128, 3, 1, 1, False, False, 'none'),
+]
+
+
+@pytest.mark.parametrize("backend", GPU_ONLY)
+@pytest.mark.parametrize("case", WIDE_REAL_CASES)
+def test_conv_wide_regime_at_the_super_presets_level_shapes(backend, case):
+    test_conv_wide_regime(backend, case)
+
+
 @pytest.mark.parametrize("backend", BACKENDS)
 @pytest.mark.parametrize("case", WIDE_CASES)
 def test_conv_wide_regime(backend, case):
