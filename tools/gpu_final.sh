@@ -8,6 +8,11 @@ timeout 600 python bench.py --breakdown-out $OUT/bd_cascade.json > $OUT/bench_ca
 timeout 300 python bench.py --precision half --no-cpu-baseline --no-secondary --no-t5 --breakdown-out $OUT/bd_half.json > $OUT/bench_half.log 2>&1; tail -1 $OUT/bench_half.log | cut -c1-200
 timeout 300 python bench.py --workload base64 --no-cpu-baseline --no-secondary --no-t5 --breakdown-out $OUT/bd_base.json > $OUT/bench_base.log 2>&1; tail -1 $OUT/bench_base.log | cut -c1-400
 timeout 600 python tools/gpu_full_parity.py > $OUT/full_parity.txt 2>&1; tail -3 $OUT/full_parity.txt
+# resident conv chains (opt-in): A/B lines and the phase trace of the chain kernel (library built with -DRS_TRACE)
+for r in 1 2; do MINIMAGEN_RESIDENT=$r timeout 300 python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-secondary --no-t5 --breakdown-out $OUT/bd_resident$r.json > $OUT/bench_resident$r.log 2>&1; tail -1 $OUT/bench_resident$r.log | cut -c1-160; done
+MINIMAGEN_RESIDENT=1 timeout 300 python bench.py --workload base64 --steps 6 --warmup 2 --no-cpu-baseline --no-secondary --no-t5 --no-breakdown > $OUT/bench_base_resident1.log 2>&1; tail -1 $OUT/bench_base_resident1.log | cut -c1-160
+if [ -f minimagen_amd/libminimagen_hip_trace.so ]; then MINIMAGEN_HIP_LIB=$ROOTDIR/minimagen_amd/libminimagen_hip_trace.so timeout 200 python tools/bench_resident.py 64 > $OUT/resident_trace.txt 2>&1; fi
+timeout 200 python tools/bench_resident.py 64 > $OUT/resident_notrace.txt 2>&1; tail -1 $OUT/resident_notrace.txt
 CMD="python $ROOTDIR/bench.py --steps 1 --warmup 0 --timesteps 25 --no-cpu-baseline --no-secondary --no-breakdown --no-t5 --no-pipeline"
 cd /tmp; export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_trace -o cascade -- $CMD > $OUT/rocprof_trace.log 2>&1
