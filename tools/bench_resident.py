@@ -57,7 +57,7 @@ def main():
                 w = bw.reshape(64, 8, 16, 4).astype(np.int64) * 0.01
                 for wg in (0, 1, 5):
                     base = w[wg, 2, 0, 0]
-                    print(f"  workgroup {wg}, layer 2, per wave (mma done, halo published, before barrier, after barrier) relative to wave 0's mma-done:")
+                    print(f"  workgroup {wg}, layer 2, per wave (mma done, y + residual done, before the reduction barrier, after it) relative to wave 0's mma-done:")
                     for wv in range(8):
                         print("     wave", wv, " ".join(f"{w[wg, 2, wv, k] - base:6.2f}" for k in range(4)))
             for li in range(ch.n):
