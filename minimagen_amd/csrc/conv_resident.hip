@@ -80,10 +80,17 @@ __device__ __forceinline__ int rs_clamp_exp(int k) { return k < -60 ? -60 : (k >
 
 enum { RS_CUR = 0, RS_XR = 1, RS_GLB = 2 };
 
+// waves per SIMD the register allocation must leave room for (2 = all 512 registers of a SIMD lane for the two waves of one workgroup).
+// RS_LEAN=1: the light kernels (8 output channels, 32-wide images) at 128 registers, so that another stream's kernels can share the CU
+#ifndef RS_LEAN
+#define RS_LEAN 0
+#endif
+#define RS_WAVES_PER_EU(TW_, R_, NJ_) (((TW_) == 64 && (R_) == 8) ? 4 : ((RS_LEAN && ((NJ_) == 1 || (TW_) == 32)) ? 4 : 2))
+
 // TW: image width (a slab spans it), R: rows per slab, NW: waves per workgroup, NJ: N tiles of 8 output channels the accumulators are
 // sized for (NJX: every layer has exactly 8 NJ output channels), HALF: one fp16 term per product (tensors with st = 1 are bf16 in memory)
 template <int TW, int R, int NW, int NJ, bool NJX, bool HALF>
-__global__ __launch_bounds__(64 * NW, (TW == 64 && R == 8) ? 4 : 2) void resident_convs_kernel(const mi_resident_params p) {
+__global__ __launch_bounds__(64 * NW, RS_WAVES_PER_EU(TW, R, NJ)) void resident_convs_kernel(const mi_resident_params p) {
     constexpr int T = 64 * NW;
     constexpr int IH = R + 2, PW = TW + 8, PLANE = IH * PW;                  // staged window (rows), LDS pitch / plane size in 16-byte chunks
     constexpr int GX = TW / 16, GY = R / 2, NG = GX * GY, GPW = NG / NW;     // 16-pixel x 2-row groups; per wave

@@ -337,3 +337,31 @@ def test_sampling_loop_with_resident_chains(backend, resident_on):
     d = (a.cpu() - ref).abs()
     print(f"base stage T={T} with resident chains vs oracle: max|d| = {d.max():.2e}, mean {d.mean():.2e}")
     assert d.max() < 1e-4 and d.mean() < 1e-5
+
+
+@pytest.mark.parametrize("backend", [pytest.param("gpu", marks=pytest.mark.gpu)])
+def test_resident_chains_of_two_streams_side_by_side(backend):
+    """Two chains (64 images each: 2 x 256 workgroups of 512 work-items, more than the GPU holds at once) launched back to back on two
+    streams, 40 rounds: the slabs of an image are claimed by ticket after a workgroup is resident, so the launches interleave on the CUs
+    without deadlock; every launch reproduces the chain's stand-alone result bit for bit and no workgroup reports a timeout."""
+    dev = setup(backend)
+    chains, streams, refs = [], [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)], []
+    for k, variant in enumerate(("down", "up")):
+        ch = Chain(dev, 64, 64, 64, seed=40 + k)
+        sr_level_chain(ch, 64, 64, 64, variant)
+        ch.run()
+        ch.check()
+        refs.append([o.clone() for o, _, _ in ch.outs])
+        chains.append(ch)
+    torch.cuda.synchronize()
+    lib = L.lib()
+    for rnd in range(40):
+        for ch, st in zip(chains, streams):
+            with torch.cuda.stream(st):
+                L.check(lib.mi_resident_convs_fwd(C.byref(ch.p), st.cuda_stream), "resident")
+        if rnd % 8 == 7:
+            torch.cuda.synchronize()
+            for ch, ref in zip(chains, refs):
+                off = lib.mi_resident_error_offset()
+                assert int(ch.sync[off:off + 4].cpu().view(torch.int32).item()) == 0
+                assert all(torch.equal(a, o) for a, (o, _, _) in zip(ref, ch.outs))
