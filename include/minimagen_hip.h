@@ -308,6 +308,16 @@ int mi_posterior_fwd(const mi_posterior_params* p, void* stream);
 #define MI_SAMPLER_SMALL_N 16384
 int mi_sampler_step_small_fwd(const mi_cfg_x0_params* c, const mi_quantile_params* q, const mi_posterior_params* pp, void* stream);
 
+/* The same fused tail for LARGE images (n % 4 == 0): mi_sampler_group_size(n) workgroups of 1024 work-items per image keep their share of
+ * x0 in registers across the three radix passes; the passes' histograms are combined with integer agent-scope atomics and a counter barrier
+ * among the workgroups of an image (claimed by ticket once resident: no cooperative launch; bounded spins, error word at byte 8 of `sync`).
+ * Replaces mi_cfg_x0_fwd + mi_quantile_fwd (4 launches) + mi_posterior_fwd; bit-identical results.  `sync`: mi_sampler_group_sync_bytes(B, n)
+ * bytes, zero-filled once, private to one stream's launches.  c->x0 / c->pred_out / q->s_out / q->v_out are written when non-NULL; c->hist0 /
+ * q->hist / pp->x0 / pp->s_q are not used. */
+int mi_sampler_group_size(int n);                          /* workgroups per image; 0: unsupported */
+long long mi_sampler_group_sync_bytes(int B, int n);
+int mi_sampler_step_group_fwd(const mi_cfg_x0_params* c, const mi_quantile_params* q, const mi_posterior_params* pp, void* sync, void* stream);
+
 /* t -= 1 ; times[b] = t  (diffusion_model.py:81-87, one step of the list) */
 int mi_step_advance(int* t_state, int64_t* times, int B, void* stream);
 /* t -= n ; times[b] = t  (the steps of one captured graph address *t_state - k and advance once) */

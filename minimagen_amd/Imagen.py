@@ -18,6 +18,9 @@ from .helpers import (cast_tuple, cubic_taps, default, eval_decorator, exists, m
                       resize_image_to)
 from .t5 import get_encoded_dim, t5_encode_text
 
+# the sampler tail of images too large for one workgroup (the super-resolution stages) as ONE launch of cooperating workgroups
+# (mi_sampler_step_group_fwd) instead of five launches; 0: the separate kernels
+SAMPLER_GROUP = int(os.environ.get("MINIMAGEN_SAMPLER_GROUP", "1"))
 SAMPLE_LANES = max(1, int(os.environ.get("MINIMAGEN_SAMPLE_LANES", "2")))     # independent call lanes of sample(_async=True)
 _STAGE_STREAMS = {}          # (device, lanes, stages, priority mode) -> [lane][stage] HIP streams, process-wide (see sample())
 
@@ -211,13 +214,16 @@ class Imagen(nn.Module):
                                      L.ptr(st.seed_dev) if noise_dev is None else 0)
 
             small = n <= 16384 and os.environ.get("MINIMAGEN_SAMPLER_FUSED", "1") != "0"      # MI_SAMPLER_SMALL_N: the whole tail in one launch
+            group = (not small) and SAMPLER_GROUP and lib.mi_sampler_group_size(n) > 0 and os.environ.get("MINIMAGEN_SAMPLER_FUSED", "1") != "0"
+            if group and not hasattr(st, "group_sync"):
+                st.group_sync = torch.zeros(lib.mi_sampler_group_sync_bytes(B, n), dtype=torch.uint8, device=ws.dev)   # this workspace's launches only
             offsets = eng.step_offsets_supported(ws)          # the k-th step of a graph addresses *t_state - k; one advance per graph
 
             def tail_params(k):
                 c_, p_ = L.MiCfgX0Params.from_buffer_copy(cp), L.MiPosteriorParams.from_buffer_copy(pp)
                 c_.t_off = p_.t_off = k
-                if small:
-                    c_.x0 = c_.hist0 = 0                      # x0 stays in registers, the histograms in LDS
+                if small or group:
+                    c_.x0 = c_.hist0 = 0                      # x0 stays in registers, the histograms in LDS (and per-image counters)
                 return c_, p_
             tails = {}
 
@@ -228,6 +234,8 @@ class Imagen(nn.Module):
                 c_, p_ = tails[k]
                 if small:
                     L.check(lib.mi_sampler_step_small_fwd(C.byref(c_), C.byref(qp), C.byref(p_), stream), "mi_sampler_step_small_fwd")
+                elif group:
+                    L.check(lib.mi_sampler_step_group_fwd(C.byref(c_), C.byref(qp), C.byref(p_), L.ptr(st.group_sync), stream), "mi_sampler_step_group_fwd")
                 else:
                     L.check(lib.mi_cfg_x0_fwd(C.byref(c_), stream), "mi_cfg_x0_fwd")
                     L.check(lib.mi_quantile_fwd(C.byref(qp), stream), "mi_quantile_fwd")
@@ -425,12 +433,35 @@ class Imagen(nn.Module):
                     return img
                 caller_stream.wait_event(prev_done)          # the device -> host copy below runs on the caller's stream
                 img.record_stream(caller_stream)
-                return _to_pil_images(img)
+                pil = _to_pil_images(img)
+                self.check_device_status()
+                return pil
             caller_stream.wait_event(prev_done)
             img.record_stream(caller_stream)
         if not return_pil_images:
             return img
-        return _to_pil_images(img)
+        pil = _to_pil_images(img)
+        self.check_device_status()
+        return pil
+
+
+def _check_device_status(self):
+    """Host-side check (synchronises the device): no kernel whose workgroups wait for each other (the grouped sampler tail, resident conv
+    chains) gave up waiting.  Such a launch leaves its outputs unwritten and sets a sticky error word; sample() itself never host-syncs,
+    so callers that need the guarantee call this after their own synchronisation point (the PIL path of sample() does)."""
+    for unet in self.unets:
+        eng = unet.engine()
+        for ws in eng._ws.values():
+            eng.check_resident(ws)
+            for st in ws.__dict__.get("sampler_state", {}).values():
+                sync = getattr(st, "group_sync", None)
+                if sync is not None:
+                    err = int(sync[8:12].cpu().view(torch.int32).item())
+                    if err:
+                        raise L.MinImagenHipError(f"grouped sampler tail reported {err:#x}: a workgroup timed out waiting for its image's other workgroups")
+
+
+Imagen.check_device_status = _check_device_status
 
 
 def _wait_pending_samples(self, stream=None):

@@ -208,6 +208,11 @@ def _bind(lib):
     lib.mi_step_advance_by.argtypes = [vp, vp, i32, i32, vp]
     lib.mi_sampler_step_small_fwd.argtypes = [vp, vp, vp, vp]
     lib.mi_sampler_step_small_fwd.restype = i32
+    lib.mi_sampler_step_group_fwd.argtypes = [vp, vp, vp, vp, vp]
+    lib.mi_sampler_step_group_fwd.restype = i32
+    lib.mi_sampler_group_size.argtypes = [i32]
+    lib.mi_sampler_group_sync_bytes.argtypes = [i32, i32]
+    lib.mi_sampler_group_sync_bytes.restype = C.c_longlong
     lib.mi_step_set.argtypes = [vp, vp, i32, i32, vp]
     lib.mi_randn_fill.argtypes = [vp, i32, i32, u64, i32, i32, vp]
     lib.mi_finalize_images.argtypes = [vp, vp, i64, i32, vp]

@@ -302,6 +302,7 @@ static inline mi_u64 mi_agent_load_u64(const mi_u64* p) { return __atomic_load_n
 static inline void mi_agent_store_u64(mi_u64* p, mi_u64 v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
 static inline mi_u64 mi_agent_add_u64(mi_u64* p, mi_u64 v) { return __atomic_fetch_add(p, v, __ATOMIC_ACQ_REL); }
 static inline void mi_agent_store_u32(unsigned* p, unsigned v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
+static inline unsigned mi_agent_load_u32(const unsigned* p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
 // 16 bytes = two 8-byte {tag, value} granules: each half is one atomic access (what the hardware was observed to do for sc1 dwordx4)
 static inline f32x4 mi_buf_load_f32x4_sc1(const mi_buf& r, unsigned voff) {
     mi_u64 h[2] = {__atomic_load_n(reinterpret_cast<const mi_u64*>(r.base + voff), __ATOMIC_ACQUIRE), __atomic_load_n(reinterpret_cast<const mi_u64*>(r.base + voff + 8), __ATOMIC_ACQUIRE)};
@@ -319,6 +320,7 @@ __device__ __forceinline__ mi_u64 mi_agent_load_u64(const mi_u64* p) { return __
 __device__ __forceinline__ void mi_agent_store_u64(mi_u64* p, mi_u64 v) { __hip_atomic_store(mi_global(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ mi_u64 mi_agent_add_u64(mi_u64* p, mi_u64 v) { return __hip_atomic_fetch_add(mi_global(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void mi_agent_store_u32(unsigned* p, unsigned v) { __hip_atomic_store(mi_global(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned mi_agent_load_u32(const unsigned* p) { return __hip_atomic_load(mi_global(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // aux / cache-policy bit 4 = sc1 on gfx940+ (bit 0 = sc0, bit 1 = nt)
 __device__ __forceinline__ f32x4 mi_buf_load_f32x4_sc1(const mi_buf& r, unsigned voff) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, 0, 16));

@@ -568,6 +568,168 @@ inline int grid_for(long long n, int cap = 2048) {
     return (int)(g < 1 ? 1 : (g > cap ? cap : g));
 }
 
+
+// ------------------------------------------------------------------ K11 epilogue + K12 + K13 in one launch (large images)
+// The tail of a denoising step for images too large for one workgroup: G workgroups of 1024 work-items per image, every work-item keeps its
+// SG_MAXQ quads of x0 (and x_t) in registers from the guidance combine to the posterior draw; the three radix passes are LDS histograms
+// per workgroup, added into per-image histograms with integer agent-scope atomics, and a counter barrier per pass among the G workgroups of
+// the image.  Replaces five launches (cfg_x0 + pass 0, pass 1, pass 2, finish, posterior: 71 us at 256^2, B = 32) and two round trips of x0
+// through memory.  Same operations in the same order per element: bit-identical to the separate kernels.
+// Inter-workgroup protocol as conv_resident.hip: the workgroups of an image are claimed by ticket after they are resident (no cooperative
+// launch, no deadlock with other launches in flight); everything exchanged is touched by agent-scope atomics / sc1 accesses only; the
+// histograms are double-buffered by launch parity and the idle copy is zeroed for the next launch; bounded spins.
+constexpr int SG_NT = 1024, SG_MAXQ = 6;
+constexpr unsigned SG_SPIN_LIMIT = 1u << 22;
+struct sg_layout { long long counters, hist, total; };
+__host__ __device__ inline sg_layout sg_sync_layout(int B) {
+    sg_layout l;
+    l.counters = 64;                                                        // [0] ticket (u64), [8] error word (u32)
+    l.hist = l.counters + (((long long)B * 8 + 63) & ~63ll);               // counters: u64 [B]
+    l.total = l.hist + (long long)2 * B * 5 * MI_Q_BINS * 4;               // hist: u32 [parity][B][5 = pass 0 | pass 1 x 2 | pass 2 x 2][MI_Q_BINS]
+    return l;
+}
+
+__global__ __launch_bounds__(SG_NT) void sampler_group_kernel(const mi_cfg_x0_params c, const mi_quantile_params q, const mi_posterior_params pp, char* sync, const int G) {
+    __shared__ unsigned lh[2][MI_Q_BINS];
+    __shared__ __attribute__((aligned(16))) unsigned hc[2][MI_Q_BINS];
+    __shared__ int scratch[8];
+    __shared__ unsigned nan_sh;
+    __shared__ mi_u64 sTicket;
+    __shared__ int sAbort;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = c.n, nq = n >> 2;
+    if (tid == 0) { sTicket = mi_agent_add_u64(reinterpret_cast<mi_u64*>(sync), 1ull); sAbort = 0; nan_sh = 0u; }
+    for (int i = tid; i < 2 * MI_Q_BINS; i += SG_NT) (&lh[0][0])[i] = 0u;
+    __syncthreads();
+    const sg_layout lay = sg_sync_layout(c.B);
+    const mi_u64 tk = sTicket, Gt = (mi_u64)c.B * (mi_u64)G, seq = tk / Gt;
+    const int local = (int)(tk - seq * Gt), b = local / G, g = local - b * G, par = (int)(seq & 1);
+    mi_u64* const counter = reinterpret_cast<mi_u64*>(sync + lay.counters) + b;
+    unsigned* const H = reinterpret_cast<unsigned*>(sync + lay.hist) + ((size_t)par * c.B + b) * 5 * MI_Q_BINS;
+    const mi_buf hbuf = mi_make_buf(H);
+    const mi_buf zbuf = mi_make_buf(sync + lay.hist + ((size_t)(par ^ 1) * c.B + b) * 5 * MI_Q_BINS * 4);
+    // the idle parity's histograms of this image, zeroed for the next launch (write-through: the next launch's atomics find zeros in memory)
+    for (int i = g * SG_NT + tid; i < 5 * MI_Q_BINS / 4; i += G * SG_NT) mi_buf_store_f32x4_sc1(zbuf, (unsigned)i * 16u, (f32x4){0.f, 0.f, 0.f, 0.f});
+
+    const int t = *c.t_state - c.t_off;
+    const float ca = c.coef[t * 8 + 0], cb = c.coef[t * 8 + 1];
+    const float c1 = c.coef[t * 8 + 2], c2 = c.coef[t * 8 + 3], sigma = c.coef[t * 8 + 4];
+    const size_t ob = (size_t)b * n, on = (size_t)(b + c.B) * n;
+    const int q0 = g * SG_NT * SG_MAXQ;                        // this workgroup's quads: q0 + tid + u * SG_NT
+    float x0v[SG_MAXQ][4], xtv[SG_MAXQ][4];
+#pragma unroll
+    for (int u = 0; u < SG_MAXQ; ++u) {
+        const int qd = q0 + tid + u * SG_NT;
+        float cc[4], nl[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { cc[e] = nl[e] = xtv[u][e] = x0v[u][e] = 0.0f; }
+        if (qd < nq) {
+            const float4 a = mi_ldg4(c.pred2 + ob + 4 * qd), xx = mi_ldg4(c.x_t + ob + 4 * qd);
+            const float4 d = c.two ? mi_ldg4(c.pred2 + on + 4 * qd) : a;
+            cc[0] = a.x; cc[1] = a.y; cc[2] = a.z; cc[3] = a.w; nl[0] = d.x; nl[1] = d.y; nl[2] = d.z; nl[3] = d.w;
+            xtv[u][0] = xx.x; xtv[u][1] = xx.y; xtv[u][2] = xx.z; xtv[u][3] = xx.w;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float pr = cc[e];
+                if (c.two) pr = __fadd_rn(nl[e], __fmul_rn(__fsub_rn(cc[e], nl[e]), c.cond_scale));       // Unet.py:506
+                x0v[u][e] = __fsub_rn(__fmul_rn(ca, xtv[u][e]), __fmul_rn(cb, pr));                       // diffusion_model.py:159-162
+                atomicAdd(&lh[0][__float_as_uint(fabsf(x0v[u][e])) >> 20], 1u);
+                if (c.pred_out) c.pred_out[ob + 4 * qd + e] = pr;
+                if (c.x0) c.x0[ob + 4 * qd + e] = x0v[u][e];
+            }
+        }
+    }
+    // one pass of the radix select across the image's workgroups: add this workgroup's `nh` LDS histograms into the image's, wait for all
+    // G workgroups, copy the totals into LDS (hc)
+    auto exchange = [&](int phase, int slot0, int nh) -> bool {
+        __syncthreads();
+        for (int i = tid; i < nh * MI_Q_BINS; i += SG_NT) {
+            const unsigned v = (&lh[0][0])[i];
+            if (v) atomicAdd(&H[(size_t)slot0 * MI_Q_BINS + i], v);
+        }
+        mi_drain_vmem();                                   // every wave's atomics are performed before the arrival is counted
+        __syncthreads();
+        if (tid == 0) mi_agent_add_u64(counter, 1ull);
+        if (wave == 0) {
+            const mi_u64 target = (seq * 3 + (mi_u64)phase + 1) * (mi_u64)G;
+            for (unsigned spins = 0;;) {
+                const mi_u64 v = mi_agent_load_u64(counter);
+                if (__all(v >= target)) break;
+                if (++spins > SG_SPIN_LIMIT) { if (lane == 0) { mi_agent_store_u32(reinterpret_cast<unsigned*>(sync + 8), 0x300u + (unsigned)phase); sAbort = 1; } break; }
+                mi_sleep();
+            }
+        }
+        __syncthreads();
+        if (sAbort) return false;
+        for (int i = tid; i < nh * MI_Q_BINS / 4; i += SG_NT)
+            reinterpret_cast<f32x4*>(&hc[0][0])[i] = mi_buf_load_f32x4_sc1(hbuf, (unsigned)((slot0 * MI_Q_BINS + 4 * i) * 4));
+        __syncthreads();
+        return true;
+    };
+    if (!exchange(0, 0, 1)) return;
+    // torch.quantile returns NaN for a row that contains a NaN: NaN patterns sit in the top bins of pass 0 (as quantile_finish_kernel)
+    if (tid < MI_Q_BINS - 0x7F9) { const unsigned v = hc[0][0x7F9 + tid]; if (v) atomicAdd(&nan_sh, v); }
+    unsigned prefix[2] = {0u, 0u}, rk[2] = {(unsigned)q.k_lo, (unsigned)q.k_hi};
+    bool one = true;
+#pragma unroll
+    for (int ps = 0; ps < 3; ++ps) {
+        if (ps > 0) {
+            __syncthreads();
+            for (int i = tid; i < 2 * MI_Q_BINS; i += SG_NT) (&lh[0][0])[i] = 0u;
+            __syncthreads();
+            const int shift = q_shift(ps), nb = q_bits(ps);
+            const unsigned mask = (1u << nb) - 1u;
+            one = prefix[0] == prefix[1];          // both ranks in one bin so far (the usual case: neighbours): one histogram serves both
+#pragma unroll
+            for (int u = 0; u < SG_MAXQ; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (q0 + tid + u * SG_NT < nq) {
+                        const unsigned key = __float_as_uint(fabsf(x0v[u][e]));
+                        const unsigned hi = key >> (shift + nb), bin = (key >> shift) & mask;
+                        if (hi == prefix[0]) atomicAdd(&lh[0][bin], 1u);
+                        if (!one && hi == prefix[1]) atomicAdd(&lh[1][bin], 1u);
+                    }
+                }
+            if (!exchange(ps, 2 * ps - 1, one ? 1 : 2)) return;
+        }
+#pragma unroll
+        for (int sel = 0; sel < 2; ++sel) {
+            unsigned bin, rr;
+            q_find_bin(&hc[one ? 0 : sel][0], rk[sel], scratch, bin, rr, tid < 256);
+            prefix[sel] = (prefix[sel] << q_bits(ps)) | bin;
+            rk[sel] = rr;
+        }
+    }
+    float a = __uint_as_float(prefix[0]), bb = __uint_as_float(prefix[1]);
+    if (nan_sh) a = bb = __uint_as_float(0x7FC00000u);
+    const float d = __fsub_rn(bb, a);
+    const float sq = (fabsf(q.w) < 0.5f) ? fmaf(q.w, d, a) : fmaf(__fsub_rn(q.w, 1.0f), d, bb);      // ATen lerp (fused multiply-add)
+    if (tid == 0 && g == 0) {
+        if (q.s_out) q.s_out[b] = sq;
+        if (q.v_out) { q.v_out[2 * b] = a; q.v_out[2 * b + 1] = bb; }
+    }
+    const float s = (sq < 1.0f) ? 1.0f : sq;                                     // Imagen.py:320 clamp_(min=1.): a NaN threshold stays NaN
+    const int k = (pp.T - 1) - t;
+    const float* nz = pp.noise ? pp.noise + ((size_t)k * pp.B + b) * n : nullptr;
+#pragma unroll
+    for (int u = 0; u < SG_MAXQ; ++u) {
+        const int qd = q0 + tid + u * SG_NT;
+        if (qd >= nq) continue;
+        float z[4];
+        if (nz) { const float4 v = mi_ldg4(nz + 4 * qd); z[0] = v.x; z[1] = v.y; z[2] = v.z; z[3] = v.w; }
+        else randn4(pp.seed_dev ? *pp.seed_dev : pp.seed, (unsigned)(pp.sample0 + b), (unsigned)(pp.stream_base + k), (unsigned)qd, z);
+        float r[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float x0 = x0v[u][e];
+            x0 = __fdiv_rn(x0 != x0 ? x0 : fminf(fmaxf(x0, -s), s), s);                  // Imagen.py:323 (torch.clamp propagates NaN)
+            const float mean = __fadd_rn(__fmul_rn(c1, x0), __fmul_rn(c2, xtv[u][e]));     // diffusion_model.py:118-121
+            r[e] = __fadd_rn(mean, __fmul_rn(sigma, z[e]));                               // Imagen.py:370
+        }
+        mi_stg4(pp.x + ob + 4 * qd, make_float4(r[0], r[1], r[2], r[3]));
+    }
+}
+
 }  // namespace
 
 extern "C" int mi_cfg_x0_fwd(const mi_cfg_x0_params* p, void* stream) {
@@ -601,6 +763,27 @@ extern "C" int mi_sampler_step_small_fwd(const mi_cfg_x0_params* c, const mi_qua
     if (q->k_lo < 0 || q->k_hi >= q->n || q->k_lo > q->k_hi) { mi_set_error("mi_sampler_step_small_fwd: bad ranks"); return MI_ERR_INVALID; }
     hipLaunchKernelGGL(sampler_small_kernel, dim3(c->B), dim3(SS_NT), 0, (hipStream_t)stream, *c, *q, *pp);
     return mi_check_launch("sampler_small_kernel");
+}
+
+extern "C" int mi_sampler_group_size(int n) {
+    if (n <= 0 || (n & 3)) return 0;
+    const int g = ((n >> 2) + SG_NT * SG_MAXQ - 1) / (SG_NT * SG_MAXQ);
+    return g <= 256 ? g : 0;
+}
+extern "C" long long mi_sampler_group_sync_bytes(int B, int n) {
+    return (B > 0 && mi_sampler_group_size(n) > 0) ? sg_sync_layout(B).total : 0;
+}
+extern "C" int mi_sampler_step_group_fwd(const mi_cfg_x0_params* c, const mi_quantile_params* q, const mi_posterior_params* pp, void* sync, void* stream) {
+    if (c->B <= 0 || c->n <= 0 || q->B != c->B || pp->B != c->B || q->n != c->n || pp->n != c->n) { mi_set_error("mi_sampler_step_group_fwd: inconsistent B / n"); return MI_ERR_INVALID; }
+    const int G = mi_sampler_group_size(c->n);
+    if (!G) { mi_set_error("mi_sampler_step_group_fwd: n = %d unsupported (a multiple of 4, at most %d)", c->n, 256 * SG_NT * SG_MAXQ * 4); return MI_ERR_UNSUPPORTED; }
+    if (!sync) { mi_set_error("mi_sampler_step_group_fwd: sync buffer missing"); return MI_ERR_INVALID; }
+    if (!c->x_t || !c->coef || !c->t_state || !pp->x || c->t_state != pp->t_state || c->t_off != pp->t_off || c->coef != pp->coef || c->x_t != pp->x) {
+        mi_set_error("mi_sampler_step_group_fwd: needs x_t == x, one coef table and one t_state / t_off for the step"); return MI_ERR_INVALID;
+    }
+    if (q->k_lo < 0 || q->k_hi >= q->n || q->k_lo > q->k_hi) { mi_set_error("mi_sampler_step_group_fwd: bad ranks"); return MI_ERR_INVALID; }
+    hipLaunchKernelGGL(sampler_group_kernel, dim3(c->B * G), dim3(SG_NT), 0, (hipStream_t)stream, *c, *q, *pp, (char*)sync, G);
+    return mi_check_launch("sampler_group_kernel");
 }
 
 extern "C" int mi_posterior_fwd(const mi_posterior_params* p, void* stream) {

@@ -848,6 +848,77 @@ def test_sampler_elementwise_bit_exact(backend, side):
     assert torch.equal(oo.cpu(), (xx.clamp(-1, 1) + 1) * 0.5)
 
 
+GROUP_SIDES = [96, 160]
+
+
+def _group_tail_case(dev, side, B=2, T=25, rounds=3, nan_row=False, two=1):
+    """mi_sampler_step_group_fwd against mi_cfg_x0_fwd + mi_quantile_fwd + mi_posterior_fwd on the same inputs: bit for bit, several launches in
+    a row on one sync buffer (both parities of the double-buffered histograms, the step offset of multi-step graphs)."""
+    lib = L.lib()
+    from minimagen_amd.diffusion_model import GaussianDiffusion
+    n = 3 * side * side
+    G = lib.mi_sampler_group_size(n)
+    assert G >= 2
+    coef = GaussianDiffusion(timesteps=T).sampler_coef_table().to(dev)
+    g = torch.Generator().manual_seed(side)
+    k_lo, k_hi, w = quantile_rank(n, 0.9)
+    sync = torch.zeros(lib.mi_sampler_group_sync_bytes(B, n), dtype=torch.uint8, device=dev)
+    hist = torch.zeros(3 * B * 2 * 2048, dtype=torch.int32, device=dev)
+    noise = torch.randn(T, B, n, generator=g).to(dev)
+    for r in range(rounds):
+        t, off = (13, 0) if r == 0 else ((0, 2) if r == 1 else (7, 1))
+        use_noise = r != 2
+        pred2 = (torch.randn(2 * B, n, generator=g) * (1.0 + r)).to(dev)
+        xt = torch.randn(B, n, generator=g).to(dev)
+        if nan_row and r == 1:
+            pred2[0, 5] = float("nan")
+        ts, ts2 = torch.tensor([t], dtype=torch.int32, device=dev), torch.tensor([t + off], dtype=torch.int32, device=dev)
+        nzp = noise.data_ptr() if use_noise else 0
+        # the separate kernels
+        xa, x0, pg, s, v = xt.clone(), torch.zeros(B, n, device=dev), torch.zeros(B, n, device=dev), torch.zeros(B, device=dev), torch.zeros(B, 2, device=dev)
+        cp = L.MiCfgX0Params(B, n, pred2.data_ptr(), two, 3.0, xa.data_ptr(), coef.data_ptr(), ts.data_ptr(), pg.data_ptr(), x0.data_ptr(), hist.data_ptr())
+        L.check(lib.mi_cfg_x0_fwd(C.byref(cp), L.current_stream()))
+        qp = L.MiQuantileParams(B, n, x0.data_ptr(), k_lo, k_hi, w, hist.data_ptr(), s.data_ptr(), v.data_ptr(), 1, 1)
+        L.check(lib.mi_quantile_fwd(C.byref(qp), L.current_stream()))
+        pp = L.MiPosteriorParams(B, n, T, x0.data_ptr(), s.data_ptr(), xa.data_ptr(), coef.data_ptr(), ts.data_ptr(), nzp, 77, 5, 3 << 20)
+        L.check(lib.mi_posterior_fwd(C.byref(pp), L.current_stream()))
+        # one launch
+        xb, x0g, pgg, sg, vg = xt.clone(), torch.zeros(B, n, device=dev), torch.zeros(B, n, device=dev), torch.zeros(B, device=dev), torch.zeros(B, 2, device=dev)
+        cf = L.MiCfgX0Params(B, n, pred2.data_ptr(), two, 3.0, xb.data_ptr(), coef.data_ptr(), ts2.data_ptr(), pgg.data_ptr() if r else 0, x0g.data_ptr() if r else 0, 0, off)
+        qf = L.MiQuantileParams(B, n, 0, k_lo, k_hi, w, 0, sg.data_ptr(), vg.data_ptr(), 0, 0)
+        pf = L.MiPosteriorParams(B, n, T, 0, 0, xb.data_ptr(), coef.data_ptr(), ts2.data_ptr(), nzp, 77, 5, 3 << 20, 0, off)
+        L.check(lib.mi_sampler_step_group_fwd(C.byref(cf), C.byref(qf), C.byref(pf), sync.data_ptr(), L.current_stream()), "grouped tail")
+        eq = (lambda a, b: torch.equal(a, b)) if not (nan_row and r == 1) else (lambda a, b: torch.equal(torch.nan_to_num(a, nan=7e7), torch.nan_to_num(b, nan=7e7)))
+        assert eq(sg, s) and eq(vg, v), (side, r, sg, s)
+        assert eq(xb, xa), (side, r)
+        if r:
+            assert eq(x0g, x0) and eq(pgg, pg)
+        if nan_row and r == 1:
+            assert torch.isnan(sg[0]) and not torch.isnan(sg[1])
+        words = sync[:16].cpu().view(torch.int64)
+        assert int(words[0]) == (r + 1) * B * G and int(words[1]) == 0            # tickets taken, error word clear
+    lay_hist = sync[64 + ((B * 8 + 63) & ~63):].view(torch.int32).view(2, B, 5, 2048)
+    assert int(lay_hist[rounds & 1].abs().sum()) == 0                            # the parity the next launch uses is clean
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("side", GROUP_SIDES)
+def test_sampler_group_tail_bit_exact(backend, side):
+    dev = setup(backend)
+    _group_tail_case(dev, side, nan_row=(side == 96))
+
+
+@pytest.mark.gpu
+def test_sampler_group_tail_bit_exact_at_the_sr_stage_size():
+    """the 256^2 stage of the headline cascade (B = 32, G = 8: 256 workgroups), without guidance too"""
+    dev = setup("gpu")
+    _group_tail_case(dev, 256, B=32, rounds=3)
+    _group_tail_case(dev, 256, B=3, rounds=3, two=0)
+    lib = L.lib()
+    assert lib.mi_sampler_group_size(3 * 256 * 256) == 8 and lib.mi_sampler_group_size(3 * 1024 * 1024) == 128
+    assert lib.mi_sampler_group_size(3 * 15 * 15) == 0
+
+
 @pytest.mark.parametrize("backend", BACKENDS)
 def test_randn_keyed_by_global_sample(backend):
     dev = setup(backend)

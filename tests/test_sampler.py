@@ -408,6 +408,41 @@ def test_sampler_argument_sweep_vs_oracle(backend, case):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
+def test_grouped_sampler_tail_in_the_sampling_loop(backend, monkeypatch):
+    """images too large for the one-workgroup tail (n > 16384) take mi_sampler_step_group_fwd: same pixels as the separate kernels, bit
+    for bit, through graphs of several steps (the step offsets), with injected noise and with the on-device generator; and the oracle's
+    values.  (The emulator runs a smaller image -- one workgroup per image; tests/test_kernels.py covers 2 and 4 there.)"""
+    from minimagen_amd import Imagen as IM
+    dev = setup(backend)
+    gpu = backend == "gpu"
+    torch.manual_seed(4)
+    S, T = (96, 25) if gpu else (76, 25)                       # n = 27648: two workgroups per image / 17328: one
+    kw = dict(dim=8, dim_mults=(1, 2), num_resnet_blocks=1, layer_attns=False, layer_cross_attns=False, memory_efficient=True)
+    sd = {k: v.clone() for k, v in Unet(**kw).state_dict().items()}
+    emb, mask = R.synthetic_text(2, length=10, seed=3)
+    outs = {}
+    for grp in (1, 0):
+        monkeypatch.setattr(IM, "SAMPLER_GROUP", grp)
+        im = Imagen([Unet(**kw)], text_encoder_name="t5_small", image_sizes=[S], timesteps=T, cond_drop_prob=0.15)
+        im.unets[0].load_state_dict(sd)
+        im = im.to(dev)
+        args = dict(text_embeds=emb.to(dev), text_masks=mask.to(dev), cond_scale=2.)
+        outs[grp, "gen"] = im.sample(**args, _seed=11).cpu()
+        if gpu:
+            outs[grp, "gen2"] = im.sample(**args, _seed=11).cpu()          # the cached graph again, on the same sync words
+            outs[grp, "noise"] = im.sample(**args, _noise=R.make_randn(5)).cpu()
+        im.check_device_status()
+        st = next(iter(im.unets[0].engine()._ws.values())).sampler_state
+        assert any(hasattr(v, "group_sync") for v in st.values()) == bool(grp)
+    assert torch.equal(outs[1, "gen"], outs[0, "gen"])
+    assert outs[1, "gen"].isfinite().all() and outs[1, "gen"].std() > 0.01
+    if gpu:
+        assert torch.equal(outs[1, "gen2"], outs[1, "gen"]) and torch.equal(outs[1, "noise"], outs[0, "noise"])
+        ref = R.sample([sd], [S], T, text_embeds=emb, text_masks=mask, cond_scale=2., randn=R.make_randn(5))
+        assert (outs[1, "noise"] - ref).abs().max() < 1e-4
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
 def test_degenerate_T20_schedule_is_all_nan_like_the_reference(backend):
     """timesteps=20 passes the reference's assert (diffusion_model.py:24) but gives beta_T = 1: sqrt_recip_alphas_cumprod[T-1] is
     inf, x0 becomes inf - inf, torch.quantile / clamp propagate the NaN and the reference returns an all-NaN image.  Same here."""
