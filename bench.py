@@ -579,7 +579,7 @@ def main():
             k = 0.25 * ((3.0 if args.precision == "fp32" else 1.0) if attn_f16 else 1.0)
             ex = dom["alg_flops"] * k / (dom["ms"] * 1e-3) / 1e12
             res["roofline"]["executed"] = {"achieved": ex, "frac": ex / peak,
-                                           "note": f"MFMA flops actually issued = {k:g} x algorithmic (folded attention" + ((", fp16x3 split" if args.precision == "fp32" else ", single fp16 term") + "; v_mfma_f32_16x16x16_f16 (QK^T) and 16x16x32_f16 (PV)" if attn_f16 else "; v_mfma_f32_16x16x4_f32") + ")"}
+                                           "note": f"MFMA flops actually issued = {k:g} x algorithmic (folded attention" + ((", fp16x3 split" if args.precision == "fp32" else ", single fp16 term") + "; v_mfma_f32_16x16x32_f16 for both contractions: QK^T per tile as {G hi|G lo}.{x hi|x hi} + {G hi|G lo}.{x lo|0} -- two pipe slots instead of three K = 16 ones, a quarter of the issued K is zero padding and not counted" if attn_f16 else "; v_mfma_f32_16x16x4_f32") + ")"}
         res["roofline"].update(pmc_traffic(dom, B * (2 if args.cond_scale != 1 else 1), sizes[stage]))
         # SURVEY 8(d) algorithmic bytes of ONE image-forward, summed over this U-Net's own launch plan: every entry's bytes divided by the
         # rows it serves (a tensor the engine computes once for both guidance halves still counts once per forward, as in the reference)

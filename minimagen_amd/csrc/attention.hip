@@ -265,7 +265,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #define ATTN_QPF 1          // prefetch the next QK^T fragment (one tile ahead) in the 3-term kernel
 #endif
 #ifndef ATTN_QK32
-#define ATTN_QK32 0
+#define ATTN_QK32 2         // 2: QK^T as two K = 32 instructions per tile (one shape, chained); 0: three K = 16 instructions; 1: the mixed-shape form (broken, see above)
 #endif
 
 __device__ __forceinline__ void split_f16(const float (&x)[4], f16x4& hi, f16x4& lo) { mi_split_f16(x, hi, lo); }
@@ -387,7 +387,16 @@ __global__ __launch_bounds__(64 * NWV, WPS) void cross_attn_f16x3_kernel(const m
                 else g.u = frag[hb][(jt * QC + kc) * 64 + lane];
                 const f16x4 ghi = g.h2[0];
                 if constexpr (!HALF) {
-#if ATTN_QK32
+#if ATTN_QK32 == 2
+                    // both instructions of ONE shape (K = 32), so the accumulator may be chained: {G hi | G lo} . {x lo | 0} + {G hi | G lo} . {x hi | x hi}.
+                    // The A operand is the LDS chunk as it lies; a K = 16 instruction occupies the matrix pipe as long as a K = 32 one
+                    // (profiles/r01_mfma_f16_chain_ubench.txt), so this is two pipe slots per tile instead of three.
+                    const f16x4 z4 = {(_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0};
+                    const f16x8 xhh = __builtin_shufflevector(xhi[kc], xhi[kc], 0, 1, 2, 3, 4, 5, 6, 7);
+                    const f16x8 xl0 = __builtin_shufflevector(xlo[kc], z4, 0, 1, 2, 3, 4, 5, 6, 7);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, g.u), xl0, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, g.u), xhh, acc, 0, 0, 0);
+#elif ATTN_QK32
                     // {G hi | G lo} . {x hi | x hi} on the K = 32 instruction (the LDS chunk IS that A operand) + G hi . x lo on the K = 16 one:
                     // two instructions per tile instead of three
                     const f16x8 xhh = __builtin_shufflevector(xhi[kc], xhi[kc], 0, 1, 2, 3, 4, 5, 6, 7);
