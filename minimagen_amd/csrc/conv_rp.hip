@@ -142,7 +142,9 @@ __global__ __launch_bounds__(256, CFG::WPS) void conv_rp_kernel(const mi_conv_pa
     // producer -> consumer hand-over of an image stay in one L2
     int b, strip;
     if ((p.B & 7) == 0) {
-        const int L = blockIdx.x, k = L >> 3;
+        const int L = blockIdx.x;
+        int k = L >> 3;
+        if (p.tile_cfg & MI_CONV_REVERSE) k = (int)(gridDim.x >> 3) - 1 - k;   // last image group first: what the previous launch wrote last is read first
         b = (L & 7) + 8 * (k / strips);
         strip = k % strips;
     } else {

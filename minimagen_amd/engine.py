@@ -33,6 +33,7 @@ RP_TILE = {k: int(os.environ.get("MINIMAGEN_RP_TILE_" + k, d)) for k, d in (("L"
 RP_MIN_HW = int(os.environ.get("MINIMAGEN_RP_MIN_HW", "0"))             # ... for images of at least this many pixels
 CE_MFMA = os.environ.get("MINIMAGEN_CE_MFMA", "1") != "0"                  # CrossEmbed on the matrix cores (0: the fp32 VALU kernel)
 STORE16 = os.environ.get("MINIMAGEN_STORE16", "1") != "0"                  # reduced-precision configuration: bf16 activation storage
+CONV_REVERSE = int(os.environ.get("MINIMAGEN_CONV_REVERSE", "1"))        # a row-paired conv walks the image groups opposite to its producer (0 = off)
 RP_NTILE = int(os.environ.get("MINIMAGEN_RP_NTILE", "0"))               # tiles per workgroup of the row-paired kernel (0 = the library's choice)
 TILE64 = int(os.environ.get("MINIMAGEN_TILE64", "-1"))                  # force a conv tile shape at 64x64 / 128x128 (experiments)
 TILE128 = int(os.environ.get("MINIMAGEN_TILE128", "-1"))       # 1: 16-channel 3x3 outputs as two 8-channel workgroups
@@ -51,11 +52,12 @@ JT = 17     # context tiles of 16 rows: 1 null + (2|4) time tokens + 256 text ro
 class Act:
     """An NCHW activation (fp32, or bf16 in the reduced-precision configuration) plus the per-channel partial statistics its producer
     emitted (always fp32)."""
-    __slots__ = ("t", "stats", "nt", "C", "H", "W", "batch", "uses")
+    __slots__ = ("t", "stats", "nt", "C", "H", "W", "batch", "uses", "rev")
 
     def __init__(self, t, stats, nt, C_, H, W, batch):
         self.t, self.stats, self.nt, self.C, self.H, self.W, self.batch = t, stats, nt, C_, H, W, batch
         self.uses = 0
+        self.rev = False            # the producing launch walked the image groups in reverse order (conv(): the consumer goes the other way)
 
     @property
     def st(self) -> int:
@@ -395,6 +397,11 @@ class UnetEngine:
             ws.tensors += [coef, exps]
             p.gn_coef, p.gn_exps = L.ptr(coef), L.ptr(exps)
         if rp:
+            # the consumer walks the image groups in the opposite order of its producer: what was written last (still in the memory-side
+            # cache / L2) is read first (speed only; measured -1.2 % on the SR step)
+            out.rev = bool(CONV_REVERSE) and batch % 8 == 0 and not in0.rev
+            if out.rev:
+                p.tile_cfg |= 0x200
             p.tile_cfg |= (RP_NTILE & 0xf) << 12
             frag, p.w_rp_exp = pk.conv_rp[id(wpack)]
             p.w_rp = L.ptr(frag)

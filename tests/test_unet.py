@@ -142,6 +142,33 @@ def test_wide_channel_unet_vs_oracle(backend):
     assert d < FWD_ATOL * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_reversed_image_order_of_alternate_convs_is_bit_exact(backend, monkeypatch):
+    """MINIMAGEN_CONV_REVERSE (default on, batches that are multiples of 8): a row-paired conv walks the image groups opposite to its
+    producer -- a placement choice only: same bits as with the knob off, and the oracle's values"""
+    from minimagen_amd import engine as E
+    dev = setup(backend)
+    torch.manual_seed(6)
+    kw = dict(dim=8, dim_mults=(1, 2), num_resnet_blocks=1, layer_attns=False, layer_cross_attns=(False, True), memory_efficient=True)
+    sd = {k: v.clone() for k, v in Unet(**kw).state_dict().items()}
+    B, S = 8, (64 if backend == "gpu" else 16)
+    emb, mask = R.synthetic_text(B, length=9, seed=4)
+    x, tm = I.seeded((B, 3, S, S), 33), torch.arange(B) * 3 + 1
+    outs = []
+    for rev in (1, 0):
+        monkeypatch.setattr(E, "CONV_REVERSE", rev)
+        u = Unet(**kw)
+        u.load_state_dict(sd)
+        u = u.to(dev).eval()
+        outs.append(u(x.to(dev), tm.to(dev), text_embeds=emb.to(dev), text_mask=mask.to(dev)).cpu())
+        plan = next(iter(u.engine()._ws.values()))
+        flagged = sum(1 for _, prm, name in plan.prog if hasattr(prm, "tile_cfg") and hasattr(prm, "w_rp") and (prm.tile_cfg & 0x200))
+        assert (flagged > 0) == bool(rev), flagged
+    assert torch.equal(outs[0], outs[1])
+    ref = R.unet_forward(sd, x, tm, text_embeds=emb, text_mask=mask)
+    assert (outs[0] - ref).abs().max() < FWD_ATOL * max(1.0, ref.abs().max().item())
+
+
 @pytest.mark.parametrize("backend", GPU_ONLY)
 def test_default_unet_vs_oracle(backend):
     """``Unet()`` with the reference's default arguments (dim 128, dim_mults (1, 2, 4), self- and cross-attention at every level,
