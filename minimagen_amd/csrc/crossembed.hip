@@ -300,33 +300,45 @@ __global__ __launch_bounds__(256, 2) void crossembed_mfma_kernel(const mi_crosse
     __syncthreads();
     CE_TPHASE(1);
 
-    // ---- the GEMM: rows of the window outermost, B fragments shared by the wave's G groups
+    // ---- the GEMM.  One step = one K = 32 instruction triple per group and N tile:
+    //   k15: (window row r, column half h): the 8 column positions 2 lg + dx + 8 h of the 16-column window, 4 channels each;
+    //   k7:  rides on the k15 fragments of window rows 4 .. 17 (its taps are positions 4 .. 10: both halves);
+    //   k3:  its own dense step per window row PAIR (r, r + 1) and N tile (channels 0-1, 2-3): lane groups 0-1 take row r, 2-3 row r + 1,
+    //        positions 6 .. 9 (the 4th is a zero weight).  (On the k15 fragments the k3 member cost 40 steps x 2 tiles per group; dense: 5 x 2.)
+    // The loop is bound by LDS reads (A fragments: 2 KB per step and group), then by the matrix pipe: 1344 -> 984 instructions and 576 -> 476 KB
+    // of LDS reads per wave against round 3's all-on-k15 form; an own (aligned) step for k7 as well would cut the instructions to 816 but
+    // read 640 KB -- measured slower.
+    // The operands of step s + 1 are read from LDS while the MFMAs of step s run (two register sets); the rows are walked in row pairs with
+    // a compile-time step list, so that there is no branch between the reads and their use.
     f32x4 acc[G][4];
 #pragma unroll
     for (int g = 0; g < G; ++g)
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[g][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int bch = co2 * 4 + lg;                           // this lane's chunk within a (row, h, hi | lo) block of the table
-    // One step = (window row r, column half h): the B fragments of the N tiles that can hold a tap there (shared by the wave's G
-    // groups) and one A fragment per group.  The operands of step s + 1 are read from LDS while the MFMAs of step s run (two register
-    // sets); the rows are walked in five segments with a compile-time set of live N tiles so that there is no branch between the
-    // reads and their use (the waits stay counted).
-    struct Ops { ce_f16x8 bh[4], bl[4], ah[G], al[G]; };
-    auto load = [&](auto mask_tag, int r, int h, Ops& o) {
-        constexpr int MASK = decltype(mask_tag)::value;
+    struct Ops { ce_f16x8 bh[2], bl[2], ah[G], al[G]; };
+    // KIND 0 / 1: k15 half 0 / 1 (+ k7 when W7), 3: k3
+    auto load = [&](auto kind_tag, auto w7_tag, int r, Ops& o) {
+        constexpr int KIND = decltype(kind_tag)::value;
+        constexpr bool W7 = decltype(w7_tag)::value;
+        constexpr int NB = (KIND == 3 || W7) ? 2 : 1;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            if (!((MASK >> t) & 1)) continue;
-            const int K = t == 3 ? 15 : (t == 2 ? 7 : 3), row0 = t == 3 ? 16 : (t == 2 ? 8 : 4 * t), off = t == 3 ? 0 : (t == 2 ? 4 : 6);
-            const int q = r - dy - off;
-            const int row = row0 + ((unsigned)q < (unsigned)K ? q : K);               // taps outside the kernel: the zero row
-            o.bh[t] = __builtin_bit_cast(ce_f16x8, tab[row * TP + (2 * h) * 8 + bch]);
-            if constexpr (!HALF) o.bl[t] = __builtin_bit_cast(ce_f16x8, tab[row * TP + (2 * h + 1) * 8 + bch]);
+        for (int t = 0; t < NB; ++t) {
+            int row, hsel = 0;
+            if constexpr (KIND <= 1) {
+                hsel = KIND;
+                if (t == 0) { const int q = r - dy; row = 16 + ((unsigned)q < 15u ? q : 15); }
+                else { const int q = r - dy - 4; row = 8 + ((unsigned)q < 7u ? q : 7); }
+            } else { const int q = r - dy - 5; row = (unsigned)q < 4u ? 4 * t + q : 31; }      // q = q' + 1, q' = r - dy - 6 in -1 .. 2; else the zero row
+            o.bh[t] = __builtin_bit_cast(ce_f16x8, tab[row * TP + (2 * hsel) * 8 + bch]);
+            if constexpr (!HALF) o.bl[t] = __builtin_bit_cast(ce_f16x8, tab[row * TP + (2 * hsel + 1) * 8 + bch]);
         }
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             const int gi = wave * G + g, gyy = gi / GX, gxx = gi % GX;
-            const int idx = (8 * gyy + r) * PW + 16 * gxx + 1 + lq + 2 * lg + 8 * h;
+            int idx = 16 * gxx + 1 + lq;
+            if constexpr (KIND <= 1) idx += (8 * gyy + r) * PW + 2 * lg + 8 * KIND;
+            else idx += (8 * gyy + r + (lg >> 1)) * PW + 6 + 2 * (lg & 1);
             const uint2 h0 = actH[idx], h1 = actH[idx + 1];
             o.ah[g] = __builtin_bit_cast(ce_f16x8, make_uint4(h0.x, h0.y, h1.x, h1.y));
             if constexpr (!HALF) {
@@ -335,38 +347,58 @@ __global__ __launch_bounds__(256, 2) void crossembed_mfma_kernel(const mi_crosse
             }
         }
     };
-    auto mma = [&](auto mask_tag, const Ops& o) {
-        constexpr int MASK = decltype(mask_tag)::value;
+    auto mma = [&](auto kind_tag, auto w7_tag, const Ops& o) {
+        constexpr int KIND = decltype(kind_tag)::value;
+        constexpr bool W7 = decltype(w7_tag)::value;
+        constexpr int NB = (KIND == 3 || W7) ? 2 : 1;
         // term-major over the wave's groups: consecutive MFMAs write different accumulators (no back-to-back dependency)
 #pragma unroll
-        for (int t = 3; t >= 0; --t) {
-            if (!((MASK >> t) & 1)) continue;
+        for (int t = 0; t < NB; ++t) {
+            const int T = KIND == 3 ? t : 3 - t;                    // accumulator: k3 -> 0, 1; k15 -> 3, k7 -> 2
             if constexpr (!HALF) {
 #pragma unroll
-                for (int g = 0; g < G; ++g) acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(o.al[g], o.bh[t], acc[g][t], 0, 0, 0);
+                for (int g = 0; g < G; ++g) acc[g][T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(o.al[g], o.bh[t], acc[g][T], 0, 0, 0);
 #pragma unroll
-                for (int g = 0; g < G; ++g) acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(o.ah[g], o.bl[t], acc[g][t], 0, 0, 0);
+                for (int g = 0; g < G; ++g) acc[g][T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(o.ah[g], o.bl[t], acc[g][T], 0, 0, 0);
             }
 #pragma unroll
-            for (int g = 0; g < G; ++g) acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(o.ah[g], o.bh[t], acc[g][t], 0, 0, 0);
+            for (int g = 0; g < G; ++g) acc[g][T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(o.ah[g], o.bh[t], acc[g][T], 0, 0, 0);
         }
     };
-    auto segment = [&](auto mask_tag, int r_lo, int r_hi) {
-        Ops o0, o1;
-        load(mask_tag, r_lo, 0, o0);
+    using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>; using K3 = std::integral_constant<int, 3>;
+    using Y = std::true_type; using N = std::false_type;
+    // One row PAIR (r, r + 1), r even: steps k15(r, 0) k15(r, 1) [k3(r)] k15(r + 1, 0) k15(r + 1, 1).  `x` holds the operands of the first
+    // step on entry; the operands of k15(rn, 0) -- the next pair's first step, with k7 iff W7N -- are loaded under the last step's MFMAs and
+    // end up in `x` again (even step count), or in `y` for the 5-step form.
+    auto pair4 = [&](auto w7, auto w7n, int r, int rn, Ops& x, Ops& y) {
+        load(K1{}, w7, r, y);        mma(K0{}, w7, x);
+        load(K0{}, w7, r + 1, x);    mma(K1{}, w7, y);
+        load(K1{}, w7, r + 1, y);    mma(K0{}, w7, x);
+        load(K0{}, w7n, rn, x);      mma(K1{}, w7, y);
+    };
+    auto pair5 = [&](auto w7n, int r, int rn, Ops& x, Ops& y) {
+        load(K1{}, Y{}, r, y);        mma(K0{}, Y{}, x);
+        load(K3{}, N{}, r, x);        mma(K1{}, Y{}, y);
+        load(K0{}, Y{}, r + 1, y);    mma(K3{}, N{}, x);
+        load(K1{}, Y{}, r + 1, x);    mma(K0{}, Y{}, y);
+        load(K0{}, w7n, rn, y);       mma(K1{}, Y{}, x);
+    };
+    {
+        Ops oa, ob;
+        load(K0{}, N{}, 0, oa);
+        pair4(N{}, N{}, 0, 2, oa, ob);                          // rows that hold taps of the 15x15 kernel only
+        pair4(N{}, Y{}, 2, 4, oa, ob);
+        pair4(Y{}, Y{}, 4, 6, oa, ob);                          // + the 7x7 kernel (window rows 4 .. 17)
 #pragma unroll 1
-        for (int r = r_lo; r < r_hi; ++r) {
-            load(mask_tag, r, 1, o1);
-            mma(mask_tag, o0);
-            load(mask_tag, r + 1 < r_hi ? r + 1 : r, 0, o0);         // (the last one is a harmless re-read: no branch around the reads)
-            mma(mask_tag, o1);
+        for (int r = 6; r < 14; r += 4) {                       // + the 3x3 kernel (window rows 6 .. 15, one step per row pair)
+            pair5(Y{}, r, r + 2, oa, ob);
+            pair5(Y{}, r + 2, r + 4, ob, oa);
         }
-    };
-    segment(std::integral_constant<int, 8>{}, 0, 4);            // rows that hold taps of the 15x15 kernel only
-    segment(std::integral_constant<int, 12>{}, 4, 6);           // + the 7x7 kernel (window rows 4 .. 17)
-    segment(std::integral_constant<int, 15>{}, 6, 16);          // + the 3x3 kernel (window rows 6 .. 15)
-    segment(std::integral_constant<int, 12>{}, 16, 18);
-    segment(std::integral_constant<int, 8>{}, 18, 22);
+        pair5(Y{}, 14, 16, oa, ob);
+        pair4(Y{}, N{}, 16, 18, ob, oa);
+        pair4(N{}, N{}, 18, 20, ob, oa);
+        pair4(N{}, N{}, 20, 20, ob, oa);                        // (the last load is a harmless re-read: no branch around the reads)
+    }
     CE_TPHASE(2);
 
     // ---- epilogue: lane (lq = 8 co2 + dy, lg) holds pixels 4 lg .. 4 lg + 3 of output row dy, channel 2 t + co2 of every group

@@ -148,20 +148,22 @@ def layernorm_bound(weight, bias, n: int) -> float:
 
 
 CE_TILES = ((0, 0), (0, 2), (1, 0), (2, 0))       # N tiles of the matrix-core CrossEmbed: (conv index, first output channel)
-CE_ROWS = (0, 4, 8, 16)                            # first table row of each tile (K + 1 rows each: 3+1, 3+1, 7+1, 15+1)
 CE_TABLE_ROWS = 32
 
 
 def pack_crossembed_mfma(ws, chan0: int, cin: int):
     """CrossEmbedLayer weights (dim_scales (4, 2, 2), kernel sizes (3, 7, 15); layers.py:254-305) for crossembed_mfma_kernel.
 
-    The three convs are one Toeplitz GEMM per 16-pixel x 8-row group: N = (output channel pair co2, output row dy), K = (input row r
-    of the 22-row window; 2 adjacent columns x 4 channels per lane, lane group lg and half h select the column pair 2 lg + 8 h of the
-    16-column window).  B[(r, h, lg, dx, ci)][(co2, dy)] = W[co][ci][ky = r - dy - off][kx = 2 lg + dx + 8 h - off], off = 7 - pad --
-    a function of r - dy only, so the table holds one row per vertical tap (plus a zero row for taps outside the kernel) and every
-    lane picks its own row: [tile 4 -> 32 rows][h 2][hi | lo][co2 2][lg 4][8 fp16].  ws: the three [cout][Cin_total][k][k] weights;
-    channels chan0 .. chan0 + cin - 1 are packed (cin <= 4).  Returns (table [32][256] fp16, [3] power-of-two exponents: each conv is
-    pre-scaled so that max|w| lands in [128, 256))."""
+    The three convs are Toeplitz GEMMs per 16-pixel x 8-row group: N = (output channel pair co2, output row dy); a lane supplies 2
+    adjacent columns x 4 channels (8 fp16) of one window row, the 4 lane groups lg make up K = 32.  A B operand depends on (window row
+    - dy) only, so the table holds one row per vertical tap and every lane picks its own row (row 31 is all zero: taps outside a kernel):
+      k15 (rows 16 .. 30 = ky): two steps per window row, halves h = 0 / 1: kx = 2 lg + dx + 8 h (kx = 15: zero);
+      k7  (rows 8 .. 14 = ky; 15 zero): on the k15 fragments of window rows 4 .. 17: kx = 2 lg + dx + 8 h - 4;
+      k3  (rows 0 .. 3 for channels 0-1, 4 .. 7 for channels 2-3): one step per window row PAIR (r, r + 1): lane groups 0-1 take row r,
+          2-3 row r + 1, columns kx = 2 (lg & 1) + dx (kx = 3: zero); table row q = (r - dy - 6) + 1 in 0 .. 3, ky = q - 1 + (lg >> 1).
+    Layout [row 32][h 2][hi | lo][co2 2][lg 4][8 fp16 = 4 dx + ci]; k3 uses the h = 0 half.  ws: the three [cout][Cin_total][k][k]
+    weights; channels chan0 .. chan0 + cin - 1 are packed (cin <= 4).  Returns (table [32][256] fp16, [3] power-of-two exponents: each
+    conv is pre-scaled so that max|w| lands in [128, 256))."""
     assert cin <= 4 and len(ws) == 3 and [w.shape[-1] for w in ws] == [3, 7, 15] and [w.shape[0] for w in ws] == [4, 2, 2]
     exps, scaled = [], []
     for w in ws:
@@ -172,18 +174,23 @@ def pack_crossembed_mfma(ws, chan0: int, cin: int):
         exps.append(e)
         scaled.append(wd * (2.0 ** e))
     tab = torch.zeros(CE_TABLE_ROWS, 2, 2, 2, 4, 8, dtype=torch.float64)       # [row][h][hi|lo][co2][lg][e = 4 dx + ci]
-    for (k, co0), row0 in zip(CE_TILES, CE_ROWS):
-        w = scaled[k]
-        K = w.shape[-1]
-        off = 7 - (K - 1) // 2
-        for h in range(2):
-            for lg in range(4):
-                for dx in range(2):
-                    kx = 2 * lg + dx + 8 * h - off
-                    if 0 <= kx < K:
-                        # [co2][ci][q] -> rows q, channels co0 + co2
-                        v = w[co0:co0 + 2, :, :, kx]                            # [2][cin][K]
-                        tab[row0:row0 + K, h, 0, :, lg, 4 * dx:4 * dx + cin] = v.permute(2, 0, 1)
+    w3, w7, w15 = scaled
+    for lg in range(4):
+        for dx in range(2):
+            for h in range(2):                                                   # k15: rows 16 + ky
+                kx = 2 * lg + dx + 8 * h
+                if kx < 15:
+                    tab[16:31, h, 0, :, lg, 4 * dx:4 * dx + cin] = w15[:, :, :, kx].permute(2, 0, 1)      # [ky][co2][ci]
+                kx = 2 * lg + dx + 8 * h - 4                                     # k7 on the same fragments: rows 8 + ky
+                if 0 <= kx < 7:
+                    tab[8:15, h, 0, :, lg, 4 * dx:4 * dx + cin] = w7[:, :, :, kx].permute(2, 0, 1)
+            kx = 2 * (lg & 1) + dx                                               # k3: rows 4 t + q
+            if kx < 3:
+                for t in range(2):
+                    for q in range(4):
+                        ky = q - 1 + (lg >> 1)
+                        if 0 <= ky < 3:
+                            tab[4 * t + q, 0, 0, :, lg, 4 * dx:4 * dx + cin] = w3[2 * t:2 * t + 2, :, ky, kx]  # [co2][ci]
     hi = tab[:, :, 0].float().half()
     lo = (tab[:, :, 0] - hi.double()).float().half()
     out = torch.stack((hi, lo), dim=2)                                           # [row][h][hl][co2][lg][8]
