@@ -69,6 +69,12 @@ def entry_cost(name, p, cond_dim=8):
             elems += p.B * cres * p.H * p.W + p.B * p.Cout * p.H * p.W + p.Cout * cres + p.Cout
             flops += 2.0 * p.B * p.H * p.W * p.Cout * cres
         return elems * 4.0, flops, "hbm"
+    if name == "conv_tail":           # block2 + final conv in one launch: the sum of the two layers
+        by = fl = 0.0
+        for q in p._fused:
+            b_, f_, _ = entry_cost("conv", q, cond_dim)
+            by, fl = by + b_, fl + f_
+        return by, fl, "hbm"
     if name == "resident":            # a run of convs in one launch: the sum of its layers (the definition counts every Conv2d call)
         by = fl = 0.0
         for q in p._fused:
@@ -129,12 +135,15 @@ def op_breakdown(im, stage, B, cond_scale, reps=20, precision="fp32"):
         elif name == "resident":
             desc = f"resident chain of {p.n_layers} convs @{p.H}x{p.W} B{p.B} (" + ", ".join(
                 f"{q.in0.C + (q.in1.C if q.in1.data else 0)}->{q.Cout}{'+res' if q.res0.data else ''}" for q in p._fused) + ")"
+        elif name == "conv_tail":
+            q1, q2 = p._fused
+            desc = f"conv tail (block2 8->8 gn res + conv 8->{q2.Cout}, fused) @{q1.H}x{q1.W} B{q1.B}"
         elif name == "cross_attn":
             desc = f"cross_attn C{p.C} tokens{p.HW} ctx{p.J} B{p.B2}"
         elif name == "crossembed":
             desc = f"crossembed {p.C0 + (p.C1 if p.in1 else 0)}->{sum(p.cout[i] for i in range(p.n_kernels))} @{p.H}x{p.W} B{p.B}"
         rows.append(dict(op=desc, kernel=name, ms=ms, alg_bytes=by, alg_flops=fl, bound=bound,
-                         rows=int(getattr(p, "B", 0) or getattr(p, "B2", 0) or 0)))
+                         rows=int(getattr(p, "B", 0) or getattr(p, "B2", 0) or (p.conv.B if name == "conv_tail" else 0))))
     # work the engine hoists out of the step (the low-res half of CrossEmbed, once per sample()) is still part of every forward of the
     # reference: its algorithmic bytes count, its time does not appear here
     for fn, p, name in getattr(ws, "prog_pre", []):

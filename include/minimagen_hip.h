@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MI_ABI_VERSION 6
+#define MI_ABI_VERSION 7
 
 enum mi_status {
     MI_OK = 0,
@@ -102,6 +102,22 @@ typedef struct mi_conv_params {
 #define MI_CONV_HALF    0x400   /* row-paired matrix-core path: single fp16 term per product (reduced-precision configuration; parity gate 3e-2) */
 #define MI_CONV_REVERSE 0x200  /* tile_cfg | MI_CONV_REVERSE (row-paired path): workgroups take the images in reverse order (speed only) */
 #define MI_CONV_RP_FIRST 5      /* tile_cfg 5: 16x64, 6: 8x64, 7: 8x32 output tiles of the row-paired matrix-core path */
+
+/* ResnetBlock.block2 (+ 1x1 residual conv) fused with the conv that follows it WITHOUT a normalisation in between -- the tail of the
+ * U-Net (reference: Unet.py:464-472, final_res_block -> final_conv; layers.py:417-439): `conv` describes the first conv exactly as for
+ * mi_conv_fwd (row-paired path: 8 GroupNorm-ed input channels, 1x1 residual conv over 8 or 16 channels -- the identity residual of a
+ * ResnetBlock(dim, dim) is passed as the 1x1 conv with the unit matrix: the intermediate is rounded to the fp16 hi + lo pair either way --,
+ * 8 output channels; conv.out / conv.out_stats are NOT written), w2_rp / w2_rp_exp / bias2 the second 3x3 conv (8 -> Cout2 <= 8 channels, fragments as w_rp), out2 its fp32
+ * output [B][Cout2][H][W].  The 8-channel intermediate stays in LDS (halo recomputed per tile): 2 x 4 x 8 x H x W bytes per image less traffic. */
+typedef struct {
+    mi_conv_params conv;
+    const void* w2_rp;
+    int w2_rp_exp;
+    int Cout2;
+    const float* bias2;
+    float* out2;
+} mi_conv_tail_params;
+int mi_conv_tail_fwd(const mi_conv_tail_params* p, void* stream);
 
 /* tile_cfg -> output tile (th x tw) handled by one workgroup; out_nt = ceil(H/th)*ceil(W/tw) */
 int mi_conv_tile_shape(int tile_cfg, int* th, int* tw);

@@ -181,9 +181,13 @@ class MiResidentParams(C.Structure):
                 ("sync", C.c_void_p), ("half", C.c_int), ("layer", MiResLayer * RES_MAX_LAYERS)]
 
 
+class MiConvTailParams(C.Structure):
+    _fields_ = [("conv", MiConvParams), ("w2_rp", C.c_void_p), ("w2_rp_exp", C.c_int), ("Cout2", C.c_int), ("bias2", C.c_void_p), ("out2", C.c_void_p)]
+
+
 _STRUCTS = {0: MiAct, 1: MiConvParams, 2: MiCrossEmbedParams, 3: MiLinear, 4: MiTextCondParams, 5: MiCondStepParams,
             6: MiAttnFoldParams, 7: MiCrossAttnParams, 8: MiCfgX0Params, 9: MiQuantileParams, 10: MiPosteriorParams,
-            11: MiResizeParams, 12: MiSelfAttnParams, 13: MiChanFFParams, 14: MiFlashAttnParams, 15: MiTokensToNchwParams, 16: MiConvWgradParams, 17: MiBlockBwdParams, 18: MiCrossEmbedWgradParams, 19: MiFoldedAttnParams, 20: MiResLayer, 21: MiResidentParams}
+            11: MiResizeParams, 12: MiSelfAttnParams, 13: MiChanFFParams, 14: MiFlashAttnParams, 15: MiTokensToNchwParams, 16: MiConvWgradParams, 17: MiBlockBwdParams, 18: MiCrossEmbedWgradParams, 19: MiFoldedAttnParams, 20: MiResLayer, 21: MiResidentParams, 22: MiConvTailParams}
 
 _lib = None
 _backend = None
@@ -201,7 +205,7 @@ def _bind(lib):
     vp, i32, i64, u64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float
     for name in ("mi_conv_fwd", "mi_gn_coef_fwd", "mi_crossembed_fwd", "mi_text_cond_fwd", "mi_cond_step_fwd", "mi_attn_fold_rows", "mi_cross_attn_fwd",
                  "mi_cfg_x0_fwd", "mi_quantile_fwd", "mi_posterior_fwd", "mi_resize_fwd", "mi_self_attn_fwd", "mi_chan_ff_fwd",
-                 "mi_flash_attn_fwd", "mi_tokens_to_nchw_fwd", "mi_conv_wgrad", "mi_block_bwd", "mi_crossembed_wgrad", "mi_folded_attn_fwd", "mi_folded_attn_bwd", "mi_resident_convs_fwd"):
+                 "mi_flash_attn_fwd", "mi_tokens_to_nchw_fwd", "mi_conv_wgrad", "mi_block_bwd", "mi_crossembed_wgrad", "mi_folded_attn_fwd", "mi_folded_attn_bwd", "mi_resident_convs_fwd", "mi_conv_tail_fwd"):
         getattr(lib, name).argtypes = [vp, vp]
         getattr(lib, name).restype = i32
     lib.mi_step_advance.argtypes = [vp, vp, i32, vp]

@@ -48,6 +48,7 @@ extern "C" int mi_struct_size(int which) {
         case 19: return (int)sizeof(mi_folded_attn_params);
         case 20: return (int)sizeof(mi_res_layer);
         case 21: return (int)sizeof(mi_resident_params);
+        case 22: return (int)sizeof(mi_conv_tail_params);
     }
     return -1;
 }

@@ -33,6 +33,12 @@ RP_TILE = {k: int(os.environ.get("MINIMAGEN_RP_TILE_" + k, d)) for k, d in (("L"
 RP_MIN_HW = int(os.environ.get("MINIMAGEN_RP_MIN_HW", "0"))             # ... for images of at least this many pixels
 CE_MFMA = os.environ.get("MINIMAGEN_CE_MFMA", "1") != "0"                  # CrossEmbed on the matrix cores (0: the fp32 VALU kernel)
 STORE16 = os.environ.get("MINIMAGEN_STORE16", "1") != "0"                  # reduced-precision configuration: bf16 activation storage
+# the U-Net's tail -- final_res_block.block2 (+ residual) and final_conv, no normalisation in between -- as ONE launch that keeps the
+# 8-channel full-resolution intermediate in LDS (mi_conv_tail_fwd), for images of at least TAIL_FUSE^2 pixels.  0 = off, the default:
+# measured on MI355X at 256^2, B = 64 the fused launch moves 42 % fewer bytes but takes 186 us against 179 us for the two launches -- the
+# 8-channel fp16x3 convs are balanced between HBM and their own VALU / LDS / MFMA work, and the halo recompute (x 1.29) plus the 256-register
+# tile eat what the traffic saves
+TAIL_FUSE = int(os.environ.get("MINIMAGEN_TAIL_FUSE", "0"))
 CONV_REVERSE = int(os.environ.get("MINIMAGEN_CONV_REVERSE", "1"))        # a row-paired conv walks the image groups opposite to its producer (0 = off)
 RP_NTILE = int(os.environ.get("MINIMAGEN_RP_NTILE", "0"))               # tiles per workgroup of the row-paired kernel (0 = the library's choice)
 TILE64 = int(os.environ.get("MINIMAGEN_TILE64", "-1"))                  # force a conv tile shape at 64x64 / 128x128 (experiments)
@@ -416,6 +422,34 @@ class UnetEngine:
                        out=out, narrow=rp and not wide, ksize=ksize, stride=stride, up2=up2, cin=cin_tot, cres=cres, skip_scale=skip_scale)
         return out
 
+    def _fuse_tail(self, ws):
+        """The plan's last two launches, if they are ResnetBlock.block2 (+ residual) and the conv that consumes it directly (Unet.py:464-472),
+        become one mi_conv_tail_fwd launch."""
+        lib = L.lib()
+        if len(ws.prog) < 2 or any(e[0] is not lib.mi_conv_fwd or not hasattr(e[1], "_meta") for e in ws.prog[-2:]):
+            return
+        p1, p2 = ws.prog[-2][1], ws.prog[-1][1]
+        m1, m2 = p1._meta, p2._meta
+        ok = (m2["in0"] is m1["out"] and m1["out"].uses == 1 and m2["in1"] is None and m2["res0"] is None and not p2.gn_groups
+              and m1["narrow"] and m2["narrow"] and all(m["ksize"] == 3 and m["stride"] == 1 and not m["up2"] for m in (m1, m2))
+              and m1["cin"] == 8 and p1.Cout == 8 and p1.gn_groups > 0 and 8 % p1.gn_groups == 0 and p2.Cout <= 8 and not p2.out_st
+              and p1.H * p1.W >= TAIL_FUSE * TAIL_FUSE and p1.W % 4 == 0 and m1["res0"] is not None
+              and ((m1["res_conv"] and m1["cres"] == 16) or (not m1["res_conv"] and m1["res0"].C == 8 and m1["res1"] is None)))
+        if not ok:
+            return
+        tp = L.MiConvTailParams()
+        tp.conv = p1                          # (a copy; the tensors it points to stay in ws.tensors)
+        if not m1["res_conv"]:
+            # ResnetBlock(dim, dim): the identity residual rides through the kernel's 1x1-residual rounds as the unit matrix (exact in fp16; the
+            # intermediate is rounded to the fp16 hi + lo pair right after, so nothing is lost against the fp32 add of the separate launch)
+            eye, eexp = P.pack_conv_weight_rp(torch.eye(8, device=ws.dev).reshape(8, 8, 1, 1))
+            ws.tensors.append(eye)
+            tp.conv.res_w, tp.conv.res_w_rp, tp.conv.res_w_rp_exp, tp.conv.res_b = L.ptr(eye), L.ptr(eye), eexp, 0
+        tp.w2_rp, tp.w2_rp_exp, tp.Cout2, tp.bias2, tp.out2 = p2.w_rp, p2.w_rp_exp, p2.Cout, p2.bias, p2.out
+        tp._fused = (p1, p2)
+        del ws.prog[-2:]
+        ws.prog.append((lib.mi_conv_tail_fwd, tp, "conv_tail"))
+
     def _emit_resnet(self, ws, pk, rb: ResnetBlock, in0: Act, in1: Optional[Act]) -> Act:
         """layers.py:417-439"""
         u = self.unet
@@ -734,6 +768,8 @@ class UnetEngine:
         out = self._emit_conv(ws, pk, cur, None, wpack=pk.conv[id(u.final_conv)], bias=u.final_conv.bias, Cout=u.channels_out,
                               want_stats=False, conditioned=True, out_fp32=True)       # the prediction feeds the (fp32, bit-exact) sampler
         ws.pred = out.t
+        if TAIL_FUSE:
+            self._fuse_tail(ws)
         if (out.H, out.W) != (H, W):
             raise L.MinImagenHipError(f"U-Net output is {out.H}x{out.W} for a {H}x{W} input (image size must be divisible by the down-sampling factor)")
         # time-token rows of the folded context, every step
