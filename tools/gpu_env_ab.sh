@@ -10,6 +10,6 @@ for e in "$@"; do
 import json
 d=json.loads(open("$OUT/env_bench_$i.log").read().strip().splitlines()[-1])
 r=d["roofline"]
-print("[$e]", round(d["value"]), "one lane", round(d.get("value_one_lane",0)), "sync", round(d["value_no_pipeline"]), "|", r["kernel"], round(r["kernel_ms"]*1e3,1), "us")
+print("[$e]", round(d["value"]), "one lane", round(d.get("value_one_lane",0)), "sync", round(d["value_no_pipeline"]), "| graph step", round(d["unet_eval"]["graph_step_ms"], 4), "ms |", r["kernel"], round(r["kernel_ms"]*1e3,1), "us")
 PY
 done

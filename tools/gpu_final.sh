@@ -11,6 +11,12 @@ timeout 600 python tools/gpu_full_parity.py > $OUT/full_parity.txt 2>&1; tail -3
 # resident conv chains (opt-in): A/B lines and the phase trace of the chain kernel (library built with -DRS_TRACE)
 for r in 1 2; do MINIMAGEN_RESIDENT=$r timeout 300 python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-secondary --no-t5 --breakdown-out $OUT/bd_resident$r.json > $OUT/bench_resident$r.log 2>&1; tail -1 $OUT/bench_resident$r.log | cut -c1-160; done
 MINIMAGEN_RESIDENT=1 timeout 300 python bench.py --workload base64 --steps 6 --warmup 2 --no-cpu-baseline --no-secondary --no-t5 --no-breakdown > $OUT/bench_base_resident1.log 2>&1; tail -1 $OUT/bench_base_resident1.log | cut -c1-160
+# A/B lines of this round's default-path changes (each knob back to the previous behaviour) and of the opt-in fused tail
+for e in "MINIMAGEN_SAMPLER_GROUP=0" "MINIMAGEN_CONV_REVERSE=0" "MINIMAGEN_TAIL_FUSE=128"; do
+  env $e timeout 300 python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-secondary --no-t5 > $OUT/bench_ab_${e%%=*}.log 2>&1; echo "$e $(tail -1 $OUT/bench_ab_${e%%=*}.log | cut -c1-130)"; done
+timeout 200 python tools/bench_sampler_tail.py 256 32 > $OUT/ubench_sampler_tail.txt 2>&1; timeout 100 python tools/bench_sampler_tail.py 1024 4 >> $OUT/ubench_sampler_tail.txt 2>&1
+timeout 200 python tools/bench_tail.py 64 256 256 0 > $OUT/ubench_conv_tail.txt 2>&1
+timeout 100 python tools/bench_ce.py > $OUT/ubench_crossembed.txt 2>&1
 if [ -f minimagen_amd/libminimagen_hip_trace.so ]; then MINIMAGEN_HIP_LIB=$ROOTDIR/minimagen_amd/libminimagen_hip_trace.so timeout 200 python tools/bench_resident.py 64 > $OUT/resident_trace.txt 2>&1; fi
 timeout 200 python tools/bench_resident.py 64 > $OUT/resident_notrace.txt 2>&1; tail -1 $OUT/resident_notrace.txt
 CMD="python $ROOTDIR/bench.py --steps 1 --warmup 0 --timesteps 25 --no-cpu-baseline --no-secondary --no-breakdown --no-t5 --no-pipeline"
