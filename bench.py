@@ -502,10 +502,16 @@ def main():
         chk = one_step(7, True, gather=False)
         torch.cuda.synchronize()
         pipe_ok = bool(torch.equal(chk, ref_out))
-        assert pipe_ok, "pipelined sample() differs from the synchronous call"
+        if not pipe_ok:
+            ne = chk != ref_out
+            nan_both = torch.isnan(chk) & torch.isnan(ref_out)
+            where = ne.nonzero()[:4].tolist()
+            raise AssertionError(f"pipelined sample() differs from the synchronous call: {int(ne.sum())} of {ne.numel()} elements ({int((ne & ~nan_both).sum())} not NaN in both), "
+                                 f"per image {ne.flatten(1).sum(1).tolist()}, max |d| {float((chk - ref_out).abs().nan_to_num().max()):.3e}, first at {where}")
         del ref_out, chk
     dt, mine, out = timed(args.steps, pipelined)
     assert torch.isfinite(out).all() and out.shape[0] == gB
+    im.check_device_status()            # no kernel with inter-workgroup waits (grouped sampler tail, resident chains) gave up waiting
     dt_sync = dt_one = None
     if pipelined:                       # the reference's sample() is synchronous: report that mode beside the pipelined headline
         dt_sync, _, _ = timed(max(2, min(args.steps, 8)), False)

@@ -21,6 +21,11 @@ from .t5 import get_encoded_dim, t5_encode_text
 # the sampler tail of images too large for one workgroup (the super-resolution stages) as ONE launch of cooperating workgroups
 # (mi_sampler_step_group_fwd) instead of five launches; 0: the separate kernels
 SAMPLER_GROUP = int(os.environ.get("MINIMAGEN_SAMPLER_GROUP", "1"))
+# ... for at most this many workgroups per image (8: up to 256^2).  The workgroups of an image wait for each other, so a launch is only safe
+# next to OTHER launches of the same kind while the partial groups of all of them fit the chip beside everything else that is resident: two
+# 1024^2 tails (128 workgroups of 1024 work-items per image, one per CU) in flight on two call lanes starved each other's last image until the
+# bounded spin gave up (profiles/r04_sampler_group_config5.txt) -- large images keep the separate kernels
+SAMPLER_GROUP_MAX = int(os.environ.get("MINIMAGEN_SAMPLER_GROUP_MAX", "8"))
 SAMPLE_LANES = max(1, int(os.environ.get("MINIMAGEN_SAMPLE_LANES", "2")))     # independent call lanes of sample(_async=True)
 _STAGE_STREAMS = {}          # (device, lanes, stages, priority mode) -> [lane][stage] HIP streams, process-wide (see sample())
 
@@ -214,7 +219,7 @@ class Imagen(nn.Module):
                                      L.ptr(st.seed_dev) if noise_dev is None else 0)
 
             small = n <= 16384 and os.environ.get("MINIMAGEN_SAMPLER_FUSED", "1") != "0"      # MI_SAMPLER_SMALL_N: the whole tail in one launch
-            group = (not small) and SAMPLER_GROUP and lib.mi_sampler_group_size(n) > 0 and os.environ.get("MINIMAGEN_SAMPLER_FUSED", "1") != "0"
+            group = (not small) and SAMPLER_GROUP and 0 < lib.mi_sampler_group_size(n) <= SAMPLER_GROUP_MAX and os.environ.get("MINIMAGEN_SAMPLER_FUSED", "1") != "0"
             if group and not hasattr(st, "group_sync"):
                 st.group_sync = torch.zeros(lib.mi_sampler_group_sync_bytes(B, n), dtype=torch.uint8, device=ws.dev)   # this workspace's launches only
             offsets = eng.step_offsets_supported(ws)          # the k-th step of a graph addresses *t_state - k; one advance per graph
