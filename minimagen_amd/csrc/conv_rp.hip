@@ -28,14 +28,24 @@ typedef float rp_f32x2 __attribute__((ext_vector_type(2)));
 #ifdef MI_TRACE
 // development aid (tools/bench_conv.py): accumulated shader-clock time per phase of the first workgroups of the last launch, and
 // (slot 7) their start / end on the 100 MHz wall clock
-__device__ unsigned long long mi_trace_rp_buf[1024 * 8];
+// slots 8 .. 15: finer stamps inside the MFMA-loop and epilogue phases (RP_TFINE; -DRP_TRACE_FINE): 8 residual + prefetch loads issued,
+// 9 the MFMA loop proper, 10 epilogue arithmetic (incl. the wait for the residual loads), 11 stores issued, 12 statistics shuffles,
+// 13 the barrier + partial-statistics store
+__device__ unsigned long long mi_trace_rp_buf[1024 * 16];
 extern "C" int mi_debug_read_trace_rp(void* dst, size_t bytes) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(mi_trace_rp_buf), bytes); }
-#define RP_TSTART() const unsigned long long rp_t_wall0 = wall_clock64(); unsigned long long rp_t_last = clock64(), rp_t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+extern "C" int mi_debug_trace_rp_slots() { return 16; }
+#define RP_TSTART() const unsigned long long rp_t_wall0 = wall_clock64(); unsigned long long rp_t_last = clock64(), rp_t_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
 #define RP_TPHASE(k) do { const unsigned long long rp_t_now = clock64(); rp_t_acc[k] += rp_t_now - rp_t_last; rp_t_last = rp_t_now; } while (0)
-#define RP_TEND() do { rp_t_acc[7] = (rp_t_wall0 << 32) | (wall_clock64() & 0xffffffffull); if (threadIdx.x == 0 && blockIdx.x < 1024) for (int k = 0; k < 8; ++k) mi_trace_rp_buf[blockIdx.x * 8 + k] = rp_t_acc[k]; } while (0)
+#ifdef RP_TRACE_FINE
+#define RP_TFINE(k) RP_TPHASE(k)
+#else
+#define RP_TFINE(k) do { } while (0)
+#endif
+#define RP_TEND() do { rp_t_acc[7] = (rp_t_wall0 << 32) | (wall_clock64() & 0xffffffffull); if (threadIdx.x == 0 && blockIdx.x < 1024) for (int k = 0; k < 16; ++k) mi_trace_rp_buf[blockIdx.x * 16 + k] = rp_t_acc[k]; } while (0)
 #else
 #define RP_TSTART() do { } while (0)
 #define RP_TPHASE(k) do { } while (0)
+#define RP_TFINE(k) do { } while (0)
 #define RP_TEND() do { } while (0)
 #endif
 
@@ -504,6 +514,7 @@ __global__ __launch_bounds__(256, CFG::WPS) void conv_rp_kernel(const mi_conv_pa
 #if RP_SCHED_BARRIER
             __builtin_amdgcn_sched_barrier(0);      // keep the loads AHEAD of the MFMA loop (the scheduler otherwise spreads them over it)
 #endif
+            RP_TFINE(8);
             // ---- D[px 16][(dy, co)] += act[px][(r, ci)] . B[(r, ci)][(dy, co)], one instruction triple per horizontal tap
 #pragma unroll
             for (int s = 0; s < NSTEP; ++s) {
@@ -537,6 +548,7 @@ __global__ __launch_bounds__(256, CFG::WPS) void conv_rp_kernel(const mi_conv_pa
                         acc[g][jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[jt], acc[g][jt], 0, 0, 0);
                 }
             }
+            RP_TFINE(9);
             RP_TPHASE(4);       // MFMA loop (+ the next load issue)
         };
         if constexpr (STATIC_ROUNDS) {
@@ -645,6 +657,7 @@ __global__ __launch_bounds__(256, CFG::WPS) void conv_rp_kernel(const mi_conv_pa
                 }
                 yv[g] = y;
             }
+            RP_TFINE(10);
 #pragma unroll
             for (int g = 0; g < GPW; ++g) {          // ... then the (edge-masked) stores, which need no wait
                 const int G = wave * GPW + g, gyy = G / GX, gxx = G % GX;
@@ -666,6 +679,7 @@ __global__ __launch_bounds__(256, CFG::WPS) void conv_rp_kernel(const mi_conv_pa
                 csq[jt] += ok ? fmaf(y.x, y.x, fmaf(y.y, y.y, fmaf(y.z, y.z, y.w * y.w))) : 0.0f;
             }
         }
+        RP_TFINE(11);
         if (p.out_stats) {
 #pragma unroll
             for (int jt = 0; jt < NJ; ++jt) {
@@ -674,10 +688,12 @@ __global__ __launch_bounds__(256, CFG::WPS) void conv_rp_kernel(const mi_conv_pa
                 csum[jt] += __shfl_xor(csum[jt], 32); csq[jt] += __shfl_xor(csq[jt], 32);
                 if (lane < CPT) { red[wave][2 * (CPT * jt + lane)] = csum[jt]; red[wave][2 * (CPT * jt + lane) + 1] = csq[jt]; }
             }
+            RP_TFINE(12);
             __syncthreads();
             if (tid < 2 * CPT * NJ && CPT * jt0 + (tid >> 1) < p.Cout)
                 p.out_stats[((size_t)(b * p.Cout + CPT * jt0 + (tid >> 1)) * tiles + tile) * 2 + (tid & 1)] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
         }
+        RP_TFINE(13);
         RP_TPHASE(5);       // epilogue
     };
     for (int tile = tile_lo; tile + 1 < tile_hi; ++tile) do_tile(tile, std::true_type{});
@@ -788,7 +804,9 @@ int launch_rp(const mi_conv_params& p, hipStream_t st) {
     int ntile = (p.tile_cfg >> 12) & 0xf;
     // strip length: up to 4 tiles per workgroup while that leaves >= 1024 workgroups (one full wave of 4 per CU); measured on the SR
     // U-Net's shapes (tools/gpu_rp_shapes.sh): 256^2 -> 4, 128^2 -> 2, <= 64^2 -> 1
-    if (ntile == 0) { ntile = 1; while (ntile < 4 && (size_t)p.B * (tiles / (2 * ntile)) >= 1024) ntile *= 2; }
+    if (ntile == 0) {
+        ntile = 1; while (ntile < 4 && (size_t)p.B * (tiles / (2 * ntile)) >= 1024) ntile *= 2;
+    }
     const int strips = (tiles + ntile - 1) / ntile;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_rp_kernel<CFG>), dim3(strips * p.B), dim3(256), 0, st, p, (const uint4*)p.w_rp, (const uint4*)p.res_w_rp, ntile,
                        (const float4*)nullptr, (const int*)nullptr, rp_tail_args{});

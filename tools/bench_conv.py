@@ -82,15 +82,20 @@ def run(B, C0, Cout, H, W, gn, res, path, C1=0, reps=20, nt_in=None):
     mb = (B * (Cin + Cout + (Cout if res == "id" else (Cin if res == "conv" else 0))) * H * W * 4) / 1e6
     print(f"{path:5s} B{B} {Cin}->{Cout} @{H}x{W} gn={int(gn)} res={res}: {us:7.1f} us  ({mb:.0f} MB -> {mb / us * 1e-3 * 1e3:.2f} TB/s)".replace("TB/s", "GB/ms"))
     if path.startswith("rp") and hasattr(lib, "mi_debug_read_trace_rp"):
-        buf = np.zeros(1024 * 8, dtype=np.uint64)
+        NS = lib.mi_debug_trace_rp_slots() if hasattr(lib, "mi_debug_trace_rp_slots") else 8
+        buf = np.zeros(1024 * NS, dtype=np.uint64)
         lib.mi_debug_read_trace_rp.argtypes = [C.c_void_p, C.c_size_t]
         lib.mi_debug_read_trace_rp(buf.ctypes.data, buf.nbytes)
-        t = buf.reshape(1024, 8).astype(np.int64)
+        t = buf.reshape(1024, NS).astype(np.int64)
         names = ["stats+geometry+issue loads", "affine prologue", "barrier waits", "wait raw + transform + LDS write", "MFMA loop", "epilogue", "B-frag issue"]
         for i, n in enumerate(names):
             print(f"      {n:34s} {np.median(t[:, i]):9.0f} {np.percentile(t[:, i], 10):9.0f} {np.percentile(t[:, i], 90):9.0f}")
         print(f"      total                              {np.median(t[:, :7].sum(1)):9.0f}")
-        w = buf.reshape(1024, 8)[:, 7]
+        if NS > 8 and t[:, 8:14].any():
+            for i, n in zip(range(8, 14), ["  fine: residual + prefetch loads issued", "  fine: MFMA loop proper", "  fine: epilogue arithmetic (+ residual wait)", "  fine: stores issued",
+                                           "  fine: statistics shuffles", "  fine: barrier + statistics store"]):
+                print(f"      {n:46s} {np.median(t[:, i]):9.0f} {np.percentile(t[:, i], 10):9.0f} {np.percentile(t[:, i], 90):9.0f}")
+        w = buf.reshape(1024, NS)[:, 7]
         w0 = ((w >> np.uint64(32)) & np.uint64(0xffffffff)).astype(np.int64); w1 = (w & np.uint64(0xffffffff)).astype(np.int64)
         ok = w1 > 0
         if ok.any():

@@ -94,15 +94,16 @@ for name, fn in (("separate (2 launches)", separate), ("fused (1 launch)", fused
     print(f"B{B} {H}x{W} strip {strip} {name}: {e0.elapsed_time(e1) / 30 * 1e3:.1f} us")
 if hasattr(lib, "mi_debug_read_trace_rp"):        # a -DMI_TRACE build: per-phase shader clocks of the first workgroups of the last (fused) launch
     import numpy as np
-    buf = np.zeros(1024 * 8, dtype=np.uint64)
+    NS = lib.mi_debug_trace_rp_slots() if hasattr(lib, "mi_debug_trace_rp_slots") else 8
+    buf = np.zeros(1024 * NS, dtype=np.uint64)
     lib.mi_debug_read_trace_rp.argtypes = [C.c_void_p, C.c_size_t]
     lib.mi_debug_read_trace_rp(buf.ctypes.data, buf.nbytes)
-    t = buf.reshape(1024, 8).astype(np.int64)
+    t = buf.reshape(1024, NS).astype(np.int64)
     names = ["stats+geometry+issue loads", "affine prologue", "barrier waits", "wait raw + transform + LDS write", "MFMA loop", "epilogue / mid + second conv", "B-frag issue"]
     for i, n in enumerate(names):
         print(f"      {n:34s} {np.median(t[:, i]):9.0f} {np.percentile(t[:, i], 10):9.0f} {np.percentile(t[:, i], 90):9.0f}")
     print(f"      total                              {np.median(t[:, :7].sum(1)):9.0f}")
-    w = buf.reshape(1024, 8)[:, 7]
+    w = buf.reshape(1024, NS)[:, 7]
     w0 = ((w >> np.uint64(32)) & np.uint64(0xffffffff)).astype(np.int64); w1 = (w & np.uint64(0xffffffff)).astype(np.int64)
     ok = w1 > 0
     if ok.any():
