@@ -430,7 +430,8 @@ class UnetEngine:
             return
         p1, p2 = ws.prog[-2][1], ws.prog[-1][1]
         m1, m2 = p1._meta, p2._meta
-        ok = (m2["in0"] is m1["out"] and m1["out"].uses == 1 and m2["in1"] is None and m2["res0"] is None and not p2.gn_groups
+        ok = (not ws.half                      # (the single-term instantiation is far slower than the two launches: a 1.1 KB scratch frame)
+              and m2["in0"] is m1["out"] and m1["out"].uses == 1 and m2["in1"] is None and m2["res0"] is None and not p2.gn_groups
               and m1["narrow"] and m2["narrow"] and all(m["ksize"] == 3 and m["stride"] == 1 and not m["up2"] for m in (m1, m2))
               and m1["cin"] == 8 and p1.Cout == 8 and p1.gn_groups > 0 and 8 % p1.gn_groups == 0 and p2.Cout <= 8 and not p2.out_st
               and p1.H * p1.W >= TAIL_FUSE * TAIL_FUSE and p1.W % 4 == 0 and m1["res0"] is not None

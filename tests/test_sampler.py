@@ -3,6 +3,7 @@ determinism, graph == eager, and the data-parallel sharding property (bit-identi
 import pytest
 import torch
 
+from minimagen_amd import _lib as L
 from minimagen_amd.Imagen import Imagen
 from minimagen_amd.Unet import Unet
 from oracle import restated as R
@@ -434,6 +435,12 @@ def test_grouped_sampler_tail_in_the_sampling_loop(backend, monkeypatch):
         im.check_device_status()
         st = next(iter(im.unets[0].engine()._ws.values())).sampler_state
         assert any(hasattr(v, "group_sync") for v in st.values()) == bool(grp)
+        if grp:                 # a workgroup that gave up waiting leaves a sticky error word: the host-side check must be loud about it
+            sync = next(v.group_sync for v in st.values() if hasattr(v, "group_sync"))
+            sync[8:12] = torch.tensor([0x00, 0x03, 0, 0], dtype=torch.uint8, device=sync.device)
+            with pytest.raises(L.MinImagenHipError, match="0x300"):
+                im.check_device_status()
+            sync[8:12] = 0
     assert torch.equal(outs[1, "gen"], outs[0, "gen"])
     assert outs[1, "gen"].isfinite().all() and outs[1, "gen"].std() > 0.01
     if gpu:
