@@ -158,6 +158,22 @@ def test_three_stage_cascade_properties(backend):
     assert a.std() > 0.01
     e = im.sample(text_embeds=emb[1:].contiguous().to(dev), text_masks=mask[1:].contiguous().to(dev), cond_scale=3., _seed=5, _sample_offset=1)
     assert torch.equal(e, a[1:])
+    # two calls in flight on the two call lanes: their 1024^2 stages overlap.  (Round 4: the grouped sampler tail with 128 workgroups per
+    # image starved its own second launch there -- profiles/r04_sampler_group_config5.txt; the host keeps it to <= 8 workgroups per image.)
+    # B = 4: 512 workgroups per launch at 128 per image, more than the chip holds at once (reproduces with MINIMAGEN_SAMPLER_GROUP_MAX=256)
+    emb4, mask4 = R.synthetic_text(4, length=64, seed=7)
+    kw = dict(text_embeds=emb4.to(dev), text_masks=mask4.to(dev), cond_scale=3., lowres_sample_noise_level=0.2)
+    a = im.sample(**kw, _seed=5).clone()
+    torch.cuda.synchronize()
+    x = im.sample(**kw, _seed=5, _async=True)
+    y = im.sample(**kw, _seed=5, _async=True)
+    torch.cuda.synchronize()
+    assert torch.equal(x, a) and torch.equal(y, a)
+    im.check_device_status()
+    from minimagen_amd import Imagen as IM
+    st = [v for u in im.unets for ws in u.engine()._ws.values() for v in ws.__dict__.get("sampler_state", {}).values()]
+    assert [hasattr(v, "group_sync") for v in st].count(True) >= 1          # the 256^2 stage took the grouped kernel ...
+    assert IM.SAMPLER_GROUP_MAX == 8 and L.lib().mi_sampler_group_size(3 * 1024 * 1024) == 128      # ... the 1024^2 stage must not
 
 
 @pytest.mark.parametrize("backend", GPU_ONLY)

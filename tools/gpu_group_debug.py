@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench                                            # noqa: E402
 
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 25
-B = 8
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 dev = torch.device("cuda:0")
 im, sizes = bench.build_imagen("cascade64_256_1024", T, dev)
 emb, mask = bench.synthetic_text(B)
