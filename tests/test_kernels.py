@@ -943,7 +943,7 @@ def test_sampler_elementwise_bit_exact(backend, side):
 GROUP_SIDES = [96, 160]
 
 
-def _group_tail_case(dev, side, B=2, T=25, rounds=3, nan_row=False, two=1):
+def _group_tail_case(dev, side, B=2, T=25, rounds=3, nan_row=False, two=1, ties=False):
     """mi_sampler_step_group_fwd against mi_cfg_x0_fwd + mi_quantile_fwd + mi_posterior_fwd on the same inputs: bit for bit, several launches in
     a row on one sync buffer (both parities of the double-buffered histograms, the step offset of multi-step graphs)."""
     lib = L.lib()
@@ -962,6 +962,11 @@ def _group_tail_case(dev, side, B=2, T=25, rounds=3, nan_row=False, two=1):
         use_noise = r != 2
         pred2 = (torch.randn(2 * B, n, generator=g) * (1.0 + r)).to(dev)
         xt = torch.randn(B, n, generator=g).to(dev)
+        if ties:                    # heavy ties around the order statistics (and a constant image): the rank-inside-the-bin bookkeeping of all three passes
+            pred2, xt = (pred2 * 2).round() / 2, (xt * 2).round() / 2
+            if r == 2:
+                pred2[:, :] = 0.25
+                xt[0, :] = -1.5
         if nan_row and r == 1:
             pred2[0, 5] = float("nan")
         ts, ts2 = torch.tensor([t], dtype=torch.int32, device=dev), torch.tensor([t + off], dtype=torch.int32, device=dev)
@@ -998,6 +1003,9 @@ def _group_tail_case(dev, side, B=2, T=25, rounds=3, nan_row=False, two=1):
 def test_sampler_group_tail_bit_exact(backend, side):
     dev = setup(backend)
     _group_tail_case(dev, side, nan_row=(side == 96))
+    if side == 96:
+        _group_tail_case(dev, side, ties=True)
+        _group_tail_case(dev, side, B=1, rounds=2, two=0)
 
 
 @pytest.mark.gpu
