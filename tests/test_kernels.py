@@ -271,6 +271,13 @@ def test_conv_tail_fused(backend, case):
         print(f"fused tail {case} rev {rev:#x}: max|d| = {err:.2e} (gate {3e-5 * scale:.2e}, |ref|max {ref.abs().max().item():.3g})")
         assert err < 3e-5 * scale
     # the two separate launches of the same layers
+    # the single-term instantiation (reduced-precision configuration, tile_cfg | 0x400): same launch, fp16 products, gate as the other half-precision ops
+    out_fp32 = out2.clone()
+    out2.fill_(float('nan'))
+    p.tile_cfg = 5 | (strip << 12) | 0x400
+    L.check(lib.mi_conv_tail_fwd(C.byref(tp), L.current_stream()), "fused tail, single term")
+    errh = (out2.cpu().double() - ref).abs().max().item()
+    assert errh < 3e-2 * scale, errh
     if ident:                   # the separate launch adds the residual itself (fp32)
         p.res_w, p.res_w_rp, p.res_w_rp_exp = 0, 0, 0
     nt = tile_nt(lib, 5, H, W)
@@ -286,7 +293,7 @@ def test_conv_tail_fused(backend, case):
     sep = torch.zeros(B, Cout2, H, W, device=dev)
     q.out, q.tile_cfg = sep.data_ptr(), 5
     L.check(lib.mi_conv_fwd(C.byref(q), L.current_stream()), "final conv")
-    assert (sep - out2).abs().max().item() < 3e-5 * scale
+    assert (sep - out_fp32).abs().max().item() < 3e-5 * scale
     # argument checks
     p.res_w, p.res_w_rp, p.res_w_rp_exp = 1, keep["rwf"].data_ptr(), rwexp
     p.Cout = 16
