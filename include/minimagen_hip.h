@@ -330,7 +330,12 @@ int mi_sampler_step_small_fwd(const mi_cfg_x0_params* c, const mi_quantile_param
  * among the workgroups of an image (claimed by ticket once resident: no cooperative launch; bounded spins, error word at byte 8 of `sync`).
  * Replaces mi_cfg_x0_fwd + mi_quantile_fwd (4 launches) + mi_posterior_fwd; bit-identical results.  `sync`: mi_sampler_group_sync_bytes(B, n)
  * bytes, zero-filled once, private to one stream's launches.  c->x0 / c->pred_out / q->s_out / q->v_out are written when non-NULL; c->hist0 /
- * q->hist / pp->x0 / pp->s_q are not used. */
+ * q->hist / pp->x0 / pp->s_q are not used.
+ * CO-RESIDENCY: the workgroups of an image wait for each other.  One launch cannot deadlock (work is claimed by ticket once resident), but two
+ * launches in flight on different streams can starve each other when their waiting workgroups together fill the chip (observed with 128
+ * workgroups per image at 1024^2: the bounded spin gives up, error word 0x300 + pass, and the image's step is NOT written).  Callers that run
+ * several such launches side by side must keep mi_sampler_group_size(n) small against the number of CUs -- the Python host uses this entry point for
+ * at most 8 workgroups per image (256^2) and the separate kernels above that -- and should read the error word at a synchronisation point. */
 int mi_sampler_group_size(int n);                          /* workgroups per image; 0: unsupported */
 long long mi_sampler_group_sync_bytes(int B, int n);
 int mi_sampler_step_group_fwd(const mi_cfg_x0_params* c, const mi_quantile_params* q, const mi_posterior_params* pp, void* sync, void* stream);
