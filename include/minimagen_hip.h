@@ -556,6 +556,8 @@ typedef struct mi_resident_params {
 int mi_resident_slabs(int H, int W);                      /* workgroups per image (= nt of every out_stats); 0: shape not supported */
 long long mi_resident_sync_bytes(int B, int H, int W);
 int mi_resident_convs_fwd(const mi_resident_params* p, void* stream);
+/* (co-residency: an image's 4 .. 8 slabs wait for each other; with at most 7 waiting workgroups per launch, launches of several streams cannot
+ * fill the chip with waiting workgroups -- compare the note on mi_sampler_step_group_fwd) */
 /* error word of the last launches on `sync` (0 = fine; non-zero: a workgroup gave up waiting for its neighbours -- results invalid) */
 int mi_resident_error_offset(void);                       /* byte offset of the 32-bit error word inside `sync` */
 
