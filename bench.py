@@ -58,45 +58,39 @@ def build_imagen(workload, timesteps, dev):
 # ---- algorithmic bytes / flops of one program entry (SURVEY.md 8(d) definition: every Conv2d / Linear call counts
 # input + output + weights&bias elements, an attention core counts q + k + v + out; norms/activations/adds count zero)
 def entry_cost(name, p, cond_dim=8):
-    from minimagen_amd import _lib as L
+    """(algorithmic bytes, algorithmic flops, bound) of one launch.  Bytes follow the STORED element size of every tensor: 4 for fp32,
+    2 where the reduced-precision configuration keeps the activation as bf16 (mi_act.st / out_st; SURVEY 8(d): "bf16 = half"); weights
+    and biases are fp32 in both configurations."""
     if name == "conv":
-        cin = p.in0.C + (p.in1.C if p.in1.data else 0)
+        c0, c1 = p.in0.C, (p.in1.C if p.in1.data else 0)
+        cin = c0 + c1
         hin, win = (p.H // 2, p.W // 2) if p.up2 else (p.H * p.stride, p.W * p.stride)
-        elems = p.B * cin * hin * win + p.B * p.Cout * p.H * p.W + p.Cout * cin * p.ksize * p.ksize + p.Cout
+        e_out = 2 if p.out_st else 4
+        by = p.B * hin * win * (c0 * (2 if p.in0.st else 4) + c1 * (2 if p.in1.st else 4)) + p.B * p.Cout * p.H * p.W * e_out \
+            + (p.Cout * cin * p.ksize * p.ksize + p.Cout) * 4
         flops = 2.0 * p.B * p.H * p.W * p.Cout * cin * p.ksize * p.ksize
         if p.res0.data and p.res_w:
-            cres = p.res0.C + (p.res1.C if p.res1.data else 0)
-            elems += p.B * cres * p.H * p.W + p.B * p.Cout * p.H * p.W + p.Cout * cres + p.Cout
-            flops += 2.0 * p.B * p.H * p.W * p.Cout * cres
-        return elems * 4.0, flops, "hbm"
-    if name == "conv_tail":           # block2 + final conv in one launch: the sum of the two layers
-        by = fl = 0.0
-        for q in p._fused:
-            b_, f_, _ = entry_cost("conv", q, cond_dim)
-            by, fl = by + b_, fl + f_
-        return by, fl, "hbm"
-    if name == "resident":            # a run of convs in one launch: the sum of its layers (the definition counts every Conv2d call)
-        by = fl = 0.0
-        for q in p._fused:
-            b_, f_, _ = entry_cost("conv", q, cond_dim)
-            by, fl = by + b_, fl + f_
-        return by, fl, "hbm"
+            r0, r1 = p.res0.C, (p.res1.C if p.res1.data else 0)
+            by += p.B * p.H * p.W * (r0 * (2 if p.res0.st else 4) + r1 * (2 if p.res1.st else 4)) + p.B * p.Cout * p.H * p.W * e_out + (p.Cout * (r0 + r1) + p.Cout) * 4
+            flops += 2.0 * p.B * p.H * p.W * p.Cout * (r0 + r1)
+        return float(by), flops, "hbm"
     if name == "crossembed":
         cin = p.C0 + (p.C1 if p.in1 else 0)
-        elems, flops = 0, 0.0
+        by, flops = 0, 0.0
         for i in range(p.n_kernels):
             k, co = p.ksize[i], p.cout[i]
-            elems += p.B * cin * p.H * p.W + p.B * co * p.H * p.W + co * cin * k * k + co
+            by += p.B * cin * p.H * p.W * 4 + p.B * co * p.H * p.W * (2 if p.out_st else 4) + (co * cin * k * k + co) * 4     # (the image itself is always fp32)
             flops += 2.0 * p.B * p.H * p.W * co * cin * k * k
-        return elems * 4.0, flops, "hbm"
+        return float(by), flops, "hbm"
     if name == "cross_attn":
         inner, j, i = p.heads * 64, p.J, p.HW
         cd = cond_dim
-        lin = (p.B2 * i * p.C + p.B2 * i * inner + inner * p.C) + (p.B2 * (j - 1) * cd + p.B2 * (j - 1) * 2 * inner + 2 * inner * cd) \
-            + (p.B2 * i * inner + p.B2 * i * p.C + inner * p.C)
+        e = 2 if p.x.st else 4              # q / k / v / out and the projections' activations follow the activation storage type
+        lin_act = (p.B2 * i * p.C + p.B2 * i * inner) + (p.B2 * (j - 1) * cd + p.B2 * (j - 1) * 2 * inner) + (p.B2 * i * inner + p.B2 * i * p.C)
+        lin_w = inner * p.C + 2 * inner * cd + inner * p.C
         core = 2 * p.B2 * i * inner + 2 * p.B2 * j * inner
         flops = p.B2 * (4.0 * p.heads * i * j * 64 + 2 * 2.0 * i * p.C * inner)
-        return (lin + core) * 4.0, flops, "mfma"
+        return float((lin_act + core) * e + lin_w * 4), flops, "mfma"
     return 0.0, 0.0, "hbm"
 
 
@@ -132,24 +126,24 @@ def op_breakdown(im, stage, B, cond_scale, reps=20, precision="fp32"):
         if name == "conv":
             cin = p.in0.C + (p.in1.C if p.in1.data else 0)
             desc = f"conv k{p.ksize}s{p.stride}{'u' if p.up2 else ''} {cin}->{p.Cout} @{p.H}x{p.W} B{p.B}{' gn' if p.gn_groups else ''}{' res' if p.res0.data else ''}"
-        elif name == "resident":
-            desc = f"resident chain of {p.n_layers} convs @{p.H}x{p.W} B{p.B} (" + ", ".join(
-                f"{q.in0.C + (q.in1.C if q.in1.data else 0)}->{q.Cout}{'+res' if q.res0.data else ''}" for q in p._fused) + ")"
-        elif name == "conv_tail":
-            q1, q2 = p._fused
-            desc = f"conv tail (block2 8->8 gn res + conv 8->{q2.Cout}, fused) @{q1.H}x{q1.W} B{q1.B}"
         elif name == "cross_attn":
             desc = f"cross_attn C{p.C} tokens{p.HW} ctx{p.J} B{p.B2}"
         elif name == "crossembed":
             desc = f"crossembed {p.C0 + (p.C1 if p.in1 else 0)}->{sum(p.cout[i] for i in range(p.n_kernels))} @{p.H}x{p.W} B{p.B}"
         rows.append(dict(op=desc, kernel=name, ms=ms, alg_bytes=by, alg_flops=fl, bound=bound,
-                         rows=int(getattr(p, "B", 0) or getattr(p, "B2", 0) or (p.conv.B if name == "conv_tail" else 0))))
+                         rows=int(getattr(p, "B", 0) or getattr(p, "B2", 0))))
     # work the engine hoists out of the step (the low-res half of CrossEmbed, once per sample()) is still part of every forward of the
     # reference: its algorithmic bytes count, its time does not appear here
     for fn, p, name in getattr(ws, "prog_pre", []):
         by, fl, bound = entry_cost(name.replace("_lowres", ""), p, unet.cond_dim)
         rows.append(dict(op=name + " (hoisted: once per sample())", kernel=name, ms=0.0, alg_bytes=by, alg_flops=fl, bound=bound, rows=int(p.B), hoisted=True))
     return rows
+
+
+def unet_prog(im, stage, B, args):
+    S = im.image_sizes[stage]
+    ws = im.unets[stage].engine().workspace(B, 2 * B if args.cond_scale != 1 else B, S, S, precision=args.precision)
+    return [e for e in ws.prog if e[1] is not None]
 
 
 def graph_step_ms(im, stage, B, cond_scale, T, reps=40, precision="fp32"):
@@ -217,6 +211,74 @@ def pmc_traffic(dom, rows, S):
                     "traffic_source": f"committed-profile (not measured in this run): profiles/{os.path.basename(files[-1])}, "
                                       "rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE per launch of this launch shape (bytes)"}
     return {"traffic": None}
+
+
+def pmc_traffic_live(args, dom, rows, S):
+    """HBM bytes per launch of the dominant kernel, MEASURED IN THIS RUN when rocprofv3 is on the box: two passes of a child process that
+    runs the dominant stage's U-Net evaluation three times (`--pmc-child`), one with --pmc FETCH_SIZE, one with --pmc WRITE_SIZE -- each
+    counter in its own pass, kernel trace only, FETCH_SIZE doubled (gfx950 counts 64 B per 128-B request on wide coalesced reads), KiB ->
+    bytes: MI355X_MICROARCH.md, HBM / rocprofv3 section.  None when rocprofv3 is missing or a pass fails (the caller then falls back to the
+    committed profile, labelled as such)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if dom["kernel"] != "cross_attn" or not shutil.which("rocprofv3") or os.environ.get("MINIMAGEN_BENCH_LIVE_PMC", "1") == "0":
+        return None
+    grid = rows * (-(-(S // 4) * (S // 4) // 128)) * 512
+    tmp = tempfile.mkdtemp(prefix="mi_pmc_", dir="/tmp")
+    child = [sys.executable, os.path.abspath(__file__), "--pmc-child", "--workload", args.workload, "--batch", str(args.batch), "--precision", args.precision,
+             "--cond-scale", str(args.cond_scale), "--timesteps", str(args.timesteps)]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["TMPDIR"] = "/tmp"
+    got = {}
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, ctr)
+            r = subprocess.run(["rocprofv3", "--kernel-trace", "--output-format", "csv", "--pmc", ctr, "-d", d, "-o", "pmc", "--"] + child,
+                               capture_output=True, text=True, env=env, cwd="/tmp", timeout=300)
+            vals = []
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if "cross_attn" in row["Kernel_Name"] and int(row["Grid_Size"]) == grid and row["Counter_Name"] == ctr:
+                        vals.append(float(row["Counter_Value"]))
+            if r.returncode != 0 or not vals:
+                return None
+            got[ctr] = sum(vals) / len(vals)
+        return {"traffic": (2.0 * got["FETCH_SIZE"] + got["WRITE_SIZE"]) * 1024.0,
+                "traffic_source": "measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes over a child process that runs "
+                                  "this stage's U-Net evaluation), per launch of this launch shape, FETCH_SIZE x 2 (gfx950 correction), KiB -> bytes",
+                "traffic_fetch_bytes_x2": 2.0 * got["FETCH_SIZE"] * 1024.0, "traffic_write_bytes": got["WRITE_SIZE"] * 1024.0}
+    except Exception as exc:
+        print(f"bench: live PMC pass failed ({type(exc).__name__}: {exc}); using the committed profile", file=sys.stderr)
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def pmc_child(args):
+    """what the live PMC passes profile: the last stage's U-Net evaluation (both guidance halves), three times"""
+    from minimagen_amd import _lib as L
+    dev = torch.device("cuda:0")
+    L.use_library(L.DEFAULT_LIB)
+    im, sizes = build_imagen(args.workload, args.timesteps, dev)
+    stage, B, S = len(sizes) - 1, args.batch, sizes[-1]
+    unet = im.unets[stage]
+    eng = unet.engine()
+    eng.pack()
+    two = args.cond_scale != 1
+    ws = eng.workspace(B, 2 * B if two else B, S, S, precision=args.precision)
+    emb, mask = synthetic_text(B)
+    keep = torch.cat((torch.ones(B, dtype=torch.bool), torch.zeros(B if two else 0, dtype=torch.bool)))
+    ws.x.normal_()
+    if ws.lowres is not None:
+        ws.lowres.normal_()
+        eng.prepare_lowres(ws)
+    eng.set_text(ws, emb.to(dev), mask.to(dev), keep)
+    for _ in range(3):
+        eng.run(ws)
+    torch.cuda.synchronize()
 
 
 def cpu_baseline_reference(ncores):
@@ -309,6 +371,7 @@ def secondary_lines(timesteps, cond_scale):
                "--warmup", "3" if calls > 3 else "1", "--timesteps", str(timesteps), "--cond-scale", str(cond_scale),
                "--no-secondary", "--no-cpu-baseline", "--no-t5"] + ([] if workload == "cascade64_256_1024" else ["--no-breakdown"])
         env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+        env["MINIMAGEN_BENCH_LIVE_PMC"] = "0"          # (the secondary legs keep the committed-profile look-up: bounded run time)
         r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
         lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
         if r.returncode != 0 or not lines:
@@ -379,6 +442,9 @@ def train_step_only():
 def main():
     if "--train-step-only" in sys.argv:
         return train_step_only()
+    pmc_child_mode = "--pmc-child" in sys.argv
+    if pmc_child_mode:
+        sys.argv.remove("--pmc-child")
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=16)
@@ -402,6 +468,8 @@ def main():
     ap.add_argument("--lanes", type=int, default=0, help="independent call lanes of the pipelined mode (sets of stage streams / workspaces / graphs that "
                     "sample(_async=True) alternates between; 0 = the library default MINIMAGEN_SAMPLE_LANES = 2, 1 = one lane: only the stages of successive calls overlap)")
     args = ap.parse_args()
+    if pmc_child_mode:
+        return pmc_child(args)
 
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -511,7 +579,7 @@ def main():
         del ref_out, chk
     dt, mine, out = timed(args.steps, pipelined)
     assert torch.isfinite(out).all() and out.shape[0] == gB
-    im.check_device_status()            # no kernel with inter-workgroup waits (grouped sampler tail, resident chains) gave up waiting
+    im.check_device_status()            # no kernel with inter-workgroup waits (the grouped sampler tail) gave up waiting
     dt_sync = dt_one = None
     if pipelined:                       # the reference's sample() is synchronous: report that mode beside the pipelined headline
         dt_sync, _, _ = timed(max(2, min(args.steps, 8)), False)
@@ -595,13 +663,27 @@ def main():
             ex = dom["alg_flops"] * k / (dom["ms"] * 1e-3) / 1e12
             res["roofline"]["executed"] = {"achieved": ex, "frac": ex / peak,
                                            "note": f"MFMA flops actually issued = {k:g} x algorithmic (folded attention" + ((", fp16x3 split" if args.precision == "fp32" else ", single fp16 term") + "; v_mfma_f32_16x16x32_f16 for both contractions: QK^T per tile as {G hi|G lo}.{x hi|x hi} + {G hi|G lo}.{x lo|0} -- two pipe slots instead of three K = 16 ones, a quarter of the issued K is zero padding and not counted" if attn_f16 else "; v_mfma_f32_16x16x4_f32") + ")"}
-        res["roofline"].update(pmc_traffic(dom, B * (2 if args.cond_scale != 1 else 1), sizes[stage]))
+        live = pmc_traffic_live(args, dom, B * (2 if args.cond_scale != 1 else 1), sizes[stage]) if world == 1 else None
+        res["roofline"].update(live if live is not None else pmc_traffic(dom, B * (2 if args.cond_scale != 1 else 1), sizes[stage]))
         # SURVEY 8(d) algorithmic bytes of ONE image-forward, summed over this U-Net's own launch plan: every entry's bytes divided by the
         # rows it serves (a tensor the engine computes once for both guidance halves still counts once per forward, as in the reference)
         alg_fwd_mb = sum(r["alg_bytes"] / r["rows"] for r in rows if r["rows"]) / 1e6
         survey_mb = {("cascade64_256", 256): 124.97, ("base64", 64): 28.82}.get((args.workload, sizes[stage]))
         nfwd = 2 if args.cond_scale != 1 else 1
+        conv_rows = [r for r in rows if r["kernel"] == "conv" and not r.get("hoisted")]
+        by_level = {}
+        for r in conv_rows:
+            lv = by_level.setdefault(r["op"].split("@")[1].split()[0], {"launches": 0, "ms": 0.0, "alg_GB": 0.0})
+            lv["launches"] += 1; lv["ms"] += r["ms"]; lv["alg_GB"] += r["alg_bytes"] / 1e9
+        for lv in by_level.values():
+            lv["alg_GBps"] = lv["alg_GB"] / (lv["ms"] * 1e-3) if lv["ms"] else None
+        conv_ms, conv_gb = sum(r["ms"] for r in conv_rows), sum(r["alg_bytes"] for r in conv_rows) / 1e9
         res["unet_eval"] = {"stage": stage, "sum_kernel_ms": total_ms, "launches": sum(1 for r in rows if not r.get("hoisted")),
+                            # the conv family on ITS OWN bytes (the whole-forward fraction below is carried by the attention's algorithmic
+                            # q / k / v / projection tensors, which the folded kernel never materialises)
+                            "conv_only": {"launches": len(conv_rows), "ms": conv_ms, "alg_GB": conv_gb, "alg_GBps": conv_gb / (conv_ms * 1e-3) if conv_ms else None,
+                                          "hbm_frac": conv_gb / (conv_ms * 1e-3) / HBM_PEAK_GBS if conv_ms else None, "by_level": by_level},
+                            "activation_bytes": "bf16 storage (2 B per activation element) where mi_act.st is set" if any(getattr(p, "out_st", 0) for _, p, _ in unet_prog(im, stage, B, args)) else "fp32 (4 B per activation element)",
                             "alg_bytes_MB_per_image_forward": alg_fwd_mb, "alg_bytes_MB_per_image_forward_SURVEY_8d": survey_mb,
                             "hbm_frac_whole_forward": (alg_fwd_mb * 1e6 * B * nfwd / (total_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if alg_fwd_mb else None,
                             "by_kernel_ms": {k: sum(r["ms"] for r in rows if r["kernel"] == k) for k in sorted({r["kernel"] for r in rows})}}

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MI_ABI_VERSION 7
+#define MI_ABI_VERSION 8
 
 enum mi_status {
     MI_OK = 0,
@@ -102,22 +102,6 @@ typedef struct mi_conv_params {
 #define MI_CONV_HALF    0x400   /* row-paired matrix-core path: single fp16 term per product (reduced-precision configuration; parity gate 3e-2) */
 #define MI_CONV_REVERSE 0x200  /* tile_cfg | MI_CONV_REVERSE (row-paired path): workgroups take the images in reverse order (speed only) */
 #define MI_CONV_RP_FIRST 5      /* tile_cfg 5: 16x64, 6: 8x64, 7: 8x32 output tiles of the row-paired matrix-core path */
-
-/* ResnetBlock.block2 (+ 1x1 residual conv) fused with the conv that follows it WITHOUT a normalisation in between -- the tail of the
- * U-Net (reference: Unet.py:464-472, final_res_block -> final_conv; layers.py:417-439): `conv` describes the first conv exactly as for
- * mi_conv_fwd (row-paired path: 8 GroupNorm-ed input channels, 1x1 residual conv over 8 or 16 channels -- the identity residual of a
- * ResnetBlock(dim, dim) is passed as the 1x1 conv with the unit matrix: the intermediate is rounded to the fp16 hi + lo pair either way --,
- * 8 output channels; conv.out / conv.out_stats are NOT written), w2_rp / w2_rp_exp / bias2 the second 3x3 conv (8 -> Cout2 <= 8 channels, fragments as w_rp), out2 its fp32
- * output [B][Cout2][H][W].  The 8-channel intermediate stays in LDS (halo recomputed per tile): 2 x 4 x 8 x H x W bytes per image less traffic. */
-typedef struct {
-    mi_conv_params conv;
-    const void* w2_rp;
-    int w2_rp_exp;
-    int Cout2;
-    const float* bias2;
-    float* out2;
-} mi_conv_tail_params;
-int mi_conv_tail_fwd(const mi_conv_tail_params* p, void* stream);
 
 /* tile_cfg -> output tile (th x tw) handled by one workgroup; out_nt = ceil(H/th)*ceil(W/tw) */
 int mi_conv_tile_shape(int tile_cfg, int* th, int* tw);
@@ -327,15 +311,20 @@ int mi_sampler_step_small_fwd(const mi_cfg_x0_params* c, const mi_quantile_param
 
 /* The same fused tail for LARGE images (n % 4 == 0): mi_sampler_group_size(n) workgroups of 1024 work-items per image keep their share of
  * x0 in registers across the three radix passes; the passes' histograms are combined with integer agent-scope atomics and a counter barrier
- * among the workgroups of an image (claimed by ticket once resident: no cooperative launch; bounded spins, error word at byte 8 of `sync`).
+ * among the workgroups of an image (claimed by ticket once resident: no cooperative launch; every spin bounded).
  * Replaces mi_cfg_x0_fwd + mi_quantile_fwd (4 launches) + mi_posterior_fwd; bit-identical results.  `sync`: mi_sampler_group_sync_bytes(B, n)
  * bytes, zero-filled once, private to one stream's launches.  c->x0 / c->pred_out / q->s_out / q->v_out are written when non-NULL; c->hist0 /
  * q->hist / pp->x0 / pp->s_q are not used.
- * CO-RESIDENCY: the workgroups of an image wait for each other.  One launch cannot deadlock (work is claimed by ticket once resident), but two
+ * Header of `sync`: [0] u64 ticket | [8] u32 error word (sticky) | [12] u32 spin limit (0 = the built-in 2^22) | [16] u32 fault injection
+ * (tests: 1 = workgroup 1 of image 0 skips its arrival at radix pass 1).
+ * FAIL-STOP: the workgroups of an image wait for each other.  One launch cannot deadlock (work is claimed by ticket once resident), but
  * launches in flight on different streams can starve each other when their waiting workgroups together fill the chip (observed with 128
- * workgroups per image at 1024^2: the bounded spin gives up, error word 0x300 + pass, and the image's step is NOT written).  Callers that run
- * several such launches side by side must keep mi_sampler_group_size(n) small against the number of CUs -- the Python host uses this entry point for
- * at most 8 workgroups per image (256^2) and the separate kernels above that -- and should read the error word at a synchronisation point. */
+ * workgroups per image at 1024^2).  A workgroup whose wait runs out stores 0x300 + pass into the error word, overwrites ITS part of pp->x with
+ * NaN and leaves; every workgroup that finds the word set (peers at their next poll, every later launch on this buffer at its start) does
+ * the same without waiting: a failed step is never a stale or half-written image, it is NaN from there on.  The caller polls the word at a
+ * synchronisation point (the Python host copies it to pinned memory behind every call and raises at the next API entry), zero-fills `sync`
+ * again and should stay with the separate kernels afterwards.  Keep mi_sampler_group_size(n) small against the number of CUs -- the Python
+ * host uses this entry point for at most 8 workgroups per image (256^2). */
 int mi_sampler_group_size(int n);                          /* workgroups per image; 0: unsupported */
 long long mi_sampler_group_sync_bytes(int B, int n);
 int mi_sampler_step_group_fwd(const mi_cfg_x0_params* c, const mi_quantile_params* q, const mi_posterior_params* pp, void* sync, void* stream);
@@ -512,54 +501,6 @@ typedef struct mi_folded_attn_params {
 } mi_folded_attn_params;
 int mi_folded_attn_fwd(const mi_folded_attn_params* p, void* stream);
 int mi_folded_attn_bwd(const mi_folded_attn_params* p, void* stream);
-
-/* ---- resident conv chain (conv_resident.hip) -----------------------------------------------
- * A run of consecutive Block / ResnetBlock convolutions at ONE resolution (layers.py:131-145, 417-439; the <= 64 x 64 levels of
- * Unet.forward, Unet.py:419-465) in ONE launch: every image is cut into horizontal slabs (16 rows of a 64-wide image, 8 rows of a
- * 32-wide one), one 512-thread workgroup per slab keeps its slab of the running activation in registers from layer to layer, stages
- * the fp16 operand planes in LDS and multiplies on the matrix cores exactly like the row-paired kernel of mi_conv_fwd.  Between two
- * layers the workgroups of an image exchange only (a) their per-channel partial (sum, sum of squares) -- the next GroupNorm needs
- * whole-image moments -- and (b) their first and last row (the 3x3 halo), through write-through (sc1) stores and one flag per slab
- * (agent-scope, placement independent).  Slabs are claimed with a ticket counter by workgroups that are already resident, so the
- * workgroups of one image are co-resident by construction whatever else runs on the GPU (no cooperative launch needed, no deadlock
- * between concurrent launches of different streams).  Layer i computes
- *     y_i = conv3x3(act_i(concat(src_i, in1 * scale))) + bias [+ residual_i]
- * with act_i = GroupNorm -> [scale/shift] -> SiLU when gn_groups > 0, else the identity; y_i stays resident and is ALSO stored to
- * `out` (with its per-slab statistics in `out_stats`, nt = slabs per image) when another launch consumes it. */
-#define MI_RES_MAX_LAYERS 8
-#define MI_RES_MAXC 16          /* channels of the resident tensor (every layer's Cout) */
-typedef struct mi_res_layer {
-    int src;                /* first part of the conv input: 0 = the resident tensor (the previous layer's y), 1 = in0 (global memory) */
-    mi_act in0;             /* src == 1 */
-    mi_act in1;             /* optional second part (skip connection, Unet.py:445), global memory; data == NULL: none */
-    int gn_groups;          /* over the concatenated input; 0 = no GroupNorm / activation */
-    const float* gn_gamma; const float* gn_beta; float gn_eps;
-    int ss_off;             /* scale at scale_shift[b][ss_off + c], shift at [ss_off + Cin + c]; < 0: none */
-    const void* w_rp; int w_rp_exp;   /* fragments as mi_conv_params.w_rp */
-    const float* bias;
-    int Cout;               /* 8 or 16 */
-    int res;                /* 0 none | 1 identity: the saved resident tensor X | 2 identity: res0 (global) |
-                               3 1x1 conv over concat(X, res1 * scale) | 4 1x1 conv over concat(res0, res1 * scale) */
-    mi_act res0, res1;
-    const void* res_w_rp; int res_w_rp_exp; const float* res_b;
-    int save_x;             /* keep y_i as X (a later layer's residual input: the ResnetBlock input) */
-    float* out; int out_st; float* out_stats;   /* NULL: y_i is not needed outside the launch */
-    int out_nt;             /* partial-statistics slots per channel of out_stats (>= slabs per image; slot = slab index, the others stay as they are) */
-} mi_res_layer;
-typedef struct mi_resident_params {
-    int B, H, W, n_layers;
-    const float* scale_shift; int ss_stride;    /* [B][ss_stride] */
-    void* sync;             /* mi_resident_sync_bytes(B, H, W) bytes, zero-filled ONCE when allocated; private to one stream's launches */
-    int half;               /* single fp16 term per product (reduced-precision configuration), tensors with st = 1 are bf16 */
-    mi_res_layer layer[MI_RES_MAX_LAYERS];
-} mi_resident_params;
-int mi_resident_slabs(int H, int W);                      /* workgroups per image (= nt of every out_stats); 0: shape not supported */
-long long mi_resident_sync_bytes(int B, int H, int W);
-int mi_resident_convs_fwd(const mi_resident_params* p, void* stream);
-/* (co-residency: an image's 4 .. 8 slabs wait for each other; with at most 7 waiting workgroups per launch, launches of several streams cannot
- * fill the chip with waiting workgroups -- compare the note on mi_sampler_step_group_fwd) */
-/* error word of the last launches on `sync` (0 = fine; non-zero: a workgroup gave up waiting for its neighbours -- results invalid) */
-int mi_resident_error_offset(void);                       /* byte offset of the 32-bit error word inside `sync` */
 
 /* ---- HIP graphs: capture a sequence of the calls above once, replay it per timestep ------- */
 int mi_graph_begin(void* stream);

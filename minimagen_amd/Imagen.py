@@ -27,6 +27,9 @@ SAMPLER_GROUP = int(os.environ.get("MINIMAGEN_SAMPLER_GROUP", "1"))
 # bounded spin gave up (profiles/r04_sampler_group_config5.txt) -- large images keep the separate kernels
 SAMPLER_GROUP_MAX = int(os.environ.get("MINIMAGEN_SAMPLER_GROUP_MAX", "8"))
 SAMPLE_LANES = max(1, int(os.environ.get("MINIMAGEN_SAMPLE_LANES", "2")))     # independent call lanes of sample(_async=True)
+# 1: a synchronous sample() waits on the HOST for its last stage and checks the cooperative kernels' status words before it returns (the
+# default defers the check to the next API entry: the failed call's images are NaN -- fail-stop -- so nothing plausible-but-wrong escapes)
+STRICT_STATUS = os.environ.get("MINIMAGEN_STRICT_STATUS", "0") != "0"
 _STAGE_STREAMS = {}          # (device, lanes, stages, priority mode) -> [lane][stage] HIP streams, process-wide (see sample())
 
 
@@ -197,9 +200,18 @@ class Imagen(nn.Module):
         eng.prepare_step_tables(ws, T, st.t_state, stream)       # (timestep, text)-only conditioning of all T steps, once
 
         k_lo, k_hi, w = quantile_rank(n, self.dynamic_thresholding_percentile)
-        # the captured graph of one denoising step is cached per (workspace, guidance, threshold, noise mode, shard offset):
+        fused = os.environ.get("MINIMAGEN_SAMPLER_FUSED", "1") != "0"
+        small = n <= 16384 and fused                                    # MI_SAMPLER_SMALL_N: the whole tail in one launch of one workgroup per image
+        # ... or of <= SAMPLER_GROUP_MAX cooperating workgroups per image.  A stage state whose grouped launch ever failed (fail-stop:
+        # NaN images + the sticky error word, see _poll_status) keeps the separate kernels from then on
+        group = (not small) and fused and bool(SAMPLER_GROUP) and 0 < lib.mi_sampler_group_size(n) <= SAMPLER_GROUP_MAX \
+            and not getattr(st, "group_failed", False)
+        if getattr(st, "group_heal", False):
+            st.group_sync.zero_()               # stream-ordered behind every launch queued on this lane: ticket, counters, histograms, error word
+            st.group_heal = False
+        # the captured graph of one denoising step is cached per (workspace, guidance, threshold, noise mode, shard offset, tail kind):
         # the Philox seed lives in device memory, so replays of later sample() calls need no re-capture
-        gkey = (float(cond_scale), two, k_lo, k_hi, w, sample0, stage, T, noise_dev is None)
+        gkey = (float(cond_scale), two, k_lo, k_hi, w, sample0, stage, T, noise_dev is None, group)
         cached = getattr(st, "graphs", None)
         if cached is None:
             cached = st.graphs = {}
@@ -218,10 +230,9 @@ class Imagen(nn.Module):
                                      L.ptr(noise_dev), int(seed) & 0x7FFFFFFFFFFFFFFF, sample0, stage << 20,
                                      L.ptr(st.seed_dev) if noise_dev is None else 0)
 
-            small = n <= 16384 and os.environ.get("MINIMAGEN_SAMPLER_FUSED", "1") != "0"      # MI_SAMPLER_SMALL_N: the whole tail in one launch
-            group = (not small) and SAMPLER_GROUP and 0 < lib.mi_sampler_group_size(n) <= SAMPLER_GROUP_MAX and os.environ.get("MINIMAGEN_SAMPLER_FUSED", "1") != "0"
             if group and not hasattr(st, "group_sync"):
                 st.group_sync = torch.zeros(lib.mi_sampler_group_sync_bytes(B, n), dtype=torch.uint8, device=ws.dev)   # this workspace's launches only
+                st.group_err_host = torch.zeros(1, dtype=torch.int32).pin_memory() if L.backend() == "hip-gfx950" else torch.zeros(1, dtype=torch.int32)
             offsets = eng.step_offsets_supported(ws)          # the k-th step of a graph addresses *t_state - k; one advance per graph
 
             def tail_params(k):
@@ -289,6 +300,11 @@ class Imagen(nn.Module):
                 entry["step"]()
         img = torch.empty(shape, dtype=torch.float32, device=ws.dev)
         L.check(lib.mi_finalize_images(L.ptr(ws.x), L.ptr(img), B * n, 1 if self.auto_normalize_img else 0, stream), "mi_finalize_images")
+        if group:
+            # the grouped tail's sticky error word travels to pinned host memory behind the stage's last launch (no host synchronisation):
+            # _poll_status reads it once this call's completion event has fired
+            st.group_err_host.copy_(st.group_sync[8:12].view(torch.int32), non_blocking=True)
+            self.__dict__.setdefault("_status_stages", []).append((st, stage, (B, H, W)))
         return img
 
     def _lowres_conditioning(self, img, image_size: int, ws, lowres_noise_level: float, noise_fn, seed, sample0, stage):
@@ -340,6 +356,8 @@ class Imagen(nn.Module):
         ``_async=True`` returns without making the caller's stream wait (``self.last_sample_done`` / the returned tensor's ``sample_done`` is THIS call's completion event; ``wait_pending_samples()`` covers every lane): successive
         calls then pipeline across the per-stage streams (the base stage of the next batch under the super-resolution stage of this one)."""
         device = default(device, self.device)
+        self._poll_status()                  # a cooperative launch of an EARLIER call gave up (its images are NaN): raise here, never silently
+        self._status_stages = []
         self._reset_unets_all_one_device(device=device)
         if exists(texts) and not exists(text_embeds):
             text_embeds, text_masks = t5_encode_text(texts, name=self.text_encoder_name)
@@ -426,6 +444,12 @@ class Imagen(nn.Module):
                                           stage=stage, use_graph=_use_graph)
                 if on_gpu:
                     prev_done = streams[stage].record_event()
+        if self._status_stages:
+            self.__dict__.setdefault("_status_pending", []).append((prev_done, self._status_stages))
+            self._status_stages = []
+        if STRICT_STATUS and on_gpu and not _async:
+            prev_done.synchronize()
+            self._poll_status()
         if on_gpu:
             if _async:
                 # pipelined use: the result is ready when ``done`` is (the caller synchronises / waits on it before touching the images)
@@ -450,29 +474,52 @@ class Imagen(nn.Module):
         return pil
 
 
+def _poll_status(self, block: bool = False):
+    """Status of the kernels whose workgroups wait for each other (the grouped sampler tail).  Such a launch is fail-stop: when a wait
+    runs out it sets a sticky error word and turns the image -- and everything sampled from it afterwards -- into NaN.  Every sample()
+    call copies the word to pinned host memory behind its last launch; this looks at the calls whose completion event has fired
+    (``block=True``: waits for all of them) and raises MinImagenHipError for a failed one.  Called at every sample() entry, by
+    wait_pending_samples() and check_device_status().  Recovery is automatic: the stage state re-zeroes its sync buffer before its next
+    launch and keeps the separate (non-cooperative) kernels from then on."""
+    pending = self.__dict__.get("_status_pending", [])
+    failed, rest = [], []
+    for done, stages in pending:
+        if done is not None:
+            if block:
+                done.synchronize()
+            elif not done.query():
+                rest.append((done, stages))
+                continue
+        for st, stage, shape in stages:
+            err = int(st.group_err_host.item())
+            if err and not getattr(st, "group_failed", False):
+                st.group_failed, st.group_heal = True, True
+                failed.append(f"stage {stage} {shape}: {err:#x}")
+            elif err:
+                failed.append(f"stage {stage} {shape}: {err:#x} (call queued behind the failed one)")
+    self._status_pending = rest
+    if failed:
+        raise L.MinImagenHipError("grouped sampler tail: a workgroup timed out waiting for its image's other workgroups (" + "; ".join(failed) +
+                                  "); the images of that sample() call are NaN.  The stage falls back to the separate kernels from the next call on.")
+
+
+Imagen._poll_status = _poll_status
+
+
 def _check_device_status(self):
-    """Host-side check (synchronises the device): no kernel whose workgroups wait for each other (the grouped sampler tail, resident conv
-    chains) gave up waiting.  Such a launch leaves its outputs unwritten and sets a sticky error word; sample() itself never host-syncs,
-    so callers that need the guarantee call this after their own synchronisation point (the PIL path of sample() does)."""
-    for unet in self.unets:
-        eng = unet.engine()
-        for ws in eng._ws.values():
-            eng.check_resident(ws)
-            for st in ws.__dict__.get("sampler_state", {}).values():
-                sync = getattr(st, "group_sync", None)
-                if sync is not None:
-                    err = int(sync[8:12].cpu().view(torch.int32).item())
-                    if err:
-                        raise L.MinImagenHipError(f"grouped sampler tail reported {err:#x}: a workgroup timed out waiting for its image's other workgroups")
+    """Host-side check (waits for every sample() call in flight): no kernel whose workgroups wait for each other gave up waiting."""
+    self._poll_status(block=True)
 
 
 Imagen.check_device_status = _check_device_status
 
 
 def _wait_pending_samples(self, stream=None):
-    """Make ``stream`` (default: the caller's current stream) wait for the latest ``sample(_async=True)`` call of EVERY call lane."""
+    """Make ``stream`` (default: the caller's current stream) wait for the latest ``sample(_async=True)`` call of EVERY call lane; raises
+    if a call that has already completed reported a failed cooperative launch (check_device_status() waits on the host and covers all)."""
     for ev in self.__dict__.get("_lane_done", {}).values():
         (stream if stream is not None else torch.cuda.current_stream()).wait_event(ev)
+    self._poll_status()
 
 
 Imagen.wait_pending_samples = _wait_pending_samples

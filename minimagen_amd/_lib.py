@@ -165,29 +165,9 @@ class MiFoldedAttnParams(C.Structure):
                 ("dsum", C.c_void_p), ("dq", C.c_void_p), ("dkf", C.c_void_p), ("dvf", C.c_void_p), ("oh", C.c_void_p)]
 
 
-class MiResLayer(C.Structure):
-    _fields_ = [("src", C.c_int), ("in0", MiAct), ("in1", MiAct),
-                ("gn_groups", C.c_int), ("gn_gamma", C.c_void_p), ("gn_beta", C.c_void_p), ("gn_eps", C.c_float), ("ss_off", C.c_int),
-                ("w_rp", C.c_void_p), ("w_rp_exp", C.c_int), ("bias", C.c_void_p), ("Cout", C.c_int), ("res", C.c_int),
-                ("res0", MiAct), ("res1", MiAct), ("res_w_rp", C.c_void_p), ("res_w_rp_exp", C.c_int), ("res_b", C.c_void_p),
-                ("save_x", C.c_int), ("out", C.c_void_p), ("out_st", C.c_int), ("out_stats", C.c_void_p), ("out_nt", C.c_int)]
-
-
-RES_MAX_LAYERS = 8
-
-
-class MiResidentParams(C.Structure):
-    _fields_ = [("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("n_layers", C.c_int), ("scale_shift", C.c_void_p), ("ss_stride", C.c_int),
-                ("sync", C.c_void_p), ("half", C.c_int), ("layer", MiResLayer * RES_MAX_LAYERS)]
-
-
-class MiConvTailParams(C.Structure):
-    _fields_ = [("conv", MiConvParams), ("w2_rp", C.c_void_p), ("w2_rp_exp", C.c_int), ("Cout2", C.c_int), ("bias2", C.c_void_p), ("out2", C.c_void_p)]
-
-
 _STRUCTS = {0: MiAct, 1: MiConvParams, 2: MiCrossEmbedParams, 3: MiLinear, 4: MiTextCondParams, 5: MiCondStepParams,
             6: MiAttnFoldParams, 7: MiCrossAttnParams, 8: MiCfgX0Params, 9: MiQuantileParams, 10: MiPosteriorParams,
-            11: MiResizeParams, 12: MiSelfAttnParams, 13: MiChanFFParams, 14: MiFlashAttnParams, 15: MiTokensToNchwParams, 16: MiConvWgradParams, 17: MiBlockBwdParams, 18: MiCrossEmbedWgradParams, 19: MiFoldedAttnParams, 20: MiResLayer, 21: MiResidentParams, 22: MiConvTailParams}
+            11: MiResizeParams, 12: MiSelfAttnParams, 13: MiChanFFParams, 14: MiFlashAttnParams, 15: MiTokensToNchwParams, 16: MiConvWgradParams, 17: MiBlockBwdParams, 18: MiCrossEmbedWgradParams, 19: MiFoldedAttnParams}
 
 _lib = None
 _backend = None
@@ -205,7 +185,7 @@ def _bind(lib):
     vp, i32, i64, u64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float
     for name in ("mi_conv_fwd", "mi_gn_coef_fwd", "mi_crossembed_fwd", "mi_text_cond_fwd", "mi_cond_step_fwd", "mi_attn_fold_rows", "mi_cross_attn_fwd",
                  "mi_cfg_x0_fwd", "mi_quantile_fwd", "mi_posterior_fwd", "mi_resize_fwd", "mi_self_attn_fwd", "mi_chan_ff_fwd",
-                 "mi_flash_attn_fwd", "mi_tokens_to_nchw_fwd", "mi_conv_wgrad", "mi_block_bwd", "mi_crossembed_wgrad", "mi_folded_attn_fwd", "mi_folded_attn_bwd", "mi_resident_convs_fwd", "mi_conv_tail_fwd"):
+                 "mi_flash_attn_fwd", "mi_tokens_to_nchw_fwd", "mi_conv_wgrad", "mi_block_bwd", "mi_crossembed_wgrad", "mi_folded_attn_fwd", "mi_folded_attn_bwd"):
         getattr(lib, name).argtypes = [vp, vp]
         getattr(lib, name).restype = i32
     lib.mi_step_advance.argtypes = [vp, vp, i32, vp]
@@ -242,9 +222,6 @@ def _bind(lib):
     lib.mi_pack_conv3_floats.restype = C.c_longlong
     lib.mi_pack_conv3.argtypes = [vp, i32, i32, i32, i32, vp, vp, i32, vp]
     lib.mi_attn_fragment_floats.argtypes = [i32]
-    lib.mi_resident_slabs.argtypes = [i32, i32]
-    lib.mi_resident_sync_bytes.argtypes = [i32, i32, i32]
-    lib.mi_resident_sync_bytes.restype = C.c_longlong
     for which, st in _STRUCTS.items():
         n = lib.mi_struct_size(which)
         if n != C.sizeof(st):

@@ -46,9 +46,6 @@ extern "C" int mi_struct_size(int which) {
         case 17: return (int)sizeof(mi_block_bwd_params);
         case 18: return (int)sizeof(mi_crossembed_wgrad_params);
         case 19: return (int)sizeof(mi_folded_attn_params);
-        case 20: return (int)sizeof(mi_res_layer);
-        case 21: return (int)sizeof(mi_resident_params);
-        case 22: return (int)sizeof(mi_conv_tail_params);
     }
     return -1;
 }

@@ -284,7 +284,7 @@ __device__ __forceinline__ float mi_wave_max(float v) {
     return v;
 }
 
-// ---- inter-workgroup hand-off inside one launch (conv_resident.hip).  Per-XCD L2s are not coherent with each other and a CU's
+// ---- inter-workgroup hand-off inside one launch (sampler.hip: the grouped sampler tail).  Per-XCD L2s are not coherent with each other and a CU's
 // vector L1 is never refreshed by another CU's stores, so everything one workgroup hands to another goes through WRITE-THROUGH (sc1)
 // stores and L1-bypassing (sc1) loads -- placement independent -- and one agent-scope flag per producer: payload stores -> every storing
 // wave drains (s_waitcnt vmcnt(0)) -> __syncthreads() -> ONE lane stores the flag; the consumer polls the flag relaxed, then reads the

@@ -105,15 +105,10 @@ __device__ __forceinline__ int rp_clamp_exp(int k) { return k < -60 ? -60 : (k >
 // WIDE_: the wide-channel regime (Unet() default, Base, Super: 128 .. 2048+ channels).  The output channels are tiled over blockIdx.y
 // (8 NJ, or 16 NJ for MODE 2, per workgroup), the rounds are run-time, and the per-channel GroupNorm affine / the operand exponents come
 // precomputed from gn_coef_kernel (global memory) instead of the in-kernel statistics prologue, which is sized for <= 64 channels.
-// TAIL_: a SECOND 3x3 conv fused behind the first one (ResnetBlock.block2 + residual followed by the U-Net's final conv, Unet.py:464-472:
-// no normalisation in between): the workgroup computes the first conv on a (TH_ x TW_) tile that is the second conv's (TH_ - 2) x (TW_ - 8)
-// output tile plus a one-pixel halo (recomputed by the neighbours), keeps it in LDS as fp16 hi / lo planes and runs the second conv from
-// there.  The intermediate tensor -- 8 channels at full resolution, the largest tensor of the network -- is neither written nor read back.
-template <int TH_, int TW_, int NJ_, bool GN_, bool HALF_, int MODE_, int KO_ = -1, int RO_ = -1, bool WIDE_ = false, bool TAIL_ = false>
+template <int TH_, int TW_, int NJ_, bool GN_, bool HALF_, int MODE_, int KO_ = -1, int RO_ = -1, bool WIDE_ = false>
 struct RpCfg {
     static constexpr int TH = TH_, TW = TW_, NJ = NJ_, MODE = MODE_, KO_T = KO_, RO_T = RO_;
-    static constexpr bool WIDE = WIDE_, TAIL = TAIL_;
-    static constexpr int TH2 = TAIL_ ? TH_ - 2 : TH_, TW2 = TAIL_ ? TW_ - 8 : TW_;      // the tile grid's pitch (= the fused second conv's output tile)
+    static constexpr bool WIDE = WIDE_;
     static constexpr bool GN = GN_, HALF = HALF_;
     // staged source window (rows x units) and LDS pitch in 16-byte chunks
     static constexpr int IH = MODE_ == 0 ? TH_ + 2 : (MODE_ == 1 ? TH_ / 2 + 2 : 2 * TH_ + 2);
@@ -125,17 +120,13 @@ struct RpCfg {
     static constexpr int NSTEP = MODE_ == 2 ? 4 : 3;
     // waves per SIMD the register allocation leaves room for: 4 where that needs no spills (a spill is a counted memory operation:
     // its s_waitcnt also waits for the prefetch), else 3
-    static constexpr int WPS = TAIL_ ? 2 : ((NJ_ == 1 && TH_ * TW_ <= 512 && (KO_ + RO_ == 1 || TH_ * TW_ <= 256)) ? 4 : 3);
+    static constexpr int WPS = (NJ_ == 1 && TH_ * TW_ <= 512 && (KO_ + RO_ == 1 || TH_ * TW_ <= 256)) ? 4 : 3;
 };
-
-struct rp_tail_args { const uint4* w2; const float* bias2; float* out2; int w2_exp, Cout2; };
 
 template <class CFG>
 __global__ __launch_bounds__(256, CFG::WPS) void conv_rp_kernel(const mi_conv_params p, const uint4* __restrict__ wrp, const uint4* __restrict__ rwrp,
-                                                                const int ntile, const float4* __restrict__ coef, const int* __restrict__ exps,
-                                                                const rp_tail_args ta) {
-    constexpr bool WIDE = CFG::WIDE, TAIL = CFG::TAIL;
-    constexpr int TH2 = CFG::TH2, TW2 = CFG::TW2;
+                                                                const int ntile, const float4* __restrict__ coef, const int* __restrict__ exps) {
+    constexpr bool WIDE = CFG::WIDE;
     constexpr int TH = CFG::TH, TW = CFG::TW, NJ = CFG::NJ, IH = CFG::IH, UW = CFG::UW, PW = CFG::PW, MODE = CFG::MODE;
     constexpr int NU = CFG::NU, PER = CFG::PER, GX = CFG::GX, GPW = CFG::GPW, NSTEP = CFG::NSTEP;
     constexpr bool GN = CFG::GN, HALF = CFG::HALF;
@@ -150,14 +141,11 @@ __global__ __launch_bounds__(256, CFG::WPS) void conv_rp_kernel(const mi_conv_pa
     constexpr int WCH = NSTEP * NJ * 128;                                        // 16-byte chunks of one conv round
     constexpr int WTOT = CFG::KO_T >= 0 ? CFG::KO_T * WCH + CFG::RO_T * NJ * 128 : WCH;
     __shared__ __attribute__((aligned(16))) uint4 wl[WTOT];
-    __shared__ __attribute__((aligned(16))) uint4 wl2[TAIL ? CFG::NSTEP * 128 : 1];    // the fused second conv's B fragments (8 -> <= 8 channels)
-    __shared__ float smax[4];
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lq = lane & 15, lg = lane >> 4;
     const int H = p.H, W = p.W;
-    const int tiles_x = (W + TW2 - 1) / TW2, tiles = tiles_x * ((H + TH2 - 1) / TH2);
+    const int tiles_x = (W + TW - 1) / TW, tiles = tiles_x * ((H + TH - 1) / TH);
     const int strips = (tiles + ntile - 1) / ntile;
-    constexpr int HALO = TAIL ? 1 : 0;                      // the first conv's tile starts one pixel up / left of the grid position
     // One workgroup = one strip of `ntile` consecutive tiles of ONE image: the statistics / affine prologue is paid once per strip and
     // the next tile's loads fly under the current tile's MFMA loop and epilogue.
     // XCD-aware placement (speed only): workgroup L runs on XCD L % 8; give each XCD whole images so that halo re-reads and the
@@ -183,7 +171,7 @@ __global__ __launch_bounds__(256, CFG::WPS) void conv_rp_kernel(const mi_conv_pa
     const int KO = STATIC_ROUNDS ? CFG::KO_T : (Cin >> 3), RO = STATIC_ROUNDS ? CFG::RO_T : (Cres >> 3), rounds = KO + RO;
     constexpr int RT = STATIC_ROUNDS ? CFG::KO_T + CFG::RO_T : 1;         // static round count (1 slot in the generic kernel)
     constexpr int NSLOT = RT;                                             // raw-load register slots (one per round; <= PFD + 1 are live at a time)
-    constexpr int PFD = (RT >= 2 && !CFG::TAIL) ? 2 : 1;                  // prefetch distance in rounds (the fused-tail tile is 2.25x the pixels: one round ahead)
+    constexpr int PFD = RT >= 2 ? 2 : 1;                                  // prefetch distance in rounds
     // source image extent
     const int Hs = MODE == 0 ? H : (MODE == 1 ? H / 2 : 2 * H), Ws = MODE == 0 ? W : (MODE == 1 ? W / 2 : 2 * W);
     const int HWs = Hs * Ws;
@@ -205,7 +193,7 @@ __global__ __launch_bounds__(256, CFG::WPS) void conv_rp_kernel(const mi_conv_pa
     unsigned inmask[NSLOT];           // bit u: unit u of the tile whose loads are in the slot lies inside the image
     auto load_raw = [&](int tile, int rnd, auto slot_tag) {
         constexpr int slot = decltype(slot_tag)::value;
-        const int oy0 = (tile / tiles_x) * TH2 - HALO, ox0 = (tile % tiles_x) * TW2 - HALO;
+        const int oy0 = (tile / tiles_x) * TH, ox0 = (tile % tiles_x) * TW;
         const int sy0 = MODE == 0 ? oy0 - 1 : (MODE == 1 ? oy0 / 2 - 1 : 2 * oy0 - 1);
         const int sx0 = MODE == 0 ? ox0 - 1 : (MODE == 1 ? ox0 / 2 - 1 : 2 * ox0 - 1);
         const bool isres = rnd >= KO;
@@ -293,9 +281,6 @@ __global__ __launch_bounds__(256, CFG::WPS) void conv_rp_kernel(const mi_conv_pa
             const int k = tid + i * 256;
             if (k < WTOT) wl[k] = wreg[i];
         }
-    }
-    if constexpr (TAIL) {
-        for (int i = tid; i < CFG::NSTEP * 128; i += 256) wl2[i] = mi_ldg4u(ta.w2 + i);
     }
     if (fast) mi_gn_totals_finish(sr, tid, chS, chQ);
     else if (have_stats) mi_gn_channel_totals(p.in0, p.in1, C0, Cin, b, tid, 256, chS, chQ);
@@ -417,7 +402,7 @@ __global__ __launch_bounds__(256, CFG::WPS) void conv_rp_kernel(const mi_conv_pa
     // and force the conservative one (wait for everything) on every tile
     auto do_tile = [&](const int tile, auto has_next_tag) {
         constexpr bool HAS_NEXT = decltype(has_next_tag)::value;
-        const int oy0 = (tile / tiles_x) * TH2 - HALO, ox0 = (tile % tiles_x) * TW2 - HALO;
+        const int oy0 = (tile / tiles_x) * TH, ox0 = (tile % tiles_x) * TW;
         f32x4 acc[GPW][NJ];
 #pragma unroll
         for (int g = 0; g < GPW; ++g)
@@ -557,85 +542,6 @@ __global__ __launch_bounds__(256, CFG::WPS) void conv_rp_kernel(const mi_conv_pa
             for (int rnd = 0; rnd < rounds; ++rnd) one_round(rnd);
         }
 
-        if constexpr (TAIL) {
-            // ---------------- the first conv's result (bias, 1x1 residual included) -> fp16 hi / lo planes in LDS, zero outside the image
-            // (the second conv's zero padding); scaled by a power of two taken from the tile's own maximum
-            static_assert(NJ == 1 && MODE == 0 && !WIDE, "fused tail: one N tile, 3x3 stride 1");
-            const float unscale1 = ldexpf(1.0f, -sExp[2]);
-            const int co = lq & 7, dy = lq >> 3;
-            float mx = 0.0f;
-#pragma unroll
-            for (int g = 0; g < GPW; ++g) {
-                const int G = wave * GPW + g, gyy = G / GX, gxx = G % GX;
-                const int oy = oy0 + 2 * gyy + dy, ox = ox0 + 16 * gxx + 4 * lg;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const bool in = oy >= 0 && oy < H && ox + e >= 0 && ox + e < W && co < p.Cout;
-                    const float y = in ? fmaf(acc[g][0][e], unscale1, bvv[0]) : 0.0f;
-                    acc[g][0][e] = y;
-                    mx = fmaxf(mx, fabsf(y));
-                }
-            }
-            mx = mi_wave_max(mx);
-            __syncthreads();                                  // every wave is through with the activation planes (and with smax of the previous tile)
-            if (lane == 0) smax[wave] = mx;
-            __syncthreads();
-            mx = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
-            const int kmid = (mx > 0.f && mx < INFINITY) ? rp_clamp_exp(8 - rp_exponent(mx)) : 0;        // max |y| 2^kmid in [128, 256)
-            const float sm = ldexpf(1.0f, kmid);
-            _Float16* const mh = reinterpret_cast<_Float16*>(actH);
-            _Float16* const ml = reinterpret_cast<_Float16*>(actL);
-#pragma unroll
-            for (int g = 0; g < GPW; ++g) {
-                const int G = wave * GPW + g, gyy = G / GX, gxx = G % GX;
-                const int base = ((2 * gyy + dy) * PW + 16 * gxx + 4 * lg) * 8 + co;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float v = acc[g][0][e] * sm;
-                    const _Float16 hi = (_Float16)v;
-                    mh[base + 8 * e] = hi;
-                    if constexpr (!HALF) ml[base + 8 * e] = (_Float16)(v - (float)hi);
-                }
-            }
-            __syncthreads();
-            // ---------------- the second conv from the planes: (TH - 2) x (TW - 8) outputs (the MFMA groups cover TW columns; the last 8 belong
-            // to the next tile), same instruction form
-            constexpr int GY2 = TH2 / 2, GPW2 = GX * GY2 / 4;
-            f32x4 acc2[GPW2];
-#pragma unroll
-            for (int g = 0; g < GPW2; ++g) acc2[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int s2 = 0; s2 < NSTEP; ++s2) {
-                const rp_f16x8 bh = __builtin_bit_cast(rp_f16x8, wl2[(s2 * 64 + lane) * 2]);
-                rp_f16x8 bl = bh;
-                if constexpr (!HALF) bl = __builtin_bit_cast(rp_f16x8, wl2[(s2 * 64 + lane) * 2 + 1]);
-#pragma unroll
-                for (int g = 0; g < GPW2; ++g) {
-                    const int G = wave * GPW2 + g, gyy = G / GX, gxx = G % GX;
-                    const int idx = (2 * gyy + perm) * PW + 16 * gxx + lq + s2;
-                    const rp_f16x8 ah = __builtin_bit_cast(rp_f16x8, actH[idx]);
-                    if constexpr (!HALF) {
-                        const rp_f16x8 al = __builtin_bit_cast(rp_f16x8, actL[idx]);
-                        acc2[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc2[g], 0, 0, 0);
-                        acc2[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc2[g], 0, 0, 0);
-                    }
-                    acc2[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc2[g], 0, 0, 0);
-                }
-            }
-            const float unscale2 = ldexpf(1.0f, -(kmid + ta.w2_exp));
-            const float b2 = (ta.bias2 && co < ta.Cout2) ? ta.bias2[co] : 0.0f;
-            float* const ob2 = ta.out2 + (size_t)b * ta.Cout2 * H * W;
-#pragma unroll
-            for (int g = 0; g < GPW2; ++g) {
-                const int G = wave * GPW2 + g, gyy = G / GX, gxx = G % GX;
-                const int oy = oy0 + HALO + 2 * gyy + dy, cx = 16 * gxx + 4 * lg, ox = ox0 + HALO + cx;
-                if (co < ta.Cout2 && oy < H && ox < W && cx < TW2)
-                    mi_stg4(ob2 + ((size_t)co * H + oy) * W + ox, make_float4(fmaf(acc2[g][0], unscale2, b2), fmaf(acc2[g][1], unscale2, b2),
-                                                                              fmaf(acc2[g][2], unscale2, b2), fmaf(acc2[g][3], unscale2, b2)));
-            }
-            RP_TPHASE(5);
-            return;
-        }
         // ---------------- epilogue: lane (lq, lg) holds pixels 4lg .. 4lg+3 of column j = lq of every group
         const float unscale = ldexpf(1.0f, -sExp[2]);
         float csum[NJ], csq[NJ];
@@ -809,21 +715,8 @@ int launch_rp(const mi_conv_params& p, hipStream_t st) {
     }
     const int strips = (tiles + ntile - 1) / ntile;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_rp_kernel<CFG>), dim3(strips * p.B), dim3(256), 0, st, p, (const uint4*)p.w_rp, (const uint4*)p.res_w_rp, ntile,
-                       (const float4*)nullptr, (const int*)nullptr, rp_tail_args{});
+                       (const float4*)nullptr, (const int*)nullptr);
     return mi_check_launch("conv_rp_kernel");
-}
-
-// block2 (8 channels in, GroupNorm prologue, 1x1 residual conv over 16 channels) + the conv that follows it without a normalisation
-template <bool HALF, int RO>
-int launch_rp_tail(const mi_conv_params& p, const rp_tail_args& ta, hipStream_t st) {
-    using CFG = RpCfg<18, 64, 1, true, HALF, 0, 1, RO, false, true>;
-    const int tiles = ((p.H + CFG::TH2 - 1) / CFG::TH2) * ((p.W + CFG::TW2 - 1) / CFG::TW2);
-    int ntile = (p.tile_cfg >> 12) & 0xf;
-    if (ntile == 0) { ntile = 1; while (ntile < 4 && (size_t)p.B * (tiles / (2 * ntile)) >= 1024) ntile *= 2; }
-    const int strips = (tiles + ntile - 1) / ntile;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_rp_kernel<CFG>), dim3(strips * p.B), dim3(256), 0, st, p, (const uint4*)p.w_rp, (const uint4*)p.res_w_rp, ntile,
-                       (const float4*)nullptr, (const int*)nullptr, ta);
-    return mi_check_launch("conv_rp_kernel (fused tail)");
 }
 
 // wide-channel regime: 8x32 pixel tiles, NJ N tiles per workgroup, the layer's output channels over blockIdx.y
@@ -833,7 +726,7 @@ int launch_rp_wide(const mi_conv_params& p, hipStream_t st) {
     const int tiles = ((p.H + 7) / 8) * ((p.W + 31) / 32);
     const int cpt = MODE == 2 ? 16 : 8, njt = (p.Cout + cpt - 1) / cpt;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_rp_kernel<CFG>), dim3(tiles * p.B, (njt + NJ - 1) / NJ), dim3(256), 0, st, p, (const uint4*)p.w_rp,
-                       (const uint4*)p.res_w_rp, 1, (const float4*)p.gn_coef, (const int*)p.gn_exps, rp_tail_args{});
+                       (const uint4*)p.res_w_rp, 1, (const float4*)p.gn_coef, (const int*)p.gn_exps);
     return mi_check_launch("conv_rp_kernel (wide)");
 }
 
@@ -914,26 +807,6 @@ extern "C" int mi_gn_coef_fwd(const mi_conv_params* pp, void* stream) {
     if (p.gn_groups > 0 && (!p.in0.stats || (p.in1.data && !p.in1.stats))) { mi_set_error("mi_gn_coef_fwd: GroupNorm input without channel statistics"); return MI_ERR_INVALID; }
     hipLaunchKernelGGL(gn_coef_kernel, dim3(p.B), dim3(256), 0, (hipStream_t)stream, p);
     return mi_check_launch("gn_coef_kernel");
-}
-
-extern "C" int mi_conv_tail_fwd(const mi_conv_tail_params* tp, void* stream) {
-    const mi_conv_params& p = tp->conv;
-    const int C0 = p.in0.C, C1 = p.in1.data ? p.in1.C : 0;
-    const int Cres = (p.res0.data && p.res_w_rp) ? p.res0.C + (p.res1.data ? p.res1.C : 0) : 0;
-    if (p.B <= 0 || p.H <= 0 || p.W <= 0) { mi_set_error("mi_conv_tail_fwd: empty problem"); return MI_ERR_INVALID; }
-    if (!(p.ksize == 3 && p.stride == 1 && !p.up2 && p.w_rp && C0 + C1 == 8 && C1 == 0 && p.Cout == 8 && p.gn_groups > 0 && p.gn_groups <= MI_MAX_GROUPS &&
-          8 % p.gn_groups == 0 && (p.W & 3) == 0 && !p.gn_coef && (Cres == 8 || Cres == 16) && (p.res0.C & 7) == 0)) {
-        mi_set_error("mi_conv_tail_fwd: built for the U-Net tail: 3x3 conv of 8 GroupNorm-ed channels + 1x1 residual conv of 8 or 16 channels (an identity residual: the unit matrix), 8 channels out, W %% 4 == 0");
-        return MI_ERR_UNSUPPORTED;
-    }
-    if (!p.in0.stats) { mi_set_error("mi_conv_tail_fwd: GroupNorm input without channel statistics"); return MI_ERR_INVALID; }
-    if (!tp->w2_rp || !tp->out2 || tp->Cout2 < 1 || tp->Cout2 > 8) { mi_set_error("mi_conv_tail_fwd: second conv: fragments / output missing or more than 8 output channels"); return MI_ERR_INVALID; }
-    const bool half = (p.tile_cfg & MI_CONV_HALF) != 0;
-    if ((size_t)16 * p.H * p.W >= (1ull << 31)) { mi_set_error("mi_conv_tail_fwd: image too large for 32-bit offsets"); return MI_ERR_UNSUPPORTED; }
-    rp_tail_args ta;
-    ta.w2 = (const uint4*)tp->w2_rp; ta.bias2 = tp->bias2; ta.out2 = tp->out2; ta.w2_exp = tp->w2_rp_exp; ta.Cout2 = tp->Cout2;
-    if (Cres == 8) return half ? launch_rp_tail<true, 1>(p, ta, (hipStream_t)stream) : launch_rp_tail<false, 1>(p, ta, (hipStream_t)stream);
-    return half ? launch_rp_tail<true, 2>(p, ta, (hipStream_t)stream) : launch_rp_tail<false, 2>(p, ta, (hipStream_t)stream);
 }
 
 int mi_conv_rp_launch(const mi_conv_params& p, hipStream_t st) {

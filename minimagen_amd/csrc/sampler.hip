@@ -275,14 +275,6 @@ __global__ __launch_bounds__(256) void posterior_kernel(const mi_posterior_param
 #define SS_THREADS 1024
 #endif
 constexpr int SS_NT = SS_THREADS, SS_MAXQ = MI_SAMPLER_SMALL_N / 4 / SS_NT;      // quads per work-item
-#ifdef SS_PKCHECK
-__device__ unsigned ss_dbg_count;
-__device__ float ss_dbg[256 * 8];
-extern "C" int mi_debug_read_ss(void* dst, unsigned* count) {
-    (void)hipMemcpyFromSymbol(count, HIP_SYMBOL(ss_dbg_count), 4);
-    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(ss_dbg), sizeof(float) * 256 * 8);
-}
-#endif
 __global__ __launch_bounds__(SS_NT) void sampler_small_kernel(const mi_cfg_x0_params c, const mi_quantile_params q, const mi_posterior_params pp) {
     __shared__ unsigned lh[2][MI_Q_BINS];
     __shared__ int scratch[8];
@@ -296,9 +288,6 @@ __global__ __launch_bounds__(SS_NT) void sampler_small_kernel(const mi_cfg_x0_pa
     float x0v[SS_MAXQ][4], xtv[SS_MAXQ][4];
     for (int i = tid; i < 2 * MI_Q_BINS; i += SS_NT) (&lh[0][0])[i] = 0u;
     if (tid == 0) nan_sh = 0u;
-#if defined(SS_FENCE) && (SS_FENCE & 1)
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-#endif
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < SS_MAXQ; ++u) {
@@ -321,11 +310,7 @@ __global__ __launch_bounds__(SS_NT) void sampler_small_kernel(const mi_cfg_x0_pa
             for (int e = 0; e < 4; ++e) {
                 pr[e] = cc[e];
                 if (c.two) pr[e] = __fadd_rn(nl[e], __fmul_rn(__fsub_rn(cc[e], nl[e]), c.cond_scale));       // Unet.py:506
-#if defined(SS_BISECT) && (SS_BISECT & 1)      // development aid: keep the SLP vectorizer from pairing the two products of this statement
-                { float p0 = __fmul_rn(ca, xtv[u][e]); asm volatile("" : "+v"(p0)); x0v[u][e] = __fsub_rn(p0, __fmul_rn(cb, pr[e])); }
-#else
                 x0v[u][e] = __fsub_rn(__fmul_rn(ca, xtv[u][e]), __fmul_rn(cb, pr[e]));                      // diffusion_model.py:159-162
-#endif
                 if (4 * qd + e < n) {
                     atomicAdd(&lh[0][__float_as_uint(fabsf(x0v[u][e])) >> 20], 1u);
                     if (c.pred_out) c.pred_out[ob + 4 * qd + e] = pr[e];
@@ -392,128 +377,19 @@ __global__ __launch_bounds__(SS_NT) void sampler_small_kernel(const mi_cfg_x0_pa
             randn4(pp.seed_dev ? *pp.seed_dev : pp.seed, (unsigned)(pp.sample0 + b), (unsigned)(pp.stream_base + k), (unsigned)qd, z);
         }
         float r[4];
-#if defined(SS_PKCHECK) && SS_PKCHECK >= 3
-        // the exact packed sequence the SLP vectorizer builds for two elements (e, e + 1): P = {c1, c2} * {x0_e, xt_e1},
-        // Q = {c1, c2} * {x0_e1, xt_e}, M = P + Q with crossed halves (op_sel:[0,1] op_sel_hi:[1,0]) = {mean_e, mean_e1}; then
-        // {sigma, sigma} * {z_e, z_e1} through op_sel_hi:[0,1] and a straight packed add -- each step checked against scalar arithmetic
-        {
-            typedef float ss_f32x2 __attribute__((ext_vector_type(2)));
-            float xc[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { const float x0 = x0v[u][e]; xc[e] = __fdiv_rn(x0 != x0 ? x0 : fminf(fmaxf(x0, -s), s), s); }
-#pragma unroll
-            for (int e = 0; e < 4; e += 2) {
-                ss_f32x2 cpair = {c1, c2}, spair = {sigma, 0.0f};
-                const ss_f32x2 A = {xc[e], xtv[u][e + 1]}, Bv = {xc[e + 1], xtv[u][e]}, Z = {z[e], z[e + 1]};
-                ss_f32x2 P, Q, M, SZ, Rr;
-#if SS_PKCHECK == 6 || SS_PKCHECK == 7
-                // the pattern the bisection ends at, hand-placed: the LOW half of the pair is (re)written by v_div_fixup_f32 (x / 1 = x) in the
-                // instruction right before the in-place packed multiply (6); the same with two independent instructions in between (7)
-                {
-                    float one = 1.0f, qa = xc[e], qb = xc[e + 1], ta = xtv[u][e + 1], tb = xtv[u][e];
-                    asm volatile("" : "+v"(one));
-                    float pl, ph, ql, qh;
-#if SS_PKCHECK == 6
-                    asm volatile("v_mov_b32 v101, %4\n v_mov_b32 v103, %6\n s_nop 4\n"
-                                 "v_div_fixup_f32 v100, %3, %7, %3\n v_pk_mul_f32 v[100:101], %8, v[100:101]\n"
-                                 "v_div_fixup_f32 v102, %5, %7, %5\n v_pk_mul_f32 v[102:103], %8, v[102:103]\n s_nop 4\n"
-                                 "v_mov_b32 %0, v100\n v_mov_b32 %1, v101\n v_mov_b32 %2, v102\n v_mov_b32 %9, v103"
-                                 : "=&v"(pl), "=&v"(ph), "=&v"(ql), "+v"(qa), "+v"(ta), "+v"(qb), "+v"(tb), "+v"(one), "+s"(cpair), "=&v"(qh) : : "v100", "v101", "v102", "v103");
-#else
-                    asm volatile("v_mov_b32 v101, %4\n v_mov_b32 v103, %6\n s_nop 4\n"
-                                 "v_div_fixup_f32 v100, %3, %7, %3\n v_mov_b32 v104, %3\n v_mov_b32 v105, %4\n v_pk_mul_f32 v[100:101], %8, v[100:101]\n"
-                                 "v_div_fixup_f32 v102, %5, %7, %5\n v_mov_b32 v104, %5\n v_mov_b32 v105, %6\n v_pk_mul_f32 v[102:103], %8, v[102:103]\n s_nop 4\n"
-                                 "v_mov_b32 %0, v100\n v_mov_b32 %1, v101\n v_mov_b32 %2, v102\n v_mov_b32 %9, v103"
-                                 : "=&v"(pl), "=&v"(ph), "=&v"(ql), "+v"(qa), "+v"(ta), "+v"(qb), "+v"(tb), "+v"(one), "+s"(cpair), "=&v"(qh) : : "v100", "v101", "v102", "v103", "v104", "v105");
-#endif
-                    P = (ss_f32x2){pl, ph}; Q = (ss_f32x2){ql, qh};
-                    M = (ss_f32x2){__fadd_rn(P[0], Q[1]), __fadd_rn(P[1], Q[0])};
-                    SZ = (ss_f32x2){__fmul_rn(sigma, z[e]), __fmul_rn(sigma, z[e + 1])};
-                    Rr = (ss_f32x2){__fadd_rn(M[0], SZ[0]), __fadd_rn(M[1], SZ[1])};
-                }
-#elif SS_PKCHECK == 5
-                // as 3, but IN PLACE like the compiler's code: every packed instruction overwrites its own first vector operand
-                P = A; Q = Bv; SZ = Z;
-                asm volatile("v_pk_mul_f32 %0, %3, %0\n v_pk_mul_f32 %1, %3, %1\n v_pk_add_f32 %0, %0, %1 op_sel:[0,1] op_sel_hi:[1,0]\n"
-                             "v_pk_mul_f32 %2, %4, %2 op_sel_hi:[0,1]\n v_pk_add_f32 %0, %2, %0"
-                             : "+v"(P), "+v"(Q), "+v"(SZ) : "s"(cpair), "s"(spair));
-                M = P; Rr = P;
-                {   // (M is consumed by the last instruction: check the final result only)
-                    float m0_ = __fadd_rn(__fmul_rn(c1, xc[e]), __fmul_rn(c2, xtv[u][e])), m1_ = __fadd_rn(__fmul_rn(c1, xc[e + 1]), __fmul_rn(c2, xtv[u][e + 1]));
-                    asm volatile("" : "+v"(m0_), "+v"(m1_));
-                    M[0] = m0_; M[1] = m1_;
-                }
-#elif SS_PKCHECK == 3
-                asm volatile("v_pk_mul_f32 %0, %5, %6\n v_pk_mul_f32 %1, %5, %7\n v_pk_add_f32 %2, %0, %1 op_sel:[0,1] op_sel_hi:[1,0]\n"
-                             "v_pk_mul_f32 %3, %8, %9 op_sel_hi:[0,1]\n v_pk_add_f32 %4, %3, %2"
-                             : "=&v"(P), "=&v"(Q), "=&v"(M), "=&v"(SZ), "=&v"(Rr) : "s"(cpair), "v"(A), "v"(Bv), "s"(spair), "v"(Z));
-#else           // 4: the same arithmetic, crossed halves formed by the compiler from plain vector code (whatever it selects)
-                P = cpair * A; Q = cpair * Bv;
-                M = (ss_f32x2){P[0] + Q[1], P[1] + Q[0]};
-                SZ = (ss_f32x2){sigma, sigma} * Z;
-                Rr = SZ + M;
-#endif
-                float m0 = __fadd_rn(__fmul_rn(c1, xc[e]), __fmul_rn(c2, xtv[u][e])), m1 = __fadd_rn(__fmul_rn(c1, xc[e + 1]), __fmul_rn(c2, xtv[u][e + 1]));
-                asm volatile("" : "+v"(m0), "+v"(m1));
-                const float r0 = __fadd_rn(m0, __fmul_rn(sigma, z[e])), r1 = __fadd_rn(m1, __fmul_rn(sigma, z[e + 1]));
-                if (M[0] != m0 || M[1] != m1 || Rr[0] != r0 || Rr[1] != r1) {
-                    const unsigned slot = atomicAdd(&ss_dbg_count, 1u);
-                    if (slot < 256) { float* rr = ss_dbg + slot * 8; rr[0] = (float)b; rr[1] = (float)tid; rr[2] = (float)(4 * qd + e); rr[3] = M[0] - m0; rr[4] = M[1] - m1; rr[5] = Rr[0] - r0; rr[6] = Rr[1] - r1; rr[7] = c2 * xtv[u][e]; }
-                }
-                r[e] = Rr[0];
-                r[e + 1] = Rr[1];
-            }
-        }
-#else
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             float x0 = x0v[u][e];
             x0 = __fdiv_rn(x0 != x0 ? x0 : fminf(fmaxf(x0, -s), s), s);                  // Imagen.py:323 (torch.clamp propagates NaN)
-#if defined(SS_BISECT) && (SS_BISECT & 4)      // development aid: wait states between the division's last instruction and whatever consumes x0
-            asm volatile("s_nop 3" : "+v"(x0));
-#endif
-#if defined(SS_BISECT) && (SS_BISECT & 8)      // ... or only an (empty) scheduling barrier there
-            asm volatile("" : "+v"(x0));
-#endif
-#ifdef SS_PKCHECK
-            // development aid (tools/gpu_small_sampler_race.py, profiles/r04_pk_f32_hazard_bisect.txt): the two products as ONE packed
-            // instruction with the coefficient pair as operand, checked in place against the scalar product of the same registers
-            typedef float ss_f32x2 __attribute__((ext_vector_type(2)));
-            ss_f32x2 cpair = {c1, c2};
-#if SS_PKCHECK == 2
-            asm volatile("" : "+v"(cpair));                  // the pair in VGPRs
-#endif
-            const ss_f32x2 xpair = {x0, xtv[u][e]};
-            const ss_f32x2 prod = cpair * xpair;
-            float chk = c2 * xtv[u][e];
-            asm volatile("" : "+v"(chk));
-            if (prod[1] != chk) {
-                const unsigned slot = atomicAdd(&ss_dbg_count, 1u);
-                if (slot < 256) { float* r = ss_dbg + slot * 8; r[0] = (float)b; r[1] = (float)tid; r[2] = (float)(4 * qd + e); r[3] = c2; r[4] = xtv[u][e]; r[5] = prod[1]; r[6] = chk; r[7] = prod[0]; }
-            }
-            const float mean = __fadd_rn(prod[0], prod[1]);
-#else
-#if defined(SS_BISECT) && (SS_BISECT & 2)
-            float p1 = __fmul_rn(c1, x0);
-            asm volatile("" : "+v"(p1));
-            float mean = __fadd_rn(p1, __fmul_rn(c2, xtv[u][e]));
-            asm volatile("" : "+v"(mean));
-#else
             const float mean = __fadd_rn(__fmul_rn(c1, x0), __fmul_rn(c2, xtv[u][e]));     // diffusion_model.py:118-121
-#endif
-#endif
             r[e] = __fadd_rn(mean, __fmul_rn(sigma, z[e]));                               // Imagen.py:370
         }
-#endif
         if (vec) mi_stg4(pp.x + ob + 4 * qd, make_float4(r[0], r[1], r[2], r[3]));
         else {
 #pragma unroll
             for (int e = 0; e < 4; ++e) if (4 * qd + e < n) pp.x[ob + 4 * qd + e] = r[e];
         }
     }
-#if defined(SS_FENCE) && (SS_FENCE & 2)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-#endif
 }
 
 __global__ void step_advance_kernel(int* t_state, long long* times, int B, int set, int value) {
@@ -575,9 +451,16 @@ inline int grid_for(long long n, int cap = 2048) {
 // per workgroup, added into per-image histograms with integer agent-scope atomics, and a counter barrier per pass among the G workgroups of
 // the image.  Replaces five launches (cfg_x0 + pass 0, pass 1, pass 2, finish, posterior: 71 us at 256^2, B = 32) and two round trips of x0
 // through memory.  Same operations in the same order per element: bit-identical to the separate kernels.
-// Inter-workgroup protocol as conv_resident.hip: the workgroups of an image are claimed by ticket after they are resident (no cooperative
-// launch, no deadlock with other launches in flight); everything exchanged is touched by agent-scope atomics / sc1 accesses only; the
-// histograms are double-buffered by launch parity and the idle copy is zeroed for the next launch; bounded spins.
+// Inter-workgroup protocol: the workgroups of an image are claimed by ticket after they are resident (no cooperative launch, no deadlock
+// inside one launch); everything exchanged is touched by agent-scope atomics / sc1 accesses only; the histograms are double-buffered by
+// launch parity and the idle copy is zeroed for the next launch; every spin is bounded.
+// FAIL-STOP: a workgroup whose wait runs out sets the sticky error word (sync + 8), overwrites ITS part of x_t with NaN and leaves; every
+// workgroup that finds the word set -- its peers at their next poll, every workgroup of every later launch on this sync buffer at its
+// start -- does the same without waiting.  So a launch that could not complete never leaves a stale or half-written image behind: the
+// image (and everything sampled from it) is NaN, which the reference's own pipeline would return for a NaN state as well, and the host
+// raises at its next status poll (Imagen: the word is copied to pinned host memory at the end of every call) and re-zeroes the buffer.
+// Header of `sync`: [0] u64 ticket | [8] u32 error | [12] u32 spin limit (0: SG_SPIN_LIMIT) | [16] u32 fault injection (tests only:
+// 1 = workgroup 1 of image 0 never arrives at radix pass 1).
 constexpr int SG_NT = 1024, SG_MAXQ = 6;
 constexpr unsigned SG_SPIN_LIMIT = 1u << 22;
 struct sg_layout { long long counters, hist, total; };
@@ -596,8 +479,17 @@ __global__ __launch_bounds__(SG_NT) void sampler_group_kernel(const mi_cfg_x0_pa
     __shared__ unsigned nan_sh;
     __shared__ mi_u64 sTicket;
     __shared__ int sAbort;
+    __shared__ unsigned sLimit, sFault;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = c.n, nq = n >> 2;
-    if (tid == 0) { sTicket = mi_agent_add_u64(reinterpret_cast<mi_u64*>(sync), 1ull); sAbort = 0; nan_sh = 0u; }
+    unsigned* const errw = reinterpret_cast<unsigned*>(sync + 8);
+    if (tid == 0) {
+        sTicket = mi_agent_add_u64(reinterpret_cast<mi_u64*>(sync), 1ull);
+        sAbort = mi_agent_load_u32(errw) != 0u;                 // an earlier launch on this buffer failed: fail-stop, see above
+        const unsigned lim = mi_agent_load_u32(reinterpret_cast<const unsigned*>(sync + 12));
+        sLimit = lim ? lim : SG_SPIN_LIMIT;
+        sFault = mi_agent_load_u32(reinterpret_cast<const unsigned*>(sync + 16));
+        nan_sh = 0u;
+    }
     for (int i = tid; i < 2 * MI_Q_BINS; i += SG_NT) (&lh[0][0])[i] = 0u;
     __syncthreads();
     const sg_layout lay = sg_sync_layout(c.B);
@@ -615,6 +507,15 @@ __global__ __launch_bounds__(SG_NT) void sampler_group_kernel(const mi_cfg_x0_pa
     const float c1 = c.coef[t * 8 + 2], c2 = c.coef[t * 8 + 3], sigma = c.coef[t * 8 + 4];
     const size_t ob = (size_t)b * n, on = (size_t)(b + c.B) * n;
     const int q0 = g * SG_NT * SG_MAXQ;                        // this workgroup's quads: q0 + tid + u * SG_NT
+    // fail-stop: this workgroup's part of the image becomes NaN (never a stale or half-finished x_t)
+    auto poison = [&]() {
+        const float qn = __uint_as_float(0x7FC00000u);
+        for (int u = 0; u < SG_MAXQ; ++u) {
+            const int qd = q0 + tid + u * SG_NT;
+            if (qd < nq) mi_stg4(pp.x + ob + 4 * qd, make_float4(qn, qn, qn, qn));
+        }
+    };
+    if (sAbort) { poison(); return; }
     float x0v[SG_MAXQ][4], xtv[SG_MAXQ][4];
 #pragma unroll
     for (int u = 0; u < SG_MAXQ; ++u) {
@@ -648,13 +549,18 @@ __global__ __launch_bounds__(SG_NT) void sampler_group_kernel(const mi_cfg_x0_pa
         }
         mi_drain_vmem();                                   // every wave's atomics are performed before the arrival is counted
         __syncthreads();
-        if (tid == 0) mi_agent_add_u64(counter, 1ull);
+        if (tid == 0 && !(sFault == 1u && phase == 1 && b == 0 && g == 1)) mi_agent_add_u64(counter, 1ull);
         if (wave == 0) {
             const mi_u64 target = (seq * 3 + (mi_u64)phase + 1) * (mi_u64)G;
+            const unsigned limit = sLimit;
             for (unsigned spins = 0;;) {
                 const mi_u64 v = mi_agent_load_u64(counter);
                 if (__all(v >= target)) break;
-                if (++spins > SG_SPIN_LIMIT) { if (lane == 0) { mi_agent_store_u32(reinterpret_cast<unsigned*>(sync + 8), 0x300u + (unsigned)phase); sAbort = 1; } break; }
+                const bool peer_failed = (spins & 63u) == 63u && mi_agent_load_u32(errw) != 0u;
+                if (++spins > limit || peer_failed) {
+                    if (lane == 0) { if (!peer_failed) mi_agent_store_u32(errw, 0x300u + (unsigned)phase); sAbort = 1; }
+                    break;
+                }
                 mi_sleep();
             }
         }
@@ -665,7 +571,7 @@ __global__ __launch_bounds__(SG_NT) void sampler_group_kernel(const mi_cfg_x0_pa
         __syncthreads();
         return true;
     };
-    if (!exchange(0, 0, 1)) return;
+    if (!exchange(0, 0, 1)) { poison(); return; }
     // torch.quantile returns NaN for a row that contains a NaN: NaN patterns sit in the top bins of pass 0 (as quantile_finish_kernel)
     if (tid < MI_Q_BINS - 0x7F9) { const unsigned v = hc[0][0x7F9 + tid]; if (v) atomicAdd(&nan_sh, v); }
     unsigned prefix[2] = {0u, 0u}, rk[2] = {(unsigned)q.k_lo, (unsigned)q.k_hi};
@@ -690,7 +596,7 @@ __global__ __launch_bounds__(SG_NT) void sampler_group_kernel(const mi_cfg_x0_pa
                         if (!one && hi == prefix[1]) atomicAdd(&lh[1][bin], 1u);
                     }
                 }
-            if (!exchange(ps, 2 * ps - 1, one ? 1 : 2)) return;
+            if (!exchange(ps, 2 * ps - 1, one ? 1 : 2)) { poison(); return; }
         }
 #pragma unroll
         for (int sel = 0; sel < 2; ++sel) {

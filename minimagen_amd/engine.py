@@ -33,24 +33,10 @@ RP_TILE = {k: int(os.environ.get("MINIMAGEN_RP_TILE_" + k, d)) for k, d in (("L"
 RP_MIN_HW = int(os.environ.get("MINIMAGEN_RP_MIN_HW", "0"))             # ... for images of at least this many pixels
 CE_MFMA = os.environ.get("MINIMAGEN_CE_MFMA", "1") != "0"                  # CrossEmbed on the matrix cores (0: the fp32 VALU kernel)
 STORE16 = os.environ.get("MINIMAGEN_STORE16", "1") != "0"                  # reduced-precision configuration: bf16 activation storage
-# the U-Net's tail -- final_res_block.block2 (+ residual) and final_conv, no normalisation in between -- as ONE launch that keeps the
-# 8-channel full-resolution intermediate in LDS (mi_conv_tail_fwd), for images of at least TAIL_FUSE^2 pixels.  0 = off, the default:
-# measured on MI355X at 256^2, B = 64 the fused launch moves 42 % fewer bytes but takes 186 us against 179 us for the two launches -- the
-# 8-channel fp16x3 convs are balanced between HBM and their own VALU / LDS / MFMA work, and the halo recompute (x 1.29) plus the 256-register
-# tile eat what the traffic saves
-TAIL_FUSE = int(os.environ.get("MINIMAGEN_TAIL_FUSE", "0"))
 CONV_REVERSE = int(os.environ.get("MINIMAGEN_CONV_REVERSE", "1"))        # a row-paired conv walks the image groups opposite to its producer (0 = off)
 RP_NTILE = int(os.environ.get("MINIMAGEN_RP_NTILE", "0"))               # tiles per workgroup of the row-paired kernel (0 = the library's choice)
 TILE64 = int(os.environ.get("MINIMAGEN_TILE64", "-1"))                  # force a conv tile shape at 64x64 / 128x128 (experiments)
 TILE128 = int(os.environ.get("MINIMAGEN_TILE128", "-1"))       # 1: 16-channel 3x3 outputs as two 8-channel workgroups
-# Resident conv chains (conv_resident.hip): runs of >= RESIDENT_MIN k3 s1 convs of a <= 64-wide level as ONE launch.  0 (default): off;
-# 1: every eligible run; 2: only the light levels (<= 8 output channels at 64 wide, everything at 32 wide: the base U-Net).  Measured on
-# MI355X (profiles/r04_resident_*): it shortens a SYNCHRONOUS base stage by 8.7 % (70.5 -> 76.6 K steps/s), is at parity on the 16-channel
-# 64^2 level of the super-resolution U-Net, and costs 12 % with two call lanes in flight (its one-workgroup-per-CU launches leave no room
-# for the other lane's kernels) -- and a plan with it differs from the plan without it in the last bits (other statistics partition),
-# so it is not switched per call mode: opt-in.
-RESIDENT = int(os.environ.get("MINIMAGEN_RESIDENT", "0"))
-RESIDENT_MIN = int(os.environ.get("MINIMAGEN_RESIDENT_MIN", "2"))
 WEIGHT_FINGERPRINT = os.environ.get("MINIMAGEN_WEIGHT_FINGERPRINT", "1") != "0"   # content fingerprint of the weights at every public call (see pack())
 JT = 17     # context tiles of 16 rows: 1 null + (2|4) time tokens + 256 text rows <= 272
 
@@ -71,7 +57,7 @@ class Act:
 
     def c(self, consumer_batch: int, scale: float = 1.0) -> L.MiAct:
         bmod = self.batch if self.batch != consumer_batch else 0
-        self.uses += 1              # every consumer takes its view through here (the resident-chain pass needs to know who else reads a tensor)
+        self.uses += 1
         return L.MiAct(L.ptr(self.t), self.C, L.ptr(self.stats), self.nt, scale, bmod, self.st)
 
 
@@ -417,39 +403,7 @@ class UnetEngine:
         if wide:
             ws.prog.append((lib.mi_gn_coef_fwd, p, "gn_coef"))
         ws.prog.append((lib.mi_conv_fwd, p, "conv"))
-        # what the resident-chain pass (_fuse_resident) needs to know about this launch
-        p._meta = dict(in0=in0, in1=in1, res0=res[0] if res else None, res1=res[1] if res else None, res_conv=bool(res and res[2] is not None),
-                       out=out, narrow=rp and not wide, ksize=ksize, stride=stride, up2=up2, cin=cin_tot, cres=cres, skip_scale=skip_scale)
         return out
-
-    def _fuse_tail(self, ws):
-        """The plan's last two launches, if they are ResnetBlock.block2 (+ residual) and the conv that consumes it directly (Unet.py:464-472),
-        become one mi_conv_tail_fwd launch."""
-        lib = L.lib()
-        if len(ws.prog) < 2 or any(e[0] is not lib.mi_conv_fwd or not hasattr(e[1], "_meta") for e in ws.prog[-2:]):
-            return
-        p1, p2 = ws.prog[-2][1], ws.prog[-1][1]
-        m1, m2 = p1._meta, p2._meta
-        ok = (not ws.half                      # (the single-term instantiation is far slower than the two launches: a 1.1 KB scratch frame)
-              and m2["in0"] is m1["out"] and m1["out"].uses == 1 and m2["in1"] is None and m2["res0"] is None and not p2.gn_groups
-              and m1["narrow"] and m2["narrow"] and all(m["ksize"] == 3 and m["stride"] == 1 and not m["up2"] for m in (m1, m2))
-              and m1["cin"] == 8 and p1.Cout == 8 and p1.gn_groups > 0 and 8 % p1.gn_groups == 0 and p2.Cout <= 8 and not p2.out_st
-              and p1.H * p1.W >= TAIL_FUSE * TAIL_FUSE and p1.W % 4 == 0 and m1["res0"] is not None
-              and ((m1["res_conv"] and m1["cres"] == 16) or (not m1["res_conv"] and m1["res0"].C == 8 and m1["res1"] is None)))
-        if not ok:
-            return
-        tp = L.MiConvTailParams()
-        tp.conv = p1                          # (a copy; the tensors it points to stay in ws.tensors)
-        if not m1["res_conv"]:
-            # ResnetBlock(dim, dim): the identity residual rides through the kernel's 1x1-residual rounds as the unit matrix (exact in fp16; the
-            # intermediate is rounded to the fp16 hi + lo pair right after, so nothing is lost against the fp32 add of the separate launch)
-            eye, eexp = P.pack_conv_weight_rp(torch.eye(8, device=ws.dev).reshape(8, 8, 1, 1))
-            ws.tensors.append(eye)
-            tp.conv.res_w, tp.conv.res_w_rp, tp.conv.res_w_rp_exp, tp.conv.res_b = L.ptr(eye), L.ptr(eye), eexp, 0
-        tp.w2_rp, tp.w2_rp_exp, tp.Cout2, tp.bias2, tp.out2 = p2.w_rp, p2.w_rp_exp, p2.Cout, p2.bias, p2.out
-        tp._fused = (p1, p2)
-        del ws.prog[-2:]
-        ws.prog.append((lib.mi_conv_tail_fwd, tp, "conv_tail"))
 
     def _emit_resnet(self, ws, pk, rb: ResnetBlock, in0: Act, in1: Optional[Act]) -> Act:
         """layers.py:417-439"""
@@ -769,163 +723,11 @@ class UnetEngine:
         out = self._emit_conv(ws, pk, cur, None, wpack=pk.conv[id(u.final_conv)], bias=u.final_conv.bias, Cout=u.channels_out,
                               want_stats=False, conditioned=True, out_fp32=True)       # the prediction feeds the (fp32, bit-exact) sampler
         ws.pred = out.t
-        if TAIL_FUSE:
-            self._fuse_tail(ws)
         if (out.H, out.W) != (H, W):
             raise L.MinImagenHipError(f"U-Net output is {out.H}x{out.W} for a {H}x{W} input (image size must be divisible by the down-sampling factor)")
         # time-token rows of the folded context, every step
         if ws.gv:
             ws.prog_cond += self._fold_params(ws, pk, ws.c_time, ws.ntot * u.cond_dim, 1, ws.ntot, 0)
-        if RESIDENT:
-            self._fuse_resident(ws)
-
-    # ------------------------------------------------------------------ resident conv chains
-    def _fuse_resident(self, ws):
-        """Replace runs of consecutive narrow k3 s1 convs of one <= 64-wide level -- the Blocks of consecutive ResnetBlocks, layers.py:417-439,
-        between two launches of another kind -- by ONE resident launch each (csrc/conv_resident.hip): the running activation stays in
-        registers / LDS, the workgroups of an image exchange statistics partials and edge rows only.  A tensor is still written to memory
-        when something outside the run reads it (skip connections, the attention launches, the next level)."""
-        lib = L.lib()
-        prog, out_prog, i = ws.prog, [], 0
-        ws.resident = []
-
-        def eligible(e):
-            fn, p, name = e
-            m = getattr(p, "_meta", None) if p is not None else None
-            if name != "conv" or m is None or not m["narrow"] or m["ksize"] != 3 or m["stride"] != 1 or m["up2"]:
-                return None
-            if lib.mi_resident_slabs(p.H, p.W) <= 0 or p.Cout not in (8, 16) or m["cin"] > 32 or m["cres"] > 32:
-                return None
-            if RESIDENT == 2 and p.W == 64 and (p.Cout > 8 or m["cin"] > 16):      # only the light levels (launch-floor-bound layers)
-                return None
-            out = m["out"]
-            if out.stats is not None and out.nt < lib.mi_resident_slabs(p.H, p.W):
-                return None
-            return m
-
-        while i < len(prog):
-            m = eligible(prog[i])
-            if m is None:
-                out_prog.append(prog[i])
-                i += 1
-                continue
-            # grow the run: every further layer reads the previous layer's output as its first input; tensors it reads from memory must
-            # come from an earlier launch (workgroups of one launch only see each other's edge rows)
-            run, produced = [prog[i]], {id(m["out"])}
-            p0 = prog[i][1]
-            j = i + 1
-            while j < len(prog) and len(run) < L.RES_MAX_LAYERS:
-                mj = eligible(prog[j])
-                pj = prog[j][1]
-                if mj is None or (pj.B, pj.H, pj.W) != (p0.B, p0.H, p0.W) or mj["in0"] is not run[-1][1]._meta["out"]:
-                    break
-                others = [a for a in (mj["in1"], mj["res1"]) if a is not None]
-                if mj["res0"] is not None and not self._x_candidate(run, mj["res0"]):
-                    others.append(mj["res0"])
-                if any(id(a) in produced for a in others):
-                    break
-                run.append(prog[j])
-                produced.add(id(mj["out"]))
-                j += 1
-            if len(run) < max(RESIDENT_MIN, 1):
-                out_prog.append(prog[i])
-                i += 1
-                continue
-            entry = self._resident_entry(ws, run)
-            if entry is None:                     # (the saved-tensor bookkeeping does not work out for this run: leave it as separate launches)
-                out_prog.append(prog[i])
-                i += 1
-                continue
-            out_prog.append(entry)
-            i = j
-        ws.prog = out_prog
-
-    def check_resident(self, ws):
-        """Host-side check (synchronises): no resident launch of this workspace gave up waiting for a neighbour workgroup."""
-        off = L.lib().mi_resident_error_offset()
-        for sync in getattr(ws, "resident", []):
-            err = int(sync[off:off + 4].cpu().view(torch.int32).item())
-            if err:
-                raise L.MinImagenHipError(f"resident conv chain reported {err:#x}: a workgroup timed out waiting for its image's other slabs")
-
-    @staticmethod
-    def _x_candidate(run, act) -> bool:
-        """`act` can serve as the saved resident tensor X for the next layer of `run`: it is the output of a layer of the run, and no
-        later layer of the run needs a different X in between (one X register set)"""
-        outs = [e[1]._meta["out"] for e in run]
-        if not any(o is act for o in outs):
-            return False
-        k = max(idx for idx, o in enumerate(outs) if o is act)
-        # layers k+1 .. end of the run must not have used another tensor of the run as their residual
-        for e in run[k + 1:]:
-            r0 = e[1]._meta["res0"]
-            if r0 is not None and r0 is not act and any(o is r0 for o in outs):
-                return False
-        return True
-
-    def _resident_entry(self, ws, run):
-        lib = L.lib()
-        p0 = run[0][1]
-        rp = L.MiResidentParams()
-        rp.B, rp.H, rp.W, rp.n_layers = p0.B, p0.H, p0.W, len(run)
-        rp.half = 1 if ws.half else 0
-        sync = torch.zeros(lib.mi_resident_sync_bytes(p0.B, p0.H, p0.W), dtype=torch.uint8, device=ws.dev)
-        ws.tensors.append(sync)
-        ws.resident.append(sync)
-        rp.sync = L.ptr(sync)
-        outs = [e[1]._meta["out"] for e in run]
-        in_run = lambda a: a is not None and any(o is a for o in outs)
-        # how often each output is read THROUGH MEMORY by a layer of the run or by anything outside it
-        resident_reads = {id(o): 0 for o in outs}
-        for k, (fn, p, name) in enumerate(run):
-            m = p._meta
-            Lr = rp.layer[k]
-            if k == 0:
-                Lr.src, Lr.in0 = 1, p.in0
-            else:
-                Lr.src = 0
-                resident_reads[id(m["in0"])] += 1
-            if m["in1"] is not None:
-                Lr.in1 = p.in1
-            Lr.gn_groups, Lr.gn_gamma, Lr.gn_beta, Lr.gn_eps = p.gn_groups, p.gn_gamma, p.gn_beta, p.gn_eps
-            Lr.ss_off = p.ss_off if p.scale_shift else -1
-            if p.scale_shift:
-                rp.scale_shift, rp.ss_stride = p.scale_shift, p.ss_stride
-            Lr.w_rp, Lr.w_rp_exp, Lr.bias, Lr.Cout = p.w_rp, p.w_rp_exp, p.bias, p.Cout
-            r0 = m["res0"]
-            if r0 is not None:
-                x_res = in_run(r0)                 # (the pass only admitted it when it can be X)
-                if m["res_conv"]:
-                    Lr.res = 3 if x_res else 4
-                    Lr.res_w_rp, Lr.res_w_rp_exp, Lr.res_b = p.res_w_rp, p.res_w_rp_exp, p.res_b
-                    if m["res1"] is not None:
-                        Lr.res1 = p.res1
-                else:
-                    Lr.res = 1 if x_res else 2
-                if x_res:
-                    resident_reads[id(r0)] += 1
-                    rp.layer[max(idx for idx, o in enumerate(outs) if o is r0)].save_x = 1
-                else:
-                    Lr.res0 = p.res0
-        for k, (fn, p, name) in enumerate(run):
-            out = outs[k]
-            # a consumer took a view (Act.c) for every read: views not accounted for by the run's register-resident reads go through memory
-            if not (out.uses > resident_reads[id(out)] or out.uses == 0):
-                out.t.zero_()               # never written any more (it lives in registers): keep the allocation defined
-            else:
-                Lr = rp.layer[k]
-                Lr.out, Lr.out_st = p.out, p.out_st
-                if out.stats is not None:
-                    Lr.out_stats, Lr.out_nt = p.out_stats, out.nt
-        # one set of X registers: replay the saves and make sure every layer finds the tensor it expects
-        x_now = None
-        for k, (fn, p, name) in enumerate(run):
-            if rp.layer[k].res in (1, 3) and x_now is not p._meta["res0"]:
-                return None
-            if rp.layer[k].save_x:
-                x_now = outs[k]
-        rp._fused = [e[1] for e in run]
-        return (lib.mi_resident_convs_fwd, rp, "resident")
 
     # ------------------------------------------------------------------ execution
     def set_text(self, ws, text_embeds: torch.Tensor, text_mask: Optional[torch.Tensor], keep: torch.Tensor):

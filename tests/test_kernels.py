@@ -204,105 +204,6 @@ def test_conv_row_paired_path(backend, case):
     check_stats(ost.cpu(), ref.float())
 
 
-TAIL_CASES = [
-    # B, H, W, Cout2, strip (tile_cfg bits 12..15), x scale, residual: True / False = 1x1 conv over 8 + 8 / 16 channels, None = identity
-    (2, 40, 136, 3, 0, 1.0, None),            # ResnetBlock(dim, dim): identity residual (the BASELINE U-Nets' tail); ragged edges
-    (8, 32, 112, 3, 2, 1.0, None),            # B % 8 == 0, strips of two tiles
-    (1, 20, 64, 3, 0, 1.0 / 64, None),
-    (1, 16, 56, 3, 0, 1.0, True),             # exactly one tile
-    (2, 40, 136, 3, 0, 1.0, True),            # ragged tile edges in both directions, several tiles
-    (8, 24, 64, 3, 2, 1.0, False),            # B % 8 == 0 (XCD-aware map, reversed order below), strips of two tiles
-    (1, 36, 120, 8, 3, 1.0 / 64, True),       # 8 output channels, scaled operands, odd strips
-]
-
-
-@pytest.mark.parametrize("backend", BACKENDS)
-@pytest.mark.parametrize("case", TAIL_CASES)
-def test_conv_tail_fused(backend, case):
-    """mi_conv_tail_fwd: ResnetBlock.block2 (GroupNorm -> scale/shift -> SiLU -> 3x3 conv, + 1x1 residual conv over the 16-channel block
-    input) and the 3x3 conv behind it (Unet.py:464-472) in one launch, the 8-channel intermediate never in memory; vs torch fp64, and
-    against the two separate mi_conv_fwd launches"""
-    dev = setup(backend)
-    lib = L.lib()
-    B, H, W, Cout2, strip, xs, two_res = case
-    g = torch.Generator().manual_seed(hash(case) & 0xffff)
-    rn = lambda *s_: torch.randn(*s_, generator=g)
-    h1 = rn(B, 8, H, W) * 1.5 + 0.3
-    w, bias = rn(8, 8, 3, 3) * 0.2, rn(8)
-    gamma, beta = 1 + 0.2 * rn(8), 0.1 * rn(8)
-    sst = rn(B, 5 + 16) * 0.3
-    sk = 2 ** -0.5
-    ident = two_res is None
-    r0 = rn(B, 8 if (two_res or ident) else 16, H, W) * xs
-    r1 = rn(B, 8, H, W) * xs if two_res else None
-    rin = torch.cat((r0, r1 * sk), 1) if two_res else r0
-    rw, rb = (torch.eye(8).reshape(8, 8, 1, 1), torch.zeros(8)) if ident else (rn(8, 16, 1, 1) * 0.3 / xs, rn(8))
-    w2, b2 = rn(Cout2, 8, 3, 3) * 0.2, rn(Cout2)
-    t = F.group_norm(h1, 8, gamma, beta, 1e-5)
-    t = F.silu(t * (sst[:, 5:13, None, None] + 1) + sst[:, 13:21, None, None])
-    mid = F.conv2d(t.double(), w.double(), bias.double(), padding=1) + F.conv2d(rin.double(), rw.double(), rb.double())
-    ref = F.conv2d(mid, w2.double(), b2.double(), padding=1)
-    keep = {}
-    d = lambda name, t_: keep.setdefault(name, t_.to(dev).contiguous())
-    tp = L.MiConvTailParams()
-    p = tp.conv
-    p.B, p.H, p.W = B, H, W
-    p.in0 = L.MiAct(d("h1", h1).data_ptr(), 8, d("s0", chan_stats(h1)).data_ptr(), 1, 1.0, 0)
-    p.Cout, p.ksize, p.stride, p.up2 = 8, 3, 1, 0
-    wf, wexp = P.pack_conv_weight_rp(w)
-    p.w_rp, p.w_rp_exp, p.bias = d("wf", wf).data_ptr(), wexp, d("b", bias).data_ptr()
-    p.gn_groups, p.gn_gamma, p.gn_beta, p.gn_eps = 8, d("g", gamma).data_ptr(), d("be", beta).data_ptr(), 1e-5
-    p.scale_shift, p.ss_stride, p.ss_off = d("ss", sst).data_ptr(), sst.shape[1], 5
-    p.res0 = L.MiAct(d("r0", r0).data_ptr(), r0.shape[1], d("rs0", chan_stats(r0)).data_ptr(), 1, 1.0, 0)
-    if two_res:
-        p.res1 = L.MiAct(d("r1", r1).data_ptr(), 8, d("rs1", chan_stats(r1)).data_ptr(), 1, sk, 0)
-    p.res_w = 1                 # (an identity residual goes in as the unit matrix)
-    rwf, rwexp = P.pack_conv_weight_rp(rw)
-    p.res_w_rp, p.res_w_rp_exp, p.res_b = d("rwf", rwf).data_ptr(), rwexp, (0 if ident else d("rb", rb).data_ptr())
-    w2f, w2exp = P.pack_conv_weight_rp(w2)
-    out2 = torch.full((B, Cout2, H, W), float('nan'), device=dev)
-    tp.w2_rp, tp.w2_rp_exp, tp.Cout2, tp.bias2, tp.out2 = d("w2f", w2f).data_ptr(), w2exp, Cout2, d("b2", b2).data_ptr(), out2.data_ptr()
-    for rev in (0, 0x200):
-        out2.fill_(float('nan'))
-        p.tile_cfg = 5 | (strip << 12) | rev
-        L.check(lib.mi_conv_tail_fwd(C.byref(tp), L.current_stream()), "fused tail")
-        scale = max(1.0, ref.abs().max().item() / 8.0)
-        err = (out2.cpu().double() - ref).abs().max().item()
-        print(f"fused tail {case} rev {rev:#x}: max|d| = {err:.2e} (gate {3e-5 * scale:.2e}, |ref|max {ref.abs().max().item():.3g})")
-        assert err < 3e-5 * scale
-    # the two separate launches of the same layers
-    # the single-term instantiation (reduced-precision configuration, tile_cfg | 0x400): same launch, fp16 products, gate as the other half-precision ops
-    out_fp32 = out2.clone()
-    out2.fill_(float('nan'))
-    p.tile_cfg = 5 | (strip << 12) | 0x400
-    L.check(lib.mi_conv_tail_fwd(C.byref(tp), L.current_stream()), "fused tail, single term")
-    errh = (out2.cpu().double() - ref).abs().max().item()
-    assert errh < 3e-2 * scale, errh
-    if ident:                   # the separate launch adds the residual itself (fp32)
-        p.res_w, p.res_w_rp, p.res_w_rp_exp = 0, 0, 0
-    nt = tile_nt(lib, 5, H, W)
-    mid_d = torch.zeros(B, 8, H, W, device=dev)
-    mst = torch.zeros(B, 8, nt, 2, device=dev)
-    p.out, p.out_stats, p.tile_cfg = mid_d.data_ptr(), mst.data_ptr(), 5
-    L.check(lib.mi_conv_fwd(C.byref(p), L.current_stream()), "block2")
-    q = L.MiConvParams()
-    q.B, q.H, q.W = B, H, W
-    q.in0 = L.MiAct(mid_d.data_ptr(), 8, mst.data_ptr(), nt, 1.0, 0)
-    q.Cout, q.ksize, q.stride, q.up2 = Cout2, 3, 1, 0
-    q.w_rp, q.w_rp_exp, q.bias = keep["w2f"].data_ptr(), w2exp, keep["b2"].data_ptr()
-    sep = torch.zeros(B, Cout2, H, W, device=dev)
-    q.out, q.tile_cfg = sep.data_ptr(), 5
-    L.check(lib.mi_conv_fwd(C.byref(q), L.current_stream()), "final conv")
-    assert (sep - out_fp32).abs().max().item() < 3e-5 * scale
-    # argument checks
-    p.res_w, p.res_w_rp, p.res_w_rp_exp = 1, keep["rwf"].data_ptr(), rwexp
-    p.Cout = 16
-    assert lib.mi_conv_tail_fwd(C.byref(tp), L.current_stream()) != 0 and b"built for the U-Net tail" in lib.mi_last_error()
-    p.Cout = 8
-    tp.Cout2 = 9
-    assert lib.mi_conv_tail_fwd(C.byref(tp), L.current_stream()) != 0
-
-
 BF16_CASES = [
     # B, C0, C1, Cout, H, W, res, tile_cfg, output storage (1 = bf16, 0 = fp32: the final conv feeds the fp32 sampler)
     (2, 8, 0, 8, 16, 64, 'id', 6, 1),

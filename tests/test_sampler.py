@@ -451,18 +451,55 @@ def test_grouped_sampler_tail_in_the_sampling_loop(backend, monkeypatch):
         im.check_device_status()
         st = next(iter(im.unets[0].engine()._ws.values())).sampler_state
         assert any(hasattr(v, "group_sync") for v in st.values()) == bool(grp)
-        if grp:                 # a workgroup that gave up waiting leaves a sticky error word: the host-side check must be loud about it
-            sync = next(v.group_sync for v in st.values() if hasattr(v, "group_sync"))
-            sync[8:12] = torch.tensor([0x00, 0x03, 0, 0], dtype=torch.uint8, device=sync.device)
-            with pytest.raises(L.MinImagenHipError, match="0x300"):
-                im.check_device_status()
-            sync[8:12] = 0
     assert torch.equal(outs[1, "gen"], outs[0, "gen"])
     assert outs[1, "gen"].isfinite().all() and outs[1, "gen"].std() > 0.01
     if gpu:
         assert torch.equal(outs[1, "gen2"], outs[1, "gen"]) and torch.equal(outs[1, "noise"], outs[0, "noise"])
         ref = R.sample([sd], [S], T, text_embeds=emb, text_masks=mask, cond_scale=2., randn=R.make_randn(5))
         assert (outs[1, "noise"] - ref).abs().max() < 1e-4
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_grouped_sampler_tail_failure_is_loud_and_self_healing(backend):
+    """A cooperative launch that cannot complete must never hand back a plausible image.  Fault injection (sync header word 16: workgroup 1
+    of image 0 skips one arrival) + a short spin limit (word 12) make the grouped tail of the NEXT call time out:
+      * the tensor-returning sample() of that call yields NaN images (fail-stop: every workgroup that sees the sticky word poisons its part),
+      * the next API entry -- sample() itself, wait_pending_samples() or check_device_status() -- raises MinImagenHipError,
+      * after the exception the stage has re-zeroed its sync words and runs the separate kernels: the following call is bit-identical to
+        a healthy run."""
+    dev = setup(backend)
+    torch.manual_seed(4)
+    S, T, B = 96, 25, (2 if backend == "gpu" else 1)             # n = 27648: two workgroups per image
+    kw = dict(dim=8, dim_mults=(1, 2), num_resnet_blocks=1, layer_attns=False, layer_cross_attns=False, memory_efficient=True)
+    im = Imagen([Unet(**kw)], text_encoder_name="t5_small", image_sizes=[S], timesteps=T, cond_drop_prob=0.15).to(dev)
+    emb, mask = R.synthetic_text(B, length=10, seed=3)
+    args = dict(text_embeds=emb.to(dev), text_masks=mask.to(dev), cond_scale=2., _seed=11)
+    good = im.sample(**args).clone()
+    assert good.isfinite().all()
+    st = next(v for ws in im.unets[0].engine()._ws.values() for v in ws.sampler_state.values() if hasattr(v, "group_sync"))
+    assert L.lib().mi_sampler_group_size(3 * S * S) == 2
+    knobs = torch.tensor([2000, 1], dtype=torch.int32).view(torch.uint8)           # spin limit, fault injection
+    st.group_sync[12:20] = knobs.to(st.group_sync.device)
+    bad = im.sample(**args)                                   # returns (the check is deferred) ...
+    if backend == "gpu":
+        torch.cuda.synchronize()
+    assert torch.isnan(bad).all(), "a failed cooperative launch must leave NaN, not a stale image"     # ... with a visibly invalid result
+    with pytest.raises(L.MinImagenHipError, match="0x301"):
+        im.sample(**args)                                     # ... and the next API entry raises, from the tensor-returning path
+    assert st.group_failed
+    healed = im.sample(**args)                                # sync words re-zeroed, separate kernels from here on
+    assert torch.equal(healed, good)
+    im.check_device_status()
+    # the same through the explicit status poll
+    im2 = Imagen([Unet(**kw)], text_encoder_name="t5_small", image_sizes=[S], timesteps=T, cond_drop_prob=0.15).to(dev)
+    im2.sample(**args)
+    st2 = next(v for ws in im2.unets[0].engine()._ws.values() for v in ws.sampler_state.values() if hasattr(v, "group_sync"))
+    st2.group_sync[12:20] = knobs.to(st2.group_sync.device)
+    im2.sample(**args)
+    with pytest.raises(L.MinImagenHipError, match="timed out"):
+        im2.check_device_status()
+    im2.check_device_status()                                 # reported once; the stage has fallen back
+    assert im2.sample(**args).isfinite().all()
 
 
 @pytest.mark.parametrize("backend", BACKENDS)

@@ -169,33 +169,6 @@ def test_reversed_image_order_of_alternate_convs_is_bit_exact(backend, monkeypat
     assert (outs[0] - ref).abs().max() < FWD_ATOL * max(1.0, ref.abs().max().item())
 
 
-@pytest.mark.parametrize("backend", BACKENDS)
-def test_fused_unet_tail_vs_separate_launches_and_oracle(backend, monkeypatch):
-    """MINIMAGEN_TAIL_FUSE: final_res_block.block2 (+ identity residual) and final_conv as one launch (mi_conv_tail_fwd; default for images
-    of >= 128^2 pixels, forced on here at a small size): the oracle's values, and the separate launches' within fp32 rounding"""
-    from minimagen_amd import engine as E
-    dev = setup(backend)
-    torch.manual_seed(7)
-    kw = dict(dim=8, dim_mults=(1, 2), num_resnet_blocks=1, layer_attns=False, layer_cross_attns=(False, True), memory_efficient=True)
-    sd = {k: v.clone() for k, v in Unet(**kw).state_dict().items()}
-    B, S = (8, 128) if backend == "gpu" else (2, 40)            # 40: ragged tiles of the 16 x 56 grid
-    emb, mask = R.synthetic_text(B, length=9, seed=4)
-    x, tm = I.seeded((B, 3, S, S), 35), torch.arange(B) * 3 + 1
-    outs = []
-    for fuse in (1, 0):
-        monkeypatch.setattr(E, "TAIL_FUSE", fuse)
-        u = Unet(**kw)
-        u.load_state_dict(sd)
-        u = u.to(dev).eval()
-        outs.append(u(x.to(dev), tm.to(dev), text_embeds=emb.to(dev), text_mask=mask.to(dev)).cpu())
-        names = [name for _, _, name in next(iter(u.engine()._ws.values())).prog]
-        assert (names[-1] == "conv_tail") == bool(fuse), names[-3:]
-    ref = R.unet_forward(sd, x, tm, text_embeds=emb, text_mask=mask)
-    gate = FWD_ATOL * max(1.0, ref.abs().max().item())
-    assert (outs[0] - ref).abs().max() < gate and (outs[1] - ref).abs().max() < gate
-    assert (outs[0] - outs[1]).abs().max() < 0.1 * gate
-
-
 @pytest.mark.parametrize("backend", GPU_ONLY)
 def test_default_unet_vs_oracle(backend):
     """``Unet()`` with the reference's default arguments (dim 128, dim_mults (1, 2, 4), self- and cross-attention at every level,
