@@ -13,7 +13,9 @@
  *   - return 0 on success, a negative mi_status otherwise; mi_last_error() gives the
  *     message of the calling thread's last failure
  *   - "stats" buffers hold per-channel partial sums for the NEXT GroupNorm:
- *       float stats[B][C][nt][2] = (sum, sum of squares) over one producer tile,
+ *       double stats[B][C][nt][2] = (sum, sum of squares) over one producer tile.  fp64 since ABI 8: every producer accumulates its
+ *       tile about a local shift (a value of the tile) in fp32 and converts to the plain sums in fp64, so that var = E[x^2] - mean^2
+ *       survives activations whose mean is orders of magnitude above their deviation (a large DC offset, a constant image),
  *     written by the producing kernel's epilogue, reduced in a fixed order by the
  *     consumer (deterministic; no float atomics)
  */
@@ -46,7 +48,7 @@ int mi_struct_size(int which);
 typedef struct mi_act {
     const float* data;   /* [B][C][H][W] */
     int C;
-    const float* stats;  /* [B][C][nt][2] partial (sum, sumsq); may be NULL when no GroupNorm consumes it */
+    const double* stats; /* [B][C][nt][2] partial (sum, sumsq), fp64; may be NULL when no GroupNorm consumes it */
     int nt;
     float scale;         /* multiplies the data when consumed (skip connections: 2^-1/2, Unet.py:445) */
     int bmod;            /* >0: the tensor has only `bmod` batch rows, row b%bmod is used (tensors shared by the
@@ -82,7 +84,7 @@ typedef struct mi_conv_params {
     const float* res_b;     /* [Cout] or NULL */
     float* out;             /* [B][Cout][H][W] */
     int out_st;             /* storage of `out` (as mi_act.st; single-term kernels only) */
-    float* out_stats;       /* [B][Cout][out_nt][2] or NULL */
+    double* out_stats;      /* [B][Cout][out_nt][2] or NULL */
     int tile_cfg;           /* see mi_conv_tile_shape; | MI_CONV_SPLIT16: 16-channel outputs as two 8-channel workgroups */
     /* row-paired matrix-core path (conv_rp.hip; tile_cfg 5..7): B-operand fragments of v_mfma_f32_16x16x32_f16 with
        N = (output row parity dy, 8 output channels), K = (4 input rows, 8 input channels) per horizontal tap:
@@ -121,7 +123,7 @@ typedef struct mi_crossembed_params {
     int cout[3];                   /* channels per kernel (dim_scales) */
     const float* w[3];             /* packed [Cin][k][k][cout_i] */
     const float* bias[3];
-    float* out; float* out_stats;  /* [B][sum cout][H][W], [B][C][nt][2] */
+    float* out; double* out_stats;  /* [B][sum cout][H][W], [B][C][nt][2] */
     int out_st;                    /* storage of `out` AND of `addend` (as mi_act.st; matrix-core kernel with tile_cfg | 0x400 only) */
     int tile_cfg;
     const float* addend;           /* [B][sum cout][H][W] added to the result (the step-invariant low-res half of the
@@ -232,7 +234,7 @@ typedef struct mi_cross_attn_params {
     const float* gv;
     const float* n1_g; const float* n1_b;   /* CrossAttention.norm   gamma / beta */
     const float* n2_g; const float* n2_b;   /* to_out.1              gamma / beta */
-    float* out; float* out_stats;   /* [B2][C][HW]; stats [B2][C][ceil(HW/tok)][2], tok = 128 (variant 0) or 64 (variant 1) */
+    float* out; double* out_stats;   /* [B2][C][HW]; stats [B2][C][ceil(HW/tok)][2], tok = 128 (variant 0) or 64 (variant 1) */
     int out_st;                     /* storage of `out` (as mi_act.st; variant 7 only) */
     int x_exp, g_exp, v_exp;        /* variants 6 / 7: LayerNorm(x) is scaled by 2^x_exp before its fp16 split, the fragments carry 2^g_exp /
                                        2^v_exp (mi_attn_fold_params); the kernel undoes all three exactly (scores, output) */
@@ -368,7 +370,7 @@ typedef struct mi_self_attn_params {
     const float* gv;                /* fragments from mi_attn_fold_rows with JT = ceil(J/16) */
     const float* n1_g; const float* n1_b;   /* Attention.norm */
     const float* n2_g; const float* n2_b;   /* to_out.1 */
-    float* out; float* out_stats;   /* stats [B2][C][ceil(HW/64)][2] or NULL */
+    float* out; double* out_stats;   /* stats [B2][C][ceil(HW/64)][2] or NULL */
 } mi_self_attn_params;
 int mi_self_attn_fwd(const mi_self_attn_params* p, void* stream);
 /* ChanFeedForward + residual (layers.py:148-161, 498): y = x + W2 . CLN(gelu(W1 . CLN(x)))  (1x1 convs, no bias) */
@@ -377,7 +379,7 @@ typedef struct mi_chan_ff_params {
     mi_act x;
     const float* g1; const float* w1;   /* ChanLayerNorm g [C]; conv [Chid][C] */
     const float* g2; const float* w2;   /* ChanLayerNorm g [Chid]; conv [C][Chid] */
-    float* out; float* out_stats;       /* stats [B][C][ceil(HW/256)][2] or NULL */
+    float* out; double* out_stats;       /* stats [B][C][ceil(HW/256)][2] or NULL */
 } mi_chan_ff_params;
 int mi_chan_ff_fwd(const mi_chan_ff_params* p, void* stream);
 
@@ -401,7 +403,7 @@ typedef struct mi_tokens_to_nchw_params {
     const float* tokens;            /* [B][HW][C] */
     const float* gamma; const float* beta; float eps;   /* LayerNorm over C first (gamma NULL: none; beta may be NULL) */
     mi_act res;                     /* NCHW residual added (data NULL: none) */
-    float* out; float* out_stats;   /* [B][C][HW]; stats [B][C][ceil(HW/64)][2] or NULL */
+    float* out; double* out_stats;   /* [B][C][HW]; stats [B][C][ceil(HW/64)][2] or NULL */
 } mi_tokens_to_nchw_params;
 int mi_tokens_to_nchw_fwd(const mi_tokens_to_nchw_params* p, void* stream);
 /* y[row] = LayerNorm(x[row]) * gamma (+ beta, may be NULL) over the last dimension of [rows][dim] */
@@ -435,7 +437,7 @@ typedef struct mi_conv_wgrad_params {
     float* partial; int nwg;        /* workspace and the number of workgroups walking the pixel tiles (e.g. 512) */
     /* a_stats != NULL: `a` is the RAW input of a Block and the kernel applies SiLU(GroupNorm(a) * (scale + 1) + shift) while it stages
        the tiles (the activated tensor is never materialised): statistics [B][Cin][a_nt][2], affine, scale|shift table as in mi_conv_params */
-    const float* a_stats; int a_nt;
+    const double* a_stats; int a_nt;
     const float* gamma; const float* beta; int groups; float eps;
     const float* ss; int ss_stride, ss_off;
 } mi_conv_wgrad_params;
@@ -449,18 +451,18 @@ typedef struct mi_block_bwd_params {
     int B, C, HW, groups, nt, nchunk;   /* nchunk: row chunks per (image, channel) (grid.y of the two streaming kernels) */
     float eps;
     const float* x; const float* da;    /* [B][C][HW] */
-    const float* x_stats;               /* [B][C][nt][2] */
+    const double* x_stats;              /* [B][C][nt][2] */
     const float* gamma; const float* beta;
     const float* ss; int ss_stride, ss_off;   /* [B][ss_stride]: scale at ss_off + c, shift at ss_off + C + c; or NULL */
     float* uv;                          /* workspace [B][C][nchunk][2] */
     float* dx;                          /* [B][C][HW] */
     float* dgamma; float* dbeta;        /* [C] */
     float* dss;                         /* [B][2C] (d scale | d shift), required when ss != NULL */
-    float* dx_stats;                    /* [B][C][nchunk][2] (sum, sum of squares) of dx per row chunk, or NULL */
+    double* dx_stats;                   /* [B][C][nchunk][2] (sum, sum of squares) of dx per row chunk, or NULL */
 } mi_block_bwd_params;
 int mi_block_bwd(const mi_block_bwd_params* p, void* stream);
 /* per-(image, channel) sum and sum of squares of x [rows][HW] -> stats [rows][2] (a tensor no HIP producer left statistics for) */
-int mi_chan_stats_fwd(const float* x, float* stats, int rows, int HW, void* stream);
+int mi_chan_stats_fwd(const float* x, double* stats, int rows, int HW, void* stream);
 /* a [Cout][Cin][3][3] weight (adjoint != 0: its adjoint W'[ci][co][ky][kx] = W[co][ci][2-ky][2-kx]) times 2^exp -> the row-paired fp16 hi|lo
  * fragments of mi_conv_params.w_rp and the direct-conv layout [Cin'][3][3][cout_pad] of mi_conv_params.w, in one launch on the device
  * (the training path re-packs after every optimiser step).  mi_pack_conv3_floats(…, which): element counts (0: fp16 fragments, 1: fp32). */

@@ -177,10 +177,12 @@ class Imagen(nn.Module):
             store[key] = st
         return st
 
-    def _p_sample_loop(self, unet: Unet, shape, *, noise_scheduler: GaussianDiffusion, ws, cond_scale: float,
-                       noise_fn: Callable = None, seed: int = 0, sample0: int = 0, stage: int = 0, use_graph: bool = True):
-        """Imagen.py:373-420 + :329-370 + :261-326: T replays of
-        [U-Net (both guidance halves) -> CFG combine + x0 -> dynamic-threshold quantile -> posterior draw -> t -= 1]."""
+    def _stage_begin(self, unet: Unet, shape, *, noise_scheduler: GaussianDiffusion, ws, noise_fn: Callable = None, seed: int = 0,
+                     sample0: int = 0, stage: int = 0):
+        """Everything of a stage's loop that does not depend on the PREVIOUS stage's image: x_T (Imagen.py:400), the device-resident
+        timestep, the per-step conditioning tables of all T steps.  sample() issues it for every stage before the first stage's loop,
+        so that a later stage's stream has it done while it waits for its low-resolution input (on-device noise only: injected noise
+        must be drawn in the reference's order)."""
         lib = L.lib()
         stream = L.current_stream()
         eng = unet.engine()
@@ -188,8 +190,6 @@ class Imagen(nn.Module):
         n = Cc * H * W
         T = noise_scheduler.num_timesteps
         st = self._stage_state(ws, noise_scheduler, B, n)
-        two = ws.B2 != ws.B
-
         noise_dev = None
         if noise_fn is not None:
             ws.x.copy_(noise_fn(shape))                                          # Imagen.py:400
@@ -198,6 +198,22 @@ class Imagen(nn.Module):
             L.check(lib.mi_randn_fill(L.ptr(ws.x), B, n, seed, sample0, (stage << 20) | (1 << 19) | 1, stream), "mi_randn_fill")
         L.check(lib.mi_step_set(L.ptr(st.t_state), L.ptr(ws.times), B, T - 1, stream), "mi_step_set")
         eng.prepare_step_tables(ws, T, st.t_state, stream)       # (timestep, text)-only conditioning of all T steps, once
+        return st, noise_dev
+
+    def _p_sample_loop(self, unet: Unet, shape, *, noise_scheduler: GaussianDiffusion, ws, cond_scale: float,
+                       noise_fn: Callable = None, seed: int = 0, sample0: int = 0, stage: int = 0, use_graph: bool = True, begun=None):
+        """Imagen.py:373-420 + :329-370 + :261-326: T replays of
+        [U-Net (both guidance halves) -> CFG combine + x0 -> dynamic-threshold quantile -> posterior draw -> t -= 1]."""
+        lib = L.lib()
+        stream = L.current_stream()
+        eng = unet.engine()
+        B, Cc, H, W = shape
+        n = Cc * H * W
+        T = noise_scheduler.num_timesteps
+        two = ws.B2 != ws.B
+        if begun is None:
+            begun = self._stage_begin(unet, shape, noise_scheduler=noise_scheduler, ws=ws, noise_fn=noise_fn, seed=seed, sample0=sample0, stage=stage)
+        st, noise_dev = begun
 
         k_lo, k_hi, w = quantile_rank(n, self.dynamic_thresholding_percentile)
         fused = os.environ.get("MINIMAGEN_SAMPLER_FUSED", "1") != "0"
@@ -348,13 +364,16 @@ class Imagen(nn.Module):
     def sample(self, texts: List[str] = None, text_masks: torch.Tensor = None, text_embeds: torch.Tensor = None,
                cond_scale: float = 1., lowres_sample_noise_level: float = None, return_pil_images: bool = False,
                device: torch.device = None, *, _noise: Callable = None, _seed: int = 1234, _sample_offset: int = 0,
-               _use_graph: bool = True, _precision: str = None, _async: bool = False):
+               _use_graph: bool = True, _precision: str = None, _async: bool = False, _revalidated: bool = False):
         """minimagen/Imagen.py:424-510.  Private keyword-only extras (not in the reference): ``_noise(shape)`` injects a
         host noise stream in the reference's draw order (parity runs); otherwise noise is Philox keyed by
         (``_seed``, ``_sample_offset`` + row, stage, step, element) so a sharded batch reproduces the unsharded one;
         ``_precision`` = "fp32" (default) or "half" (single-fp16-term matrix-core contractions, see engine.UnetEngine.precision);
         ``_async=True`` returns without making the caller's stream wait (``self.last_sample_done`` / the returned tensor's ``sample_done`` is THIS call's completion event; ``wait_pending_samples()`` covers every lane): successive
         calls then pipeline across the per-stage streams (the base stage of the next batch under the super-resolution stage of this one)."""
+        call_args = dict(texts=texts, text_masks=text_masks, text_embeds=text_embeds, cond_scale=cond_scale, lowres_sample_noise_level=lowres_sample_noise_level,
+                         return_pil_images=return_pil_images, device=device, _noise=_noise, _seed=_seed, _sample_offset=_sample_offset,
+                         _use_graph=_use_graph, _precision=_precision, _async=_async)
         device = default(device, self.device)
         self._poll_status()                  # a cooperative launch of an EARLIER call gave up (its images are NaN): raise here, never silently
         self._status_stages = []
@@ -381,8 +400,16 @@ class Imagen(nn.Module):
         # wait, so the (small, latency-bound) base stage of call k + 1 runs on its stream while the super-resolution stage of call k
         # still occupies the other -- each stage owns its workspace, so nothing is shared but the finished image handed down the cascade.
         on_gpu = L.backend() == "hip-gfx950"
-        for unet in self.unets:
-            unet.engine().pack()                         # validate / refresh the packed weights once per call, on the caller's stream
+        # Packed-weight validation, once per call on the caller's stream.  Identity (pointers, version counters) is checked here; the content
+        # fingerprint's verdict is read AFTER this call's work is enqueued (engine.pack_begin): with the wait in front, a synchronous call
+        # kept the host behind the whole previous call and the GPU idle for the host's launch time.  A rare positive verdict discards the
+        # enqueued work and runs the call again on fresh packs.  Injected noise (a stateful host generator) keeps the up-front check.
+        if _noise is not None or _revalidated:
+            for unet in self.unets:
+                unet.engine().pack()
+            pack_tokens = []
+        else:
+            pack_tokens = [(unet.engine(), unet.engine().pack_begin()) for unet in self.unets]
         # LANES: asynchronous calls alternate between SAMPLE_LANES independent sets of (stage streams, workspaces, graphs), so that two
         # calls are in flight side by side -- the kernels of one call's stages fill the launch floors and tails of the other's (measured:
         # 42.8 K vs 37.7 K steps/s for the B = 32 cascade).  Calls on one lane stay ordered by its streams; lanes share
@@ -415,14 +442,14 @@ class Imagen(nn.Module):
             caller_stream = torch.cuda.current_stream(device)
             inputs_ready = caller_stream.record_event()
         from .helpers import null_context
-        img, prev_done = None, None
-        for stage, (unet, channel, image_size, noise_scheduler) in enumerate(
-                zip(self.unets, self.sample_channels, self.image_sizes, self.noise_schedulers)):
+        precision = _precision if _precision is not None else os.environ.get("MINIMAGEN_PRECISION", "fp32")
+        stages = list(enumerate(zip(self.unets, self.sample_channels, self.image_sizes, self.noise_schedulers)))
+        # ---- pass 1, every stage on its own stream: what depends on the CAPTIONS only (text conditioning, the folded context rows, x_T, the
+        # step tables) -- issued for all stages up front, so a later stage has it behind it when its low-resolution input arrives
+        wss, begun = {}, {}
+        for stage, (unet, channel, image_size, noise_scheduler) in stages:
             if on_gpu:
                 streams[stage].wait_event(inputs_ready)
-                if prev_done is not None:
-                    streams[stage].wait_event(prev_done)
-            if on_gpu:
                 # the stage streams read the caller's tensors after sample() has returned (_async) / after the caller may have dropped
                 # them: tell the caching allocator, or a block freed on the caller's stream could be handed out again while a stage's
                 # text_cond launch is still queued
@@ -432,18 +459,36 @@ class Imagen(nn.Module):
             with (torch.cuda.stream(streams[stage]) if on_gpu else null_context()):
                 eng = unet.engine()
                 # per call, never sticky engine state: a later Unet.forward stays on the engine's default precision
-                ws = eng.workspace(batch_size, B2, image_size, image_size,
-                                   precision=_precision if _precision is not None else os.environ.get("MINIMAGEN_PRECISION", "fp32"), lane=lane)
+                ws = wss[stage] = eng.workspace(batch_size, B2, image_size, image_size, precision=precision, lane=lane)
                 eng.set_text(ws, text_embeds, text_masks, keep)
+                if unet.lowres_cond:             # the augmentation level's timestep feeds the step tables (diffusion_model.py:68-69)
+                    ws.lowres_times.fill_(int(self.lowres_noise_schedule.num_timesteps * lowres_sample_noise_level))
+                if _noise is None:
+                    begun[stage] = self._stage_begin(unet, (batch_size, self.channels, image_size, image_size), noise_scheduler=noise_scheduler,
+                                                     ws=ws, seed=_seed, sample0=_sample_offset, stage=stage)
+        # ---- pass 2: the cascade
+        img, prev_done = None, None
+        for stage, (unet, channel, image_size, noise_scheduler) in stages:
+            if on_gpu and prev_done is not None:
+                streams[stage].wait_event(prev_done)
+            with (torch.cuda.stream(streams[stage]) if on_gpu else null_context()):
+                ws = wss[stage]
                 if unet.lowres_cond:
                     if on_gpu:
                         img.record_stream(streams[stage])
                     self._lowres_conditioning(img, image_size, ws, lowres_sample_noise_level, _noise, _seed, _sample_offset, stage)
                 img = self._p_sample_loop(unet, (batch_size, self.channels, image_size, image_size), noise_scheduler=noise_scheduler,
                                           ws=ws, cond_scale=cond_scale, noise_fn=_noise, seed=_seed, sample0=_sample_offset,
-                                          stage=stage, use_graph=_use_graph)
+                                          stage=stage, use_graph=_use_graph, begun=begun.get(stage))
                 if on_gpu:
                     prev_done = streams[stage].record_event()
+        if any(eng.pack_changed(tok) for eng, tok in pack_tokens):
+            # the weights' values had changed behind the version counters (p.data updates): what was enqueued ran on stale packs
+            if on_gpu:
+                torch.cuda.synchronize(device)
+            self._status_stages = []
+            call_args["_revalidated"] = True
+            return self.sample(**call_args)
         if self._status_stages:
             self.__dict__.setdefault("_status_pending", []).append((prev_done, self._status_stages))
             self._status_stages = []

@@ -20,7 +20,7 @@ __global__ __launch_bounds__(256, WPS) void cross_attn_folded_kernel(const mi_cr
     constexpr int MT = (C + 15) / 16;               // M tiles of PV (output channels)
     constexpr int FR = NGP + 4 * MT;
     constexpr int TOK_WG = 4 * 16 * NQ;             // tokens per workgroup
-    __shared__ float red[4][2 * 16 * MT];
+    __shared__ double red[4][2 * 16 * MT];
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int lq = lane & 15, lg = lane >> 4;
@@ -179,9 +179,9 @@ __global__ __launch_bounds__(256, WPS) void cross_attn_folded_kernel(const mi_cr
 
     // ---- to_out.1 LayerNorm over channels, + residual, store, statistics.
     // This lane holds channels a = 16mt + 4lg + r of token lq (rows >= C are exact zeros).
-    float csum[4 * MT], csq[4 * MT];
+    double csum[4 * MT], csq[4 * MT];         // (sum, sum of squares) per channel in fp64, valid at lq == 0 (common.hip.h)
 #pragma unroll
-    for (int e = 0; e < 4 * MT; ++e) { csum[e] = 0.0f; csq[e] = 0.0f; }
+    for (int e = 0; e < 4 * MT; ++e) { csum[e] = 0.0; csq[e] = 0.0; }
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         const int i = i0 + 16 * q + lq;
@@ -211,22 +211,22 @@ __global__ __launch_bounds__(256, WPS) void cross_attn_folded_kernel(const mi_cr
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int a = 16 * mt + 4 * lg + r;
+                float y = 0.0f;
                 if (a < C && ok) {
                     const float res = xb[(size_t)a * p.HW + i] * p.x.scale;
-                    const float y = (oacc[q][mt][r] - mean) * rstd * p.n2_g[a] + p.n2_b[a] + res;
+                    y = (oacc[q][mt][r] - mean) * rstd * p.n2_g[a] + p.n2_b[a] + res;
                     p.out[((size_t)b * C + a) * p.HW + i] = y;
-                    csum[4 * mt + r] += y;
-                    csq[4 * mt + r] = fmaf(y, y, csq[4 * mt + r]);
+                }
+                if (p.out_stats) {          // over the 16 tokens held by the lanes with the same lg
+                    double S, Q;
+                    mi_stat_reduce16(y, a < C && ok, lane, S, Q);
+                    csum[4 * mt + r] += S;
+                    csq[4 * mt + r] += Q;
                 }
             }
     }
     if (p.out_stats) {
-        // reduce over the 16 tokens held by lanes with the same lg, then over the 4 waves
-#pragma unroll
-        for (int e = 0; e < 4 * MT; ++e) {
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) { csum[e] += __shfl_xor(csum[e], o); csq[e] += __shfl_xor(csq[e], o); }
-        }
+        // ... then over the 4 waves
         if (lq == 0) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256, WPS) void cross_attn_folded_kernel(const mi_cr
         }
         __syncthreads();
         if (tid < 2 * C) {
-            const float a4 = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+            const double a4 = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
             p.out_stats[((size_t)(b * C + (tid >> 1)) * tiles + tile) * 2 + (tid & 1)] = a4;
         }
     }
@@ -278,7 +278,7 @@ template <int C, int JT, int WPS, bool HALF, int NWV>
 __global__ __launch_bounds__(64 * NWV, WPS) void cross_attn_f16x3_kernel(const mi_cross_attn_params p) {
     constexpr int KC = (C + 15) / 16, MT = (C + 15) / 16, FRH = 8 * KC + 8 * MT, TOK_WG = 16 * NWV, NT = 64 * NWV;
     constexpr int JP = (JT + 1) / 2;
-    __shared__ float red[NWV][2 * 16 * MT];
+    __shared__ double red[NWV][2 * 16 * MT];
     // One head's context fragments as they lie in global memory, [tile][chunk q][lane] 16 bytes: q < KC: G {4 hi | 4 lo}; q >= KC: the V
     // chunks, arranged per PAIR of tiles for the K = 32 PV instruction (even tile: {4 hi(t0) | 4 hi(t1)}, odd tile: {4 lo(t0) | 4 lo(t1)},
     // written that way by attn_fold_rows_kernel; tile count padded to even, the pad stays zero).  DOUBLE-buffered and filled by LDS-DMA
@@ -480,9 +480,9 @@ __global__ __launch_bounds__(64 * NWV, WPS) void cross_attn_f16x3_kernel(const m
     }
 
     // to_out.1 LayerNorm + residual + statistics (same as the fp32 kernel)
-    float csum[4 * MT], csq[4 * MT];
+    float yv[4 * MT];
 #pragma unroll
-    for (int e = 0; e < 4 * MT; ++e) { csum[e] = 0.0f; csq[e] = 0.0f; }
+    for (int e = 0; e < 4 * MT; ++e) yv[e] = 0.0f;
     {
         float s1 = 0.0f;
 #pragma unroll
@@ -507,23 +507,20 @@ __global__ __launch_bounds__(64 * NWV, WPS) void cross_attn_f16x3_kernel(const m
                     const float y = (oacc[mt][r] - mean) * rstd * p.n2_g[a] + p.n2_b[a] + ldx(a) * p.x.scale;
                     if (o16) reinterpret_cast<unsigned short*>(p.out)[((size_t)b * C + a) * p.HW + i] = (unsigned short)(mi_f32_to_bf16x2(y, 0.0f) & 0xffffu);
                     else p.out[((size_t)b * C + a) * p.HW + i] = y;
-                    csum[4 * mt + r] = y;
-                    csq[4 * mt + r] = y * y;
+                    yv[4 * mt + r] = y;
                 }
             }
     }
     if (p.out_stats) {
 #pragma unroll
-        for (int e = 0; e < 4 * MT; ++e) {
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int o = 1; o < 16; o <<= 1) { csum[e] += __shfl_xor(csum[e], o); csq[e] += __shfl_xor(csq[e], o); }
-        }
-        if (lq == 0) {
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { const int a = 16 * mt + 4 * lg + r; red[wave][2 * a] = csum[4 * mt + r]; red[wave][2 * a + 1] = csq[4 * mt + r]; }
-        }
+            for (int r = 0; r < 4; ++r) {
+                const int a = 16 * mt + 4 * lg + r;
+                double S, Q;
+                mi_stat_reduce16(yv[4 * mt + r], a < C && ok, lane, S, Q);
+                if (lq == 0) { red[wave][2 * a] = S; red[wave][2 * a + 1] = Q; }
+            }
         __syncthreads();
         const int nt64 = (p.HW + 63) / 64;               // statistics tiles are 64 tokens = 4 waves, whatever the workgroup size
         for (int sub = 0; sub < NWV / 4; ++sub) {
@@ -674,7 +671,7 @@ __global__ __launch_bounds__(256) void ln_tokens_kernel(const mi_act x, int HW, 
 template <int C, int JTC>
 __global__ __launch_bounds__(256) void self_attn_folded_kernel(const mi_self_attn_params p, const int JT) {
     constexpr int KK = C / 4, NGP = KK < 4 ? 4 : KK, MT = (C + 15) / 16, FR = NGP + 4 * MT;
-    __shared__ float red[4][2 * 16 * MT];
+    __shared__ double red[4][2 * 16 * MT];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lq = lane & 15, lg = lane >> 4;
     const int tiles = (p.HW + 63) / 64;
     const int b = blockIdx.x / tiles, tile = blockIdx.x % tiles;
@@ -773,9 +770,9 @@ __global__ __launch_bounds__(256) void self_attn_folded_kernel(const mi_self_att
             for (int r = 0; r < 4; ++r) oacc[mt][r] = fmaf(oh[mt][r], linv, oacc[mt][r]);
     }
     // to_out.1 LayerNorm + residual + statistics (as in cross_attn_folded_kernel)
-    float csum[4 * MT], csq[4 * MT];
+    float yv[4 * MT];
 #pragma unroll
-    for (int e = 0; e < 4 * MT; ++e) { csum[e] = 0.0f; csq[e] = 0.0f; }
+    for (int e = 0; e < 4 * MT; ++e) yv[e] = 0.0f;
     {
         float s1 = 0.0f;
 #pragma unroll
@@ -799,23 +796,20 @@ __global__ __launch_bounds__(256) void self_attn_folded_kernel(const mi_self_att
                 if (a < C && ok) {
                     const float y = (oacc[mt][r] - mean) * rstd * p.n2_g[a] + p.n2_b[a] + xb[(size_t)a * p.HW + i] * p.x.scale;
                     p.out[((size_t)b * C + a) * p.HW + i] = y;
-                    csum[4 * mt + r] = y;
-                    csq[4 * mt + r] = y * y;
+                    yv[4 * mt + r] = y;
                 }
             }
     }
     if (p.out_stats) {
 #pragma unroll
-        for (int e = 0; e < 4 * MT; ++e) {
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int o = 1; o < 16; o <<= 1) { csum[e] += __shfl_xor(csum[e], o); csq[e] += __shfl_xor(csq[e], o); }
-        }
-        if (lq == 0) {
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { const int a = 16 * mt + 4 * lg + r; red[wave][2 * a] = csum[4 * mt + r]; red[wave][2 * a + 1] = csq[4 * mt + r]; }
-        }
+            for (int r = 0; r < 4; ++r) {
+                const int a = 16 * mt + 4 * lg + r;
+                double S, Q;
+                mi_stat_reduce16(yv[4 * mt + r], a < C && ok, lane, S, Q);
+                if (lq == 0) { red[wave][2 * a] = S; red[wave][2 * a + 1] = Q; }
+            }
         __syncthreads();
         if (tid < 2 * C) p.out_stats[((size_t)(b * C + (tid >> 1)) * tiles + tile) * 2 + (tid & 1)] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
     }
@@ -827,7 +821,7 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + e
 template <int C, int CH>
 __global__ __launch_bounds__(256) void chan_ff_kernel(const mi_chan_ff_params p, const float* __restrict__ w1, const float* __restrict__ w2,
                                                       const float* __restrict__ g1, const float* __restrict__ g2) {
-    __shared__ float red[2 * C][4];
+    __shared__ double red[2 * C][4];
     const int b = blockIdx.y, tid = threadIdx.x;
     const int bx = mi_row_of(b, p.x.bmod);
     const int i = blockIdx.x * 256 + tid;
@@ -867,8 +861,8 @@ __global__ __launch_bounds__(256) void chan_ff_kernel(const mi_chan_ff_params p,
         const float y = a + x[c];
         if (ok) p.out[((size_t)b * C + c) * p.HW + i] = y;
         if (p.out_stats) {
-            float ys = ok ? y : 0.0f, yq = ok ? y * y : 0.0f;
-            ys = mi_wave_sum(ys); yq = mi_wave_sum(yq);
+            double ys, yq;
+            mi_stat_reduce64(ok ? y : 0.0f, ok, ys, yq);
             if ((tid & 63) == 0) { red[2 * c][tid >> 6] = ys; red[2 * c + 1][tid >> 6] = yq; }
         }
     }

@@ -353,7 +353,8 @@ __global__ __launch_bounds__(256) void tokens_to_nchw_kernel(const mi_tokens_to_
                 p.out[((size_t)b * p.C + c) * p.HW + tok] = y;
             }
             if (p.out_stats) {
-                const float s_ = mi_wave_sum(y), q_ = mi_wave_sum(y * y);
+                double s_, q_;
+                mi_stat_reduce64(y, ok, s_, q_);
                 if (lane == 0) {
                     p.out_stats[((size_t)(b * p.C + c) * nt + tile) * 2] = s_;
                     p.out_stats[((size_t)(b * p.C + c) * nt + tile) * 2 + 1] = q_;

@@ -32,12 +32,12 @@ __device__ __forceinline__ float mi_silu(float v) {
 
 // ---- training path helpers (train_bwd.hip, conv_wgrad.hip)
 // mean / rstd of the group of channel c of image b from the per-channel statistics [B][C][nt][2]; executed by one wave, result in all lanes
-__device__ __forceinline__ void mi_group_moments(const float* stats, int nt, int C, int groups, int HW, float eps, int b, int c, float& mu, float& r) {
+__device__ __forceinline__ void mi_group_moments(const double* stats, int nt, int C, int groups, int HW, float eps, int b, int c, float& mu, float& r) {
     const int lane = threadIdx.x & 63;
     const int cpg = C / groups, g = c / cpg;
-    const float* base = stats + ((size_t)b * C + (size_t)g * cpg) * nt * 2;
+    const double* base = stats + ((size_t)b * C + (size_t)g * cpg) * nt * 2;
     double s = 0.0, q = 0.0;
-    for (int i = lane; i < cpg * nt; i += 64) { s += (double)base[2 * i]; q += (double)base[2 * i + 1]; }
+    for (int i = lane; i < cpg * nt; i += 64) { s += base[2 * i]; q += base[2 * i + 1]; }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
     const double n = (double)cpg * (double)HW;
@@ -158,22 +158,22 @@ __device__ __forceinline__ void mi_gn_channel_totals(const mi_act& in0, const mi
             const mi_act& a = second ? in1 : in0;
             const int cc = second ? c - C0 : c;
             const int ba = mi_row_of(b, a.bmod);
-            const float* st = a.stats + ((size_t)(ba * a.C + cc) * a.nt) * 2;
+            const double* st = a.stats + ((size_t)(ba * a.C + cc) * a.nt) * 2;
             int t = sub;
             for (; t + 3 * TPC < a.nt; t += 4 * TPC) {          // four independent loads in flight, added in tile order
-                const float2 v0 = *reinterpret_cast<const float2*>(st + 2 * t);
-                const float2 v1 = *reinterpret_cast<const float2*>(st + 2 * (t + TPC));
-                const float2 v2 = *reinterpret_cast<const float2*>(st + 2 * (t + 2 * TPC));
-                const float2 v3 = *reinterpret_cast<const float2*>(st + 2 * (t + 3 * TPC));
-                s += (double)v0.x; q += (double)v0.y;
-                s += (double)v1.x; q += (double)v1.y;
-                s += (double)v2.x; q += (double)v2.y;
-                s += (double)v3.x; q += (double)v3.y;
+                const double2 v0 = *reinterpret_cast<const double2*>(st + 2 * t);
+                const double2 v1 = *reinterpret_cast<const double2*>(st + 2 * (t + TPC));
+                const double2 v2 = *reinterpret_cast<const double2*>(st + 2 * (t + 2 * TPC));
+                const double2 v3 = *reinterpret_cast<const double2*>(st + 2 * (t + 3 * TPC));
+                s += v0.x; q += v0.y;
+                s += v1.x; q += v1.y;
+                s += v2.x; q += v2.y;
+                s += v3.x; q += v3.y;
             }
             for (; t < a.nt; t += TPC) {
-                const float2 v = *reinterpret_cast<const float2*>(st + 2 * t);
-                s += (double)v.x;
-                q += (double)v.y;
+                const double2 v = *reinterpret_cast<const double2*>(st + 2 * t);
+                s += v.x;
+                q += v.y;
             }
             s *= (double)a.scale;
             q *= (double)a.scale * (double)a.scale;
@@ -181,6 +181,46 @@ __device__ __forceinline__ void mi_gn_channel_totals(const mi_act& in0, const mi
         for (int o = TPC >> 1; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
         if (c < Cin && sub == 0) { chS[c] = s; chQ[c] = q; }
     }
+}
+
+// Producer side of the statistics: a work-item accumulates ITS elements of one channel about a local shift c (its first value), so the
+// squares it adds are deviations, not magnitudes -- sum (x - c)^2 keeps ~24 bits of the VARIANCE where a plain fp32 sum x^2 keeps 24 bits
+// of the second moment (useless once mean^2 >> variance: a large DC offset, a constant image: tests/test_unet.py hostile weights).  The
+// conversion to the plain (sum, sum of squares) the consumers add up happens once per work-item in fp64, and so do all further reductions.
+struct mi_stat_acc { float c, s, q; int n; };
+__device__ __forceinline__ void mi_stat_begin(mi_stat_acc& a, float first) { a.c = first; a.s = 0.0f; a.q = 0.0f; a.n = 0; }
+__device__ __forceinline__ void mi_stat_add(mi_stat_acc& a, float y, bool ok) {
+    const float d = ok ? y - a.c : 0.0f;
+    a.s += d;
+    a.q = fmaf(d, d, a.q);
+    a.n += ok ? 1 : 0;
+}
+__device__ __forceinline__ void mi_stat_finish(const mi_stat_acc& a, double& S, double& Q) {
+    const double c = (double)a.c, n = (double)a.n, s = (double)a.s;
+    S = fma(n, c, s);
+    Q = fma(c, fma(n, c, 2.0 * s), (double)a.q);             // sum (d + c)^2 = sum d^2 + 2 c sum d + n c^2
+}
+// one value per lane: (sum, sum of squares) over the 16 lanes lq = 0 .. 15 of this lane's group (valid at lq == 0) / over the whole wave
+// (valid in every lane), shifted by the group's / wave's first lane's value
+__device__ __forceinline__ void mi_stat_reduce16(float y, bool ok, int lane, double& S, double& Q) {
+    mi_stat_acc a;
+    a.c = __shfl(y, lane & 48);
+    a.s = ok ? y - a.c : 0.0f;
+    a.q = a.s * a.s;
+    a.n = ok ? 1 : 0;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) { a.s += __shfl_xor(a.s, o); a.q += __shfl_xor(a.q, o); a.n += __shfl_xor(a.n, o); }
+    mi_stat_finish(a, S, Q);
+}
+__device__ __forceinline__ void mi_stat_reduce64(float y, bool ok, double& S, double& Q) {
+    mi_stat_acc a;
+    a.c = __shfl(y, 0);
+    a.s = ok ? y - a.c : 0.0f;
+    a.q = a.s * a.s;
+    a.n = ok ? 1 : 0;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { a.s += __shfl_xor(a.s, o); a.q += __shfl_xor(a.q, o); a.n += __shfl_xor(a.n, o); }
+    mi_stat_finish(a, S, Q);
 }
 
 // global-memory accessors with the address space pinned (see mi_global)
@@ -225,7 +265,7 @@ __device__ __forceinline__ void mi_buf_store_f32x4(const mi_buf& r, unsigned vof
 // them up in fp64 in a fixed order.  Returns false (nothing issued) when the problem does not fit the fast path -- the caller then
 // uses mi_gn_channel_totals.
 #define MI_STATS_K 8
-struct mi_stats_regs { float2 v[MI_STATS_K]; int c, tpc; float scale; };
+struct mi_stats_regs { double2 v[MI_STATS_K]; int c, tpc; float scale; };
 __device__ __forceinline__ bool mi_gn_totals_issue(const mi_act& in0, const mi_act& in1, int C0, int Cin, int b, int lane, int nlanes, mi_stats_regs& r) {
     int TPC = 1;
     while (TPC < 64 && TPC * 2 * Cin <= nlanes) TPC *= 2;
@@ -237,13 +277,13 @@ __device__ __forceinline__ bool mi_gn_totals_issue(const mi_act& in0, const mi_a
     const mi_act& a = second ? in1 : in0;
     const int cc = live ? (second ? c - C0 : c) : 0;
     const int ba = mi_row_of(b, a.bmod);
-    const mi_gptr<const float> st = mi_global(a.stats) + ((size_t)(ba * a.C + cc) * a.nt) * 2;
+    const mi_gptr<const double> st = mi_global(a.stats) + ((size_t)(ba * a.C + cc) * a.nt) * 2;
 #pragma unroll
     for (int k = 0; k < MI_STATS_K; ++k) {
         const int t = sub + k * TPC;
         const bool ok = live && t < a.nt;
-        const float x = st[2 * (ok ? t : 0)], y = st[2 * (ok ? t : 0) + 1];
-        r.v[k] = make_float2(ok ? x : 0.0f, ok ? y : 0.0f);
+        const double x = st[2 * (ok ? t : 0)], y = st[2 * (ok ? t : 0) + 1];
+        r.v[k] = make_double2(ok ? x : 0.0, ok ? y : 0.0);
     }
     r.c = live ? c : -1;
     r.tpc = TPC;
@@ -253,7 +293,7 @@ __device__ __forceinline__ bool mi_gn_totals_issue(const mi_act& in0, const mi_a
 __device__ __forceinline__ void mi_gn_totals_finish(const mi_stats_regs& r, int lane, double* chS, double* chQ) {
     double s = 0.0, q = 0.0;
 #pragma unroll
-    for (int k = 0; k < MI_STATS_K; ++k) { s += (double)r.v[k].x; q += (double)r.v[k].y; }
+    for (int k = 0; k < MI_STATS_K; ++k) { s += r.v[k].x; q += r.v[k].y; }
     s *= (double)r.scale;
     q *= (double)r.scale * (double)r.scale;
     for (int o = r.tpc >> 1; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }

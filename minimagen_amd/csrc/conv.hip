@@ -341,43 +341,48 @@ __global__ __launch_bounds__(CFG::NT) void conv_tile_kernel(const mi_conv_params
             }
         }
     }
-    float ssum[COUT_T], ssq[COUT_T];
+    // per-channel (sum, sum of squares) of this work-item's four pixels, in fp64 from the start (common.hip.h: why the statistics are fp64)
+    double ssum[COUT_T], ssq[COUT_T];
 #pragma unroll
     for (int co = 0; co < COUT_T; ++co) {
-        float s = 0.0f, q = 0.0f;
+        double s = 0.0, q = 0.0;
         if (row_ok && (co0 + co) < p.Cout) {
             float* dst = p.out + ((size_t)(b * p.Cout + co0 + co) * p.H + oy) * p.W + ox;
             if (ox + 3 < p.W && (p.W & 3) == 0) {
                 mi_stg4(dst, make_float4(acc[0][co], acc[1][co], acc[2][co], acc[3][co]));
 #pragma unroll
-                for (int px = 0; px < 4; ++px) { s += acc[px][co]; q = fmaf(acc[px][co], acc[px][co], q); }
+                for (int px = 0; px < 4; ++px) { const double v = (double)acc[px][co]; s += v; q = fma(v, v, q); }
             } else {
 #pragma unroll
                 for (int px = 0; px < 4; ++px)
-                    if (ox + px < p.W) { mi_stg(dst + px, acc[px][co]); s += acc[px][co]; q = fmaf(acc[px][co], acc[px][co], q); }
+                    if (ox + px < p.W) { mi_stg(dst + px, acc[px][co]); const double v = (double)acc[px][co]; s += v; q = fma(v, v, q); }
             }
         }
         ssum[co] = s;
         ssq[co] = q;
     }
     if (p.out_stats) {
-        constexpr int R = 2 * COUT_T, SEG = NT / R;
+        static_assert(NT % 64 == 0 && 2 * COUT_T <= NT, "statistics reduction: whole waves");
+        constexpr int NW = NT / 64;
+        static_assert(2 * COUT_T * NW * 2 <= CFG::SMEM_FLOATS, "statistics staging fits the tile buffer");
         __syncthreads();   // staging buffer no longer read
+        double* const redd = reinterpret_cast<double*>(smem);          // [2 * COUT_T][NW]
 #pragma unroll
         for (int co = 0; co < COUT_T; ++co) {
-            smem[(2 * co) * (NT + 1) + tid] = ssum[co];
-            smem[(2 * co + 1) * (NT + 1) + tid] = ssq[co];
+            double s = ssum[co], q = ssq[co];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
+            if ((tid & 63) == 0) { redd[(2 * co) * NW + (tid >> 6)] = s; redd[(2 * co + 1) * NW + (tid >> 6)] = q; }
         }
         __syncthreads();
-        const int rrow = tid / SEG, seg = tid % SEG;
-        float a = 0.0f;
-        for (int i = seg; i < NT; i += SEG) a += smem[rrow * (NT + 1) + i];
-#pragma unroll
-        for (int o = SEG / 2; o > 0; o >>= 1) a += __shfl_xor(a, o);
-        const int co = co0 + (rrow >> 1);
-        if (seg == 0 && co < p.Cout) {
-            const int nt = gridDim.x;
-            p.out_stats[((size_t)(b * p.Cout + co) * nt + tile) * 2 + (rrow & 1)] = a;
+        if (tid < 2 * COUT_T) {
+            double a = 0.0;
+            for (int w = 0; w < NW; ++w) a += redd[tid * NW + w];
+            const int co = co0 + (tid >> 1);
+            if (co < p.Cout) {
+                const int nt = gridDim.x;
+                p.out_stats[((size_t)(b * p.Cout + co) * nt + tile) * 2 + (tid & 1)] = a;
+            }
         }
     }
     MI_TPHASE(6);

@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256, CFG::WPS) void conv_rp_kernel(const mi_conv_pa
     __shared__ __attribute__((aligned(16))) float4 chP[RP_MAXC];
     __shared__ double chS[RP_MAXC], chQ[RP_MAXC], chS2[RP_MAXC], chQ2[RP_MAXC];
     __shared__ float gMean[MI_MAX_GROUPS], gRstd[MI_MAX_GROUPS];
-    __shared__ float red[4][NJ * (MODE == 2 ? 32 : 16)];
+    __shared__ double red[4][NJ * (MODE == 2 ? 32 : 16)];
     __shared__ int sExp[4];
     // B fragments [step][jt][lane][hi, lo]: every round's set when the round structure is static (staged once per strip), else one round's
     constexpr int WCH = NSTEP * NJ * 128;                                        // 16-byte chunks of one conv round
@@ -544,10 +544,12 @@ __global__ __launch_bounds__(256, CFG::WPS) void conv_rp_kernel(const mi_conv_pa
 
         // ---------------- epilogue: lane (lq, lg) holds pixels 4lg .. 4lg+3 of column j = lq of every group
         const float unscale = ldexpf(1.0f, -sExp[2]);
-        float csum[NJ], csq[NJ];
+        // statistics of the output about a per-channel shift (the first value of the channel's first lane): common.hip.h mi_stat_acc
+        float csum[NJ], csq[NJ], cshift[NJ];
+        int ccnt[NJ];
 #pragma unroll
         for (int jt = 0; jt < NJ; ++jt) {
-            csum[jt] = 0.f; csq[jt] = 0.f;
+            csum[jt] = 0.f; csq[jt] = 0.f; ccnt[jt] = 0;
             const int co = MODE == 2 ? 16 * (jt0 + jt) + lq : 8 * (jt0 + jt) + (lq & 7);
             const int dy = MODE == 2 ? 0 : lq >> 3;
             const float bv = bvv[jt];
@@ -564,6 +566,8 @@ __global__ __launch_bounds__(256, CFG::WPS) void conv_rp_kernel(const mi_conv_pa
                 yv[g] = y;
             }
             RP_TFINE(10);
+            const float cs_ = __shfl(yv[0].x, MODE == 2 ? lq : (lq & 7));
+            cshift[jt] = cs_;
 #pragma unroll
             for (int g = 0; g < GPW; ++g) {          // ... then the (edge-masked) stores, which need no wait
                 const int G = wave * GPW + g, gyy = G / GX, gxx = G % GX;
@@ -581,18 +585,23 @@ __global__ __launch_bounds__(256, CFG::WPS) void conv_rp_kernel(const mi_conv_pa
                     if (ok) *reinterpret_cast<mi_gptr<f32x4>>(reinterpret_cast<mi_gptr<char>>(obuf) + (unsigned)((co * H + oy) * W + ox) * 4u) = (f32x4){y.x, y.y, y.z, y.w};
                 }
 #endif
-                csum[jt] += ok ? (y.x + y.y) + (y.z + y.w) : 0.0f;
-                csq[jt] += ok ? fmaf(y.x, y.x, fmaf(y.y, y.y, fmaf(y.z, y.z, y.w * y.w))) : 0.0f;
+                const float d0 = y.x - cs_, d1 = y.y - cs_, d2 = y.z - cs_, d3 = y.w - cs_;
+                csum[jt] += ok ? (d0 + d1) + (d2 + d3) : 0.0f;
+                csq[jt] += ok ? fmaf(d0, d0, fmaf(d1, d1, fmaf(d2, d2, d3 * d3))) : 0.0f;
+                ccnt[jt] += ok ? 4 : 0;
             }
         }
         RP_TFINE(11);
         if (p.out_stats) {
 #pragma unroll
             for (int jt = 0; jt < NJ; ++jt) {
-                if (MODE != 2) { csum[jt] += __shfl_xor(csum[jt], 8); csq[jt] += __shfl_xor(csq[jt], 8); }
-                csum[jt] += __shfl_xor(csum[jt], 16); csq[jt] += __shfl_xor(csq[jt], 16);
-                csum[jt] += __shfl_xor(csum[jt], 32); csq[jt] += __shfl_xor(csq[jt], 32);
-                if (lane < CPT) { red[wave][2 * (CPT * jt + lane)] = csum[jt]; red[wave][2 * (CPT * jt + lane) + 1] = csq[jt]; }
+                if (MODE != 2) { csum[jt] += __shfl_xor(csum[jt], 8); csq[jt] += __shfl_xor(csq[jt], 8); ccnt[jt] += __shfl_xor(ccnt[jt], 8); }
+                csum[jt] += __shfl_xor(csum[jt], 16); csq[jt] += __shfl_xor(csq[jt], 16); ccnt[jt] += __shfl_xor(ccnt[jt], 16);
+                csum[jt] += __shfl_xor(csum[jt], 32); csq[jt] += __shfl_xor(csq[jt], 32); ccnt[jt] += __shfl_xor(ccnt[jt], 32);
+                if (lane < CPT) {
+                    mi_stat_acc a; a.c = cshift[jt]; a.s = csum[jt]; a.q = csq[jt]; a.n = ccnt[jt];
+                    mi_stat_finish(a, red[wave][2 * (CPT * jt + lane)], red[wave][2 * (CPT * jt + lane) + 1]);
+                }
             }
             RP_TFINE(12);
             __syncthreads();

@@ -20,7 +20,7 @@ struct WgradArgs {
     const float* a; const float* dy; float* partial; float* partial_db;
     int B, Cin, Cout, H, W, nciB, ncoB, tiles_x, tiles_y;
     // fused activation of the A operand (a_stats != NULL): a = SiLU(GroupNorm(x) * (scale + 1) + shift), computed while the tile is staged
-    const float* a_stats; int a_nt; const float* gamma; const float* beta; int groups; float eps; const float* ss; int ss_stride, ss_off;
+    const double* a_stats; int a_nt; const float* gamma; const float* beta; int groups; float eps; const float* ss; int ss_stride, ss_off;
 };
 
 // PACK (Cin <= 8): the N dimension holds TWO taps x 8 input channels (lanes 0-7 of a column group: tap 2m, lanes 8-15: tap 2m + 1), so the nine taps

@@ -137,39 +137,42 @@ __global__ __launch_bounds__(NT) void crossembed_422_kernel(const mi_crossembed_
 
     const int oy = oy0 + ty, ox = ox0 + tx * 4;
     const bool row_ok = oy < p.H;
-    float ssum[COUT], ssq[COUT];
+    double ssum[COUT], ssq[COUT];               // fp64 statistics (common.hip.h)
 #pragma unroll
     for (int co = 0; co < COUT; ++co) {
         const float* bp = co < 4 ? p.bias[0] : (co < 6 ? p.bias[1] : p.bias[2]);
         const float bv = bp ? bp[co < 4 ? co : (co < 6 ? co - 4 : co - 6)] : 0.0f;
-        float s = 0.0f, q = 0.0f;
+        double s = 0.0, q = 0.0;
         if (row_ok) {
             float* dst = p.out + ((size_t)(b * COUT + co) * p.H + oy) * p.W + ox;
             const float* add = p.addend ? p.addend + ((size_t)(b * COUT + co) * p.H + oy) * p.W + ox : nullptr;
 #pragma unroll
             for (int px = 0; px < 4; ++px) {
                 const float v = acc[px][co] + bv + ((add && ox + px < p.W) ? add[px] : 0.0f);
-                if (ox + px < p.W) { dst[px] = v; s += v; q = fmaf(v, v, q); }
+                if (ox + px < p.W) { dst[px] = v; s += (double)v; q = fma((double)v, (double)v, q); }
             }
         }
         ssum[co] = s;
         ssq[co] = q;
     }
     if (p.out_stats) {
-        constexpr int R = 2 * COUT, SEG = NT / R;
+        static_assert(NT % 64 == 0 && 2 * COUT <= NT, "statistics reduction: whole waves");
+        constexpr int NW = NT / 64;
         __syncthreads();
+        double* const redd = reinterpret_cast<double*>(smem);          // [2 * COUT][NW]
 #pragma unroll
         for (int co = 0; co < COUT; ++co) {
-            smem[(2 * co) * (NT + 1) + tid] = ssum[co];
-            smem[(2 * co + 1) * (NT + 1) + tid] = ssq[co];
+            double s = ssum[co], q = ssq[co];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
+            if ((tid & 63) == 0) { redd[(2 * co) * NW + (tid >> 6)] = s; redd[(2 * co + 1) * NW + (tid >> 6)] = q; }
         }
         __syncthreads();
-        const int rrow = tid / SEG, seg = tid % SEG;
-        float a = 0.0f;
-        for (int i = seg; i < NT; i += SEG) a += smem[rrow * (NT + 1) + i];
-#pragma unroll
-        for (int o = SEG / 2; o > 0; o >>= 1) a += __shfl_xor(a, o);
-        if (seg == 0) p.out_stats[((size_t)(b * COUT + (rrow >> 1)) * gridDim.x + tile) * 2 + (rrow & 1)] = a;
+        if (tid < 2 * COUT) {
+            double a = 0.0;
+            for (int w = 0; w < NW; ++w) a += redd[tid * NW + w];
+            p.out_stats[((size_t)(b * COUT + (tid >> 1)) * gridDim.x + tile) * 2 + (tid & 1)] = a;
+        }
     }
 }
 
@@ -206,7 +209,7 @@ __global__ __launch_bounds__(256, 2) void crossembed_mfma_kernel(const mi_crosse
     __shared__ __attribute__((aligned(16))) uint2 actH[IH * PW];
     __shared__ __attribute__((aligned(16))) uint2 actL[HALF ? 2 : IH * PW];
     __shared__ __attribute__((aligned(16))) uint4 tab[32 * TP];
-    __shared__ float red[4][16];
+    __shared__ double red[4][16];
     __shared__ float smax[4];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lq = lane & 15, lg = lane >> 4;
     const int H = p.H, W = p.W, HW = H * W;
@@ -402,7 +405,9 @@ __global__ __launch_bounds__(256, 2) void crossembed_mfma_kernel(const mi_crosse
     CE_TPHASE(2);
 
     // ---- epilogue: lane (lq = 8 co2 + dy, lg) holds pixels 4 lg .. 4 lg + 3 of output row dy, channel 2 t + co2 of every group
-    float ssum[4], ssq[4];
+    // statistics about a per-channel shift (the first value of the channel's first lane): common.hip.h mi_stat_acc
+    float ssum[4], ssq[4], sshift[4];
+    int scnt[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int k = t < 2 ? 0 : t - 1;                                   // conv of this N tile
@@ -411,6 +416,8 @@ __global__ __launch_bounds__(256, 2) void crossembed_mfma_kernel(const mi_crosse
         const float* bp = p.bias[k];
         const float bv = bp ? bp[t == 1 ? 2 + co2 : co2] : 0.0f;
         float s = 0.0f, q2 = 0.0f;
+        int cn = 0;
+        const float sh = __shfl(fmaf(acc[0][t][0], us, bv) + (p.addend ? addv[0][t].x : 0.0f), 8 * co2);
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             const int gi = wave * G + g, gyy = gi / GX, gxx = gi % GX;
@@ -422,21 +429,27 @@ __global__ __launch_bounds__(256, 2) void crossembed_mfma_kernel(const mi_crosse
             if (ok) {
                 if (HALF && p.out_st) mi_stg2u(reinterpret_cast<unsigned short*>(p.out) + o, mi_f32x4_to_bf16(y));
                 else mi_stg4(p.out + o, y);
-                s += (y.x + y.y) + (y.z + y.w);
-                q2 += fmaf(y.x, y.x, fmaf(y.y, y.y, fmaf(y.z, y.z, y.w * y.w)));
+                const float d0 = y.x - sh, d1 = y.y - sh, d2 = y.z - sh, d3 = y.w - sh;
+                s += (d0 + d1) + (d2 + d3);
+                q2 += fmaf(d0, d0, fmaf(d1, d1, fmaf(d2, d2, d3 * d3)));
+                cn += 4;
             }
         }
-        ssum[t] = s; ssq[t] = q2;
+        ssum[t] = s; ssq[t] = q2; sshift[t] = sh; scnt[t] = cn;
     }
     if (p.out_stats) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             float s = ssum[t], q2 = ssq[t];
+            int cn = scnt[t];
 #pragma unroll
-            for (int o = 1; o <= 4; o <<= 1) { s += __shfl_xor(s, o); q2 += __shfl_xor(q2, o); }
-            s += __shfl_xor(s, 16); q2 += __shfl_xor(q2, 16);
-            s += __shfl_xor(s, 32); q2 += __shfl_xor(q2, 32);
-            if (dy == 0 && lg == 0) { red[wave][2 * (2 * t + co2)] = s; red[wave][2 * (2 * t + co2) + 1] = q2; }
+            for (int o = 1; o <= 4; o <<= 1) { s += __shfl_xor(s, o); q2 += __shfl_xor(q2, o); cn += __shfl_xor(cn, o); }
+            s += __shfl_xor(s, 16); q2 += __shfl_xor(q2, 16); cn += __shfl_xor(cn, 16);
+            s += __shfl_xor(s, 32); q2 += __shfl_xor(q2, 32); cn += __shfl_xor(cn, 32);
+            if (dy == 0 && lg == 0) {
+                mi_stat_acc a; a.c = sshift[t]; a.s = s; a.q = q2; a.n = cn;
+                mi_stat_finish(a, red[wave][2 * (2 * t + co2)], red[wave][2 * (2 * t + co2) + 1]);
+            }
         }
         __syncthreads();
         if (tid < 16) p.out_stats[((size_t)(b * 8 + (tid >> 1)) * gridDim.x + tile) * 2 + (tid & 1)] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
@@ -450,7 +463,7 @@ __global__ __launch_bounds__(256, 2) void crossembed_mfma_kernel(const mi_crosse
 template <int NT, int TW>
 __global__ __launch_bounds__(NT) void crossembed_generic_kernel(const mi_crossembed_params p, const int Ctot) {
     constexpr int TH = NT / TW;
-    __shared__ float red[2][NT / 64];
+    __shared__ double red[2][NT / 64];
     const int tid = threadIdx.x;
     const int tiles_x = (p.W + TW - 1) / TW;
     const int tile = blockIdx.x;
@@ -484,13 +497,13 @@ __global__ __launch_bounds__(NT) void crossembed_generic_kernel(const mi_crossem
         p.out[((size_t)(b * Ctot + co_g) * p.H + oy) * p.W + ox] = acc;
     }
     if (p.out_stats) {
-        float s = ok ? acc : 0.0f, q = ok ? acc * acc : 0.0f;
-        s = mi_wave_sum(s);
-        q = mi_wave_sum(q);
+        double s = ok ? (double)acc : 0.0, q = s * s;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
         if ((tid & 63) == 0) { red[0][tid >> 6] = s; red[1][tid >> 6] = q; }
         __syncthreads();
         if (tid < 2) {
-            float a = 0.0f;
+            double a = 0.0;
             for (int w = 0; w < NT / 64; ++w) a += red[tid][w];
             p.out_stats[((size_t)(b * Ctot + co_g) * gridDim.x + tile) * 2 + tid] = a;
         }

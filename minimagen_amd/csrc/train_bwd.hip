@@ -10,27 +10,23 @@
 
 namespace {
 
-__global__ __launch_bounds__(256) void channel_stats_kernel(const float* x, float* stats, int HW) {
+__global__ __launch_bounds__(256) void channel_stats_kernel(const float* x, double* stats, int HW) {
     __shared__ double red[8];
     const size_t row = blockIdx.x;
     const mi_gptr<const float> p = mi_global(x) + row * (size_t)HW;
-    float s = 0.f, q = 0.f;
-    double S = 0.0, Q = 0.0;
-    int n = 0;
-    for (int i = threadIdx.x; i < HW; i += 256) {
-        const float v = p[i];
-        s += v; q += v * v;
-        if (++n == 64) { S += (double)s; Q += (double)q; s = q = 0.f; n = 0; }        // fp32 runs of 64, then double
+    double S = 0.0, Q = 0.0;                      // fp64 from the first element: the kernel is memory-bound, and an fp32 sum of squares
+    for (int i = threadIdx.x; i < HW; i += 256) { // loses the variance of a tensor with a large mean (common.hip.h)
+        const double v = (double)p[i];
+        S += v; Q = fma(v, v, Q);
     }
-    S += (double)s; Q += (double)q;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { S += __shfl_xor(S, o); Q += __shfl_xor(Q, o); }
     const int wave = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) { red[2 * wave] = S; red[2 * wave + 1] = Q; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        stats[2 * row] = (float)((red[0] + red[2]) + (red[4] + red[6]));
-        stats[2 * row + 1] = (float)((red[1] + red[3]) + (red[5] + red[7]));
+        stats[2 * row] = (red[0] + red[2]) + (red[4] + red[6]);
+        stats[2 * row + 1] = (red[1] + red[3]) + (red[5] + red[7]);
     }
 }
 
@@ -109,21 +105,17 @@ __global__ __launch_bounds__(256) void block_bwd_apply_kernel(mi_block_bwd_param
     const mi_gptr<const float> x = mi_global(p.x) + (size_t)row * p.HW;
     const mi_gptr<const float> da = mi_global(p.da) + (size_t)row * p.HW;
     float* dx = p.dx + (size_t)row * p.HW;
-    float s = 0.f, q = 0.f;
     double S = 0.0, Q = 0.0;
-    int n = 0;
     for (int i = i0 + threadIdx.x; i < i1; i += 256) {
         const float xv = x[i];
         const float g = da[i] * mi_silu_grad(fmaf(xv, k.A, k.Bc));
         const float xh = (xv - k.mu) * k.r;
         const float d = k.r * (k.k * g - M1 - xh * M2);
         dx[i] = d;
-        s += d; q = fmaf(d, d, q);
-        if (++n == 64) { S += (double)s; Q += (double)q; s = q = 0.f; n = 0; }
+        S += (double)d; Q = fma((double)d, (double)d, Q);
     }
     if (p.dx_stats) {               // (sum, sum of squares) of this chunk of dx: the statistics the NEXT backward's data-gradient conv scales by
         __shared__ double red[8];
-        S += (double)s; Q += (double)q;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { S += __shfl_xor(S, o); Q += __shfl_xor(Q, o); }
         const int wave = threadIdx.x >> 6;
@@ -131,9 +123,9 @@ __global__ __launch_bounds__(256) void block_bwd_apply_kernel(mi_block_bwd_param
         if ((threadIdx.x & 63) == 0) { red[2 * wave] = S; red[2 * wave + 1] = Q; }
         __syncthreads();
         if (threadIdx.x == 0) {
-            float* o = p.dx_stats + ((size_t)row * gridDim.y + blockIdx.y) * 2;
-            o[0] = (float)((red[0] + red[2]) + (red[4] + red[6]));
-            o[1] = (float)((red[1] + red[3]) + (red[5] + red[7]));
+            double* o = p.dx_stats + ((size_t)row * gridDim.y + blockIdx.y) * 2;
+            o[0] = (red[0] + red[2]) + (red[4] + red[6]);
+            o[1] = (red[1] + red[3]) + (red[5] + red[7]);
         }
     }
 }
@@ -201,7 +193,7 @@ __global__ __launch_bounds__(256) void pack_conv3_kernel(const float* w, int Cou
 
 }  // namespace
 
-extern "C" int mi_chan_stats_fwd(const float* x, float* stats, int rows, int HW, void* stream) {
+extern "C" int mi_chan_stats_fwd(const float* x, double* stats, int rows, int HW, void* stream) {
     if (!x || !stats || rows <= 0 || HW <= 0) { mi_set_error("mi_chan_stats_fwd: bad arguments"); return MI_ERR_INVALID; }
     hipLaunchKernelGGL(channel_stats_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, x, stats, HW);
     return mi_check_launch("channel_stats_kernel");

@@ -43,7 +43,7 @@ JT = 17     # context tiles of 16 rows: 1 null + (2|4) time tokens + 256 text ro
 
 class Act:
     """An NCHW activation (fp32, or bf16 in the reduced-precision configuration) plus the per-channel partial statistics its producer
-    emitted (always fp32)."""
+    emitted (always fp64)."""
     __slots__ = ("t", "stats", "nt", "C", "H", "W", "batch", "uses", "rev")
 
     def __init__(self, t, stats, nt, C_, H, W, batch):
@@ -136,7 +136,8 @@ class UnetEngine:
         """Validate / rebuild the packed weights.  Identity (storage pointer + version counter of every parameter) is a host-only check;
         the content fingerprint catches ``p.data`` updates and costs two fused multi-tensor launches plus ONE small device -> host
         comparison ON THE CALLER'S STREAM (never on a stage stream: a sampling call in flight is not waited for).  Once per public call;
-        MINIMAGEN_WEIGHT_FINGERPRINT=0 trusts identity alone (no device work, no synchronisation at all)."""
+        MINIMAGEN_WEIGHT_FINGERPRINT=0 trusts identity alone (no device work, no synchronisation at all).  Imagen.sample() uses the split
+        form pack_begin() / pack_changed() instead, which takes the host wait off the front of the call."""
         key = self._param_key()
         if not WEIGHT_FINGERPRINT:
             if self._pack is not None and key == self._pack_key:
@@ -146,6 +147,37 @@ class UnetEngine:
             fp = self._fingerprint()
             if self._pack is not None and key == self._pack_key and torch.equal(fp, self._pack_fp):
                 return self._pack
+        return self._repack(key, fp)
+
+    def pack_begin(self):
+        """First half of the deferred validation: identity is checked at once (a changed key re-packs right here); the content fingerprint
+        is launched and its comparison with the packed state goes to pinned host memory WITHOUT a host wait.  Returns a token for
+        pack_changed(), or None when nothing is pending.  The caller enqueues its work on the assumption that the values are unchanged and
+        asks pack_changed() afterwards: the host wait then sits BEHIND the enqueued work instead of in front of it (a synchronous sample()
+        made the host wait for the whole previous call before it could enqueue anything: the GPU idled for the host's launch time)."""
+        key = self._param_key()
+        if self._pack is None or key != self._pack_key or not WEIGHT_FINGERPRINT:
+            self.pack()
+            return None
+        fp = self._fingerprint()
+        flag = self.__dict__.get("_fp_flag")
+        if flag is None or flag.device != torch.device("cpu"):
+            flag = self._fp_flag = torch.zeros(1, dtype=torch.int32).pin_memory() if fp.is_cuda else torch.zeros(1, dtype=torch.int32)
+        flag.copy_((fp != self._pack_fp).any().to(torch.int32).reshape(1), non_blocking=True)
+        ev = torch.cuda.current_stream(fp.device).record_event() if fp.is_cuda else None
+        return (flag, ev, fp)
+
+    def pack_changed(self, token) -> bool:
+        """Second half: True when the weights' VALUES differ from the packed copies (``p.data`` updates behind the version counter).  The
+        caller must then discard what it enqueued, let the device drain, and call pack() (Imagen.sample does)."""
+        if token is None:
+            return False
+        flag, ev, _ = token
+        if ev is not None:
+            ev.synchronize()
+        return bool(flag.item())
+
+    def _repack(self, key, fp):
         self.invalidate()
         self._pack_fp = fp
         self._check_params()
@@ -319,7 +351,7 @@ class UnetEngine:
 
     def _new_act(self, ws, batch, Cc, H, W, nt, fp32: bool = False) -> Act:
         t = torch.empty(batch, Cc, H, W, dtype=torch.float32 if (fp32 or not ws.store16) else torch.bfloat16, device=ws.dev)
-        st = torch.zeros(batch, Cc, max(nt, 1), 2, dtype=torch.float32, device=ws.dev) if nt else None
+        st = torch.zeros(batch, Cc, max(nt, 1), 2, dtype=torch.float64, device=ws.dev) if nt else None      # fp64 partial (sum, sumsq): include/minimagen_hip.h
         ws.tensors += [t, st]
         return Act(t, st, nt, Cc, H, W, batch)
 

@@ -138,18 +138,29 @@ class T5EncoderHIP:
         mask = None if attention_mask is None else attention_mask.to(self.dev).to(torch.uint8).contiguous()
         L.require_device(ids, mask)
         pl = self._plan(B, Lq)
-        pl["ids"].copy_(ids)
-        if mask is None:
-            pl["mask"].fill_(1)
-        else:
-            pl["mask"].copy_(mask)
+
+        def stage():
+            pl["ids"].copy_(ids)
+            if mask is None:
+                pl["mask"].fill_(1)
+            else:
+                pl["mask"].copy_(mask)
+
         if _use_graph and L.backend() == "hip-gfx950":
+            # Everything that touches the plan's static buffers -- the staging copies, the replay, the copy-out -- runs on the encoder's ONE
+            # private stream: encode() calls of the same shape from different caller streams are then ordered among themselves (a second
+            # call cannot overwrite ids / mask while the first replay still reads them), each caller stream only waits for its own result.
+            # (The captured graph addresses the encoder's own weight tensors; they are never re-homed: T5EncoderHIP owns private copies.)
             cur = torch.cuda.current_stream(self.dev)
             side = self.__dict__.get("_stream")
             if side is None:
                 side = self._stream = torch.cuda.Stream(device=self.dev)     # (graphs cannot be captured on the legacy default stream)
             side.wait_stream(cur)
+            for t_in in (ids, mask):
+                if t_in is not None:
+                    t_in.record_stream(side)
             with torch.cuda.stream(side):
+                stage()
                 st = side.cuda_stream
                 if pl["graph"] is None:
                     L.check(lib.mi_graph_begin(st), "mi_graph_begin")
@@ -161,25 +172,181 @@ class T5EncoderHIP:
                     L.check(rc, "mi_graph_end")
                     pl["graph"] = g
                 L.check(lib.mi_graph_launch(pl["graph"], st), "mi_graph_launch")
+                out, mk = pl["out"].clone().reshape(B, Lq, self.cfg["d_model"]), pl["mask"].bool()
             cur.wait_stream(side)
-        else:
-            self._launch(pl, B, Lq, L.current_stream())
+            out.record_stream(cur)
+            mk.record_stream(cur)
+            return out, mk
+        stage()
+        self._launch(pl, B, Lq, L.current_stream())
         return pl["out"].clone().reshape(B, Lq, self.cfg["d_model"]), pl["mask"].bool()
+
+    # ------------------------------------------------------------------ checkpoints from disk (no network)
+    @classmethod
+    def from_directory(cls, path: str, device="cuda"):
+        """A T5 encoder from a Hugging Face checkpoint DIRECTORY -- ``config.json`` + ``model.safetensors`` (or ``pytorch_model.bin``, also
+        sharded ``*.safetensors`` / ``*.bin`` with their index) -- read directly: no ``from_pretrained``, no hub / network call.  Covers the
+        original checkpoints (ReLU feed-forward, tied ``shared.weight``) and the t5-v1.1 family (gated-GELU, ``wi_0`` / ``wi_1``).  Decoder
+        and LM-head tensors of full T5 checkpoints are ignored.  (minimagen/t5.py:24-28 obtains the same tensors through
+        ``T5EncoderModel.from_pretrained``.)"""
+        import glob
+        import json
+        import os
+        with open(os.path.join(path, "config.json")) as f:
+            c = json.load(f)
+        sd = {}
+        files = sorted(glob.glob(os.path.join(path, "*.safetensors")))
+        if files:
+            from safetensors.torch import load_file
+            for fn in files:
+                sd.update(load_file(fn, device="cpu"))
+        else:
+            files = sorted(glob.glob(os.path.join(path, "pytorch_model*.bin")))
+            if not files:
+                raise FileNotFoundError(f"no *.safetensors / pytorch_model*.bin under {path}")
+            for fn in files:
+                sd.update(torch.load(fn, map_location="cpu", weights_only=True))
+        sd = {k: v for k, v in sd.items() if k.startswith("encoder.") or k == "shared.weight"}
+        if "shared.weight" not in sd and "encoder.embed_tokens.weight" not in sd:
+            raise KeyError(f"{path}: neither shared.weight nor encoder.embed_tokens.weight in the checkpoint")
+        ff = c.get("feed_forward_proj", "relu")
+        if ff not in ("relu", "gated-gelu", "gelu", "gated-relu"):
+            raise NotImplementedError(f"feed_forward_proj {ff!r}")
+        return cls(sd, d_model=c["d_model"], d_kv=c["d_kv"], num_heads=c["num_heads"], d_ff=c["d_ff"], num_layers=c["num_layers"],
+                   relative_attention_num_buckets=c.get("relative_attention_num_buckets", 32),
+                   relative_attention_max_distance=c.get("relative_attention_max_distance", 128),
+                   layer_norm_epsilon=c.get("layer_norm_epsilon", 1e-6), feed_forward_proj=ff, device=device)
+
+
+# ---------------------------------------------------------------------- the reference's front-end (minimagen/t5.py:24-84), offline-capable
+T5_LOCAL_DIR_ENV = "MINIMAGEN_T5_DIR"        # a directory holding one Hugging Face checkpoint directory per handle ('t5-small', 'google/t5-v1_1-base', ...)
+
+
+def _local_dir(handle: str):
+    """Where the files of ``handle`` lie on this machine, or None: $MINIMAGEN_T5_DIR/<handle> (also with '/' -> '--' or only the last path
+    component), else the Hugging Face hub cache (``snapshot_download(local_files_only=True)``: never touches the network)."""
+    import os
+    root = os.environ.get(T5_LOCAL_DIR_ENV)
+    if root:
+        for cand in (handle, handle.replace("/", "--"), handle.split("/")[-1]):
+            d = os.path.join(root, cand)
+            if os.path.isfile(os.path.join(d, "config.json")):
+                return d
+    try:
+        from huggingface_hub import snapshot_download
+        return snapshot_download(handle, local_files_only=True)
+    except Exception:
+        return None
+
+
+def register_t5(name: str, *, model=None, model_dir: Optional[str] = None, tokenizer=None, dim: Optional[int] = None, device=None):
+    """Install the encoder and / or tokenizer of ``name`` (an entry of T5_VERSIONS, or a new name with ``dim``) from local objects instead of
+    the hub: ``model`` = a T5EncoderHIP or a transformers T5EncoderModel, ``model_dir`` = a checkpoint directory (T5EncoderHIP.from_directory),
+    ``tokenizer`` = a Hugging Face tokenizer object or any callable ``(list[str], max_length) -> (input_ids [B, L] int64, attention_mask [B, L])``
+    (padding to the longest caption, truncation to max_length: what minimagen/t5.py:63-69 asks the tokenizer for)."""
+    if name not in T5_VERSIONS:
+        if dim is None:
+            raise KeyError(f"unknown T5 name {name!r}: pass dim= to register a new one")
+        T5_VERSIONS[name] = {'tokenizer': None, 'model': None, 'handle': name, 'dim': dim, 'size': 0.}
+    dev = device if device is not None else ("cuda" if L.backend() == "hip-gfx950" else "cpu")
+    if model_dir is not None:
+        model = T5EncoderHIP.from_directory(model_dir, device=dev)
+    if model is not None:
+        if not isinstance(model, T5EncoderHIP):
+            model = T5EncoderHIP.from_hf(model.eval(), device=dev)
+        if model.cfg["d_model"] != T5_VERSIONS[name]['dim']:
+            raise ValueError(f"{name}: encoder width {model.cfg['d_model']} != registered dim {T5_VERSIONS[name]['dim']}")
+        T5_VERSIONS[name]['model'] = model
+    if tokenizer is not None:
+        T5_VERSIONS[name]['tokenizer'] = tokenizer
+    _embed_cache_clear(name)
 
 
 def _check_downloads(name):
-    """minimagen/t5.py:24-28 (needs the Hugging Face files on disk; there is no network here)"""
-    from transformers import T5EncoderModel, T5Tokenizer
-    if T5_VERSIONS[name]['tokenizer'] is None:
-        T5_VERSIONS[name]['tokenizer'] = T5Tokenizer.from_pretrained(T5_VERSIONS[name]['handle'])
-    if T5_VERSIONS[name]['model'] is None:
-        T5_VERSIONS[name]['model'] = T5EncoderHIP.from_hf(T5EncoderModel.from_pretrained(T5_VERSIONS[name]['handle']).eval())
+    """minimagen/t5.py:24-28.  Order: whatever register_t5() installed; the checkpoint directory on this machine (_local_dir: read without
+    any hub call); last the reference's own route, ``from_pretrained(handle)``, which needs the network on first use."""
+    ver = T5_VERSIONS[name]
+    if ver['tokenizer'] is not None and ver['model'] is not None:
+        return
+    d = _local_dir(ver['handle'])
+    dev = "cuda" if L.backend() == "hip-gfx950" else "cpu"
+    if ver['tokenizer'] is None:
+        from transformers import T5Tokenizer
+        ver['tokenizer'] = T5Tokenizer.from_pretrained(d, local_files_only=True) if d else T5Tokenizer.from_pretrained(ver['handle'])
+    if ver['model'] is None:
+        if d:
+            ver['model'] = T5EncoderHIP.from_directory(d, device=dev)
+        else:
+            from transformers import T5EncoderModel
+            ver['model'] = T5EncoderHIP.from_hf(T5EncoderModel.from_pretrained(ver['handle']).eval(), device=dev)
 
 
-def t5_encode_text(text, name: str = 't5_base', max_length=MAX_LENGTH):
-    """minimagen/t5.py:31-84: tokenise (pad longest, truncate to max_length), encode with the HIP T5 stack, zero the
-    masked positions, return (embeds, bool mask)."""
-    _check_downloads(name)
-    tokenizer, model = T5_VERSIONS[name]['tokenizer'], T5_VERSIONS[name]['model']
-    tokenized = tokenizer.batch_encode_plus(text, padding='longest', max_length=max_length, truncation=True, return_tensors="pt")
-    return model.encode(tokenized.input_ids, tokenized.attention_mask)
+def _tokenize(tokenizer, text, max_length):
+    """minimagen/t5.py:63-69: pad to the longest caption, truncate to max_length -> (input_ids, attention_mask) int64 on the host"""
+    if hasattr(tokenizer, "batch_encode_plus") or hasattr(tokenizer, "pad"):
+        enc = (tokenizer.batch_encode_plus if hasattr(tokenizer, "batch_encode_plus") else tokenizer)(
+            text, padding='longest', max_length=max_length, truncation=True, return_tensors="pt")
+        return enc.input_ids, enc.attention_mask
+    ids, mask = tokenizer(list(text), max_length)
+    return torch.as_tensor(ids, dtype=torch.int64), torch.as_tensor(mask, dtype=torch.int64)
+
+
+# Caption -> embedding cache (not in the reference, which re-encodes every caption of every call): the encoder is frozen, so a caption's
+# rows are a pure function of (encoder, caption, max_length).  Entries hold the UNPADDED rows on the encoder's device; a call encodes only
+# its misses (one batch) and assembles the padded [B, L, dim] result from the cache.  Masked keys contribute exact zeros and every other
+# operation is per row, so a caption's rows do not depend on its batch beyond fp32 rounding (the block-scaled GEMM shares a power-of-two
+# scale among the rows of a tile): cached and fresh results agree to ~1e-6 (tests/test_t5.py).  MINIMAGEN_T5_CACHE = entries kept per
+# process (default 4096, 0 = off).
+import collections as _collections
+import os as _os
+
+_EMBED_CACHE = _collections.OrderedDict()
+T5_CACHE_ENTRIES = int(_os.environ.get("MINIMAGEN_T5_CACHE", "4096"))
+t5_cache_stats = {"hits": 0, "misses": 0}
+
+
+def _embed_cache_clear(name=None):
+    for k in [k for k in _EMBED_CACHE if name is None or k[0] == name]:
+        del _EMBED_CACHE[k]
+
+
+def t5_encode_text(text, name: str = 't5_base', max_length=MAX_LENGTH, tokenizer=None):
+    """minimagen/t5.py:31-84: tokenise (pad longest, truncate to max_length), encode with the HIP T5 stack, zero the masked positions,
+    return (embeds [B, L, dim] fp32, bool mask [B, L]).  ``tokenizer`` overrides the registered one for this call (see register_t5)."""
+    if tokenizer is None or T5_VERSIONS[name]['model'] is None:
+        _check_downloads(name)
+    model = T5_VERSIONS[name]['model']
+    tok = tokenizer if tokenizer is not None else T5_VERSIONS[name]['tokenizer']
+    text = list(text)
+    input_ids, attention_mask = _tokenize(tok, text, max_length)
+    B, Lq = input_ids.shape
+    lens = attention_mask.sum(1).tolist()
+    prefix = bool((attention_mask.bool() == (torch.arange(Lq)[None, :] < attention_mask.sum(1, keepdim=True))).all())      # right-padded, as every T5 tokenizer pads
+    if T5_CACHE_ENTRIES <= 0 or tokenizer is not None or not prefix or min(lens) == 0:
+        return model.encode(input_ids, attention_mask)
+    keys = [(name, cap, max_length, id(model)) for cap in text]
+    rows = [None] * B
+    miss = []
+    for b, k in enumerate(keys):
+        hit = _EMBED_CACHE.get(k)
+        if hit is not None and hit.shape[0] == lens[b]:
+            _EMBED_CACHE.move_to_end(k)
+            rows[b] = hit
+            t5_cache_stats["hits"] += 1
+        elif k not in [keys[m] for m in miss]:
+            miss.append(b)
+            t5_cache_stats["misses"] += 1
+    if miss:
+        lm = max(lens[b] for b in miss)                     # (re-pad the misses among themselves: a shorter launch)
+        emb, _ = model.encode(input_ids[miss, :lm].contiguous(), attention_mask[miss, :lm].contiguous())
+        for j, b in enumerate(miss):
+            _EMBED_CACHE[keys[b]] = emb[j, :lens[b]].clone()
+        while len(_EMBED_CACHE) > T5_CACHE_ENTRIES:
+            _EMBED_CACHE.popitem(last=False)
+    out = torch.zeros(B, Lq, model.cfg["d_model"], dtype=torch.float32, device=model.dev)
+    for b, k in enumerate(keys):
+        r = rows[b] if rows[b] is not None else _EMBED_CACHE.get(k)
+        if r is None:                                       # (evicted within this very call: capacity below the batch size)
+            r = model.encode(input_ids[b:b + 1, :lens[b]].contiguous(), attention_mask[b:b + 1, :lens[b]].contiguous())[0][0]
+        out[b, :lens[b]] = r
+    return out, attention_mask.to(model.dev).bool()

@@ -105,12 +105,22 @@ def begin_step(module: torch.nn.Module):
     if check or stale_id:
         with torch.no_grad():
             det = [w.detach() for w in ws]
-            fp = torch.stack(torch._foreach_norm(det, float("inf")) + torch._foreach_norm(det, 2)).tolist()
+            # (max |w|, ||w||_2, ||w + r||_2) with r a fixed pseudo-random pattern per weight: the third term moves when values change sign or
+            # place with both norms kept (w.data.neg_(), a channel permutation, an EMA copy of equal norm)
+            pats = []
+            for w in ws:                  # (cached on the parameter object itself)
+                r = getattr(w, "_mi_fp_pattern", None)
+                if r is None or r.shape != w.shape or r.device != w.device:
+                    g = torch.Generator().manual_seed(w.numel() * 2654435761 % (2 ** 31))
+                    r = (torch.rand(w.shape, generator=g) - 0.5).to(w.device)
+                    w._mi_fp_pattern = r
+                pats.append(r)
+            fp = torch.stack(torch._foreach_norm(det, float("inf")) + torch._foreach_norm(det, 2) + torch._foreach_norm(torch._foreach_add(det, pats), 2)).tolist()
     n = len(ws)
     for k, (m, w) in enumerate(zip(convs, ws)):
         if fp is None:
             break
-        mark = (fp[k], fp[n + k])
+        mark = (fp[k], fp[n + k], fp[2 * n + k])
         if getattr(w, "_mi_fingerprint", None) != mark:           # values changed behind the version counter: drop everything derived from them
             w._mi_fingerprint = mark
             for attr in ("_mi_train_packs", "_mi_ce_tables"):
@@ -135,7 +145,7 @@ def invalidate(module: torch.nn.Module):
 def _chan_stats(x: torch.Tensor) -> torch.Tensor:
     """per-(image, channel) sum and sum of squares, [B][C][1][2] (one statistics tile): what a producing kernel's epilogue would have left"""
     B, Cc, H, W = x.shape
-    st = torch.empty(B, Cc, 1, 2, dtype=torch.float32, device=x.device)
+    st = torch.empty(B, Cc, 1, 2, dtype=torch.float64, device=x.device)
     L.check(L.lib().mi_chan_stats_fwd(x.data_ptr(), st.data_ptr(), B * Cc, H * W, L.current_stream()), "mi_chan_stats_fwd")
     return st
 
@@ -194,7 +204,7 @@ def _conv3x3(x: torch.Tensor, pack: _Pack, bias, gn=None, ss=None, stats=None, w
     if want_stats:                  # the epilogue's per-tile partial statistics of the OUTPUT: the next Block reads them instead of a statistics pass
         th, tw = C.c_int(), C.c_int()
         lib.mi_conv_tile_shape(p.tile_cfg & 0xff, C.byref(th), C.byref(tw))
-        out_stats = torch.empty(B, Cout, (-(-H // th.value)) * (-(-W // tw.value)), 2, dtype=torch.float32, device=x.device)
+        out_stats = torch.empty(B, Cout, (-(-H // th.value)) * (-(-W // tw.value)), 2, dtype=torch.float64, device=x.device)
         p.out_stats = out_stats.data_ptr()
     L.check(lib.mi_conv_fwd(C.byref(p), L.current_stream()), "mi_conv_fwd (training)")
     return (out, out_stats) if want_stats else out
@@ -239,7 +249,7 @@ def _block_bwd(x, da, stats, gamma, beta, groups, eps, ss):
     p.x, p.da, p.x_stats, p.gamma, p.beta = x.data_ptr(), da.data_ptr(), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr()
     if ss is not None:
         p.ss, p.ss_stride, p.ss_off = ss.data_ptr(), ss.shape[1], 0
-    dx_stats = torch.empty(B, Cc, nchunk, 2, dtype=torch.float32, device=x.device)
+    dx_stats = torch.empty(B, Cc, nchunk, 2, dtype=torch.float64, device=x.device)
     p.uv, p.dx, p.dgamma, p.dbeta, p.dss, p.dx_stats = uv.data_ptr(), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), L.ptr(dss), dx_stats.data_ptr()
     L.check(lib.mi_block_bwd(C.byref(p), L.current_stream()), "mi_block_bwd")
     dx._mi_stats = (dx_stats, dx._version)        # the previous Block's backward receives this very tensor as its output gradient

@@ -25,6 +25,12 @@ SKIP_SCALE = 2 ** -0.5  # minimagen/Unet.py:194
 
 
 # ----------------------------------------------------------------------------- small layers
+# The reference computes in fp32 and so does this restatement.  tests/ may set COMPUTE_DTYPE = torch.float64 (with an fp64 state dict and
+# fp64 inputs) to obtain a higher-precision value of the SAME algorithm -- used only to measure how far fp32 arithmetic itself (the
+# reference's, the oracle's, the HIP path's) sits from the exact result on ill-conditioned weights; never for parity gates.
+COMPUTE_DTYPE = torch.float32
+
+
 def _linear(x, sd: SD, p: str):
     return F.linear(x, sd[p + ".weight"], sd.get(p + ".bias"))
 
@@ -37,7 +43,7 @@ def sinusoidal_pos_emb(t: torch.Tensor, dim: int) -> torch.Tensor:
     """minimagen/layers.py:455-465."""
     half = dim // 2
     k = math.log(10000) / (half - 1)
-    freq = torch.exp(torch.arange(half) * -k)
+    freq = torch.exp(torch.arange(half, dtype=COMPUTE_DTYPE) * -k)
     arg = t[:, None] * freq[None, :]          # int64 * fp32 -> fp32
     return torch.cat((arg.sin(), arg.cos()), dim=-1)
 
@@ -81,7 +87,7 @@ def cross_attention(x, context, sd: SD, p: str):
     v = torch.cat((nv, v), dim=-2)
     q = q * (ATTN_DIM_HEAD ** -0.5)
     sim = torch.einsum('bhid,bhjd->bhij', q, k)
-    attn = sim.softmax(dim=-1, dtype=torch.float32)
+    attn = sim.softmax(dim=-1, dtype=COMPUTE_DTYPE)
     out = torch.einsum('bhij,bhjd->bhid', attn, v)
     out = out.permute(0, 2, 1, 3).reshape(b, -1, heads * ATTN_DIM_HEAD)
     out = F.linear(out, sd[p + ".to_out.0.weight"])
@@ -101,7 +107,7 @@ def self_attention(x, sd: SD, p: str):
     k = torch.cat((nk.expand(b, 1, dh), k), dim=-2)
     v = torch.cat((nv.expand(b, 1, dh), v), dim=-2)
     sim = torch.einsum('bhid,bjd->bhij', q, k)
-    attn = sim.softmax(dim=-1, dtype=torch.float32)
+    attn = sim.softmax(dim=-1, dtype=COMPUTE_DTYPE)
     out = torch.einsum('bhij,bjd->bhid', attn, v)
     out = out.permute(0, 2, 1, 3).reshape(b, -1, heads * dh)
     out = F.linear(out, sd[p + ".to_out.0.weight"])

@@ -14,9 +14,9 @@ from tests._backend import BACKENDS, GPU_ONLY, setup
 
 
 def chan_stats(x):
-    st = torch.zeros(x.shape[0], x.shape[1], 1, 2)
-    st[:, :, 0, 0] = x.double().sum((2, 3)).float()
-    st[:, :, 0, 1] = (x.double() ** 2).sum((2, 3)).float()
+    st = torch.zeros(x.shape[0], x.shape[1], 1, 2, dtype=torch.float64)          # fp64 partial (sum, sumsq): include/minimagen_hip.h
+    st[:, :, 0, 0] = x.double().sum((2, 3))
+    st[:, :, 0, 1] = (x.double() ** 2).sum((2, 3))
     return st.contiguous()
 
 
@@ -27,6 +27,8 @@ def tile_nt(lib, cfg, H, W):
 
 
 def check_stats(ost, ref, rtol=1e-5):
+    assert ost.dtype == torch.float64
+    ref = ref.double()
     dims = tuple(range(2, ref.dim()))
     es = (ost[..., 0].sum(-1) - ref.sum(dims)).abs().max().item() / max(ref.abs().sum(dims).max().item(), 1e-6)
     eq = (ost[..., 1].sum(-1) - (ref ** 2).sum(dims)).abs().max().item() / max((ref ** 2).sum(dims).max().item(), 1e-6)
@@ -102,7 +104,7 @@ def test_conv_family(backend, case):
                 p.res1 = L.MiAct(d("r1", r1).data_ptr(), 3, 0, 0, sk, 0)
     nt = tile_nt(lib, cfg, H, W)
     out = torch.full((B, Cout, H, W), float('nan'), device=dev)
-    ost = torch.zeros(B, Cout, nt, 2, device=dev)
+    ost = torch.zeros(B, Cout, nt, 2, dtype=torch.float64, device=dev)
     p.out, p.out_stats, p.tile_cfg = out.data_ptr(), ost.data_ptr(), cfg
     L.check(lib.mi_conv_fwd(C.byref(p), L.current_stream()), "conv")
     assert (out.cpu() - ref).abs().max().item() < 2e-5
@@ -194,7 +196,7 @@ def test_conv_row_paired_path(backend, case):
                 p.res1 = L.MiAct(d("r1", r1).data_ptr(), 16, d("rs1", chan_stats(r1)).data_ptr(), 1, sk, 0)
     nt = tile_nt(lib, cfg, H, W)
     out = torch.full((B, Cout, H, W), float('nan'), device=dev)
-    ost = torch.zeros(B, Cout, nt, 2, device=dev)
+    ost = torch.zeros(B, Cout, nt, 2, dtype=torch.float64, device=dev)
     p.out, p.out_stats, p.tile_cfg = out.data_ptr(), ost.data_ptr(), cfg
     L.check(lib.mi_conv_fwd(C.byref(p), L.current_stream()), "conv rp")
     scale = max(1.0, ref.abs().max().item() / 8.0)          # unit-scale cases: outputs of magnitude ~8
@@ -261,7 +263,7 @@ def test_conv_row_paired_bf16_storage(backend, case):
             p.res1 = L.MiAct(d("r1", r1).data_ptr(), 16, d("rs1", chan_stats(r1.float())).data_ptr(), 1, sk, 0, 1)
     nt = tile_nt(lib, cfg, H, W)
     out = torch.full((B, Cout, H, W), float('nan'), device=dev).to(torch.bfloat16 if ost else torch.float32)
-    ostat = torch.zeros(B, Cout, nt, 2, device=dev)
+    ostat = torch.zeros(B, Cout, nt, 2, dtype=torch.float64, device=dev)
     p.out, p.out_st, p.out_stats, p.tile_cfg = out.data_ptr(), ost, ostat.data_ptr(), cfg | 0x400
     L.check(lib.mi_conv_fwd(C.byref(p), L.current_stream()), "conv rp (bf16 storage)")
     err = (out.cpu().double() - ref).abs()
@@ -305,7 +307,7 @@ def test_conv_row_paired_resampling(backend, case):
     p.w_rp, p.w_rp_exp, p.bias = d("wf", wf).data_ptr(), wexp, d("b", bias).data_ptr()
     nt = tile_nt(lib, cfg, H, W)
     out = torch.full((B, Cout, H, W), float('nan'), device=dev)
-    ost = torch.zeros(B, Cout, nt, 2, device=dev)
+    ost = torch.zeros(B, Cout, nt, 2, dtype=torch.float64, device=dev)
     p.out, p.out_stats, p.tile_cfg = out.data_ptr(), ost.data_ptr(), cfg
     L.check(lib.mi_conv_fwd(C.byref(p), L.current_stream()), "conv rp")
     scale = max(1.0, ref.abs().max().item() / 8.0)
@@ -407,7 +409,7 @@ def test_conv_wide_regime(backend, case):
     p.gn_coef, p.gn_exps = coef.data_ptr(), exps.data_ptr()
     nt = tile_nt(lib, 7, H, W)
     out = torch.full((B, Cout, H, W), float('nan'), device=dev)
-    ost = torch.zeros(B, Cout, nt, 2, device=dev)
+    ost = torch.zeros(B, Cout, nt, 2, dtype=torch.float64, device=dev)
     p.out, p.out_stats, p.tile_cfg = out.data_ptr(), ost.data_ptr(), 7
     L.check(lib.mi_gn_coef_fwd(C.byref(p), L.current_stream()), "gn coef")
     L.check(lib.mi_conv_fwd(C.byref(p), L.current_stream()), "conv wide")
@@ -466,7 +468,7 @@ def test_crossembed(backend, case):
         p.ksize[i], p.cout[i], p.w[i], p.bias[i] = ks[i], cout[i], wp[i].data_ptr(), bd[i].data_ptr()
     nt = tile_nt(lib, cfg, H, W)
     out = torch.full(ref.shape, float('nan'), device=dev)
-    ost = torch.zeros(B, ref.shape[1], nt, 2, device=dev)
+    ost = torch.zeros(B, ref.shape[1], nt, 2, dtype=torch.float64, device=dev)
     p.out, p.out_stats, p.tile_cfg = out.data_ptr(), ost.data_ptr(), cfg
     L.check(lib.mi_crossembed_fwd(C.byref(p), L.current_stream()), "crossembed")
     assert (out.cpu() - ref).abs().max().item() < 2e-5 + 4e-6 * ref.abs().max().item()
@@ -519,7 +521,7 @@ def test_crossembed_matrix_core(backend, case):
         p.addend = addd.data_ptr() if with_add else 0
         nt = tile_nt(lib, cfg, H, W)
         out = torch.full(ref.shape, float('nan'), device=dev)
-        ost = torch.zeros(B, 8, nt, 2, device=dev)
+        ost = torch.zeros(B, 8, nt, 2, dtype=torch.float64, device=dev)
         p.out, p.out_stats, p.tile_cfg = out.data_ptr(), ost.data_ptr(), cfg
         L.check(lib.mi_crossembed_fwd(C.byref(p), L.current_stream()), "crossembed (matrix cores)")
         err = (out.cpu().double() - ref).abs().max().item()
@@ -565,7 +567,7 @@ def test_crossembed_bf16_output(backend, case):
     p.addend = addd.data_ptr() if with_add else 0
     nt = tile_nt(lib, cfg, H, W)
     out = torch.full(ref.shape, float('nan'), device=dev).to(torch.bfloat16)
-    ost = torch.zeros(B, 8, nt, 2, device=dev)
+    ost = torch.zeros(B, 8, nt, 2, dtype=torch.float64, device=dev)
     p.out, p.out_stats, p.out_st, p.tile_cfg = out.data_ptr(), ost.data_ptr(), 1, cfg | 0x400
     L.check(lib.mi_crossembed_fwd(C.byref(p), L.current_stream()), "crossembed (bf16 storage)")
     err = (out.cpu().double() - ref).abs()
@@ -626,7 +628,7 @@ def test_cross_attention_folded(backend, case):
     ap.n2_g, ap.n2_b = sdd["a.to_out.1.gamma"].data_ptr(), sdd["a.to_out.1.beta"].data_ptr()
     nt = -(-HW // (128 if variant in (0, 5) else 64))
     out = torch.full(x.shape, float('nan'), device=dev)
-    ost = torch.zeros(B2, Cc, nt, 2, device=dev)
+    ost = torch.zeros(B2, Cc, nt, 2, dtype=torch.float64, device=dev)
     ap.out, ap.out_stats, ap.variant = out.data_ptr(), ost.data_ptr(), variant
     if variant == 6:
         ap.x_exp, ap.g_exp, ap.v_exp = x_exp, g_exp, v_exp
@@ -677,7 +679,7 @@ def test_cross_attention_bf16_io(backend, case):
     ap.n1_g, ap.n1_b = sdd["a.norm.gamma"].data_ptr(), sdd["a.norm.beta"].data_ptr()
     ap.n2_g, ap.n2_b = sdd["a.to_out.1.gamma"].data_ptr(), sdd["a.to_out.1.beta"].data_ptr()
     out = torch.full(x.shape, float('nan'), device=dev).to(torch.bfloat16)
-    ost = torch.zeros(B2, Cc, -(-HW // 64), 2, device=dev)
+    ost = torch.zeros(B2, Cc, -(-HW // 64), 2, dtype=torch.float64, device=dev)
     ap.out, ap.out_stats, ap.out_st, ap.variant = out.data_ptr(), ost.data_ptr(), 1, 7
     ap.x_exp, ap.g_exp, ap.v_exp = x_exp, g_exp, v_exp
     L.check(lib.mi_cross_attn_fwd(C.byref(ap), L.current_stream()))
@@ -1026,7 +1028,7 @@ def test_tokens_to_nchw(backend, case):
     keep = [t.to(dev).contiguous() for t in (tok, gamma, beta, r)]
     nt = -(-HW // 64)
     out = torch.full((B, Cc, HW), float('nan'), device=dev)
-    ost = torch.full((B, Cc, nt, 2), float('nan'), device=dev)
+    ost = torch.full((B, Cc, nt, 2), float('nan'), dtype=torch.float64, device=dev)
     p = L.MiTokensToNchwParams()
     p.B, p.HW, p.C, p.tokens = B, HW, Cc, keep[0].data_ptr()
     if ln:

@@ -114,3 +114,121 @@ def test_t5_api_surface():
     assert t5.get_encoded_dim("t5_small") == 512 and t5.get_encoded_dim("xxl1.1") == 4096 and t5.MAX_LENGTH == 256
     with pytest.raises(Exception):          # no tokenizer / checkpoint files offline: must fail loudly, never silently stub
         t5.t5_encode_text(["a cat"], name="t5_small")
+
+
+# ---------------------------------------------------------------------- the text front-end (minimagen/t5.py:24-84), offline
+WORDS = "a photo of the cat dog red blue green house tree sitting on under near big small painting oil water color bright dark happy sad bird fish sky sea mountain river".split()
+
+
+def _fabricate_checkpoint(path, ff="relu", seed=0):
+    """A Hugging Face checkpoint DIRECTORY made here, offline: config.json + model.safetensors of a randomised T5EncoderModel (t5-small's width
+    so that it can stand in for 't5_small' / 'small1.1') and the files of a Unigram T5Tokenizer over a small word list."""
+    from transformers import T5Config, T5EncoderModel, T5Tokenizer
+    vocab = [("<pad>", 0.0), ("</s>", 0.0), ("<unk>", 0.0), ("▁", -2.0)] + [("▁" + w, -3.0 - 0.01 * i) for i, w in enumerate(WORDS)] \
+        + [(c, -6.0) for c in "abcdefghijklmnopqrstuvwxyz"]
+    tok = T5Tokenizer(vocab=vocab, extra_ids=0)
+    torch.manual_seed(seed)
+    cfg = T5Config(vocab_size=len(tok), d_model=512, d_kv=64, num_heads=8, d_ff=1024, num_layers=2, feed_forward_proj=ff,
+                   tie_word_embeddings=(ff == "relu"))
+    m = T5EncoderModel(cfg).eval()
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if "layer_norm" in n:
+                p.copy_(1 + 0.2 * torch.randn(p.shape))
+            elif "relative_attention_bias" in n:
+                p.copy_(torch.randn(p.shape))
+            elif "shared" not in n and "embed" not in n:
+                p.mul_(0.5)
+    m.save_pretrained(path)
+    tok.save_pretrained(path)
+    return m, tok
+
+
+def _hf_reference(m, tok, texts, max_length=256):
+    enc = tok(texts, padding='longest', max_length=max_length, truncation=True, return_tensors="pt")
+    with torch.no_grad():
+        ref = m(input_ids=enc.input_ids, attention_mask=enc.attention_mask).last_hidden_state
+    return ref.masked_fill(~enc.attention_mask.bool()[:, :, None], 0.), enc.attention_mask.bool()
+
+
+@pytest.fixture
+def clean_t5_registry():
+    from minimagen_amd import t5 as T
+    saved = {k: dict(v) for k, v in T.T5_VERSIONS.items()}
+    T._embed_cache_clear()
+    yield T
+    T.T5_VERSIONS.clear()
+    T.T5_VERSIONS.update(saved)
+    T._embed_cache_clear()
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_text_front_end_from_local_checkpoints(backend, tmp_path, monkeypatch, clean_t5_registry):
+    """t5_encode_text(list[str]) end to end without a network: checkpoint directories under $MINIMAGEN_T5_DIR are read directly
+    (T5EncoderHIP.from_directory: config.json + safetensors, no from_pretrained / hub call), the tokenizer comes from the same directory;
+    original (ReLU, tied embedding) and v1.1 (gated-GELU, untied) checkpoints; values against transformers' own forward of the same
+    checkpoint and tokenizer (minimagen/t5.py:63-84); the caption cache returns the very same bits."""
+    T = clean_t5_registry
+    dev = setup(backend)
+    m0, tok0 = _fabricate_checkpoint(str(tmp_path / "t5-small"), "relu", seed=0)
+    m1, tok1 = _fabricate_checkpoint(str(tmp_path / "google--t5-v1_1-small"), "gated-gelu", seed=1)
+    monkeypatch.setenv(T.T5_LOCAL_DIR_ENV, str(tmp_path))
+    monkeypatch.setattr("huggingface_hub.snapshot_download", lambda *a, **k: (_ for _ in ()).throw(AssertionError("hub call")), raising=False)
+    texts = ["a photo of the cat", "big red house near the sea under dark sky", "oil painting of a happy zebra fish on the mountain river near a small tree"]
+    for name, m, tok in (("t5_small", m0, tok0), ("small1.1", m1, tok1)):
+        for v in ("model", "tokenizer"):
+            T.T5_VERSIONS[name][v] = None
+        emb, mask = T.t5_encode_text(texts, name=name)
+        ref, rmask = _hf_reference(m, tok, texts)
+        assert emb.shape == ref.shape and torch.equal(mask.cpu(), rmask)
+        d = (emb.cpu() - ref).abs()
+        assert d.max() < 2e-4 and d.mean() < 2e-5, (name, d.max(), d.mean())
+        assert isinstance(T.T5_VERSIONS[name]["model"], T.T5EncoderHIP) and T.T5_VERSIONS[name]["model"].gated == (name == "small1.1")
+        # the caption cache: same captions again -> no encoder launch, the very same bits; a re-ordered, differently padded batch with one new
+        # caption -> cached and fresh rows agree with a cold encode of that batch to fp32 rounding (the block-scaled GEMM shares one
+        # power-of-two scale among the 64 rows of a tile, so the last bits of a row depend on its batch neighbours)
+        h0 = T.t5_cache_stats["hits"]
+        emb2, _ = T.t5_encode_text(texts, name=name)
+        assert T.t5_cache_stats["hits"] == h0 + 3 and torch.equal(emb2, emb)
+        mixed = [texts[1], "the dog", texts[0]]
+        warm, wmask = T.t5_encode_text(mixed, name=name)
+        T._embed_cache_clear()
+        cold, cmask = T.t5_encode_text(mixed, name=name)
+        assert torch.equal(wmask, cmask) and (warm - cold).abs().max() < 2e-5
+        direct, _ = T.T5_VERSIONS[name]["model"].encode(*[t.to(dev) for t in T._tokenize(tok, mixed, 256)])
+        assert (direct - cold).abs().max() < 2e-5                # ... and with the uncached encoder call
+    # max_length truncation (t5.py:65-66) and a caller-supplied tokenizer callable
+    emb_t, mask_t = T.t5_encode_text(texts, name="t5_small", max_length=6)
+    ref_t, rmask_t = _hf_reference(m0, tok0, texts, max_length=6)
+    assert emb_t.shape[1] == 6 and torch.equal(mask_t.cpu(), rmask_t) and (emb_t.cpu() - ref_t).abs().max() < 2e-4
+
+    def my_tok(caps, max_length):
+        e = tok0(caps, padding='longest', max_length=max_length, truncation=True, return_tensors="pt")
+        return e.input_ids, e.attention_mask
+    emb_c, _ = T.t5_encode_text(texts, name="t5_small", tokenizer=my_tok)
+    assert (emb_c - T.t5_encode_text(texts, name="t5_small")[0]).abs().max() < 2e-5
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_imagen_sample_from_captions(backend, tmp_path, monkeypatch, clean_t5_registry):
+    """Imagen.sample(texts=[...]) -- the reference's caption entry point (Imagen.py:455-458 -> t5.py:31-84) -- end to end on the device path,
+    against the oracle fed with transformers' embeddings of the same captions"""
+    from minimagen_amd.Imagen import Imagen
+    from minimagen_amd.Unet import Unet
+    from oracle import restated as R
+    T = clean_t5_registry
+    dev = setup(backend)
+    m0, tok0 = _fabricate_checkpoint(str(tmp_path / "t5-small"), "relu", seed=3)
+    T.register_t5("t5_small", model_dir=str(tmp_path / "t5-small"), tokenizer=tok0, device=dev)
+    torch.manual_seed(5)
+    kw = dict(dim=8, dim_mults=(1, 2), num_resnet_blocks=1, layer_attns=False, layer_cross_attns=(False, True), memory_efficient=False)
+    im = Imagen([Unet(**kw)], text_encoder_name="t5_small", image_sizes=[32], timesteps=25, cond_drop_prob=0.15)
+    sd = {k: v.clone() for k, v in im.unets[0].state_dict().items()}
+    im = im.to(dev)
+    texts = ["a photo of the cat", "big red house near the sea under dark sky"]
+    out = im.sample(texts=texts, cond_scale=2., _noise=R.make_randn(9))
+    ref_emb, ref_mask = _hf_reference(m0, tok0, texts)
+    ref = R.sample([sd], [32], 25, text_embeds=ref_emb, text_masks=ref_mask, cond_scale=2., randn=R.make_randn(9))
+    d = (out.cpu() - ref).abs()
+    print(f"Imagen.sample(texts=...) 32x32 T=25 vs oracle on transformers' embeddings: max|d| = {d.max():.2e}")
+    assert out.shape == (2, 3, 32, 32) and d.max() < 2e-4 and d.mean() < 2e-5, (d.max(), d.mean())

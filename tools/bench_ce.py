@@ -33,7 +33,7 @@ th, tw = C.c_int(), C.c_int()
 lib.mi_conv_tile_shape(cfg, C.byref(th), C.byref(tw))
 nt = -(-H // th.value) * -(-W // tw.value)
 out = torch.empty(B, 8, H, W, device=dev)
-ost = torch.zeros(B, 8, nt, 2, device=dev)
+ost = torch.zeros(B, 8, nt, 2, dtype=torch.float64, device=dev)
 p.out, p.out_stats, p.tile_cfg, p.addend = out.data_ptr(), ost.data_ptr(), cfg | (0x400 if half else 0), add.data_ptr()
 st = L.current_stream()
 for _ in range(3):

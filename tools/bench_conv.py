@@ -24,7 +24,7 @@ def run(B, C0, Cout, H, W, gn, res, path, C1=0, reps=20, nt_in=None):
     nt_in = nt_in or max(1, (H // 16) * (W // 64))
 
     def stats(x):
-        st = torch.zeros(x.shape[0], x.shape[1], nt_in, 2, device=dev)
+        st = torch.zeros(x.shape[0], x.shape[1], nt_in, 2, dtype=torch.float64, device=dev)
         st[:, :, 0, 0] = x.sum((2, 3)); st[:, :, 0, 1] = (x * x).sum((2, 3))
         return st
     s0, s1 = stats(x0), (stats(x1) if C1 else None)
@@ -67,7 +67,7 @@ def run(B, C0, Cout, H, W, gn, res, path, C1=0, reps=20, nt_in=None):
     lib.mi_conv_tile_shape(cfg & 0xff, C.byref(th), C.byref(tw))
     nt = -(-H // th.value) * -(-W // tw.value)
     out = torch.empty(B, Cout, H, W, device=dev)
-    ost = torch.zeros(B, Cout, nt, 2, device=dev)
+    ost = torch.zeros(B, Cout, nt, 2, dtype=torch.float64, device=dev)
     p.out, p.out_stats, p.tile_cfg = out.data_ptr(), ost.data_ptr(), cfg
     st = L.current_stream()
     for _ in range(3):

@@ -38,12 +38,14 @@ struct dim3 {
 struct hipemu_uint3 { unsigned x, y, z; };
 
 struct alignas(8) float2 { float x, y; };
+struct alignas(16) double2 { double x, y; };
 struct alignas(16) float4 { float x, y, z, w; };
 struct alignas(8) int2 { int x, y; };
 struct alignas(16) int4 { int x, y, z, w; };
 struct alignas(8) uint2 { unsigned x, y; };
 struct alignas(16) uint4 { unsigned x, y, z, w; };
 static inline float2 make_float2(float x, float y) { return {x, y}; }
+static inline double2 make_double2(double x, double y) { return {x, y}; }
 static inline float4 make_float4(float x, float y, float z, float w) { return {x, y, z, w}; }
 static inline int2 make_int2(int x, int y) { return {x, y}; }
 static inline uint2 make_uint2(unsigned x, unsigned y) { return {x, y}; }
