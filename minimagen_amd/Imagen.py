@@ -400,16 +400,15 @@ class Imagen(nn.Module):
         # wait, so the (small, latency-bound) base stage of call k + 1 runs on its stream while the super-resolution stage of call k
         # still occupies the other -- each stage owns its workspace, so nothing is shared but the finished image handed down the cascade.
         on_gpu = L.backend() == "hip-gfx950"
-        # Packed-weight validation, once per call on the caller's stream.  Identity (pointers, version counters) is checked here; the content
-        # fingerprint's verdict is read AFTER this call's work is enqueued (engine.pack_begin): with the wait in front, a synchronous call
-        # kept the host behind the whole previous call and the GPU idle for the host's launch time.  A rare positive verdict discards the
-        # enqueued work and runs the call again on fresh packs.  Injected noise (a stateful host generator) keeps the up-front check.
-        if _noise is not None or _revalidated:
-            for unet in self.unets:
+        # Packed-weight validation, once per call.  Identity (pointers, version counters: host only) up front; the content fingerprint -- device
+        # work on the caller's stream + one small device -> host copy -- is launched and read AFTER this call's work is enqueued (see
+        # engine.pack_identity).  A rare positive verdict discards the enqueued work and runs the call again on fresh packs.  Injected noise
+        # (a stateful host generator: the call cannot be repeated) keeps the whole check up front.
+        for unet in self.unets:
+            if _noise is not None or _revalidated:
                 unet.engine().pack()
-            pack_tokens = []
-        else:
-            pack_tokens = [(unet.engine(), unet.engine().pack_begin()) for unet in self.unets]
+            else:
+                unet.engine().pack_identity()
         # LANES: asynchronous calls alternate between SAMPLE_LANES independent sets of (stage streams, workspaces, graphs), so that two
         # calls are in flight side by side -- the kernels of one call's stages fill the launch floors and tails of the other's (measured:
         # 42.8 K vs 37.7 K steps/s for the B = 32 cascade).  Calls on one lane stay ordered by its streams; lanes share
@@ -482,6 +481,7 @@ class Imagen(nn.Module):
                                           stage=stage, use_graph=_use_graph, begun=begun.get(stage))
                 if on_gpu:
                     prev_done = streams[stage].record_event()
+        pack_tokens = [] if (_noise is not None or _revalidated) else [(unet.engine(), unet.engine().pack_begin()) for unet in self.unets]
         if any(eng.pack_changed(tok) for eng, tok in pack_tokens):
             # the weights' values had changed behind the version counters (p.data updates): what was enqueued ran on stale packs
             if on_gpu:

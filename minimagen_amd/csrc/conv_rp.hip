@@ -546,10 +546,9 @@ __global__ __launch_bounds__(256, CFG::WPS) void conv_rp_kernel(const mi_conv_pa
         const float unscale = ldexpf(1.0f, -sExp[2]);
         // statistics of the output about a per-channel shift (the first value of the channel's first lane): common.hip.h mi_stat_acc
         float csum[NJ], csq[NJ], cshift[NJ];
-        int ccnt[NJ];
 #pragma unroll
         for (int jt = 0; jt < NJ; ++jt) {
-            csum[jt] = 0.f; csq[jt] = 0.f; ccnt[jt] = 0;
+            csum[jt] = 0.f; csq[jt] = 0.f;
             const int co = MODE == 2 ? 16 * (jt0 + jt) + lq : 8 * (jt0 + jt) + (lq & 7);
             const int dy = MODE == 2 ? 0 : lq >> 3;
             const float bv = bvv[jt];
@@ -588,18 +587,26 @@ __global__ __launch_bounds__(256, CFG::WPS) void conv_rp_kernel(const mi_conv_pa
                 const float d0 = y.x - cs_, d1 = y.y - cs_, d2 = y.z - cs_, d3 = y.w - cs_;
                 csum[jt] += ok ? (d0 + d1) + (d2 + d3) : 0.0f;
                 csq[jt] += ok ? fmaf(d0, d0, fmaf(d1, d1, fmaf(d2, d2, d3 * d3))) : 0.0f;
-                ccnt[jt] += ok ? 4 : 0;
             }
         }
         RP_TFINE(11);
         if (p.out_stats) {
+            // pixels of this tile the wave's groups cover inside the image (wave-uniform; the same for every channel)
+            int wcnt = 0;
+#pragma unroll
+            for (int g = 0; g < GPW; ++g) {
+                const int G = wave * GPW + g, gyy = G / GX, gxx = G % GX;
+                const int wx = W - (ox0 + 16 * gxx), nx = wx < 0 ? 0 : (wx > 16 ? 16 : wx);
+                const int ny = MODE == 2 ? (oy0 + gyy < H ? 1 : 0) : ((oy0 + 2 * gyy < H ? 1 : 0) + (oy0 + 2 * gyy + 1 < H ? 1 : 0));
+                wcnt += nx * ny;
+            }
 #pragma unroll
             for (int jt = 0; jt < NJ; ++jt) {
-                if (MODE != 2) { csum[jt] += __shfl_xor(csum[jt], 8); csq[jt] += __shfl_xor(csq[jt], 8); ccnt[jt] += __shfl_xor(ccnt[jt], 8); }
-                csum[jt] += __shfl_xor(csum[jt], 16); csq[jt] += __shfl_xor(csq[jt], 16); ccnt[jt] += __shfl_xor(ccnt[jt], 16);
-                csum[jt] += __shfl_xor(csum[jt], 32); csq[jt] += __shfl_xor(csq[jt], 32); ccnt[jt] += __shfl_xor(ccnt[jt], 32);
+                if (MODE != 2) { csum[jt] += __shfl_xor(csum[jt], 8); csq[jt] += __shfl_xor(csq[jt], 8); }
+                csum[jt] += __shfl_xor(csum[jt], 16); csq[jt] += __shfl_xor(csq[jt], 16);
+                csum[jt] += __shfl_xor(csum[jt], 32); csq[jt] += __shfl_xor(csq[jt], 32);
                 if (lane < CPT) {
-                    mi_stat_acc a; a.c = cshift[jt]; a.s = csum[jt]; a.q = csq[jt]; a.n = ccnt[jt];
+                    mi_stat_acc a; a.c = cshift[jt]; a.s = csum[jt]; a.q = csq[jt]; a.n = wcnt;
                     mi_stat_finish(a, red[wave][2 * (CPT * jt + lane)], red[wave][2 * (CPT * jt + lane) + 1]);
                 }
             }

@@ -405,9 +405,15 @@ __global__ __launch_bounds__(256, 2) void crossembed_mfma_kernel(const mi_crosse
     CE_TPHASE(2);
 
     // ---- epilogue: lane (lq = 8 co2 + dy, lg) holds pixels 4 lg .. 4 lg + 3 of output row dy, channel 2 t + co2 of every group
-    // statistics about a per-channel shift (the first value of the channel's first lane): common.hip.h mi_stat_acc
-    float ssum[4], ssq[4], sshift[4];
-    int scnt[4];
+    // statistics about a per-channel shift (the first value of the channel's first lane): common.hip.h mi_stat_acc; reduced per N tile
+    // right away (nothing kept across the loop); the pixel count is wave-uniform geometry
+    int wcnt = 0;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const int gi = wave * G + g, gyy = gi / GX, gxx = gi % GX;
+        const int wy = H - (oy0 + 8 * gyy), wx = W - (ox0 + 16 * gxx);
+        wcnt += (wy < 0 ? 0 : (wy > 8 ? 8 : wy)) * (wx < 0 ? 0 : (wx > 16 ? 16 : wx));
+    }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int k = t < 2 ? 0 : t - 1;                                   // conv of this N tile
@@ -416,8 +422,8 @@ __global__ __launch_bounds__(256, 2) void crossembed_mfma_kernel(const mi_crosse
         const float* bp = p.bias[k];
         const float bv = bp ? bp[t == 1 ? 2 + co2 : co2] : 0.0f;
         float s = 0.0f, q2 = 0.0f;
-        int cn = 0;
-        const float sh = __shfl(fmaf(acc[0][t][0], us, bv) + (p.addend ? addv[0][t].x : 0.0f), 8 * co2);
+        float sh = 0.0f;
+        if (p.out_stats) sh = __shfl(fmaf(acc[0][t][0], us, bv) + (p.addend ? addv[0][t].x : 0.0f), 8 * co2);
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             const int gi = wave * G + g, gyy = gi / GX, gxx = gi % GX;
@@ -432,25 +438,20 @@ __global__ __launch_bounds__(256, 2) void crossembed_mfma_kernel(const mi_crosse
                 const float d0 = y.x - sh, d1 = y.y - sh, d2 = y.z - sh, d3 = y.w - sh;
                 s += (d0 + d1) + (d2 + d3);
                 q2 += fmaf(d0, d0, fmaf(d1, d1, fmaf(d2, d2, d3 * d3)));
-                cn += 4;
             }
         }
-        ssum[t] = s; ssq[t] = q2; sshift[t] = sh; scnt[t] = cn;
-    }
-    if (p.out_stats) {
+        if (p.out_stats) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            float s = ssum[t], q2 = ssq[t];
-            int cn = scnt[t];
-#pragma unroll
-            for (int o = 1; o <= 4; o <<= 1) { s += __shfl_xor(s, o); q2 += __shfl_xor(q2, o); cn += __shfl_xor(cn, o); }
-            s += __shfl_xor(s, 16); q2 += __shfl_xor(q2, 16); cn += __shfl_xor(cn, 16);
-            s += __shfl_xor(s, 32); q2 += __shfl_xor(q2, 32); cn += __shfl_xor(cn, 32);
+            for (int o = 1; o <= 4; o <<= 1) { s += __shfl_xor(s, o); q2 += __shfl_xor(q2, o); }
+            s += __shfl_xor(s, 16); q2 += __shfl_xor(q2, 16);
+            s += __shfl_xor(s, 32); q2 += __shfl_xor(q2, 32);
             if (dy == 0 && lg == 0) {
-                mi_stat_acc a; a.c = sshift[t]; a.s = s; a.q = q2; a.n = cn;
+                mi_stat_acc a; a.c = sh; a.s = s; a.q = q2; a.n = wcnt;
                 mi_stat_finish(a, red[wave][2 * (2 * t + co2)], red[wave][2 * (2 * t + co2) + 1]);
             }
         }
+    }
+    if (p.out_stats) {
         __syncthreads();
         if (tid < 16) p.out_stats[((size_t)(b * 8 + (tid >> 1)) * gridDim.x + tile) * 2 + (tid & 1)] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
     }

@@ -459,8 +459,8 @@ inline int grid_for(long long n, int cap = 2048) {
 // start -- does the same without waiting.  So a launch that could not complete never leaves a stale or half-written image behind: the
 // image (and everything sampled from it) is NaN, which the reference's own pipeline would return for a NaN state as well, and the host
 // raises at its next status poll (Imagen: the word is copied to pinned host memory at the end of every call) and re-zeroes the buffer.
-// Header of `sync`: [0] u64 ticket | [8] u32 error | [12] u32 spin limit (0: SG_SPIN_LIMIT) | [16] u32 fault injection (tests only:
-// 1 = workgroup 1 of image 0 never arrives at radix pass 1).
+// Header of `sync`: [0] u64 ticket | [8] u32 error | [12] u32 knobs: bits 0..30 spin limit (0: SG_SPIN_LIMIT), bit 31 fault injection (tests
+// only: workgroup 1 of image 0 never arrives at radix pass 1) -- error and knobs are ONE 8-byte load, in flight with the ticket atomic.
 constexpr int SG_NT = 1024, SG_MAXQ = 6;
 constexpr unsigned SG_SPIN_LIMIT = 1u << 22;
 struct sg_layout { long long counters, hist, total; };
@@ -483,11 +483,12 @@ __global__ __launch_bounds__(SG_NT) void sampler_group_kernel(const mi_cfg_x0_pa
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = c.n, nq = n >> 2;
     unsigned* const errw = reinterpret_cast<unsigned*>(sync + 8);
     if (tid == 0) {
+        const mi_u64 hdr = mi_agent_load_u64(reinterpret_cast<const mi_u64*>(sync + 8));      // error | knobs
         sTicket = mi_agent_add_u64(reinterpret_cast<mi_u64*>(sync), 1ull);
-        sAbort = mi_agent_load_u32(errw) != 0u;                 // an earlier launch on this buffer failed: fail-stop, see above
-        const unsigned lim = mi_agent_load_u32(reinterpret_cast<const unsigned*>(sync + 12));
+        sAbort = (unsigned)hdr != 0u;                           // an earlier launch on this buffer failed: fail-stop, see above
+        const unsigned knobs = (unsigned)(hdr >> 32), lim = knobs & 0x7fffffffu;
         sLimit = lim ? lim : SG_SPIN_LIMIT;
-        sFault = mi_agent_load_u32(reinterpret_cast<const unsigned*>(sync + 16));
+        sFault = knobs >> 31;
         nan_sh = 0u;
     }
     for (int i = tid; i < 2 * MI_Q_BINS; i += SG_NT) (&lh[0][0])[i] = 0u;

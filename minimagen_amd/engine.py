@@ -106,14 +106,21 @@ class UnetEngine:
     # ------------------------------------------------------------------ weights
     def _param_key(self):
         """Identity of the weights the packed copies were derived from: device, every tensor's storage pointer and version counter."""
-        u = self.unet
-        ts = list(u.parameters()) + list(u.buffers())
+        ts = self._tensors()
         return (str(ts[0].device), tuple(t.data_ptr() for t in ts), sum(t._version for t in ts))
+
+    def _tensors(self):
+        """every parameter and buffer of the U-Net (the module tree is walked once; nn.Module._apply / load_state_dict re-home tensors
+        through Unet._apply -> invalidate(), which drops this list)"""
+        ts = self.__dict__.get("_tensor_list")
+        if ts is None:
+            ts = self._tensor_list = list(self.unet.parameters()) + list(self.unet.buffers())
+        return ts
 
     def _fingerprint(self):
         """Cheap content fingerprint (L1 and L2 norm of every parameter, two fused multi-tensor launches): in-place updates through
         ``p.data`` (EMA, ``.data.copy_``) do not bump ``p._version``, so identity alone would leave the packed copies stale."""
-        ts = [t.detach() for t in list(self.unet.parameters()) + list(self.unet.buffers()) if t.is_floating_point()]
+        ts = [t.detach() for t in self._tensors() if t.is_floating_point()]
         return torch.stack(torch._foreach_norm(ts, 1) + torch._foreach_norm(ts, 2))
 
     def invalidate(self):
@@ -123,6 +130,7 @@ class UnetEngine:
             _close_workspace(ws)
         self._ws = {}
         self._pack = self._pack_key = self._pack_fp = None
+        self.__dict__.pop("_tensor_list", None)
 
     def _check_params(self):
         for name, t in list(self.unet.named_parameters()) + list(self.unet.named_buffers()):
@@ -149,15 +157,26 @@ class UnetEngine:
                 return self._pack
         return self._repack(key, fp)
 
-    def pack_begin(self):
-        """First half of the deferred validation: identity is checked at once (a changed key re-packs right here); the content fingerprint
-        is launched and its comparison with the packed state goes to pinned host memory WITHOUT a host wait.  Returns a token for
-        pack_changed(), or None when nothing is pending.  The caller enqueues its work on the assumption that the values are unchanged and
-        asks pack_changed() afterwards: the host wait then sits BEHIND the enqueued work instead of in front of it (a synchronous sample()
-        made the host wait for the whole previous call before it could enqueue anything: the GPU idled for the host's launch time)."""
-        key = self._param_key()
-        if self._pack is None or key != self._pack_key or not WEIGHT_FINGERPRINT:
+    def pack_identity(self):
+        """Host-only half of the validation (storage pointers + version counters: what every optimiser step, load_state_dict and .to()
+        change): re-packs right here when it fails.  Imagen.sample() calls it up front and runs the content fingerprint (pack_begin /
+        pack_changed) BEHIND the work it enqueues: with the fingerprint in front, a synchronous call kept the host behind the whole
+        previous call (one device -> host comparison on the caller's stream) and the GPU idle for the host's ~2 ms of list walking and
+        launch time (profiles/r05_sync_call_gaps.txt)."""
+        if self._pack is None or self._param_key() != self._pack_key:
             self.pack()
+
+    def pack_begin(self):
+        """Launch the content fingerprint; its comparison with the packed state goes to pinned host memory WITHOUT a host wait.  Returns a
+        token for pack_changed(), or None when there is nothing to compare (MINIMAGEN_WEIGHT_FINGERPRINT=0).  Call after pack_identity()."""
+        # (the module tree is walked HERE, where the host has slack: a parameter object replaced since the list was cached -- module.weight =
+        # nn.Parameter(...) -- counts as a change)
+        fresh = list(self.unet.parameters()) + list(self.unet.buffers())
+        cached = self._tensors()
+        if len(fresh) != len(cached) or any(a is not b for a, b in zip(fresh, cached)):
+            self.__dict__.pop("_tensor_list", None)
+            return (None, None, None)
+        if not WEIGHT_FINGERPRINT or self._pack is None or self._pack_fp is None:
             return None
         fp = self._fingerprint()
         flag = self.__dict__.get("_fp_flag")
@@ -173,6 +192,8 @@ class UnetEngine:
         if token is None:
             return False
         flag, ev, _ = token
+        if flag is None:
+            return True
         if ev is not None:
             ev.synchronize()
         return bool(flag.item())

@@ -461,8 +461,8 @@ def test_grouped_sampler_tail_in_the_sampling_loop(backend, monkeypatch):
 
 @pytest.mark.parametrize("backend", BACKENDS)
 def test_grouped_sampler_tail_failure_is_loud_and_self_healing(backend):
-    """A cooperative launch that cannot complete must never hand back a plausible image.  Fault injection (sync header word 16: workgroup 1
-    of image 0 skips one arrival) + a short spin limit (word 12) make the grouped tail of the NEXT call time out:
+    """A cooperative launch that cannot complete must never hand back a plausible image.  Fault injection (sync header word 12, bit 31:
+    workgroup 1 of image 0 skips one arrival) + a short spin limit (its low bits) make the grouped tail of the NEXT call time out:
       * the tensor-returning sample() of that call yields NaN images (fail-stop: every workgroup that sees the sticky word poisons its part),
       * the next API entry -- sample() itself, wait_pending_samples() or check_device_status() -- raises MinImagenHipError,
       * after the exception the stage has re-zeroed its sync words and runs the separate kernels: the following call is bit-identical to
@@ -478,8 +478,8 @@ def test_grouped_sampler_tail_failure_is_loud_and_self_healing(backend):
     assert good.isfinite().all()
     st = next(v for ws in im.unets[0].engine()._ws.values() for v in ws.sampler_state.values() if hasattr(v, "group_sync"))
     assert L.lib().mi_sampler_group_size(3 * S * S) == 2
-    knobs = torch.tensor([2000, 1], dtype=torch.int32).view(torch.uint8)           # spin limit, fault injection
-    st.group_sync[12:20] = knobs.to(st.group_sync.device)
+    knobs = torch.tensor([2000 - 2 ** 31], dtype=torch.int32).view(torch.uint8)    # spin limit 2000 | bit 31: fault injection
+    st.group_sync[12:16] = knobs.to(st.group_sync.device)
     bad = im.sample(**args)                                   # returns (the check is deferred) ...
     if backend == "gpu":
         torch.cuda.synchronize()
@@ -494,12 +494,37 @@ def test_grouped_sampler_tail_failure_is_loud_and_self_healing(backend):
     im2 = Imagen([Unet(**kw)], text_encoder_name="t5_small", image_sizes=[S], timesteps=T, cond_drop_prob=0.15).to(dev)
     im2.sample(**args)
     st2 = next(v for ws in im2.unets[0].engine()._ws.values() for v in ws.sampler_state.values() if hasattr(v, "group_sync"))
-    st2.group_sync[12:20] = knobs.to(st2.group_sync.device)
+    st2.group_sync[12:16] = knobs.to(st2.group_sync.device)
     im2.sample(**args)
     with pytest.raises(L.MinImagenHipError, match="timed out"):
         im2.check_device_status()
     im2.check_device_status()                                 # reported once; the stage has fallen back
     assert im2.sample(**args).isfinite().all()
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_sample_notices_weight_updates_made_through_data(backend):
+    """sample() validates the packed weights with a DEFERRED content-fingerprint check (engine.pack_begin / pack_changed: the verdict is read
+    after the call's work is enqueued).  A ``p.data`` update between two calls bumps no version counter; the second call must still return
+    the images of the NEW weights (it discards what it enqueued on the stale packs and runs again)."""
+    dev = setup(backend)
+    torch.manual_seed(4)
+    kw = dict(dim=8, dim_mults=(1, 2), num_resnet_blocks=1, layer_attns=False, layer_cross_attns=False, memory_efficient=True)
+    im = Imagen([Unet(**kw)], text_encoder_name="t5_small", image_sizes=[32], timesteps=25, cond_drop_prob=0.15).to(dev)
+    emb, mask = R.synthetic_text(2, length=10, seed=3)
+    args = dict(text_embeds=emb.to(dev), text_masks=mask.to(dev), cond_scale=2., _seed=11)
+    a = im.sample(**args).clone()
+    with torch.no_grad():
+        for name, prm in im.unets[0].named_parameters():
+            if name.endswith("final_conv.weight") or "init_conv" in name:
+                prm.data.mul_(1.25)                          # no version bump
+    b = im.sample(**args).clone()
+    assert not torch.equal(a, b)
+    im2 = Imagen([Unet(**kw)], text_encoder_name="t5_small", image_sizes=[32], timesteps=25, cond_drop_prob=0.15)
+    im2.unets[0].load_state_dict({k: v.detach().cpu() for k, v in im.unets[0].state_dict().items()})
+    im2 = im2.to(dev)
+    assert torch.equal(im2.sample(**args), b)
+    assert torch.equal(im.sample(**args), b)                 # and the steady state stays on the new packs
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
