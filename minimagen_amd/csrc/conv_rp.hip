@@ -832,7 +832,7 @@ __global__ __launch_bounds__(256, 2) void conv_rp_dma_kernel(const mi_conv_param
             for (int g = 0; g < GPW; ++g) {
                 const int G = wave * GPW + g, gyy = G / GX, gxx = G % GX;
                 const int oy = oy0 + 2 * gyy + dy, ox = ox0 + 16 * gxx + 4 * lg;
-                const float* r = rbase + ((size_t)(co < p.Cout ? co : 0) * H + oy) * W + ox;
+                const float* r = (RP_ABL & 128) ? rbase + ((size_t)(tile * 4 + wave) * GPW + g) * 256 + lane * 4 : rbase + ((size_t)(co < p.Cout ? co : 0) * H + oy) * W + ox;
 #if defined(HIPEMU)
                 memcpy(&rv[g], r, 16);
 #else
@@ -889,6 +889,9 @@ __global__ __launch_bounds__(256, 2) void conv_rp_dma_kernel(const mi_conv_param
             const int G = wave * GPW + g, gyy = G / GX, gxx = G % GX;
             const int oy = oy0 + 2 * gyy + dy, ox = ox0 + 16 * gxx + 4 * lg;
             const float4 y = yv[g];
+            if (RP_ABL & 64) {        // timing only: the same bytes as whole 1 KB rows per instruction (wrong places inside the image's output)
+                *reinterpret_cast<mi_gptr<f32x4>>(mi_global(obase + ((size_t)(tile * 4 + wave) * GPW + g) * 256 + lane * 4)) = (f32x4){y.x, y.y, y.z, y.w};
+            } else
             if (co < p.Cout && (!(RP_ABL & 4) || y.x == 12345.f)) *reinterpret_cast<mi_gptr<f32x4>>(mi_global(obase + ((size_t)co * H + oy) * W + ox)) = (f32x4){y.x, y.y, y.z, y.w};
             const float d0 = y.x - cs_, d1 = y.y - cs_, d2 = y.z - cs_, d3 = y.w - cs_;
             csum += (d0 + d1) + (d2 + d3);

@@ -12,7 +12,7 @@ run() { # name lib cfgx
 : > $OUT/ablation.txt
 run "register form (product)" $ROOTDIR/minimagen_amd/libminimagen_hip.so 0
 run "LDS-DMA form (product build)" $ROOTDIR/minimagen_amd/libminimagen_hip.so 0x10000
-for n in 1 2 4 8 16 32 18 63; do
+for n in ${ABLS:-1 2 4 8 16 32 18 63}; do
   run "LDS-DMA form, RP_ABL=$n" $ROOTDIR/minimagen_amd/libminimagen_hip_abl$n.so 0x10000
 done
 cat $OUT/ablation.txt
