@@ -120,7 +120,11 @@ struct RpCfg {
     static constexpr int NSTEP = MODE_ == 2 ? 4 : 3;
     // waves per SIMD the register allocation leaves room for: 4 where that needs no spills (a spill is a counted memory operation:
     // its s_waitcnt also waits for the prefetch), else 3
-    static constexpr int WPS = (NJ_ == 1 && TH_ * TW_ <= 512 && (KO_ + RO_ == 1 || TH_ * TW_ <= 256)) ? 4 : 3;
+    // ... two for the 16-output-channel members on 8 x 64 tiles: at three they keep 168 registers and spill 21 (every spill reload's
+    // s_waitcnt also waits for the prefetch); their launches at 64^2 are one round of <= 2 workgroups per CU anyway.  Measured, same box,
+    // back to back: the 17 conv launches of the SR U-Net's 64^2 level 423 -> 383 us, SR step 1.461 -> 1.425 ms (profiles/r05_summary.md)
+    // (the wide regime's four-N-tile kernels also spill at three, 39 registers, but measured no better at two: 32.9 vs 32.5 ms per step of Unet())
+    static constexpr int WPS = (NJ_ == 1 && TH_ * TW_ <= 512 && (KO_ + RO_ == 1 || TH_ * TW_ <= 256)) ? 4 : ((NJ_ == 2 && TH_ * TW_ == 512 && !WIDE_) ? 2 : 3);
 };
 
 template <class CFG>
@@ -565,7 +569,11 @@ __global__ __launch_bounds__(256, CFG::WPS) void conv_rp_kernel(const mi_conv_pa
                 yv[g] = y;
             }
             RP_TFINE(10);
+#ifdef MI_STATS_PLAIN      // timing A/B only: statistics about zero (the fp32 sums of round 4)
+            const float cs_ = 0.0f;
+#else
             const float cs_ = __shfl(yv[0].x, MODE == 2 ? lq : (lq & 7));
+#endif
             cshift[jt] = cs_;
 #pragma unroll
             for (int g = 0; g < GPW; ++g) {          // ... then the (edge-masked) stores, which need no wait
@@ -623,298 +631,6 @@ __global__ __launch_bounds__(256, CFG::WPS) void conv_rp_kernel(const mi_conv_pa
     RP_TEND();
 }
 
-
-// ------------------------------------------------------------------ LDS-DMA form of the 8 -> <= 8 channel, 3x3 stride-1 member (8 x 64 tiles)
-// Same arithmetic, same tile grid, same statistics partition as conv_rp_kernel<RpCfg<8, 64, 1, GN, false, 0, 1, 0>> -- bit-identical
-// results -- but the raw fp32 planes of a tile do not pass through registers: every wave copies its share of the tile's aligned window
-// global -> LDS with global_load_lds_dwordx4 (16 bytes per lane, 1 KB per instruction: 6 instructions per wave and tile instead of 24
-// dword loads per work-item), into a DOUBLE buffer that runs two tiles ahead of the transform.  The loads cost no VGPRs and almost no
-// issue slots in the computing waves: the phase trace of the register form had 45 % of a workgroup's life in
-// blocked vector-memory issue.  The transform (GroupNorm affine + SiLU + fp16 split) reads the planes back from LDS (8 conflict-free
-// ds_read_b32 per pixel) and writes the operand chunks as before.  Full tiles only (H % 8 == 0, W % 64 == 0): every wave issues the
-// same number of vector-memory operations per tile, which is what makes the explicit wait counts below exact.
-// The DMA loads and the identity-residual loads are inline asm (the compiler's own s_waitcnt placement would otherwise wait for the
-// prefetch of tile t + 2 wherever it waits for anything); everything the compiler loads itself is consumed before the tile loop.
-#if defined(HIPEMU)
-#define RP_DMA16(gptr, ldsptr, lane_) memcpy(reinterpret_cast<char*>(ldsptr) + (lane_) * 16, (gptr), 16)
-#define RP_WAIT_VM(n) do { } while (0)
-#else
-#define RP_DMA16(gptr, ldsptr, lane_) \
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gptr), "s"(__builtin_amdgcn_readfirstlane((unsigned)(size_t)(ldsptr))) : "memory", "m0")
-#define RP_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(n) : "memory")
-#endif
-
-#if !defined(HIPEMU)
-#pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Winline-asm"      // m0 on the clobber list: the compiler sets m0 itself right before every use
-#endif
-#ifndef RP_ABL
-#define RP_ABL 0      // development aid (tools/gpu_conv_ablation.sh): timing-only builds that drop one phase each -- 1 no exp / rcp in the transform,
-#endif                // 2 no MFMA loop, 4 no stores / statistics, 8 no DMA after the prologue, 16 no transform, 32 no residual loads.  Results are garbage.
-template <bool GN>
-__global__ __launch_bounds__(256, 2) void conv_rp_dma_kernel(const mi_conv_params p, const uint4* __restrict__ wrp, const int ntile) {
-    constexpr int TH = 8, TW = 64, IH = TH + 2, UW = TW + 2, PW = TW + 8, PLANE = IH * PW, NU = IH * UW, PER = (NU + 255) / 256;
-    constexpr int GX = TW / 16, GPW = (GX * TH / 2) / 4, NSTEP = 3;
-    constexpr int RPW = TW + 8, NPX = RPW / 4, NP = 8 * IH * NPX;            // raw window: [ox0 - 4, ox0 + TW + 4) x IH rows x 8 planes, in 16-byte pieces
-    constexpr int NDMA = (NP + 255) / 256, RAWF = NDMA * 256 * 4;             // DMA instructions per wave and tile (the last one partly clamped); floats per buffer
-    __shared__ __attribute__((aligned(16))) float rawL[2][RAWF];
-    __shared__ __attribute__((aligned(16))) uint4 actH[PLANE];
-    __shared__ __attribute__((aligned(16))) uint4 actL[PLANE];
-    __shared__ __attribute__((aligned(16))) float4 chP[8];
-    __shared__ double chS[8], chQ[8];
-    __shared__ float gMean[MI_MAX_GROUPS], gRstd[MI_MAX_GROUPS];
-    __shared__ double red[4][16];
-    __shared__ int sExp[4];
-    constexpr int WTOT = NSTEP * 128;
-    __shared__ __attribute__((aligned(16))) uint4 wl[WTOT];
-
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lq = lane & 15, lg = lane >> 4;
-    const int H = p.H, W = p.W, HW = H * W;
-    const int tiles_x = W / TW, tiles = tiles_x * (H / TH);
-    const int strips = (tiles + ntile - 1) / ntile;
-    int b, strip;
-    if ((p.B & 7) == 0) {                          // XCD-aware workgroup -> image map (as conv_rp_kernel)
-        const int L = blockIdx.x;
-        int k = L >> 3;
-        if (p.tile_cfg & MI_CONV_REVERSE) k = (int)(gridDim.x >> 3) - 1 - k;
-        b = (L & 7) + 8 * (k / strips);
-        strip = k % strips;
-    } else {
-        b = blockIdx.x / strips;
-        strip = blockIdx.x % strips;
-    }
-    const int tile_lo = strip * ntile, tile_hi = (tile_lo + ntile < tiles) ? tile_lo + ntile : tiles;
-    constexpr int Cin = 8;
-    const int bb = mi_row_of(b, p.in0.bmod);
-    const float* const xin = p.in0.data + (size_t)bb * Cin * HW;
-
-    // ---- this wave's pieces of a tile window: piece q = (i * 4 + wave) * 64 + lane -> (plane j, row iy, 16-byte column cx); the same for every tile
-    int pj[NDMA], pyx[NDMA];
-#pragma unroll
-    for (int i = 0; i < NDMA; ++i) {
-        int q = (i * 4 + wave) * 64 + lane;
-        q = q < NP ? q : NP - 1;                                               // (the pad of the last instruction re-reads the last piece)
-        pj[i] = q / (IH * NPX);
-        const int r = q - pj[i] * (IH * NPX);
-        pyx[i] = ((r / NPX) << 8) | (r % NPX);
-    }
-    auto issue_tile = [&](int tile, int buf) {
-        const int oy0 = (tile / tiles_x) * TH, ox0 = (tile % tiles_x) * TW;
-#pragma unroll
-        for (int i = 0; i < NDMA; ++i) {
-            int gy = oy0 - 1 + (pyx[i] >> 8), gx = ox0 - 4 + 4 * (pyx[i] & 255);
-            gy = gy < 0 ? 0 : (gy > H - 1 ? H - 1 : gy);                        // clamped rows / columns lie outside the image: masked in the transform
-            gx = gx < 0 ? 0 : (gx > W - 4 ? W - 4 : gx);
-            const float* g = xin + ((size_t)pj[i] * H + gy) * W + gx;
-            RP_DMA16(g, &rawL[buf][(i * 4 + wave) * 256], lane);
-        }
-    };
-
-    // ---- prologue: the first two tiles' windows are in flight before anything else; weights, statistics, affine as conv_rp_kernel
-    issue_tile(tile_lo, 0);
-    if (tile_lo + 1 < tile_hi) issue_tile(tile_lo + 1, 1);
-    constexpr int WPER = (WTOT + 255) / 256;
-    uint4 wreg[WPER];
-#pragma unroll
-    for (int i = 0; i < WPER; ++i) { const int k = tid + i * 256; wreg[i] = mi_ldg4u(wrp + (k < WTOT ? k : 0)); }
-    const bool have_stats = GN || p.in0.stats != nullptr;
-    mi_stats_regs sr;
-    const mi_act none{};
-    const bool fast = have_stats && mi_gn_totals_issue(p.in0, none, Cin, Cin, b, tid, 256, sr);
-    float pg = 0.f, pb = 0.f, psc = 1.f, psh = 0.f;
-    if constexpr (GN) {
-        const int c = lane < Cin ? lane : 0;
-        pg = p.gn_gamma[c];
-        pb = p.gn_beta[c];
-        if (p.scale_shift) {
-            const float* ss = p.scale_shift + (size_t)b * p.ss_stride + p.ss_off;
-            psc = ss[c] + 1.0f;
-            psh = ss[Cin + c];
-        }
-    }
-    const int co = lq & 7, dy = lq >> 3;
-    const float bv = (p.bias && co < p.Cout) ? p.bias[co] : 0.0f;
-#pragma unroll
-    for (int i = 0; i < WPER; ++i) { const int k = tid + i * 256; if (k < WTOT) wl[k] = wreg[i]; }
-    if (fast) mi_gn_totals_finish(sr, tid, chS, chQ);
-    else if (have_stats) mi_gn_channel_totals(p.in0, none, Cin, Cin, b, tid, 256, chS, chQ);
-    if (have_stats) __syncthreads();
-    if constexpr (GN) {
-        const int cpg = Cin / p.gn_groups;
-        for (int g = tid; g < p.gn_groups; g += 256)
-            mi_gn_group_moments(chS, chQ, g * cpg, (g + 1) * cpg, (double)cpg * (double)HW, p.gn_eps, gMean[g], gRstd[g]);
-        __syncthreads();
-    }
-    if (wave == 0) {
-        const int c = lane;
-        float A = 0.f, Bc = 0.f, m = 0.f;
-        if constexpr (GN) {
-            if (c < Cin) {
-                const int cpg = Cin / p.gn_groups, g = c / cpg;
-                float An = pg, Bn = pb;
-                A = gRstd[g] * pg;
-                Bc = pb - gMean[g] * A;
-                if (p.scale_shift) { A *= psc; Bc = Bc * psc + psh; An *= psc; Bn = Bn * psc + psh; }
-                A *= p.in0.scale;
-                m = 4.0f * fabsf(An) + fabsf(Bn);
-            }
-            m = mi_wave_max(m);
-        } else if (have_stats) {
-            double q = (c < Cin) ? chQ[c] : 0.0;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
-            m = 4.0f * sqrtf((float)(q / ((double)Cin * (double)HW)));
-        }
-        const int ka = (m > 0.f) ? rp_clamp_exp(4 - rp_exponent(m)) : 0;
-        if (c < Cin) {
-            if constexpr (GN) chP[c] = make_float4(ldexpf(A, ka), ldexpf(Bc, ka), A * -1.44269504088896340736f, Bc * -1.44269504088896340736f);
-            else chP[c] = make_float4(ldexpf(p.in0.scale, ka), 0.f, 0.f, 0.f);
-        }
-        if (lane == 0) { sExp[0] = ka; sExp[2] = ka + p.w_rp_exp; }
-    }
-    // (chP / sExp / wl become visible at the first tile's barrier)
-
-    const int perm = ((lg & 1) << 1) | (lg >> 1);
-    const bool idres = p.res0.data != nullptr;
-    float* const obase = p.out + (size_t)b * p.Cout * HW;
-    const float* const rbase = idres ? p.res0.data + (size_t)mi_row_of(b, p.res0.bmod) * p.res0.C * HW : p.out;
-    const float rs = idres ? p.res0.scale : 0.0f;
-    int ldst[PER];
-#pragma unroll
-    for (int u = 0; u < PER; ++u) {
-        const int q = tid + u * 256;
-        ldst[u] = q < NU ? (q / UW) * PW + (q % UW) : -1;
-    }
-
-    for (int tile = tile_lo; tile < tile_hi; ++tile) {
-        const int buf = (tile - tile_lo) & 1;
-        const int oy0 = (tile / tiles_x) * TH, ox0 = (tile % tiles_x) * TW;
-        // this wave's share of tile `tile` has landed: everything older than the NDMA loads of tile + 1 and the GPW stores of tile - 1
-        // (issued after it, in that order) is complete
-        if (tile + 1 < tile_hi) { if (tile > tile_lo) RP_WAIT_VM(NDMA + GPW); else RP_WAIT_VM(NDMA); }
-        else RP_WAIT_VM(0);
-        __syncthreads();          // everybody's share has; the previous tile's operand planes are consumed; (first tile: chP / sExp / wl visible)
-        if (!(RP_ABL & 16) || tile == tile_lo) {
-            const float* const rw = &rawL[buf][0];
-#pragma unroll
-            for (int u = 0; u < PER; ++u) {
-                if (ldst[u] < 0) continue;
-                const int q = tid + u * 256, iy = q / UW, c = q - iy * UW;
-                const int gy = oy0 - 1 + iy, gx = ox0 - 1 + c;
-                const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
-                float y[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float x = rw[(j * IH + iy) * RPW + c + 3];
-                    const float4 P = chP[j];
-                    if constexpr (GN) {
-                        const float a = fmaf(x, P.x, P.y);
-                        if (RP_ABL & 1) { y[j] = a * fmaf(x, P.z, P.w); continue; }
-                        const float ex = __builtin_amdgcn_exp2f(fmaf(x, P.z, P.w));
-                        y[j] = a * __builtin_amdgcn_rcpf(1.0f + ex);
-                    } else {
-                        y[j] = x * P.x;
-                    }
-                }
-                uint4 hv, lv;
-                rp_split8(y, hv, lv);
-                if (!in) { hv = make_uint4(0u, 0u, 0u, 0u); lv = hv; }
-                actH[ldst[u]] = hv;
-                actL[ldst[u]] = lv;
-            }
-        }
-        __syncthreads();          // operand planes complete; raw buffer `buf` is free again
-        // identity residual of THIS tile, then the window of tile + 2 into the buffer just consumed
-        f32x4 rv[GPW];
-        if (RP_ABL & 32) { for (int g = 0; g < GPW; ++g) rv[g] = (f32x4){1.f, 2.f, 3.f, 4.f}; }
-        if (idres && !(RP_ABL & 32)) {
-#pragma unroll
-            for (int g = 0; g < GPW; ++g) {
-                const int G = wave * GPW + g, gyy = G / GX, gxx = G % GX;
-                const int oy = oy0 + 2 * gyy + dy, ox = ox0 + 16 * gxx + 4 * lg;
-                const float* r = (RP_ABL & 128) ? rbase + ((size_t)(tile * 4 + wave) * GPW + g) * 256 + lane * 4 : rbase + ((size_t)(co < p.Cout ? co : 0) * H + oy) * W + ox;
-#if defined(HIPEMU)
-                memcpy(&rv[g], r, 16);
-#else
-                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rv[g]) : "v"(r) : "memory");
-#endif
-            }
-        }
-        const bool more = tile + 2 < tile_hi && !(RP_ABL & 8);
-        if (more) issue_tile(tile + 2, buf);
-#if RP_SCHED_BARRIER
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-        f32x4 acc[GPW];
-#pragma unroll
-        for (int g = 0; g < GPW; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < ((RP_ABL & 2) ? 0 : NSTEP); ++s) {
-            const rp_f16x8 bh = __builtin_bit_cast(rp_f16x8, wl[(s * 64 + lane) * 2]);
-            const rp_f16x8 bl = __builtin_bit_cast(rp_f16x8, wl[(s * 64 + lane) * 2 + 1]);
-#pragma unroll
-            for (int g = 0; g < GPW; ++g) {
-                const int G = wave * GPW + g, gyy = G / GX, gxx = G % GX;
-                const int idx = (2 * gyy + perm) * PW + 16 * gxx + lq + s;
-                const rp_f16x8 ah = __builtin_bit_cast(rp_f16x8, actH[idx]);
-                const rp_f16x8 al = __builtin_bit_cast(rp_f16x8, actL[idx]);
-                acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc[g], 0, 0, 0);
-                acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc[g], 0, 0, 0);
-                acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[g], 0, 0, 0);
-            }
-        }
-        if (RP_ABL & 2) { for (int g = 0; g < GPW; ++g) acc[g] = (f32x4){(float)actH[lane + g].x, 0.f, 0.f, 0.f}; }
-        // ---- epilogue (as conv_rp_kernel): bias, identity residual, stores, statistics about a per-channel shift
-        const float unscale = ldexpf(1.0f, -sExp[2]);
-        if (idres && !(RP_ABL & 32)) {              // the residual loads are older than the NDMA loads of tile + 2 (when those were issued)
-#if !defined(HIPEMU)
-            if (more) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(rv[0]), "+v"(rv[1]), "+v"(rv[2]), "+v"(rv[3]) : "n"(NDMA) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" : "+v"(rv[0]), "+v"(rv[1]), "+v"(rv[2]), "+v"(rv[3]) : : "memory");
-#endif
-        }
-        static_assert(GPW == 4, "the residual wait above names four registers");
-        float4 yv[GPW];
-#pragma unroll
-        for (int g = 0; g < GPW; ++g) {
-            float4 y;
-            y.x = fmaf(acc[g][0], unscale, bv); y.y = fmaf(acc[g][1], unscale, bv);
-            y.z = fmaf(acc[g][2], unscale, bv); y.w = fmaf(acc[g][3], unscale, bv);
-            if (idres) { y.x = fmaf(rv[g][0], rs, y.x); y.y = fmaf(rv[g][1], rs, y.y); y.z = fmaf(rv[g][2], rs, y.z); y.w = fmaf(rv[g][3], rs, y.w); }
-            yv[g] = y;
-        }
-        const float cs_ = __shfl(yv[0].x, lq & 7);
-        float csum = 0.f, csq = 0.f;
-#pragma unroll
-        for (int g = 0; g < GPW; ++g) {
-            const int G = wave * GPW + g, gyy = G / GX, gxx = G % GX;
-            const int oy = oy0 + 2 * gyy + dy, ox = ox0 + 16 * gxx + 4 * lg;
-            const float4 y = yv[g];
-            if (RP_ABL & 64) {        // timing only: the same bytes as whole 1 KB rows per instruction (wrong places inside the image's output)
-                *reinterpret_cast<mi_gptr<f32x4>>(mi_global(obase + ((size_t)(tile * 4 + wave) * GPW + g) * 256 + lane * 4)) = (f32x4){y.x, y.y, y.z, y.w};
-            } else
-            if (co < p.Cout && (!(RP_ABL & 4) || y.x == 12345.f)) *reinterpret_cast<mi_gptr<f32x4>>(mi_global(obase + ((size_t)co * H + oy) * W + ox)) = (f32x4){y.x, y.y, y.z, y.w};
-            const float d0 = y.x - cs_, d1 = y.y - cs_, d2 = y.z - cs_, d3 = y.w - cs_;
-            csum += (d0 + d1) + (d2 + d3);
-            csq += fmaf(d0, d0, fmaf(d1, d1, fmaf(d2, d2, d3 * d3)));
-        }
-        if (p.out_stats && (!(RP_ABL & 4) || csum == 12345.f)) {
-            csum += __shfl_xor(csum, 8); csq += __shfl_xor(csq, 8);
-            csum += __shfl_xor(csum, 16); csq += __shfl_xor(csq, 16);
-            csum += __shfl_xor(csum, 32); csq += __shfl_xor(csq, 32);
-            if (lane < 8) {
-                mi_stat_acc a; a.c = cs_; a.s = csum; a.q = csq; a.n = GPW * 32;        // full tiles: 4 groups x 2 rows x 16 pixels per wave
-                mi_stat_finish(a, red[wave][2 * lane], red[wave][2 * lane + 1]);
-            }
-            __syncthreads();
-            if (tid < 16 && (tid >> 1) < p.Cout)
-                p.out_stats[((size_t)(b * p.Cout + (tid >> 1)) * tiles + tile) * 2 + (tid & 1)] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
-        }
-    }
-}
-
-#if !defined(HIPEMU)
-#pragma clang diagnostic pop
-#endif
 
 // Wide-channel regime: per image, the per-channel affine of the fused GroupNorm -> scale/shift (or the plain input scale) and the
 // power-of-two operand exponents -- what the narrow kernel's prologue computes in LDS for <= 64 channels -- into global memory.
@@ -1053,26 +769,9 @@ int launch_rp_wide_m(const mi_conv_params& p, hipStream_t st) {
     return half ? launch_rp_wide<1, false, true, MODE>(p, st) : launch_rp_wide<1, false, false, MODE>(p, st);
 }
 
-template <bool GN>
-int launch_rp_dma(const mi_conv_params& p, hipStream_t st) {
-    const int tiles = (p.H / 8) * (p.W / 64);
-    int ntile = (p.tile_cfg >> 12) & 0xf;
-    // two workgroups per CU, each two tiles ahead: strips long enough to amortise the prologue (one memory round trip per strip) while
-    // the launch still has >= 2 workgroups per CU
-    if (ntile == 0) { ntile = 2; while (ntile < 8 && (size_t)p.B * (tiles / (2 * ntile)) >= 512) ntile *= 2; }
-    const int strips = (tiles + ntile - 1) / ntile;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_rp_dma_kernel<GN>), dim3(strips * p.B), dim3(256), 0, st, p, (const uint4*)p.w_rp, ntile);
-    return mi_check_launch("conv_rp_dma_kernel");
-}
-
 template <int TH, int TW, int NJ, int MODE, int KO, int RO>
 int launch_rp_v(const mi_conv_params& p, hipStream_t st) {
     const bool half = (p.tile_cfg & MI_CONV_HALF) != 0;
-    if constexpr (TH == 8 && TW == 64 && NJ == 1 && MODE == 0 && KO == 1 && RO == 0) {
-        if ((p.tile_cfg & MI_CONV_DMA) && !half && !p.in1.data && p.in0.C == 8 && (p.H & 7) == 0 && (p.W & 63) == 0 && !p.in0.st && !p.out_st &&
-            (!p.res0.data || (!p.res_w && p.res0.C >= p.Cout && !p.res0.st)))
-            return p.gn_groups > 0 ? launch_rp_dma<true>(p, st) : launch_rp_dma<false>(p, st);
-    }
     if constexpr (MODE == 0) {
         if (p.gn_groups > 0) return half ? launch_rp<TH, TW, NJ, true, true, MODE, KO, RO>(p, st) : launch_rp<TH, TW, NJ, true, false, MODE, KO, RO>(p, st);
     }

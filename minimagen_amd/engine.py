@@ -34,10 +34,6 @@ RP_MIN_HW = int(os.environ.get("MINIMAGEN_RP_MIN_HW", "0"))             # ... fo
 CE_MFMA = os.environ.get("MINIMAGEN_CE_MFMA", "1") != "0"                  # CrossEmbed on the matrix cores (0: the fp32 VALU kernel)
 STORE16 = os.environ.get("MINIMAGEN_STORE16", "1") != "0"                  # reduced-precision configuration: bf16 activation storage
 CONV_REVERSE = int(os.environ.get("MINIMAGEN_CONV_REVERSE", "1"))        # a row-paired conv walks the image groups opposite to its producer (0 = off)
-# the LDS-DMA form of the 8 -> <= 8 channel convs on full 8x64 tiles (conv_rp.hip conv_rp_dma_kernel; same bits as the register form): 0 off,
-# 1 on; DMA_NTILE = its strip length (0: the library's choice)
-CONV_DMA = int(os.environ.get("MINIMAGEN_CONV_DMA", "0"))
-DMA_NTILE = int(os.environ.get("MINIMAGEN_DMA_NTILE", "0"))
 RP_NTILE = int(os.environ.get("MINIMAGEN_RP_NTILE", "0"))               # tiles per workgroup of the row-paired kernel (0 = the library's choice)
 TILE64 = int(os.environ.get("MINIMAGEN_TILE64", "-1"))                  # force a conv tile shape at 64x64 / 128x128 (experiments)
 TILE128 = int(os.environ.get("MINIMAGEN_TILE128", "-1"))       # 1: 16-channel 3x3 outputs as two 8-channel workgroups
@@ -451,12 +447,7 @@ class UnetEngine:
             out.rev = bool(CONV_REVERSE) and batch % 8 == 0 and not in0.rev
             if out.rev:
                 p.tile_cfg |= 0x200
-            dma = bool(CONV_DMA) and not wide and cfg == 6 and not up2 and stride == 1 and ksize == 3 and cin_tot == 8 and in1 is None and Cout <= 8 \
-                and Ho % 8 == 0 and Wo % 64 == 0 and not ws.half and (res is None or res[2] is None)
-            if dma:
-                p.tile_cfg |= 0x10000 | ((DMA_NTILE & 0xf) << 12)
-            else:
-                p.tile_cfg |= (RP_NTILE & 0xf) << 12
+            p.tile_cfg |= (RP_NTILE & 0xf) << 12
             frag, p.w_rp_exp = pk.conv_rp[id(wpack)]
             p.w_rp = L.ptr(frag)
             if res is not None and res[2] is not None:

@@ -41,7 +41,7 @@ def run(B, C0, Cout, H, W, gn, res, path, C1=0, reps=20, nt_in=None):
         wf, p.w_rp_exp = P.pack_conv_weight_rp(w)
         wf = wf.to(dev); keep.append(wf)
         p.w_rp = wf.data_ptr()
-        cfg = int(path[2:3]) | (int(os.environ.get("NTILE", "0")) << 12) | int(os.environ.get("CFGX", "0"), 0)      # CFGX=0x10000: the LDS-DMA form
+        cfg = int(path[2:3]) | (int(os.environ.get("NTILE", "0")) << 12)
     else:
         ct = lib.mi_conv_cout_tile(Cout)
         wp = P.pack_conv_weight(w, ct).to(dev); keep.append(wp)
