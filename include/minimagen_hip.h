@@ -504,6 +504,22 @@ typedef struct mi_folded_attn_params {
 int mi_folded_attn_fwd(const mi_folded_attn_params* p, void* stream);
 int mi_folded_attn_bwd(const mi_folded_attn_params* p, void* stream);
 
+/* ---- optimiser step of the training path: torch.optim.Adam's update for every tensor of a model in ONE launch ---------------------------
+ * (reference: train.py:99-100, training.py:375-377).  `tensors`, `chunk_tensor`, `chunk_off` are DEVICE arrays: one mi_adam_tensor per
+ * parameter, and one (tensor index, chunk offset) pair per launched workgroup (chunk k of a tensor covers elements [k * chunk, (k + 1) * chunk)).
+ * bias_correction1/2 = 1 - beta^step (computed by the host: the step count is host state, as in torch); grad_scale: optional device scalar every
+ * gradient is multiplied by (a clipping coefficient computed on the device), or NULL. */
+typedef struct { float* p; const float* g; float* m; float* v; long long n; } mi_adam_tensor;
+typedef struct {
+    const mi_adam_tensor* tensors;
+    const int* chunk_tensor; const int* chunk_off;
+    int nchunks, chunk;
+    float lr, beta1, beta2, eps, weight_decay, bias_correction1, bias_correction2;
+    float one_minus_beta1, one_minus_beta2;     /* formed in double by the host like torch's Python scalars (1 - 0.999f is off by 5e-5 relative) */
+    const float* grad_scale;
+} mi_adam_params;
+int mi_adam_step(const mi_adam_params* p, void* stream);
+
 /* ---- HIP graphs: capture a sequence of the calls above once, replay it per timestep ------- */
 int mi_graph_begin(void* stream);
 int mi_graph_end(void* stream, void** graph_exec);

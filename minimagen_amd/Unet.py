@@ -223,6 +223,7 @@ class Unet(nn.Module):
         if dev_path:
             train_ops.begin_step(self)
         conv3 = lambda m, v: train_ops.conv3x3_forward(m, v) if (dev_path and train_ops.is_plain_conv3x3(m, v)) else m(v)
+        resample = lambda m, v: train_ops.conv4x4s2_forward(m, v) if (dev_path and train_ops.is_conv4x4s2(m, v)) else m(v)      # Downsample k4 s2
         # ---- conditioning (Unet.py:508-634)
         hid = self.to_time_hiddens(time)
         t, tokens = self.to_time_cond(hid), self.to_time_tokens[0](hid).reshape(b, self.num_time_tokens, self.cond_dim)
@@ -257,7 +258,7 @@ class Unet(nn.Module):
         hiddens = []
         for pre, first, blocks, attn, post in self.downs:
             if exists(pre):
-                x = pre(x)
+                x = resample(pre, x)
             x = first(x, t, c)
             for blk in blocks:
                 x = blk(x, t)
@@ -265,7 +266,7 @@ class Unet(nn.Module):
             x = attn(x)
             hiddens.append(x)
             if exists(post):
-                x = post(x)
+                x = resample(post, x)
         x = self.mid_block1(x, t, c)
         if exists(self.mid_attn):
             x = self.mid_attn(x)

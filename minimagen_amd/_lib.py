@@ -165,9 +165,20 @@ class MiFoldedAttnParams(C.Structure):
                 ("dsum", C.c_void_p), ("dq", C.c_void_p), ("dkf", C.c_void_p), ("dvf", C.c_void_p), ("oh", C.c_void_p)]
 
 
+class MiAdamTensor(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("n", C.c_longlong)]
+
+
+class MiAdamParams(C.Structure):
+    _fields_ = [("tensors", C.c_void_p), ("chunk_tensor", C.c_void_p), ("chunk_off", C.c_void_p), ("nchunks", C.c_int), ("chunk", C.c_int),
+                ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("weight_decay", C.c_float),
+                ("bias_correction1", C.c_float), ("bias_correction2", C.c_float), ("one_minus_beta1", C.c_float), ("one_minus_beta2", C.c_float),
+                ("grad_scale", C.c_void_p)]
+
+
 _STRUCTS = {0: MiAct, 1: MiConvParams, 2: MiCrossEmbedParams, 3: MiLinear, 4: MiTextCondParams, 5: MiCondStepParams,
             6: MiAttnFoldParams, 7: MiCrossAttnParams, 8: MiCfgX0Params, 9: MiQuantileParams, 10: MiPosteriorParams,
-            11: MiResizeParams, 12: MiSelfAttnParams, 13: MiChanFFParams, 14: MiFlashAttnParams, 15: MiTokensToNchwParams, 16: MiConvWgradParams, 17: MiBlockBwdParams, 18: MiCrossEmbedWgradParams, 19: MiFoldedAttnParams}
+            11: MiResizeParams, 12: MiSelfAttnParams, 13: MiChanFFParams, 14: MiFlashAttnParams, 15: MiTokensToNchwParams, 16: MiConvWgradParams, 17: MiBlockBwdParams, 18: MiCrossEmbedWgradParams, 19: MiFoldedAttnParams, 20: MiAdamTensor, 21: MiAdamParams}
 
 _lib = None
 _backend = None
@@ -185,7 +196,7 @@ def _bind(lib):
     vp, i32, i64, u64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float
     for name in ("mi_conv_fwd", "mi_gn_coef_fwd", "mi_crossembed_fwd", "mi_text_cond_fwd", "mi_cond_step_fwd", "mi_attn_fold_rows", "mi_cross_attn_fwd",
                  "mi_cfg_x0_fwd", "mi_quantile_fwd", "mi_posterior_fwd", "mi_resize_fwd", "mi_self_attn_fwd", "mi_chan_ff_fwd",
-                 "mi_flash_attn_fwd", "mi_tokens_to_nchw_fwd", "mi_conv_wgrad", "mi_block_bwd", "mi_crossembed_wgrad", "mi_folded_attn_fwd", "mi_folded_attn_bwd"):
+                 "mi_flash_attn_fwd", "mi_tokens_to_nchw_fwd", "mi_conv_wgrad", "mi_block_bwd", "mi_crossembed_wgrad", "mi_folded_attn_fwd", "mi_folded_attn_bwd", "mi_adam_step"):
         getattr(lib, name).argtypes = [vp, vp]
         getattr(lib, name).restype = i32
     lib.mi_step_advance.argtypes = [vp, vp, i32, vp]

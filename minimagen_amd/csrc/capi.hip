@@ -46,6 +46,8 @@ extern "C" int mi_struct_size(int which) {
         case 17: return (int)sizeof(mi_block_bwd_params);
         case 18: return (int)sizeof(mi_crossembed_wgrad_params);
         case 19: return (int)sizeof(mi_folded_attn_params);
+        case 20: return (int)sizeof(mi_adam_tensor);
+        case 21: return (int)sizeof(mi_adam_params);
     }
     return -1;
 }

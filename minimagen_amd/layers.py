@@ -101,6 +101,10 @@ class Parallel(_Container):
         self.fns = nn.ModuleList(fns)
 
     def forward(self, x):
+        if torch.is_grad_enabled() and train_ops.active(x):          # training on the device: every member on the HIP conv kernels where it fits
+            one = lambda fn: (train_ops.conv3x3_forward(fn, x) if train_ops.is_plain_conv3x3(fn, x) else
+                              (train_ops.conv1x1_forward(fn, x) if train_ops.is_conv1x1(fn, x) else fn(x)))
+            return sum(one(fn) for fn in self.fns)
         return sum(fn(x) for fn in self.fns)
 
 
@@ -298,6 +302,8 @@ class ResnetBlock(_Container):
             assert exists(cond)
             h = self.cross_attn(h, context=cond) + h
         h = self.block2(h, scale_shift=scale_shift)
+        if torch.is_grad_enabled() and train_ops.active(x) and train_ops.is_conv1x1(self.res_conv, x):      # training on the device: the HIP 3x3 kernels
+            return h + train_ops.conv1x1_forward(self.res_conv, x)
         return h + self.res_conv(x)
 
 

@@ -304,25 +304,26 @@ class _ConvFn(torch.autograd.Function):
     parameter gradients on the HIP kernels"""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, exp=None):
         x = x.contiguous()
-        fwd, _ = _packs(weight)
+        fwd, _ = _packs(weight, exp)
         out = _conv3x3(x, fwd, None if bias is None else bias.detach())
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
+        ctx.exp = exp
         return out
 
     @staticmethod
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
         dy = dy.contiguous()
-        _, bwd = _packs(weight)
+        _, bwd = _packs(weight, ctx.exp)
         need = ctx.needs_input_grad
         dx = _conv3x3(dy, bwd, None) if need[0] else None
         dw = db = None
         if need[1] or (ctx.has_bias and need[2]):
             dw, db = _wgrad(x, dy, ctx.has_bias and need[2])
-        return dx, (dw if need[1] else None), db
+        return dx, (dw if need[1] else None), db, None
 
 
 def _ce_tables(convs, channels: int):
@@ -483,6 +484,52 @@ def block_forward(block, x: torch.Tensor, scale_shift=None) -> torch.Tensor:
 
 def conv3x3_forward(conv: torch.nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
     return _ConvFn.apply(x, conv.weight, conv.bias)
+
+
+def _weight_exp(weight: torch.Tensor):
+    """exponent of the fragment scaling from the max |w| that begin_step() already brought to the host (None: _packs fetches it)"""
+    mark = getattr(weight, "_mi_fingerprint", None)
+    return P.rp_weight_exponent(mark[0]) if mark is not None else None
+
+
+def is_conv1x1(m, x=None) -> bool:
+    ok = isinstance(m, torch.nn.Conv2d) and m.kernel_size == (1, 1) and m.stride == (1, 1) and m.padding == (0, 0) and m.groups == 1
+    if ok and x is not None:
+        ok = conv_shape_supported(m.in_channels, m.out_channels, x.shape[-1])
+    return ok
+
+
+def conv1x1_forward(conv: torch.nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
+    """A 1x1 convolution (ResnetBlock.res_conv, layers.py:415; Parallel's second member, :346-356) as the centre tap of a 3x3 one: forward, data
+    gradient and weight gradient on the HIP 3x3 kernels (the zero taps cost matrix-core work on an 8..32-channel layer that is bound by its
+    activation traffic); autograd takes the centre of the 3x3 weight gradient back to the parameter."""
+    w3 = F.pad(conv.weight, (1, 1, 1, 1))
+    return _ConvFn.apply(x, w3, conv.bias, _weight_exp(conv.weight))
+
+
+def is_conv4x4s2(m, x=None) -> bool:
+    ok = isinstance(m, torch.nn.Conv2d) and m.kernel_size == (4, 4) and m.stride == (2, 2) and m.padding == (1, 1) and m.groups == 1 \
+        and m.dilation == (1, 1) and m.padding_mode == "zeros"
+    if ok and x is not None:
+        ok = x.shape[-1] % 2 == 0 and x.shape[-2] % 2 == 0 and conv_shape_supported(4 * m.in_channels, m.out_channels, x.shape[-1] // 2)
+    return ok
+
+
+def conv4x4s2_forward(conv: torch.nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
+    """Downsample (layers.py:308-319: Conv2d k4 s2 p1) as a 3x3 stride-1 convolution over the space-to-depth image: with x'[4c + 2py + px][Y][X] =
+    x[c][2Y + py][2X + px] the tap ky of the stride-2 kernel reads row 2y + ky - 1 = 2 (y + a) + py, (a, py) = (-1, 1), (0, 0), (0, 1), (1, 0)
+    for ky = 0..3 -- a 3x3 kernel over 4 Cin channels in which 20 of the 36 (a, py, b, px) combinations are zero.  pixel_unshuffle is one copy;
+    forward, data gradient and weight gradient then run on the HIP 3x3 kernels, and autograd scatters / gathers between the two weight layouts
+    (16 slices of a [Cout, Cin, 4, 4] tensor)."""
+    w = conv.weight
+    Cout, Cin = w.shape[0], w.shape[1]
+    w3 = w.new_zeros(Cout, Cin, 2, 2, 3, 3)                       # [co, c, py, px, a + 1, b + 1]
+    tap = ((0, 1), (1, 0), (1, 1), (2, 0))                        # ky -> (a + 1, py)
+    for ky in range(4):
+        for kx in range(4):
+            (ay, py), (ax, px) = tap[ky], tap[kx]
+            w3[:, :, py, px, ay, ax] = w[:, :, ky, kx]
+    return _ConvFn.apply(F.pixel_unshuffle(x, 2), w3.reshape(Cout, 4 * Cin, 3, 3), conv.bias, _weight_exp(w))
 
 
 def conv_shape_supported(cin: int, cout: int, W: int, groups: int = 0) -> bool:

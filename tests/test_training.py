@@ -500,3 +500,33 @@ def test_optimiser_steps_on_the_device_path_track_the_torch_op_path(backend):
     assert worst < 4 * 2e-3, worst
     close = sum(int(((a - b).abs() < 2e-4).sum()) for a, b in zip(runs[True][1], runs[False][1])) / sum(a.numel() for a in runs[True][1])
     assert close > 0.97, close
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("case", [("k4s2", 8, 8, 2, 16, 32), ("k4s2", 8, 16, 1, 24, 16), ("1x1", 16, 8, 2, 16, 32), ("1x1", 32, 16, 1, 8, 16)])
+def test_downsample_and_1x1_convs_on_the_hip_3x3_kernels(backend, case):
+    """Downsample (Conv2d k4 s2 p1, layers.py:308-319) as a 3x3 conv over the space-to-depth image and the 1x1 res_conv (layers.py:415) as the centre
+    tap of a 3x3 one (train_ops.conv4x4s2_forward / conv1x1_forward): output, input gradient, weight and bias gradients against torch's conv2d"""
+    from minimagen_amd import train_ops
+    kind, Cin, Cout, B, H, W = case
+    dev = setup(backend)
+    g = torch.Generator().manual_seed(hash(case) & 0xffff)
+    conv = torch.nn.Conv2d(Cin, Cout, 4, 2, 1) if kind == "k4s2" else torch.nn.Conv2d(Cin, Cout, 1)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) * 0.3)
+        conv.bias.copy_(torch.randn(Cout, generator=g))
+    conv = conv.to(dev)
+    x = (torch.randn(B, Cin, H, W, generator=g) * 1.3 + 0.2).to(dev).requires_grad_(True)
+    gy = torch.randn(B, Cout, H // (2 if kind == "k4s2" else 1), W // (2 if kind == "k4s2" else 1), generator=g).to(dev)
+    ref = conv(x)
+    rgx, rgw, rgb = torch.autograd.grad(ref, (x, conv.weight, conv.bias), gy)
+    train_ops.FORCE = backend == "emu"
+    try:
+        assert (train_ops.is_conv4x4s2(conv, x) if kind == "k4s2" else train_ops.is_conv1x1(conv, x)) and train_ops.active(x)
+        out = train_ops.conv4x4s2_forward(conv, x) if kind == "k4s2" else train_ops.conv1x1_forward(conv, x)
+        gx, gw, gb = torch.autograd.grad(out, (x, conv.weight, conv.bias), gy)
+    finally:
+        train_ops.FORCE = False
+    for name, a, b in (("out", out, ref), ("dx", gx, rgx), ("dw", gw, rgw), ("db", gb, rgb)):
+        err, mag = float((a - b).abs().max()), float(b.abs().max())
+        assert a.shape == b.shape and err < 3e-5 * max(1.0, mag), (case, name, err, mag)
