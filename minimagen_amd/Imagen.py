@@ -458,7 +458,8 @@ class Imagen(nn.Module):
             with (torch.cuda.stream(streams[stage]) if on_gpu else null_context()):
                 eng = unet.engine()
                 # per call, never sticky engine state: a later Unet.forward stays on the engine's default precision
-                ws = wss[stage] = eng.workspace(batch_size, B2, image_size, image_size, precision=precision, lane=lane)
+                ws = wss[stage] = eng.workspace(batch_size, B2, image_size, image_size, precision=precision, lane=lane,
+                                                pipelined=bool(_async and on_gpu and SAMPLE_LANES > 1))
                 eng.set_text(ws, text_embeds, text_masks, keep)
                 if unet.lowres_cond:             # the augmentation level's timestep feeds the step tables (diffusion_model.py:68-69)
                     ws.lowres_times.fill_(int(self.lowres_noise_schedule.num_timesteps * lowres_sample_noise_level))

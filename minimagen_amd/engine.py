@@ -35,6 +35,12 @@ CE_MFMA = os.environ.get("MINIMAGEN_CE_MFMA", "1") != "0"                  # Cro
 STORE16 = os.environ.get("MINIMAGEN_STORE16", "1") != "0"                  # reduced-precision configuration: bf16 activation storage
 CONV_REVERSE = int(os.environ.get("MINIMAGEN_CONV_REVERSE", "1"))        # a row-paired conv walks the image groups opposite to its producer (0 = off)
 RP_NTILE = int(os.environ.get("MINIMAGEN_RP_NTILE", "0"))               # tiles per workgroup of the row-paired kernel (0 = the library's choice)
+RP_NTILE_BY = {k: int(os.environ.get("MINIMAGEN_RP_NTILE_" + k, "0")) for k in ("L", "M", "S")}     # ... per image-size class (> 128^2 / > 64^2 / smaller)
+# ... and for workspaces of PIPELINED calls (Imagen.sample(_async=True) with two call lanes in flight): longer strips = fewer, longer workgroups
+# per launch leave the other lane's kernels room on the CUs.  Measured on one box, back to back (profiles/r05_summary.md): two tiles per workgroup
+# at <= 64^2 and four at 128^2 give 44.1 K against 42.3 K denoising-steps/s with two lanes -- and 31.0 K against 33.5 K for synchronous calls, which
+# therefore keep the library's choice.  Speed only: the per-tile statistics (hence every bit of the result) do not depend on the strip length.
+RP_NTILE_PIPE = {k: int(os.environ.get("MINIMAGEN_RP_NTILE_PIPE_" + k, d)) for k, d in (("L", "0"), ("M", "4"), ("S", "2"))}
 TILE64 = int(os.environ.get("MINIMAGEN_TILE64", "-1"))                  # force a conv tile shape at 64x64 / 128x128 (experiments)
 TILE128 = int(os.environ.get("MINIMAGEN_TILE128", "-1"))       # 1: 16-channel 3x3 outputs as two 8-channel workgroups
 WEIGHT_FINGERPRINT = os.environ.get("MINIMAGEN_WEIGHT_FINGERPRINT", "1") != "0"   # content fingerprint of the weights at every public call (see pack())
@@ -311,20 +317,23 @@ class UnetEngine:
         host behind that stage's queued work)."""
         return self._pack if self._pack is not None else self.pack()
 
-    def workspace(self, B: int, B2: int, H: int, W: int, precision: Optional[str] = None, has_text: bool = True, lane: int = 0) -> Workspace:
+    def workspace(self, B: int, B2: int, H: int, W: int, precision: Optional[str] = None, has_text: bool = True, lane: int = 0,
+                  pipelined: bool = False) -> Workspace:
         """``lane``: independent workspaces (buffers, step tables, captured graphs) of one shape, so that two sample() calls can be in
-        flight side by side (Imagen.sample(_async=True) alternates lanes)"""
+        flight side by side (Imagen.sample(_async=True) alternates lanes); ``pipelined``: the launch plan of calls that share the GPU with
+        another lane (strip lengths RP_NTILE_PIPE; same results, another workspace)"""
         pk = self.packed()
         dev = next(self.unet.parameters()).device
         precision = self.precision if precision is None else precision
         assert precision in ("fp32", "half"), precision
-        key = (B, B2, H, W, str(dev), precision, has_text) + ((lane,) if lane else ())
+        key = (B, B2, H, W, str(dev), precision, has_text) + ((lane,) if lane else ()) + (("pipe",) if pipelined else ())
         ws = self._ws.get(key)
         if ws is not None:
             return ws
         u = self.unet
         ws = Workspace()
         ws.B, ws.B2, ws.H, ws.W, ws.dev = B, B2, H, W, dev
+        ws.pipelined = pipelined
         ws.half = precision == "half"
         f = lambda *shape: torch.zeros(*shape, dtype=torch.float32, device=dev)
         ws.x = f(B, u.channels, H, W)
@@ -447,7 +456,9 @@ class UnetEngine:
             out.rev = bool(CONV_REVERSE) and batch % 8 == 0 and not in0.rev
             if out.rev:
                 p.tile_cfg |= 0x200
-            p.tile_cfg |= (RP_NTILE & 0xf) << 12
+            cls = "L" if Ho * Wo > 128 * 128 else ("M" if Ho * Wo > 64 * 64 else "S")
+            nt_knob = RP_NTILE_BY[cls] or RP_NTILE or (RP_NTILE_PIPE[cls] if ws.pipelined else 0)
+            p.tile_cfg |= (nt_knob & 0xf) << 12
             frag, p.w_rp_exp = pk.conv_rp[id(wpack)]
             p.w_rp = L.ptr(frag)
             if res is not None and res[2] is not None:

@@ -21,6 +21,7 @@ class Adam(torch.optim.Optimizer):
             raise ValueError("invalid Adam hyper-parameters")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._tables = {}
+        self._count = {}          # parameter -> step count as a Python int (the ``step`` tensors of the state are written on state_dict())
 
     def _state_of(self, p):
         st = self.state[p]
@@ -28,7 +29,21 @@ class Adam(torch.optim.Optimizer):
             st["step"] = torch.tensor(0.0, dtype=torch.float32)
             st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
             st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            self._count[p] = 0
+        elif p not in self._count:                      # state that came in through load_state_dict
+            self._count[p] = int(float(st["step"]))
         return st
+
+    def state_dict(self):
+        for p, n in self._count.items():
+            if p in self.state:
+                self.state[p]["step"].fill_(float(n))
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._count = {}
+        self._tables = {}
 
     def _table(self, gi, ps):
         """device-resident tensor / chunk tables of one parameter group, rebuilt only when a pointer changed (zero_grad(set_to_none=True)
@@ -70,11 +85,12 @@ class Adam(torch.optim.Optimizer):
                     and (p.is_cuda or L.backend() == "hipemu") and p.device == p.grad.device
                 (fast if ok else slow).append(p)
             for p in fast + slow:
-                self._state_of(p)["step"] += 1
+                self._state_of(p)
+                self._count[p] += 1
             # parameters of one group share the step count in every ordinary use; groups whose counts differ are split by count
             by_step = {}
             for p in fast:
-                by_step.setdefault(float(self.state[p]["step"]), []).append(p)
+                by_step.setdefault(float(self._count[p]), []).append(p)
             for t, ps in by_step.items():
                 _, tens, ct, co, nchunks = self._table((gi, t if len(by_step) > 1 else None), ps)
                 a = L.MiAdamParams()
@@ -86,7 +102,7 @@ class Adam(torch.optim.Optimizer):
             for p in slow:                                  # torch's single-tensor update, same formulas
                 st = self.state[p]
                 g = p.grad if group["weight_decay"] == 0 else p.grad.add(p, alpha=group["weight_decay"])
-                t = float(st["step"])
+                t = float(self._count[p])
                 st["exp_avg"].lerp_(g, 1 - b1)
                 st["exp_avg_sq"].mul_(b2).addcmul_(g, g, value=1 - b2)
                 denom = (st["exp_avg_sq"].sqrt() / (1 - b2 ** t) ** 0.5).add_(group["eps"])
