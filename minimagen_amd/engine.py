@@ -457,7 +457,9 @@ class UnetEngine:
             if out.rev:
                 p.tile_cfg |= 0x200
             cls = "L" if Ho * Wo > 128 * 128 else ("M" if Ho * Wo > 64 * 64 else "S")
-            nt_knob = RP_NTILE_BY[cls] or RP_NTILE or (RP_NTILE_PIPE[cls] if ws.pipelined else 0)
+            nt_knob = RP_NTILE_BY[cls] or RP_NTILE
+            if not nt_knob and ws.pipelined and RP_NTILE_PIPE[cls] and batch * nt // RP_NTILE_PIPE[cls] >= 256:
+                nt_knob = RP_NTILE_PIPE[cls]        # (only while the launch still has a workgroup per CU: smaller batches keep the library's choice -- config 3 at B = 16: 39.1 K with, 40.7 K without)
             p.tile_cfg |= (nt_knob & 0xf) << 12
             frag, p.w_rp_exp = pk.conv_rp[id(wpack)]
             p.w_rp = L.ptr(frag)
