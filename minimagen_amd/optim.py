@@ -99,6 +99,8 @@ class Adam(torch.optim.Optimizer):
                 a.bias_correction1, a.bias_correction2 = 1.0 - b1 ** t, 1.0 - b2 ** t
                 a.one_minus_beta1, a.one_minus_beta2 = 1.0 - b1, 1.0 - b2
                 L.check(lib.mi_adam_step(C.byref(a), L.current_stream()), "mi_adam_step")
+                for p in ps:                                # the kernel wrote through raw pointers: tell autograd / every version-keyed cache
+                    torch.autograd.graph.increment_version(p)
             for p in slow:                                  # torch's single-tensor update, same formulas
                 st = self.state[p]
                 g = p.grad if group["weight_decay"] == 0 else p.grad.add(p, alpha=group["weight_decay"])
