@@ -103,3 +103,113 @@ def allreduce_gradients(params, *, bucket_mb: float = 64.0, group=None, average:
                 p.grad.copy_(g)
             off += p.numel()
     return len(buckets)
+
+
+class GradientBucketReducer:
+    """``allreduce_gradients`` OVERLAPPED with the backward pass: parameters are grouped into flat fp32 buckets in reverse registration order
+    (the order in which the backward produces their gradients); a post-accumulate hook on every parameter counts its bucket down, and a
+    bucket whose gradients are all there is copied into its flat buffer and all-reduced asynchronously (RCCL on its own stream) while the
+    backward continues below it.  Buckets are always launched in index order -- bucket k waits for bucket k - 1 even if it completes first --
+    so every rank issues the same sequence of collectives whatever its autograd scheduling does.  ``finish()`` after ``loss.backward()``
+    launches what is left (parameters that received no gradient contribute zeros), waits, averages and writes the results back into
+    ``p.grad``.  Usage per step: ``loss.backward(); reducer.finish(); optimizer.step()``.  ``with reducer.no_sync():`` skips the reduction for
+    gradient-accumulation steps."""
+
+    def __init__(self, params, *, bucket_mb: float = 64.0, group=None, average: bool = True):
+        self.group, self.average = group, average
+        self.ws = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.params = [p for p in params if p.requires_grad]
+        limit = max(1, int(bucket_mb * (1 << 20) / 4))
+        self.buckets, cur, n = [], [], 0
+        for p in reversed(self.params):
+            if cur and n + p.numel() > limit:
+                self.buckets.append(cur)
+                cur, n = [], 0
+            cur.append(p)
+            n += p.numel()
+        if cur:
+            self.buckets.append(cur)
+        self.where = {p: k for k, b in enumerate(self.buckets) for p in b}
+        self.flat = [None] * len(self.buckets)
+        self.enabled = True
+        self.launched_in_backward = 0
+        self._reset()
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params] if self.ws > 1 else []
+
+    def _reset(self):
+        self.missing = [len(b) for b in self.buckets]
+        self.seen = set()
+        self.next = 0
+        self.work = []
+        self.dirty = False           # a hook fired while enabled: this step has something to reduce
+
+    def _launch(self, k):
+        bucket = self.buckets[k]
+        n = sum(p.numel() for p in bucket)
+        flat = self.flat[k]
+        if flat is None or flat.device != bucket[0].device:
+            flat = self.flat[k] = torch.empty(n, dtype=torch.float32, device=bucket[0].device)
+        off = 0
+        for p in bucket:
+            dst = flat[off:off + p.numel()]
+            if p.grad is None or p not in self.seen:
+                dst.zero_()                      # no gradient on this rank this step: zeros (every rank issues the same collectives)
+            else:
+                dst.copy_(p.grad.reshape(-1))
+            off += p.numel()
+        self.work.append((k, dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)))
+
+    def _on_grad(self, p):
+        if not self.enabled or p in self.seen:
+            return
+        self.dirty = True
+        self.seen.add(p)
+        self.missing[self.where[p]] -= 1
+        while self.next < len(self.buckets) and self.missing[self.next] == 0:
+            self._launch(self.next)
+            self.next += 1
+            self.launched_in_backward += 1
+
+    def finish(self, force: bool = False) -> int:
+        """-> number of collectives of this step (0 after a ``no_sync`` backward; ``force=True`` reduces even if no hook fired on this rank --
+        a rank whose step produced no gradient at all must still take part when the others reduce)"""
+        if self.ws == 1 or not self.enabled or not (self.dirty or force):
+            self._reset()
+            return 0
+        while self.next < len(self.buckets):
+            self._launch(self.next)
+            self.next += 1
+        for k, handle in self.work:
+            handle.wait()
+            flat = self.flat[k]
+            if self.average:
+                flat.div_(self.ws)
+            off = 0
+            for p in self.buckets[k]:
+                g = flat[off:off + p.numel()].view_as(p)
+                if p.grad is None:
+                    p.grad = g.clone()
+                else:
+                    p.grad.copy_(g)
+                off += p.numel()
+        n = len(self.work)
+        self._reset()
+        return n
+
+    def no_sync(self):
+        from contextlib import contextmanager
+
+        @contextmanager
+        def ctx():
+            prev, self.enabled = self.enabled, False
+            try:
+                yield
+            finally:
+                self.enabled = prev
+                self._reset()
+        return ctx()
+
+    def remove(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []

@@ -325,6 +325,24 @@ im.zero_grad(set_to_none=True)
 loss_of(slice(0, B)).mean().backward()
 for g, p in zip(mine, im.unets[0].parameters()):
     assert (g - p.grad).abs().max() < (1e-6 if backend == "gloo" else 2e-5) * max(1.0, float(p.grad.abs().max())), "averaged shard gradients differ from the full-batch gradient"
+# the same reduction OVERLAPPED with the backward (GradientBucketReducer: post-accumulate hooks launch a bucket's all-reduce as soon as its
+# gradients exist, in bucket order): same averaged gradients, and collectives really were in flight before backward() returned
+from minimagen_amd.distributed import GradientBucketReducer
+red = GradientBucketReducer(im.unets[0].parameters(), bucket_mb=0.01)
+assert len(red.buckets) > 2
+im.zero_grad(set_to_none=True)
+(loss_of(slice(lo, hi)).sum() / (hi - lo)).backward()
+early = red.launched_in_backward
+assert early >= len(red.buckets) - 1, (early, len(red.buckets))
+assert red.finish() == len(red.buckets)
+for g, p in zip(mine, im.unets[0].parameters()):
+    assert torch.equal(g, p.grad) or (g - p.grad).abs().max() < 1e-6 * max(1.0, float(g.abs().max())), "hook-overlapped reduction differs from allreduce_gradients"
+with red.no_sync():                         # an accumulation step: no collectives, local gradients untouched
+    im.zero_grad(set_to_none=True)
+    (loss_of(slice(lo, hi)).sum() / (hi - lo)).backward()
+    local = [p.grad.clone() for p in im.unets[0].parameters()]
+assert red.finish() == 0 and all(torch.equal(a, p.grad) for a, p in zip(local, im.unets[0].parameters()))
+red.remove()
 dist.barrier()
 dist.destroy_process_group()
 print("ok")
