@@ -318,7 +318,7 @@ int mi_sampler_step_small_fwd(const mi_cfg_x0_params* c, const mi_quantile_param
  * bytes, zero-filled once, private to one stream's launches.  c->x0 / c->pred_out / q->s_out / q->v_out are written when non-NULL; c->hist0 /
  * q->hist / pp->x0 / pp->s_q are not used.
  * Header of `sync`: [0] u64 ticket | [8] u32 error word (sticky) | [12] u32 knobs: bits 0..30 spin limit (0 = the built-in 2^22), bit 31
- * fault injection (tests: workgroup 1 of image 0 skips its arrival at radix pass 1).
+ * fault injection (tests: the last workgroup of image 0 skips its arrival at radix pass 1).
  * FAIL-STOP: the workgroups of an image wait for each other.  One launch cannot deadlock (work is claimed by ticket once resident), but
  * launches in flight on different streams can starve each other when their waiting workgroups together fill the chip (observed with 128
  * workgroups per image at 1024^2).  A workgroup whose wait runs out stores 0x300 + pass into the error word, overwrites ITS part of pp->x with

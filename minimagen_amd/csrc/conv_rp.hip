@@ -124,6 +124,7 @@ struct RpCfg {
     // s_waitcnt also waits for the prefetch); their launches at 64^2 are one round of <= 2 workgroups per CU anyway.  Measured, same box,
     // back to back: the 17 conv launches of the SR U-Net's 64^2 level 423 -> 383 us, SR step 1.461 -> 1.425 ms (profiles/r05_summary.md)
     // (the wide regime's four-N-tile kernels also spill at three, 39 registers, but measured no better at two: 32.9 vs 32.5 ms per step of Unet())
+    // (16 x 64 tiles at 256^2, with or without their 17 spills: 285 / 327 us against 270-277 us for the four launches on 8 x 64 tiles)
     static constexpr int WPS = (NJ_ == 1 && TH_ * TW_ <= 512 && (KO_ + RO_ == 1 || TH_ * TW_ <= 256)) ? 4 : ((NJ_ == 2 && TH_ * TW_ == 512 && !WIDE_) ? 2 : 3);
 };
 

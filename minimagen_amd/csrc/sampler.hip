@@ -460,7 +460,7 @@ inline int grid_for(long long n, int cap = 2048) {
 // image (and everything sampled from it) is NaN, which the reference's own pipeline would return for a NaN state as well, and the host
 // raises at its next status poll (Imagen: the word is copied to pinned host memory at the end of every call) and re-zeroes the buffer.
 // Header of `sync`: [0] u64 ticket | [8] u32 error | [12] u32 knobs: bits 0..30 spin limit (0: SG_SPIN_LIMIT), bit 31 fault injection (tests
-// only: workgroup 1 of image 0 never arrives at radix pass 1) -- error and knobs are ONE 8-byte load, in flight with the ticket atomic.
+// only: the last workgroup of image 0 never arrives at radix pass 1) -- error and knobs are ONE 8-byte load, in flight with the ticket atomic.
 constexpr int SG_NT = 1024, SG_MAXQ = 6;
 constexpr unsigned SG_SPIN_LIMIT = 1u << 22;
 struct sg_layout { long long counters, hist, total; };
@@ -550,7 +550,7 @@ __global__ __launch_bounds__(SG_NT) void sampler_group_kernel(const mi_cfg_x0_pa
         }
         mi_drain_vmem();                                   // every wave's atomics are performed before the arrival is counted
         __syncthreads();
-        if (tid == 0 && !(sFault == 1u && phase == 1 && b == 0 && g == 1)) mi_agent_add_u64(counter, 1ull);
+        if (tid == 0 && !(sFault == 1u && phase == 1 && b == 0 && g == G - 1)) mi_agent_add_u64(counter, 1ull);
         if (wave == 0) {
             const mi_u64 target = (seq * 3 + (mi_u64)phase + 1) * (mi_u64)G;
             const unsigned limit = sLimit;
