@@ -86,6 +86,12 @@ __device__ __forceinline__ uint4 rp_hi8(const float (&y)[8]) {
 template <class F, int... I>
 __device__ __forceinline__ void rp_for_rounds(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
 
+// B fragments lie in global memory as [block of 64 lanes][lane][hi | lo] (packing.pack_conv_weight_rp); read like that from LDS, a wave's 64 hi
+// (or lo) chunks are 32 bytes apart: lanes i and i + 8 of every 16-lane pass hit the same banks (2-way conflict on every B read: the 14-23 % of
+// LDS cycles the PMC passes showed as bank conflicts in every instantiation).  In LDS the two halves of a block are therefore kept as planes:
+// chunk k = 128 blk + 2 lane + t  ->  128 blk + 64 t + lane.
+__device__ __forceinline__ int rp_wl_index(int k) { return (k & ~127) | ((k & 1) << 6) | ((k & 127) >> 1); }
+
 // exponent e with |m| in [2^(e-1), 2^e); 0 for zero / non-finite input (-> no scaling)
 __device__ __forceinline__ int rp_exponent(float m) {
     const unsigned u = __float_as_uint(m) & 0x7fffffffu;
@@ -284,7 +290,7 @@ __global__ __launch_bounds__(256, CFG::WPS) void conv_rp_kernel(const mi_conv_pa
 #pragma unroll
         for (int i = 0; i < WPER; ++i) {
             const int k = tid + i * 256;
-            if (k < WTOT) wl[k] = wreg[i];
+            if (k < WTOT) wl[rp_wl_index(k)] = wreg[i];
         }
     }
     if (fast) mi_gn_totals_finish(sr, tid, chS, chQ);
@@ -391,7 +397,7 @@ __global__ __launch_bounds__(256, CFG::WPS) void conv_rp_kernel(const mi_conv_pa
 #pragma unroll
         for (int i = 0; i < WPER; ++i) {
             const int k = tid + i * 256;
-            if (k < n) wl[k] = wreg[i];
+            if (k < n) wl[rp_wl_index(k)] = wreg[i];
         }
     };
     // bias per N tile (this lane's output channel), once per strip: a load inside the tile loop would have to wait for the prefetch
@@ -514,8 +520,8 @@ __global__ __launch_bounds__(256, CFG::WPS) void conv_rp_kernel(const mi_conv_pa
 #pragma unroll
                 for (int jt = 0; jt < NJ; ++jt) {
                     const int wo = STATIC_ROUNDS ? (isres ? CFG::KO_T * WCH + k8 * NJ * 128 : k8 * WCH) : 0;
-                    bh[jt] = __builtin_bit_cast(rp_f16x8, wl[wo + ((s * NJ + jt) * 64 + lane) * 2]);
-                    if constexpr (!HALF) bl[jt] = __builtin_bit_cast(rp_f16x8, wl[wo + ((s * NJ + jt) * 64 + lane) * 2 + 1]);
+                    bh[jt] = __builtin_bit_cast(rp_f16x8, wl[wo + (s * NJ + jt) * 128 + lane]);
+                    if constexpr (!HALF) bl[jt] = __builtin_bit_cast(rp_f16x8, wl[wo + (s * NJ + jt) * 128 + 64 + lane]);
                 }
 #pragma unroll
                 for (int g = 0; g < GPW; ++g) {
