@@ -21,6 +21,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # before the first HIP call (minimagen_amd sets the same default at import)
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

@@ -131,7 +131,7 @@ struct RpCfg {
     // back to back: the 17 conv launches of the SR U-Net's 64^2 level 423 -> 383 us, SR step 1.461 -> 1.425 ms (profiles/r05_summary.md)
     // (the wide regime's four-N-tile kernels also spill at three, 39 registers, but measured no better at two: 32.9 vs 32.5 ms per step of Unet())
     // (16 x 64 tiles at 256^2, with or without their 17 spills: 285 / 327 us against 270-277 us for the four launches on 8 x 64 tiles)
-    static constexpr int WPS = (NJ_ == 1 && TH_ * TW_ <= 512 && (KO_ + RO_ == 1 || TH_ * TW_ <= 256)) ? 4 : ((NJ_ == 2 && TH_ * TW_ == 512 && !WIDE_) ? 2 : 3);
+    static constexpr int WPS = (NJ_ == 1 && TH_ * TW_ <= 512 && (KO_ + RO_ == 1 || TH_ * TW_ <= 256)) ? 4 : ((NJ_ >= 2 && TH_ * TW_ == 512) ? 2 : 3);
 };
 
 template <class CFG>
@@ -750,11 +750,11 @@ int launch_rp(const mi_conv_params& p, hipStream_t st) {
     return mi_check_launch("conv_rp_kernel");
 }
 
-// wide-channel regime: 8x32 pixel tiles, NJ N tiles per workgroup, the layer's output channels over blockIdx.y
-template <int NJ, bool GN, bool HALF, int MODE>
+// wide-channel regime: 8 x 32 (tile_cfg 7) or 8 x 64 (tile_cfg 6, MODE 0 only) pixel tiles, NJ N tiles per workgroup, the layer's output channels over blockIdx.y
+template <int TWW, int NJ, bool GN, bool HALF, int MODE>
 int launch_rp_wide(const mi_conv_params& p, hipStream_t st) {
-    using CFG = RpCfg<8, 32, NJ, GN, HALF, MODE, -1, -1, true>;
-    const int tiles = ((p.H + 7) / 8) * ((p.W + 31) / 32);
+    using CFG = RpCfg<8, TWW, NJ, GN, HALF, MODE, -1, -1, true>;
+    const int tiles = ((p.H + 7) / 8) * ((p.W + TWW - 1) / TWW);
     const int cpt = MODE == 2 ? 16 : 8, njt = (p.Cout + cpt - 1) / cpt;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_rp_kernel<CFG>), dim3(tiles * p.B, (njt + NJ - 1) / NJ), dim3(256), 0, st, p, (const uint4*)p.w_rp,
                        (const uint4*)p.res_w_rp, 1, (const float4*)p.gn_coef, (const int*)p.gn_exps);
@@ -766,14 +766,18 @@ int launch_rp_wide_m(const mi_conv_params& p, hipStream_t st) {
     const bool half = (p.tile_cfg & MI_CONV_HALF) != 0;
     const int cpt = MODE == 2 ? 16 : 8, njt = (p.Cout + cpt - 1) / cpt;
     if constexpr (MODE == 0) {
+        if ((p.tile_cfg & 0xff) == 6 && njt >= 4 && !half) {          // 8 x 64 tiles: the B fragments of a round serve twice the pixels
+            if (p.gn_groups > 0) return launch_rp_wide<64, 4, true, false, MODE>(p, st);
+            return launch_rp_wide<64, 4, false, false, MODE>(p, st);
+        }
         if (p.gn_groups > 0) {
-            if (njt >= 4) return half ? launch_rp_wide<4, true, true, MODE>(p, st) : launch_rp_wide<4, true, false, MODE>(p, st);
-            return half ? launch_rp_wide<1, true, true, MODE>(p, st) : launch_rp_wide<1, true, false, MODE>(p, st);
+            if (njt >= 4) return half ? launch_rp_wide<32, 4, true, true, MODE>(p, st) : launch_rp_wide<32, 4, true, false, MODE>(p, st);
+            return half ? launch_rp_wide<32, 1, true, true, MODE>(p, st) : launch_rp_wide<32, 1, true, false, MODE>(p, st);
         }
     }
-    if (njt >= 4 && MODE != 2) return half ? launch_rp_wide<4, false, true, MODE>(p, st) : launch_rp_wide<4, false, false, MODE>(p, st);
-    if (njt >= 2 && MODE == 2) return half ? launch_rp_wide<2, false, true, MODE>(p, st) : launch_rp_wide<2, false, false, MODE>(p, st);
-    return half ? launch_rp_wide<1, false, true, MODE>(p, st) : launch_rp_wide<1, false, false, MODE>(p, st);
+    if (njt >= 4 && MODE != 2) return half ? launch_rp_wide<32, 4, false, true, MODE>(p, st) : launch_rp_wide<32, 4, false, false, MODE>(p, st);
+    if (njt >= 2 && MODE == 2) return half ? launch_rp_wide<32, 2, false, true, MODE>(p, st) : launch_rp_wide<32, 2, false, false, MODE>(p, st);
+    return half ? launch_rp_wide<32, 1, false, true, MODE>(p, st) : launch_rp_wide<32, 1, false, false, MODE>(p, st);
 }
 
 template <int TH, int TW, int NJ, int MODE, int KO, int RO>
@@ -857,7 +861,7 @@ int mi_conv_rp_launch(const mi_conv_params& p, hipStream_t st) {
     if (biggest >= (1ull << 31)) { mi_set_error("mi_conv_fwd: row-paired path indexes one image with 32-bit offsets"); return MI_ERR_UNSUPPORTED; }
     if (wide) {
         if (!p.gn_exps) { mi_set_error("mi_conv_fwd: wide regime needs gn_exps (mi_gn_coef_fwd first)"); return MI_ERR_INVALID; }
-        if ((p.tile_cfg & 0xff) != 7) { mi_set_error("mi_conv_fwd: the wide regime uses tile_cfg 7 (8x32)"); return MI_ERR_INVALID; }
+        if ((p.tile_cfg & 0xff) != 7 && !((p.tile_cfg & 0xff) == 6 && mode == 0)) { mi_set_error("mi_conv_fwd: the wide regime uses tile_cfg 7 (8x32), or 6 (8x64) for the k3 s1 member"); return MI_ERR_INVALID; }
         return mode == 0 ? launch_rp_wide_m<0>(p, st) : (mode == 1 ? launch_rp_wide_m<1>(p, st) : launch_rp_wide_m<2>(p, st));
     }
     if (mode == 1) {

@@ -30,6 +30,7 @@ CONV_SPLIT16 = int(os.environ.get("MINIMAGEN_CONV_SPLIT16", "1"))
 CONV_SPLIT8 = int(os.environ.get("MINIMAGEN_CONV_SPLIT8", "64"))        # 8-channel outputs of images up to SPLIT8^2 pixels as two 4-channel workgroups (0 = off)
 CONV_RP = int(os.environ.get("MINIMAGEN_CONV_RP", "2"))                 # 1: narrow k3 s1 convs (channels in multiples of 8, <= 64 in) on the row-paired matrix-core kernel; 2: also nearest-x2 + k3 and k4 s2
 RP_TILE = {k: int(os.environ.get("MINIMAGEN_RP_TILE_" + k, d)) for k, d in (("L", "6"), ("M", "6"), ("S", "6"))}   # tile_cfg for images > 128^2 / > 64^2 / smaller
+RP_TILE_WIDE = int(os.environ.get("MINIMAGEN_RP_TILE_WIDE", "6"))          # tile of the wide k3 s1 convs: 6 = 8x64 where the image is a multiple of 64 wide (the B fragments of a round serve twice the pixels: Unet() default 32.2 -> 31.7 ms per step), 7 = 8x32
 RP_MIN_HW = int(os.environ.get("MINIMAGEN_RP_MIN_HW", "0"))             # ... for images of at least this many pixels
 CE_MFMA = os.environ.get("MINIMAGEN_CE_MFMA", "1") != "0"                  # CrossEmbed on the matrix cores (0: the fp32 VALU kernel)
 STORE16 = os.environ.get("MINIMAGEN_STORE16", "1") != "0"                  # reduced-precision configuration: bf16 activation storage
@@ -421,6 +422,8 @@ class UnetEngine:
                 cfg = 6                  # the up- / down-sampling members have one tile shape each
             if stride == 2 or wide:
                 cfg = 7
+            if wide and RP_TILE_WIDE == 6 and stride == 1 and not up2 and Wo % 64 == 0 and Cout >= 32 and not ws.half:
+                cfg = 6                  # 8 x 64 tiles for the wide k3 s1 convs
             th, tw = {5: (16, 64), 6: (8, 64), 7: (8, 32)}[cfg]
             nt = -(-Ho // th) * -(-Wo // tw)
         if ws.store16 and (not rp or wide):

@@ -328,6 +328,8 @@ WIDE_CASES = [
     (1, 72, 0, 3, 16, 32, 3, 1, 0, False, False, 'none'),         # final conv of a wide net
     (1, 128, 0, 64, 16, 32, 3, 1, 1, False, False, 'none'),       # nearest x2 + conv
     (1, 64, 0, 136, 8, 32, 4, 2, 0, False, False, 'none'),        # downsample k4 s2
+    (1, 128, 0, 64, 16, 128, 3, 1, 0, True, True, 'id', 6),       # 8 x 64 tiles (tile_cfg 6: the wide k3 s1 member where the image is a multiple of 64 wide)
+    (2, 96, 64, 72, 8, 64, 3, 1, 0, False, False, 'conv', 6),     # ... concat input, 1x1 residual over the concat, ragged N tiles, no GroupNorm
 ]
 
 
@@ -356,7 +358,8 @@ def test_conv_wide_regime(backend, case):
     exponents from mi_gn_coef_fwd) vs torch fp32"""
     dev = setup(backend)
     lib = L.lib()
-    B, C0, C1, Cout, H, W, ks, stride, up2, gn, ss, res = case
+    B, C0, C1, Cout, H, W, ks, stride, up2, gn, ss, res = case[:12]
+    tcfg = case[12] if len(case) > 12 else 7
     g = torch.Generator().manual_seed(sum(int(v) if not isinstance(v, str) else len(v) for v in case))
     rn = lambda *s_: torch.randn(*s_, generator=g)
     Hin, Win = (H // 2, W // 2) if up2 else (H * stride, W * stride)
@@ -407,10 +410,10 @@ def test_conv_wide_regime(backend, case):
     coef = torch.zeros(B, Cin, 4, device=dev)
     exps = torch.zeros(B, 2, dtype=torch.int32, device=dev)
     p.gn_coef, p.gn_exps = coef.data_ptr(), exps.data_ptr()
-    nt = tile_nt(lib, 7, H, W)
+    nt = tile_nt(lib, tcfg, H, W)
     out = torch.full((B, Cout, H, W), float('nan'), device=dev)
     ost = torch.zeros(B, Cout, nt, 2, dtype=torch.float64, device=dev)
-    p.out, p.out_stats, p.tile_cfg = out.data_ptr(), ost.data_ptr(), 7
+    p.out, p.out_stats, p.tile_cfg = out.data_ptr(), ost.data_ptr(), tcfg
     L.check(lib.mi_gn_coef_fwd(C.byref(p), L.current_stream()), "gn coef")
     L.check(lib.mi_conv_fwd(C.byref(p), L.current_stream()), "conv wide")
     scale = max(1.0, ref.abs().max().item() / 8.0)
