@@ -396,8 +396,13 @@ typedef struct mi_flash_attn_params {
     const float* k0; const float* v0; int n0, ld0; long long bs0;
     const float* k1; const float* v1; int n1, ld1; long long bs1;
     float* out;                     /* [B][HW][heads*64] */
+    /* optional workspace of mi_flash_kv_prep_bytes(B, J) bytes (J = context rows incl. the null row); with it the multi-query form (kv_heads == 1,
+       heads % 4 == 0) prepares its K / V operands once per launch (a small kernel) and streams them global -> LDS by LDS-DMA instead of every
+       workgroup re-staging the whole context; NULL: the self-staging kernel */
+    void* kv_prep; long long kv_prep_bytes;
 } mi_flash_attn_params;
 int mi_flash_attn_fwd(const mi_flash_attn_params* p, void* stream);
+long long mi_flash_kv_prep_bytes(int B, int J);
 typedef struct mi_tokens_to_nchw_params {
     int B, HW, C;
     const float* tokens;            /* [B][HW][C] */

@@ -109,7 +109,8 @@ class MiFlashAttnParams(C.Structure):
     _fields_ = [("B", C.c_int), ("HW", C.c_int), ("heads", C.c_int), ("kv_heads", C.c_int), ("q", C.c_void_p), ("q_scale", C.c_float),
                 ("null_k", C.c_void_p), ("null_v", C.c_void_p),
                 ("k0", C.c_void_p), ("v0", C.c_void_p), ("n0", C.c_int), ("ld0", C.c_int), ("bs0", C.c_longlong),
-                ("k1", C.c_void_p), ("v1", C.c_void_p), ("n1", C.c_int), ("ld1", C.c_int), ("bs1", C.c_longlong), ("out", C.c_void_p)]
+                ("k1", C.c_void_p), ("v1", C.c_void_p), ("n1", C.c_int), ("ld1", C.c_int), ("bs1", C.c_longlong), ("out", C.c_void_p),
+                ("kv_prep", C.c_void_p), ("kv_prep_bytes", C.c_longlong)]
 
 
 class MiTokensToNchwParams(C.Structure):
@@ -199,6 +200,8 @@ def _bind(lib):
                  "mi_flash_attn_fwd", "mi_tokens_to_nchw_fwd", "mi_conv_wgrad", "mi_block_bwd", "mi_crossembed_wgrad", "mi_folded_attn_fwd", "mi_folded_attn_bwd", "mi_adam_step"):
         getattr(lib, name).argtypes = [vp, vp]
         getattr(lib, name).restype = i32
+    lib.mi_flash_kv_prep_bytes.argtypes = [i32, i32]
+    lib.mi_flash_kv_prep_bytes.restype = C.c_longlong
     lib.mi_step_advance.argtypes = [vp, vp, i32, vp]
     lib.mi_step_advance_by.argtypes = [vp, vp, i32, i32, vp]
     lib.mi_sampler_step_small_fwd.argtypes = [vp, vp, vp, vp]

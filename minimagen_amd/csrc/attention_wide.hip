@@ -305,6 +305,218 @@ __global__ __launch_bounds__(64 * NW) void flash_attn_f16x3_kernel(const mi_flas
     }
 }
 
+// ---- multi-query attention with the K / V operands prepared ONCE per launch (p.kv_prep): flash_kv_prep_kernel splits, scales and transposes
+// every 64-row context chunk into the exact LDS image flash_attn_f16x3_kernel builds for itself -- [K hi | K lo | V^T hi | V^T lo], 4 x 64 x 9
+// 16-byte chunks, plus the chunk's two block-scaling exponents -- and flash_attn_mq_kernel copies a chunk global -> LDS by LDS-DMA into a
+// double buffer, the next chunk under the current one's matrix work, one barrier per chunk.  In the staged form every workgroup (64 queries)
+// re-did that preparation for all 65 chunks of a 4096-token context: two reductions, the split, 2-byte scattered LDS writes and three barriers
+// per chunk, 64 times per image -- 11.5 us per chunk and workgroup against ~3 us of LDS reads + matrix work.  Same arithmetic, same bits.
+constexpr int FW_CP = 9, FW_CHUNK16 = 4 * 64 * FW_CP;         // 16-byte chunks of one prepared context chunk (36 864 bytes)
+
+__global__ __launch_bounds__(256) void flash_kv_prep_kernel(const mi_flash_attn_params p, const int nchunk) {
+    constexpr int D = 64, CP = FW_CP, EPT = 16, PPR = 4;
+    __shared__ __attribute__((aligned(16))) uint4 img[FW_CHUNK16];          // KsH | KsL | VtH | VtL
+    __shared__ float smax[2][4];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int c = blockIdx.x, b = blockIdx.z, j0 = 64 * c;
+    const int nnull = p.null_k ? 1 : 0, J = nnull + p.n0 + p.n1;
+    const int srow = tid / PPR, sd0 = (tid % PPR) * EPT;
+    const int spos = (srow & 32) | (((srow >> 2) & 3) << 3) | (((srow >> 4) & 1) << 2) | (srow & 3);
+    float kf[EPT], vf[EPT];
+    {
+        const int jj = j0 + srow;
+        const float* ksrc = nullptr;
+        const float* vsrc = nullptr;
+        if (jj < J) {
+            if (jj < nnull) { ksrc = p.null_k; vsrc = p.null_v; }
+            else if (jj - nnull < p.n0) { const size_t o_ = (size_t)b * p.bs0 + (size_t)(jj - nnull) * p.ld0; ksrc = p.k0 + o_; vsrc = p.v0 + o_; }
+            else { const size_t o_ = (size_t)b * p.bs1 + (size_t)(jj - nnull - p.n0) * p.ld1; ksrc = p.k1 + o_; vsrc = p.v1 + o_; }
+        }
+#pragma unroll
+        for (int e = 0; e < EPT; e += 4) {
+            float4 k4 = make_float4(0.f, 0.f, 0.f, 0.f), v4 = k4;
+            if (ksrc) { k4 = *reinterpret_cast<const float4*>(ksrc + sd0 + e); v4 = *reinterpret_cast<const float4*>(vsrc + sd0 + e); }
+            kf[e] = k4.x; kf[e + 1] = k4.y; kf[e + 2] = k4.z; kf[e + 3] = k4.w;
+            vf[e] = v4.x; vf[e + 1] = v4.y; vf[e + 2] = v4.z; vf[e + 3] = v4.w;
+        }
+    }
+    float mk = 0.0f, mv = 0.0f;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) { mk = fmaxf(mk, fabsf(kf[e])); mv = fmaxf(mv, fabsf(vf[e])); }
+    mk = mi_wave_max(mk); mv = mi_wave_max(mv);
+    for (int i = tid; i < FW_CHUNK16; i += 256) img[i] = make_uint4(0u, 0u, 0u, 0u);      // (the pad chunks are copied too: keep them defined)
+    if (lane == 0) { smax[0][wave] = mk; smax[1][wave] = mv; }
+    __syncthreads();
+    const float mka = fmaxf(fmaxf(smax[0][0], smax[0][1]), fmaxf(smax[0][2], smax[0][3])), mva = fmaxf(fmaxf(smax[1][0], smax[1][1]), fmaxf(smax[1][2], smax[1][3]));
+    const int ek = fw_scale_exp(mka), ev = fw_scale_exp(mva);
+    {
+        const float sk = ldexpf(1.0f, ek), sv = ldexpf(1.0f, ev);
+        _Float16* ksh = reinterpret_cast<_Float16*>(img);
+        _Float16* ksl = reinterpret_cast<_Float16*>(img + 64 * CP);
+        _Float16* vth = reinterpret_cast<_Float16*>(img + 2 * 64 * CP);
+        _Float16* vtl = reinterpret_cast<_Float16*>(img + 3 * 64 * CP);
+#pragma unroll
+        for (int e = 0; e < EPT; e += 4) {
+            unsigned hb[2], lb[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const float x0 = kf[e + 2 * q] * sk, x1 = kf[e + 2 * q + 1] * sk;
+                const mi_f16x2 h2 = {(_Float16)x0, (_Float16)x1};
+                hb[q] = __builtin_bit_cast(unsigned, h2);
+                lb[q] = mi_split_lo2(hb[q], x0, x1);
+            }
+            *reinterpret_cast<uint2*>(ksh + srow * (8 * CP) + sd0 + e) = make_uint2(hb[0], hb[1]);
+            *reinterpret_cast<uint2*>(ksl + srow * (8 * CP) + sd0 + e) = make_uint2(lb[0], lb[1]);
+        }
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const float x = vf[e] * sv;
+            const _Float16 hi = (_Float16)x, lo = (_Float16)(x - (float)hi);
+            vth[(sd0 + e) * (8 * CP) + spos] = hi;
+            vtl[(sd0 + e) * (8 * CP) + spos] = lo;
+        }
+    }
+    __syncthreads();
+    uint4* dst = reinterpret_cast<uint4*>(p.kv_prep) + ((size_t)b * nchunk + c) * FW_CHUNK16;
+    for (int i = tid; i < FW_CHUNK16; i += 256) dst[i] = img[i];
+    if (tid == 0) {
+        int* ex = reinterpret_cast<int*>(reinterpret_cast<uint4*>(p.kv_prep) + (size_t)p.B * nchunk * FW_CHUNK16) + ((size_t)b * nchunk + c) * 2;
+        ex[0] = ek; ex[1] = ev;
+    }
+}
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void flash_attn_mq_kernel(const mi_flash_attn_params p, const int nchunk) {
+    constexpr int D = 64, CP = FW_CP, NH = NW / 4;
+    __shared__ __attribute__((aligned(16))) uint4 kv[2][FW_CHUNK16];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lq = lane & 15, lg = lane >> 4;
+    const int h = blockIdx.y * NH + (wave >> 2), b = blockIdx.z;
+    const int inner = p.heads * D;
+    const int tok = (blockIdx.x * 4 + (wave & 3)) * 16 + lq;
+    const int tokc = tok < p.HW ? tok : p.HW - 1;
+    const int nnull = p.null_k ? 1 : 0, J = nnull + p.n0 + p.n1;
+    const uint4* const prep = reinterpret_cast<const uint4*>(p.kv_prep) + (size_t)b * nchunk * FW_CHUNK16;
+    const int* const exps = reinterpret_cast<const int*>(reinterpret_cast<const uint4*>(p.kv_prep) + (size_t)p.B * nchunk * FW_CHUNK16) + (size_t)b * nchunk * 2;
+    auto issue_chunk = [&](int c, int buf) {
+        for (int r = wave; r < FW_CHUNK16 / 64; r += NW) {           // one 1 KB row (64 lanes x 16 bytes) per instruction
+            const uint4* src = prep + (size_t)c * FW_CHUNK16 + r * 64 + lane;
+#if defined(HIPEMU)
+            kv[buf][r * 64 + lane] = *src;
+#else
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)&kv[buf][r * 64], 16, 0, 0);
+#endif
+        }
+    };
+    issue_chunk(0, 0);
+    // Q as the B operand (as flash_attn_f16x3_kernel)
+    fw_f16x8 qh[2], ql[2];
+    int eq;
+    {
+        const float* qr = p.q + ((size_t)b * p.HW + tokc) * inner + h * D;
+        float qv[2][8];
+        float mq = 0.0f;
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const float4 a = *reinterpret_cast<const float4*>(qr + 32 * hf + 8 * lg), c4 = *reinterpret_cast<const float4*>(qr + 32 * hf + 8 * lg + 4);
+            const float t[8] = {a.x, a.y, a.z, a.w, c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { qv[hf][e] = t[e] * p.q_scale; mq = fmaxf(mq, fabsf(qv[hf][e])); }
+        }
+        eq = fw_scale_exp(mi_wave_max(mq));
+        const float sq = ldexpf(1.0f, eq);
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            float t[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t[e] = qv[hf][e] * sq;
+            uint4 hi, lo;
+            fw_split8(t, hi, lo);
+            qh[hf] = __builtin_bit_cast(fw_f16x8, hi);
+            ql[hf] = __builtin_bit_cast(fw_f16x8, lo);
+        }
+    }
+    float m = -INFINITY, l = 0.0f;
+    f32x4 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < nchunk; ++c) {
+        const int j0 = 64 * c, buf = c & 1;
+#if !defined(HIPEMU)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of chunk c has landed in LDS ...
+#endif
+        __syncthreads();                                  // ... everybody's has, and nobody reads chunk c - 1's buffer any more
+        if (c + 1 < nchunk) issue_chunk(c + 1, buf ^ 1);
+        const uint4* const KsH = kv[buf], * const KsL = kv[buf] + 64 * CP, * const VtH = kv[buf] + 2 * 64 * CP, * const VtL = kv[buf] + 3 * 64 * CP;
+        const int ek = exps[2 * c], ev = exps[2 * c + 1];
+        const float us = ldexpf(1.0f, -(ek + eq)), uv = ldexpf(1.0f, -ev);
+        f32x4 s[4];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+            f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const fw_f16x8 kh = __builtin_bit_cast(fw_f16x8, KsH[(16 * jt + lq) * CP + 4 * hf + lg]), kl = __builtin_bit_cast(fw_f16x8, KsL[(16 * jt + lq) * CP + 4 * hf + lg]);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl, qh[hf], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, ql[hf], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, qh[hf], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                acc[r] *= us;
+                if (j0 + 16 * jt + 4 * lg + r >= J) acc[r] = -INFINITY;
+                mx = fmaxf(mx, acc[r]);
+            }
+            s[jt] = acc;
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float mn = fmaxf(m, mx);
+        const float alpha = __builtin_amdgcn_exp2f(m - mn);
+        m = mn;
+        l *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[dt][r] *= alpha;
+        fw_f16x8 ph[2], pl[2];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            float pe[8];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { pe[4 * t + r] = __builtin_amdgcn_exp2f(s[2 * hf + t][r] - mn); l += pe[4 * t + r]; }
+            uint4 hi, lo;
+            fw_split8(pe, hi, lo);
+            ph[hf] = __builtin_bit_cast(fw_f16x8, hi);
+            pl[hf] = __builtin_bit_cast(fw_f16x8, lo);
+        }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            f32x4 sl = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const fw_f16x8 vh = __builtin_bit_cast(fw_f16x8, VtH[(16 * dt + lq) * CP + 4 * hf + lg]), vl = __builtin_bit_cast(fw_f16x8, VtL[(16 * dt + lq) * CP + 4 * hf + lg]);
+                sl = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl, ph[hf], sl, 0, 0, 0);
+                sl = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, pl[hf], sl, 0, 0, 0);
+                sl = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, ph[hf], sl, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[dt][r] = fmaf(sl[r], uv, o[dt][r]);
+        }
+    }
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+    const float linv = 1.0f / l;
+    if (tok < p.HW) {
+        float* orow = p.out + ((size_t)b * p.HW + tok) * inner + h * D;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+            *reinterpret_cast<float4*>(orow + 16 * dt + 4 * lg) = make_float4(o[dt][0] * linv, o[dt][1] * linv, o[dt][2] * linv, o[dt][3] * linv);
+    }
+}
+
 // ---- tokens [B][HW][C] -> NCHW, with an optional LayerNorm over C (gamma, beta) in front, a residual NCHW tensor added and the next
 // GroupNorm's partial statistics (64-token tiles) emitted: to_out.1 + residual of both attentions, and the tail of ChanFeedForward
 // A workgroup = 64 tokens.  Token rows are read channel-contiguous (a wave per token row: coalesced), the 64 x 64 (token, channel) blocks go
@@ -397,6 +609,12 @@ extern "C" int mi_flash_attn_fwd(const mi_flash_attn_params* p, void* stream) {
     static const bool exact = getenv("MI_FLASH_EXACT_F32") != nullptr;
     static const bool one_head = getenv("MI_FLASH_ONE_HEAD") != nullptr;
     if (exact) hipLaunchKernelGGL(flash_attn_kernel, dim3((p->HW + 63) / 64, p->heads, p->B), dim3(256), 0, (hipStream_t)stream, *p);
+    else if (p->kv_heads == 1 && (p->heads & 3) == 0 && !one_head && p->kv_prep) {       // multi-query with prepared K / V (see flash_kv_prep_kernel)
+        const int nnull = p->null_k ? 1 : 0, nchunk = (nnull + p->n0 + p->n1 + 63) / 64;
+        if (p->kv_prep_bytes < mi_flash_kv_prep_bytes(p->B, nnull + p->n0 + p->n1)) { mi_set_error("mi_flash_attn_fwd: kv_prep buffer too small"); return MI_ERR_INVALID; }
+        hipLaunchKernelGGL(flash_kv_prep_kernel, dim3(nchunk, 1, p->B), dim3(256), 0, (hipStream_t)stream, *p, nchunk);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(flash_attn_mq_kernel<16>), dim3((p->HW + 63) / 64, p->heads / 4, p->B), dim3(1024), 0, (hipStream_t)stream, *p, nchunk);
+    }
     else if (p->kv_heads == 1 && (p->heads & 3) == 0 && !one_head) {    // multi-query: heads of the same 64 queries share every staged K / V chunk
         static const int two_heads = getenv("MI_FLASH_TWO_HEADS") ? atoi(getenv("MI_FLASH_TWO_HEADS")) : 0;
         if (two_heads) hipLaunchKernelGGL(HIP_KERNEL_NAME(flash_attn_f16x3_kernel<8>), dim3((p->HW + 63) / 64, p->heads / 2, p->B), dim3(512), 0, (hipStream_t)stream, *p);
@@ -404,6 +622,11 @@ extern "C" int mi_flash_attn_fwd(const mi_flash_attn_params* p, void* stream) {
     }
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(flash_attn_f16x3_kernel<4>), dim3((p->HW + 63) / 64, p->heads, p->B), dim3(256), 0, (hipStream_t)stream, *p);
     return mi_check_launch("flash_attn_kernel");
+}
+
+extern "C" long long mi_flash_kv_prep_bytes(int B, int J) {
+    const long long nchunk = (J + 63) / 64;
+    return (long long)B * nchunk * (FW_CHUNK16 * 16 + 8);
 }
 
 extern "C" int mi_tokens_to_nchw_fwd(const mi_tokens_to_nchw_params* p, void* stream) {

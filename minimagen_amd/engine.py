@@ -31,6 +31,7 @@ CONV_SPLIT8 = int(os.environ.get("MINIMAGEN_CONV_SPLIT8", "64"))        # 8-chan
 CONV_RP = int(os.environ.get("MINIMAGEN_CONV_RP", "2"))                 # 1: narrow k3 s1 convs (channels in multiples of 8, <= 64 in) on the row-paired matrix-core kernel; 2: also nearest-x2 + k3 and k4 s2
 RP_TILE = {k: int(os.environ.get("MINIMAGEN_RP_TILE_" + k, d)) for k, d in (("L", "6"), ("M", "6"), ("S", "6"))}   # tile_cfg for images > 128^2 / > 64^2 / smaller
 RP_TILE_WIDE = int(os.environ.get("MINIMAGEN_RP_TILE_WIDE", "6"))          # tile of the wide k3 s1 convs: 6 = 8x64 where the image is a multiple of 64 wide (the B fragments of a round serve twice the pixels: Unet() default 32.2 -> 31.7 ms per step), 7 = 8x32
+FLASH_KV_PREP = os.environ.get("MINIMAGEN_FLASH_KV_PREP", "1") != "0"     # multi-query self-attention of the wide presets: K / V prepared once per launch, LDS-DMA into the workgroups
 RP_MIN_HW = int(os.environ.get("MINIMAGEN_RP_MIN_HW", "0"))             # ... for images of at least this many pixels
 CE_MFMA = os.environ.get("MINIMAGEN_CE_MFMA", "1") != "0"                  # CrossEmbed on the matrix cores (0: the fp32 VALU kernel)
 STORE16 = os.environ.get("MINIMAGEN_STORE16", "1") != "0"                  # reduced-precision configuration: bf16 activation storage
@@ -566,6 +567,11 @@ class UnetEngine:
         p.null_k, p.null_v = L.ptr(at.null_kv), L.ptr(at.null_kv) + 4 * 64
         p.k0, p.v0, p.n0, p.ld0, p.bs0 = L.ptr(kv), L.ptr(kv) + 4 * 64, HW, 128, HW * 128
         p.out = L.ptr(o)
+        if FLASH_KV_PREP and at.heads % 4 == 0:
+            # K / V split + transposed once per launch, streamed to LDS by DMA (attention_wide.hip: flash_kv_prep_kernel)
+            nbytes = lib.mi_flash_kv_prep_bytes(batch, HW + 1)
+            prep = self._buf(ws, (nbytes + 3) // 4)
+            p.kv_prep, p.kv_prep_bytes = L.ptr(prep), nbytes
         ws.prog.append((lib.mi_flash_attn_fwd, p, "flash_attn"))
         ws.prog.append(self._call(lib.mi_gemm_f32, "gemm_out", L.ptr(o), L.ptr(at.to_out[0].weight), 0, 0, L.ptr(t), batch * HW, Cc, inner, 0))
         return self._emit_tokens_out(ws, t, batch, Cc, x.H, x.W, at.to_out[1], x, want_stats)

@@ -701,6 +701,7 @@ FLASH_CASES = [
     (2, 100, 2, 2, 4, 40, True, 1.0, 1.0, 1.0),            # CrossAttention: null + time tokens + text rows, per-head k / v, ragged HW and J
     (1, 64, 3, 1, 64, 0, True, 1.0, 1.0, 1.0),             # multi-query self-attention: one shared k / v head, context = the tokens themselves
     (2, 150, 8, 1, 150, 0, True, 1.0, 1.0, 1.0),           # multi-query with heads % 4 == 0: four heads per workgroup share the staged chunks
+    (1, 70, 4, 1, 70, 60, False, 30.0, 1.0 / 64, 300.0),   # ... three chunks over two segments, no null row, far from unit scale
     (1, 80, 2, 2, 130, 0, False, 30.0, 1.0 / 64, 300.0),   # three chunks, no null row, operands far from unit scale
     (1, 16, 1, 1, 3, 0, True, 1.0 / 256, 256.0, 1.0 / 512),
 ]
@@ -750,6 +751,18 @@ def test_flash_attention_unfolded(backend, case):
     gate = 2e-5 * max(1.0, ref.abs().max().item())
     print(f"flash attention {case}: max|d| = {err:.2e} (gate {gate:.2e})")
     assert torch.isfinite(out).all() and err < gate
+    if kvh == 1 and heads % 4 == 0:
+        # the same launch with its K / V operands prepared once (flash_kv_prep_kernel + LDS-DMA): the same arithmetic, the same bits
+        J = (1 if has_null else 0) + n0 + n1
+        nbytes = lib.mi_flash_kv_prep_bytes(B, J)
+        assert nbytes == B * ((J + 63) // 64) * (4 * 64 * 9 * 16 + 8)
+        prep = torch.full(((nbytes + 3) // 4,), float('nan'), device=dev)
+        out2 = torch.full((B, HW, inner), float('nan'), device=dev)
+        p.out, p.kv_prep, p.kv_prep_bytes = L.ptr(out2), L.ptr(prep), nbytes
+        L.check(lib.mi_flash_attn_fwd(C.byref(p), L.current_stream()), "flash (prepared k / v)")
+        assert torch.equal(out2.cpu(), out.cpu())
+        p.kv_prep_bytes = nbytes - 1
+        assert lib.mi_flash_attn_fwd(C.byref(p), L.current_stream()) != 0
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
