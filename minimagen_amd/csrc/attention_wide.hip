@@ -4,6 +4,7 @@
 // The folded kernels of attention.hip pay K = C per score, which only wins while C <= 32; from 64 channels up the reference's own
 // factorisation (dim_head 64) is the cheaper one.  Everything here is exact fp32 on v_mfma_f32_16x16x4_f32 (no operand splits).
 #include "common.hip.h"
+#include <type_traits>
 #include <cstdlib>
 
 namespace {
@@ -262,7 +263,7 @@ __global__ __launch_bounds__(64 * NW) void flash_attn_f16x3_kernel(const mi_flas
         const float mn = fmaxf(m, mx);                      // finite: every chunk holds at least one live row
         const float alpha = __builtin_amdgcn_exp2f(m - mn);  // m = -inf on the first chunk -> 0
         m = mn;
-        l *= alpha;
+        l = mi_mul_rounded(l, alpha);                  // (the prepared-K/V kernel below skips this when alpha == 1: same bits either way)
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
@@ -385,15 +386,15 @@ __global__ __launch_bounds__(256) void flash_kv_prep_kernel(const mi_flash_attn_
     }
 }
 
-template <int NW>
-__global__ __launch_bounds__(64 * NW) void flash_attn_mq_kernel(const mi_flash_attn_params p, const int nchunk) {
-    constexpr int D = 64, CP = FW_CP, NH = NW / 4;
+template <int NW, int QT, int WPS>
+__global__ __launch_bounds__(64 * NW, WPS) void flash_attn_mq_kernel(const mi_flash_attn_params p, const int nchunk) {
+    // a workgroup = 64 queries x NH heads; a wave = QT 16-query tiles of one head: every K / V fragment read from LDS feeds QT x 3 matrix
+    // instructions (with QT = 1 and 16 waves the LDS reads -- each wave reads the whole 36 KB chunk -- took longer than the matrix work)
+    constexpr int D = 64, CP = FW_CP, WPH = 4 / QT, NH = NW / WPH;
     __shared__ __attribute__((aligned(16))) uint4 kv[2][FW_CHUNK16];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lq = lane & 15, lg = lane >> 4;
-    const int h = blockIdx.y * NH + (wave >> 2), b = blockIdx.z;
+    const int h = blockIdx.y * NH + wave / WPH, b = blockIdx.z;
     const int inner = p.heads * D;
-    const int tok = (blockIdx.x * 4 + (wave & 3)) * 16 + lq;
-    const int tokc = tok < p.HW ? tok : p.HW - 1;
     const int nnull = p.null_k ? 1 : 0, J = nnull + p.n0 + p.n1;
     const uint4* const prep = reinterpret_cast<const uint4*>(p.kv_prep) + (size_t)b * nchunk * FW_CHUNK16;
     const int* const exps = reinterpret_cast<const int*>(reinterpret_cast<const uint4*>(p.kv_prep) + (size_t)p.B * nchunk * FW_CHUNK16) + (size_t)b * nchunk * 2;
@@ -408,38 +409,47 @@ __global__ __launch_bounds__(64 * NW) void flash_attn_mq_kernel(const mi_flash_a
         }
     };
     issue_chunk(0, 0);
-    // Q as the B operand (as flash_attn_f16x3_kernel)
-    fw_f16x8 qh[2], ql[2];
-    int eq;
-    {
+    // Q as the B operand (as flash_attn_f16x3_kernel), one block-scaling exponent per 16-query tile
+    fw_f16x8 qh[QT][2], ql[QT][2];
+    int eq[QT], tok[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        tok[t] = (blockIdx.x * 4 + (wave % WPH) * QT + t) * 16 + lq;
+        const int tokc = tok[t] < p.HW ? tok[t] : p.HW - 1;
         const float* qr = p.q + ((size_t)b * p.HW + tokc) * inner + h * D;
         float qv[2][8];
         float mq = 0.0f;
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
             const float4 a = *reinterpret_cast<const float4*>(qr + 32 * hf + 8 * lg), c4 = *reinterpret_cast<const float4*>(qr + 32 * hf + 8 * lg + 4);
-            const float t[8] = {a.x, a.y, a.z, a.w, c4.x, c4.y, c4.z, c4.w};
+            const float w[8] = {a.x, a.y, a.z, a.w, c4.x, c4.y, c4.z, c4.w};
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { qv[hf][e] = t[e] * p.q_scale; mq = fmaxf(mq, fabsf(qv[hf][e])); }
+            for (int e = 0; e < 8; ++e) { qv[hf][e] = w[e] * p.q_scale; mq = fmaxf(mq, fabsf(qv[hf][e])); }
         }
-        eq = fw_scale_exp(mi_wave_max(mq));
-        const float sq = ldexpf(1.0f, eq);
+        eq[t] = fw_scale_exp(mi_wave_max(mq));
+        const float sq = ldexpf(1.0f, eq[t]);
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
-            float t[8];
+            float w[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) t[e] = qv[hf][e] * sq;
+            for (int e = 0; e < 8; ++e) w[e] = qv[hf][e] * sq;
             uint4 hi, lo;
-            fw_split8(t, hi, lo);
-            qh[hf] = __builtin_bit_cast(fw_f16x8, hi);
-            ql[hf] = __builtin_bit_cast(fw_f16x8, lo);
+            fw_split8(w, hi, lo);
+            qh[t][hf] = __builtin_bit_cast(fw_f16x8, hi);
+            ql[t][hf] = __builtin_bit_cast(fw_f16x8, lo);
         }
     }
-    float m = -INFINITY, l = 0.0f;
-    f32x4 o[4];
+    float m[QT], l[QT];
+    f32x4 o[QT][4];
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int c = 0; c < nchunk; ++c) {
+    for (int t = 0; t < QT; ++t) {
+        m[t] = -INFINITY; l[t] = 0.0f;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[t][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    // one context chunk; MASKED only for the last one (the only chunk that can hold rows >= J).  The block scale `us` is a power of two, so
+    // max(s) * us and fma(s, us, -max) are the values max(s * us) and s * us - max of the self-staging kernel, without the multiplies.
+    auto chunk = [&](const int c, auto masked) {
         const int j0 = 64 * c, buf = c & 1;
 #if !defined(HIPEMU)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of chunk c has landed in LDS ...
@@ -448,72 +458,96 @@ __global__ __launch_bounds__(64 * NW) void flash_attn_mq_kernel(const mi_flash_a
         if (c + 1 < nchunk) issue_chunk(c + 1, buf ^ 1);
         const uint4* const KsH = kv[buf], * const KsL = kv[buf] + 64 * CP, * const VtH = kv[buf] + 2 * 64 * CP, * const VtL = kv[buf] + 3 * 64 * CP;
         const int ek = exps[2 * c], ev = exps[2 * c + 1];
-        const float us = ldexpf(1.0f, -(ek + eq)), uv = ldexpf(1.0f, -ev);
-        f32x4 s[4];
-        float mx = -INFINITY;
+        const float uv = ldexpf(1.0f, -ev);
+        f32x4 s[QT][4];
 #pragma unroll
         for (int jt = 0; jt < 4; ++jt) {
-            f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < QT; ++t) s[t][jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
                 const fw_f16x8 kh = __builtin_bit_cast(fw_f16x8, KsH[(16 * jt + lq) * CP + 4 * hf + lg]), kl = __builtin_bit_cast(fw_f16x8, KsL[(16 * jt + lq) * CP + 4 * hf + lg]);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl, qh[hf], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, ql[hf], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, qh[hf], acc, 0, 0, 0);
-            }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                acc[r] *= us;
-                if (j0 + 16 * jt + 4 * lg + r >= J) acc[r] = -INFINITY;
-                mx = fmaxf(mx, acc[r]);
+                for (int t = 0; t < QT; ++t) {
+                    s[t][jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl, qh[t][hf], s[t][jt], 0, 0, 0);
+                    s[t][jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, ql[t][hf], s[t][jt], 0, 0, 0);
+                    s[t][jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, qh[t][hf], s[t][jt], 0, 0, 0);
+                }
             }
-            s[jt] = acc;
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 16));
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float mn = fmaxf(m, mx);
-        const float alpha = __builtin_amdgcn_exp2f(m - mn);
-        m = mn;
-        l *= alpha;
+        fw_f16x8 ph[QT][2], pl[QT][2];
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
+        for (int t = 0; t < QT; ++t) {
+            const float us = ldexpf(1.0f, -(ek + eq[t]));
+            float mx = -INFINITY;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[dt][r] *= alpha;
-        fw_f16x8 ph[2], pl[2];
+            for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-            float pe[8];
+                for (int r = 0; r < 4; ++r) {
+                    if (decltype(masked)::value && j0 + 16 * jt + 4 * lg + r >= J) s[t][jt][r] = -INFINITY;
+                    mx = fmaxf(mx, s[t][jt][r]);
+                }
+            mx *= us;
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float mn = fmaxf(m[t], mx);
+            if (__any(mn != m[t])) {                        // (else every lane's alpha is exp2(0) = 1)
+                const float alpha = __builtin_amdgcn_exp2f(m[t] - mn);
+                m[t] = mn;
+                l[t] = mi_mul_rounded(l[t], alpha);
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+                for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { pe[4 * t + r] = __builtin_amdgcn_exp2f(s[2 * hf + t][r] - mn); l += pe[4 * t + r]; }
-            uint4 hi, lo;
-            fw_split8(pe, hi, lo);
-            ph[hf] = __builtin_bit_cast(fw_f16x8, hi);
-            pl[hf] = __builtin_bit_cast(fw_f16x8, lo);
+                    for (int r = 0; r < 4; ++r) o[t][dt][r] *= alpha;
+            }
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                float pe[8];
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { pe[4 * u + r] = __builtin_amdgcn_exp2f(fmaf(s[t][2 * hf + u][r], us, -mn)); l[t] += pe[4 * u + r]; }
+                uint4 hi, lo;
+                fw_split8(pe, hi, lo);
+                ph[t][hf] = __builtin_bit_cast(fw_f16x8, hi);
+                pl[t][hf] = __builtin_bit_cast(fw_f16x8, lo);
+            }
         }
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
-            f32x4 sl = (f32x4){0.f, 0.f, 0.f, 0.f};
+            f32x4 sl[QT];
+#pragma unroll
+            for (int t = 0; t < QT; ++t) sl[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
                 const fw_f16x8 vh = __builtin_bit_cast(fw_f16x8, VtH[(16 * dt + lq) * CP + 4 * hf + lg]), vl = __builtin_bit_cast(fw_f16x8, VtL[(16 * dt + lq) * CP + 4 * hf + lg]);
-                sl = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl, ph[hf], sl, 0, 0, 0);
-                sl = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, pl[hf], sl, 0, 0, 0);
-                sl = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, ph[hf], sl, 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < QT; ++t) {
+                    sl[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl, ph[t][hf], sl[t], 0, 0, 0);
+                    sl[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, pl[t][hf], sl[t], 0, 0, 0);
+                    sl[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, ph[t][hf], sl[t], 0, 0, 0);
+                }
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[dt][r] = fmaf(sl[r], uv, o[dt][r]);
-        }
-    }
-    l += __shfl_xor(l, 16);
-    l += __shfl_xor(l, 32);
-    const float linv = 1.0f / l;
-    if (tok < p.HW) {
-        float* orow = p.out + ((size_t)b * p.HW + tok) * inner + h * D;
+            for (int t = 0; t < QT; ++t)
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
-            *reinterpret_cast<float4*>(orow + 16 * dt + 4 * lg) = make_float4(o[dt][0] * linv, o[dt][1] * linv, o[dt][2] * linv, o[dt][3] * linv);
+                for (int r = 0; r < 4; ++r) o[t][dt][r] = fmaf(sl[t][r], uv, o[t][dt][r]);
+        }
+    };
+    for (int c = 0; c + 1 < nchunk; ++c) chunk(c, std::false_type{});
+    chunk(nchunk - 1, std::true_type{});
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        float lt = l[t];
+        lt += __shfl_xor(lt, 16);
+        lt += __shfl_xor(lt, 32);
+        const float linv = 1.0f / lt;
+        if (tok[t] < p.HW) {
+            float* orow = p.out + ((size_t)b * p.HW + tok[t]) * inner + h * D;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                *reinterpret_cast<float4*>(orow + 16 * dt + 4 * lg) = make_float4(o[t][dt][0] * linv, o[t][dt][1] * linv, o[t][dt][2] * linv, o[t][dt][3] * linv);
+        }
     }
 }
 
@@ -613,7 +647,10 @@ extern "C" int mi_flash_attn_fwd(const mi_flash_attn_params* p, void* stream) {
         const int nnull = p->null_k ? 1 : 0, nchunk = (nnull + p->n0 + p->n1 + 63) / 64;
         if (p->kv_prep_bytes < mi_flash_kv_prep_bytes(p->B, nnull + p->n0 + p->n1)) { mi_set_error("mi_flash_attn_fwd: kv_prep buffer too small"); return MI_ERR_INVALID; }
         hipLaunchKernelGGL(flash_kv_prep_kernel, dim3(nchunk, 1, p->B), dim3(256), 0, (hipStream_t)stream, *p, nchunk);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(flash_attn_mq_kernel<16>), dim3((p->HW + 63) / 64, p->heads / 4, p->B), dim3(1024), 0, (hipStream_t)stream, *p, nchunk);
+        static const int qt = getenv("MI_FLASH_MQ_QT") ? atoi(getenv("MI_FLASH_MQ_QT")) : 2;         // 16-query tiles per wave (A/B knob: 1 = 16 waves of one tile each)
+        const dim3 grid((p->HW + 63) / 64, p->heads / 4, p->B);
+        if (qt == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(flash_attn_mq_kernel<16, 1, 4>), grid, dim3(1024), 0, (hipStream_t)stream, *p, nchunk);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(flash_attn_mq_kernel<8, 2, 2>), grid, dim3(512), 0, (hipStream_t)stream, *p, nchunk);
     }
     else if (p->kv_heads == 1 && (p->heads & 3) == 0 && !one_head) {    // multi-query: heads of the same 64 queries share every staged K / V chunk
         static const int two_heads = getenv("MI_FLASH_TWO_HEADS") ? atoi(getenv("MI_FLASH_TWO_HEADS")) : 0;

@@ -318,6 +318,13 @@ __device__ __forceinline__ float mi_wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
+// a * b rounded on its own: never contracted with a following add into one fma (hipcc's default -ffp-contract=fast-honor-pragmas would), for
+// values whose bits have to agree between two kernels that place the multiply differently
+__device__ __forceinline__ float mi_mul_rounded(float a, float b) {
+#pragma clang fp contract(off)
+    return a * b;
+}
+
 __device__ __forceinline__ float mi_wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
