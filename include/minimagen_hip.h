@@ -103,7 +103,7 @@ typedef struct mi_conv_params {
 #define MI_CONV_SPLIT8  0x800   /* 8-channel outputs as two 4-channel workgroups (small, latency-bound launches) */
 #define MI_CONV_HALF    0x400   /* row-paired matrix-core path: single fp16 term per product (reduced-precision configuration; parity gate 3e-2) */
 #define MI_CONV_REVERSE 0x200  /* tile_cfg | MI_CONV_REVERSE (row-paired path): workgroups take the images in reverse order (speed only) */
-#define MI_CONV_RP_FIRST 5      /* tile_cfg 5: 16x64, 6: 8x64, 7: 8x32 output tiles of the row-paired matrix-core path */
+#define MI_CONV_RP_FIRST 5      /* tile_cfg 5: 16x64, 6: 8x64, 7: 8x32 output tiles of the row-paired matrix-core path; 10: 16x16 (wide k3 s1 convs on images <= 16 wide) */
 
 /* tile_cfg -> output tile (th x tw) handled by one workgroup; out_nt = ceil(H/th)*ceil(W/tw) */
 int mi_conv_tile_shape(int tile_cfg, int* th, int* tw);

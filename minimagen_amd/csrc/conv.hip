@@ -438,6 +438,7 @@ extern "C" int mi_conv_tile_shape(int tile_cfg, int* th, int* tw) {
         case 5: *th = 16; *tw = 64; return MI_OK;     // row-paired matrix-core path (conv_rp.hip)
         case 6: *th = 8; *tw = 64; return MI_OK;
         case 7: *th = 8; *tw = 32; return MI_OK;
+        case 10: *th = 16; *tw = 16; return MI_OK;    // (wide k3 s1 member only)
         case 0: *th = 16; *tw = 64; return MI_OK;
         case 1: *th = 32; *tw = 32; return MI_OK;
         case 2: *th = 8; *tw = 32; return MI_OK;

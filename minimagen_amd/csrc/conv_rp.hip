@@ -750,11 +750,12 @@ int launch_rp(const mi_conv_params& p, hipStream_t st) {
     return mi_check_launch("conv_rp_kernel");
 }
 
-// wide-channel regime: 8 x 32 (tile_cfg 7) or 8 x 64 (tile_cfg 6, MODE 0 only) pixel tiles, NJ N tiles per workgroup, the layer's output channels over blockIdx.y
-template <int TWW, int NJ, bool GN, bool HALF, int MODE>
+// wide-channel regime: 8 x 32 (tile_cfg 7), 8 x 64 (tile_cfg 6) or 16 x 16 (tile_cfg 10; both MODE 0 only) pixel tiles, NJ N tiles per workgroup, the layer's
+// output channels over blockIdx.y
+template <int TWW, int NJ, bool GN, bool HALF, int MODE, int THH = 8>
 int launch_rp_wide(const mi_conv_params& p, hipStream_t st) {
-    using CFG = RpCfg<8, TWW, NJ, GN, HALF, MODE, -1, -1, true>;
-    const int tiles = ((p.H + 7) / 8) * ((p.W + TWW - 1) / TWW);
+    using CFG = RpCfg<THH, TWW, NJ, GN, HALF, MODE, -1, -1, true>;
+    const int tiles = ((p.H + THH - 1) / THH) * ((p.W + TWW - 1) / TWW);
     const int cpt = MODE == 2 ? 16 : 8, njt = (p.Cout + cpt - 1) / cpt;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_rp_kernel<CFG>), dim3(tiles * p.B, (njt + NJ - 1) / NJ), dim3(256), 0, st, p, (const uint4*)p.w_rp,
                        (const uint4*)p.res_w_rp, 1, (const float4*)p.gn_coef, (const int*)p.gn_exps);
@@ -769,6 +770,10 @@ int launch_rp_wide_m(const mi_conv_params& p, hipStream_t st) {
         if ((p.tile_cfg & 0xff) == 6 && njt >= 4 && !half) {          // 8 x 64 tiles: the B fragments of a round serve twice the pixels
             if (p.gn_groups > 0) return launch_rp_wide<64, 4, true, false, MODE>(p, st);
             return launch_rp_wide<64, 4, false, false, MODE>(p, st);
+        }
+        if ((p.tile_cfg & 0xff) == 10 && njt >= 4 && !half) {         // 16 x 16 tiles: images no wider than 16 (half of an 8 x 32 tile would hang over the edge)
+            if (p.gn_groups > 0) return launch_rp_wide<16, 4, true, false, MODE, 16>(p, st);
+            return launch_rp_wide<16, 4, false, false, MODE, 16>(p, st);
         }
         if (p.gn_groups > 0) {
             if (njt >= 4) return half ? launch_rp_wide<32, 4, true, true, MODE>(p, st) : launch_rp_wide<32, 4, true, false, MODE>(p, st);
@@ -861,7 +866,8 @@ int mi_conv_rp_launch(const mi_conv_params& p, hipStream_t st) {
     if (biggest >= (1ull << 31)) { mi_set_error("mi_conv_fwd: row-paired path indexes one image with 32-bit offsets"); return MI_ERR_UNSUPPORTED; }
     if (wide) {
         if (!p.gn_exps) { mi_set_error("mi_conv_fwd: wide regime needs gn_exps (mi_gn_coef_fwd first)"); return MI_ERR_INVALID; }
-        if ((p.tile_cfg & 0xff) != 7 && !((p.tile_cfg & 0xff) == 6 && mode == 0)) { mi_set_error("mi_conv_fwd: the wide regime uses tile_cfg 7 (8x32), or 6 (8x64) for the k3 s1 member"); return MI_ERR_INVALID; }
+        const int tc = p.tile_cfg & 0xff;
+        if (tc != 7 && !((tc == 6 || tc == 10) && mode == 0)) { mi_set_error("mi_conv_fwd: the wide regime uses tile_cfg 7 (8x32), or 6 (8x64) / 10 (16x16) for the k3 s1 member"); return MI_ERR_INVALID; }
         return mode == 0 ? launch_rp_wide_m<0>(p, st) : (mode == 1 ? launch_rp_wide_m<1>(p, st) : launch_rp_wide_m<2>(p, st));
     }
     if (mode == 1) {

@@ -32,6 +32,7 @@ CONV_RP = int(os.environ.get("MINIMAGEN_CONV_RP", "2"))                 # 1: nar
 RP_TILE = {k: int(os.environ.get("MINIMAGEN_RP_TILE_" + k, d)) for k, d in (("L", "6"), ("M", "6"), ("S", "6"))}   # tile_cfg for images > 128^2 / > 64^2 / smaller
 RP_TILE_WIDE = int(os.environ.get("MINIMAGEN_RP_TILE_WIDE", "6"))          # tile of the wide k3 s1 convs: 6 = 8x64 where the image is a multiple of 64 wide (the B fragments of a round serve twice the pixels: Unet() default 32.2 -> 31.7 ms per step), 7 = 8x32
 FLASH_KV_PREP = os.environ.get("MINIMAGEN_FLASH_KV_PREP", "1") != "0"     # multi-query self-attention of the wide presets: K / V prepared once per launch, LDS-DMA into the workgroups
+RP_TILE_WIDE16 = os.environ.get("MINIMAGEN_RP_TILE_WIDE16", "1") != "0"    # wide k3 s1 convs on images <= 16 wide: 16x16 tiles (an 8x32 tile is half outside such an image)
 RP_MIN_HW = int(os.environ.get("MINIMAGEN_RP_MIN_HW", "0"))             # ... for images of at least this many pixels
 CE_MFMA = os.environ.get("MINIMAGEN_CE_MFMA", "1") != "0"                  # CrossEmbed on the matrix cores (0: the fp32 VALU kernel)
 STORE16 = os.environ.get("MINIMAGEN_STORE16", "1") != "0"                  # reduced-precision configuration: bf16 activation storage
@@ -425,7 +426,9 @@ class UnetEngine:
                 cfg = 7
             if wide and RP_TILE_WIDE == 6 and stride == 1 and not up2 and Wo % 64 == 0 and Cout >= 32 and not ws.half:
                 cfg = 6                  # 8 x 64 tiles for the wide k3 s1 convs
-            th, tw = {5: (16, 64), 6: (8, 64), 7: (8, 32)}[cfg]
+            if wide and RP_TILE_WIDE16 and stride == 1 and not up2 and Wo <= 16 and Ho > 8 and Cout >= 32 and not ws.half:
+                cfg = 10                 # 16 x 16 tiles for images no wider than 16
+            th, tw = {5: (16, 64), 6: (8, 64), 7: (8, 32), 10: (16, 16)}[cfg]
             nt = -(-Ho // th) * -(-Wo // tw)
         if ws.store16 and (not rp or wide):
             raise _Store16Unsupported()          # only the narrow row-paired kernels read bf16 activations

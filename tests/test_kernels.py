@@ -330,6 +330,8 @@ WIDE_CASES = [
     (1, 64, 0, 136, 8, 32, 4, 2, 0, False, False, 'none'),        # downsample k4 s2
     (1, 128, 0, 64, 16, 128, 3, 1, 0, True, True, 'id', 6),       # 8 x 64 tiles (tile_cfg 6: the wide k3 s1 member where the image is a multiple of 64 wide)
     (2, 96, 64, 72, 8, 64, 3, 1, 0, False, False, 'conv', 6),     # ... concat input, 1x1 residual over the concat, ragged N tiles, no GroupNorm
+    (2, 128, 0, 64, 16, 16, 3, 1, 0, True, True, 'id', 10),       # 16 x 16 tiles (tile_cfg 10: images no wider than 16)
+    (1, 96, 64, 72, 24, 12, 3, 1, 0, True, False, 'conv', 10),    # ... ragged in both directions, concat input + 1x1 residual, ragged N tiles
 ]
 
 

@@ -1,0 +1,6 @@
+#!/bin/bash
+# wide-regime check: kernel + U-Net parity tests, per-step time of sampling with the default Unet(), time per (kernel, grid)
+R=$GRAFT_REPO_ROOT; cd $R
+timeout 600 python -m pytest tests/test_kernels.py tests/test_unet.py -q -m gpu -k "wide or default_unet or preset or flash" -x 2>&1 | tail -3
+for e in "" $AB; do env $e timeout 300 python tools/gpu_wide_sample.py 16 25 2>&1 | tail -1 | sed "s/^/[$e] /"; done
+bash tools/gpu_wide_trace.sh 2>&1 | head -${ROWS:-24}
