@@ -1,6 +1,6 @@
 """Development aid: time ONE conv launch shape of the SR / base U-Net in isolation on the GPU (HIP events, back to back) and, with the
 -DMI_TRACE build of the library (MINIMAGEN_HIP_LIB=.../libminimagen_hip_trace.so), print the per-phase shader-clock breakdown of
-conv_rp.hip.   python tools/bench_conv.py B Cin Cout H W gn res(none|id|conv) path(rp5|rp6|rp7|old) [C1]"""
+conv_rp.hip.   python tools/bench_conv.py B Cin Cout H W gn res(none|id|conv) path(rp5|rp6|rp7|old|w6|w7|w10: the wide regime) [C1]"""
 import ctypes as C
 import os
 import sys
@@ -37,11 +37,14 @@ def run(B, C0, Cout, H, W, gn, res, path, C1=0, reps=20, nt_in=None):
         p.in1 = L.MiAct(x1.data_ptr(), C1, s1.data_ptr(), nt_in, 0.7071, 0)
     p.Cout, p.ksize, p.stride, p.up2 = Cout, 3, 1, 0
     keep = []
+    wide = path.startswith("w")
+    if wide:
+        path = "rp" + path[1:]
     if path.startswith("rp"):
         wf, p.w_rp_exp = P.pack_conv_weight_rp(w)
         wf = wf.to(dev); keep.append(wf)
         p.w_rp = wf.data_ptr()
-        cfg = int(path[2:3]) | (int(os.environ.get("NTILE", "0")) << 12)
+        cfg = int(path[2:]) | (int(os.environ.get("NTILE", "0")) << 12)
     else:
         ct = lib.mi_conv_cout_tile(Cout)
         wp = P.pack_conv_weight(w, ct).to(dev); keep.append(wp)
@@ -50,6 +53,8 @@ def run(B, C0, Cout, H, W, gn, res, path, C1=0, reps=20, nt_in=None):
     p.bias = bias.data_ptr()
     if gn:
         p.gn_groups, p.gn_gamma, p.gn_beta, p.gn_eps = 8, gamma.data_ptr(), beta.data_ptr(), 1e-5
+        if not all(s_ is not None for s_ in (s0,)):
+            raise SystemExit("GroupNorm needs statistics")
     if res == "id":
         r = torch.randn(B, Cout, H, W, generator=g).to(dev); keep.append(r)
         p.res0 = L.MiAct(r.data_ptr(), Cout, 0, 0, 1.0, 0)
@@ -70,6 +75,10 @@ def run(B, C0, Cout, H, W, gn, res, path, C1=0, reps=20, nt_in=None):
     ost = torch.zeros(B, Cout, nt, 2, dtype=torch.float64, device=dev)
     p.out, p.out_stats, p.tile_cfg = out.data_ptr(), ost.data_ptr(), cfg
     st = L.current_stream()
+    if wide:
+        coef = torch.zeros(B, Cin, 4, device=dev); exps = torch.zeros(B, 2, dtype=torch.int32, device=dev); keep += [coef, exps]
+        p.gn_coef, p.gn_exps = coef.data_ptr(), exps.data_ptr()
+        L.check(lib.mi_gn_coef_fwd(C.byref(p), st), "gn_coef")
     for _ in range(3):
         L.check(lib.mi_conv_fwd(C.byref(p), st), "conv")
     torch.cuda.synchronize()
@@ -80,13 +89,15 @@ def run(B, C0, Cout, H, W, gn, res, path, C1=0, reps=20, nt_in=None):
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / reps * 1e3
     mb = (B * (Cin + Cout + (Cout if res == "id" else (Cin if res == "conv" else 0))) * H * W * 4) / 1e6
-    print(f"{path:5s} B{B} {Cin}->{Cout} @{H}x{W} gn={int(gn)} res={res}: {us:7.1f} us  ({mb:.0f} MB -> {mb / us * 1e-3 * 1e3:.2f} TB/s)".replace("TB/s", "GB/ms"))
+    tf = 2.0 * (Cin * 9 + (Cin if res == "conv" else 0)) * Cout * H * W * B / us * 1e-6
+    print(f"{path:5s}{' wide' if wide else ''} B{B} {Cin}->{Cout} @{H}x{W} gn={int(gn)} res={res}: {us:7.1f} us  ({mb:.0f} MB -> {mb / us * 1e-3 * 1e3:.2f} GB/ms; {tf:.0f} TFLOP/s algorithmic, x3 split terms issued)")
     if path.startswith("rp") and hasattr(lib, "mi_debug_read_trace_rp"):
         NS = lib.mi_debug_trace_rp_slots() if hasattr(lib, "mi_debug_trace_rp_slots") else 8
         buf = np.zeros(1024 * NS, dtype=np.uint64)
         lib.mi_debug_read_trace_rp.argtypes = [C.c_void_p, C.c_size_t]
         lib.mi_debug_read_trace_rp(buf.ctypes.data, buf.nbytes)
         t = buf.reshape(1024, NS).astype(np.int64)
+        t = t[t[:, :7].sum(1) > 0]                 # (launches with fewer than 1024 workgroups along x fill only the first rows)
         names = ["stats+geometry+issue loads", "affine prologue", "barrier waits", "wait raw + transform + LDS write", "MFMA loop", "epilogue", "B-frag issue"]
         for i, n in enumerate(names):
             print(f"      {n:34s} {np.median(t[:, i]):9.0f} {np.percentile(t[:, i], 10):9.0f} {np.percentile(t[:, i], 90):9.0f}")
@@ -95,7 +106,7 @@ def run(B, C0, Cout, H, W, gn, res, path, C1=0, reps=20, nt_in=None):
             for i, n in zip(range(8, 14), ["  fine: residual + prefetch loads issued", "  fine: MFMA loop proper", "  fine: epilogue arithmetic (+ residual wait)", "  fine: stores issued",
                                            "  fine: statistics shuffles", "  fine: barrier + statistics store"]):
                 print(f"      {n:46s} {np.median(t[:, i]):9.0f} {np.percentile(t[:, i], 10):9.0f} {np.percentile(t[:, i], 90):9.0f}")
-        w = buf.reshape(1024, NS)[:, 7]
+        w = buf.reshape(1024, NS)[:len(t), 7]
         w0 = ((w >> np.uint64(32)) & np.uint64(0xffffffff)).astype(np.int64); w1 = (w & np.uint64(0xffffffff)).astype(np.int64)
         ok = w1 > 0
         if ok.any():
