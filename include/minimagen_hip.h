@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MI_ABI_VERSION 8
+#define MI_ABI_VERSION 9
 
 enum mi_status {
     MI_OK = 0,
@@ -98,15 +98,22 @@ typedef struct mi_conv_params {
        BEFORE mi_conv_fwd(p); non-NULL gn_coef selects the wide kernel (output channels tiled over the grid) */
     float* gn_coef;         /* [B][Cin][4] = {A 2^ka, B 2^ka, -log2(e) A, -log2(e) B} */
     int* gn_exps;           /* [B][2] = {ka, largest safe exponent of the 1x1-residual input} */
+    /* wide GEMM kernel (conv_wide.hip; tile_cfg 11, k3 s1, input / residual channels in multiples of 32, output channels of 128): the conv input after
+       GroupNorm / scale-shift / SiLU (and the 1x1-residual input) as fp16 hi / lo operand planes, written once per layer by mi_conv_prep_fwd(p) --
+       after mi_gn_coef_fwd(p), before mi_conv_fwd(p); mi_conv_prep_bytes() bytes; w_rp / res_w_rp then hold packing.pack_conv_weight_ig fragments
+       ([Cin/32][taps][Cout/16][hi | lo][64 lanes][8 halves]: lane (lq, lg) = W[16 nt + lq][32 g + 8 lg .. + 7][tap]) */
+    void* act_prep; long long act_prep_bytes;
 } mi_conv_params;
 #define MI_CONV_SPLIT16 0x100
 #define MI_CONV_SPLIT8  0x800   /* 8-channel outputs as two 4-channel workgroups (small, latency-bound launches) */
 #define MI_CONV_HALF    0x400   /* row-paired matrix-core path: single fp16 term per product (reduced-precision configuration; parity gate 3e-2) */
 #define MI_CONV_REVERSE 0x200  /* tile_cfg | MI_CONV_REVERSE (row-paired path): workgroups take the images in reverse order (speed only) */
-#define MI_CONV_RP_FIRST 5      /* tile_cfg 5: 16x64, 6: 8x64, 7: 8x32 output tiles of the row-paired matrix-core path; 10: 16x16 (wide k3 s1 convs on images <= 16 wide) */
+#define MI_CONV_RP_FIRST 5      /* tile_cfg 5: 16x64, 6: 8x64, 7: 8x32 output tiles of the row-paired matrix-core path; 10: 16x16 (wide k3 s1 convs on images <= 16 wide); 11: 8x16 tiles of the wide GEMM kernel (conv_wide.hip) */
 
 /* tile_cfg -> output tile (th x tw) handled by one workgroup; out_nt = ceil(H/th)*ceil(W/tw) */
 int mi_conv_tile_shape(int tile_cfg, int* th, int* tw);
+int mi_conv_prep_fwd(const mi_conv_params* p, void* stream);      /* operand planes of the wide GEMM kernel (tile_cfg 11) */
+long long mi_conv_prep_bytes(int B, int Cin, int Cres, int H, int W);
 int mi_conv_cout_tile(int Cout);               /* channel tile (4, 8 or 16) the kernels use for this Cout */
 int mi_conv_fwd(const mi_conv_params* p, void* stream);
 int mi_gn_coef_fwd(const mi_conv_params* p, void* stream);     /* fills p->gn_coef / p->gn_exps (wide-channel regime) */

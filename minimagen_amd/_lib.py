@@ -35,6 +35,7 @@ class MiConvParams(C.Structure):
         ("out", C.c_void_p), ("out_st", C.c_int), ("out_stats", C.c_void_p), ("tile_cfg", C.c_int),
         ("w_rp", C.c_void_p), ("res_w_rp", C.c_void_p), ("w_rp_exp", C.c_int), ("res_w_rp_exp", C.c_int),
         ("gn_coef", C.c_void_p), ("gn_exps", C.c_void_p),
+        ("act_prep", C.c_void_p), ("act_prep_bytes", C.c_longlong),
     ]
 
 
@@ -197,9 +198,11 @@ def _bind(lib):
     vp, i32, i64, u64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float
     for name in ("mi_conv_fwd", "mi_gn_coef_fwd", "mi_crossembed_fwd", "mi_text_cond_fwd", "mi_cond_step_fwd", "mi_attn_fold_rows", "mi_cross_attn_fwd",
                  "mi_cfg_x0_fwd", "mi_quantile_fwd", "mi_posterior_fwd", "mi_resize_fwd", "mi_self_attn_fwd", "mi_chan_ff_fwd",
-                 "mi_flash_attn_fwd", "mi_tokens_to_nchw_fwd", "mi_conv_wgrad", "mi_block_bwd", "mi_crossembed_wgrad", "mi_folded_attn_fwd", "mi_folded_attn_bwd", "mi_adam_step"):
+                 "mi_flash_attn_fwd", "mi_conv_prep_fwd", "mi_tokens_to_nchw_fwd", "mi_conv_wgrad", "mi_block_bwd", "mi_crossembed_wgrad", "mi_folded_attn_fwd", "mi_folded_attn_bwd", "mi_adam_step"):
         getattr(lib, name).argtypes = [vp, vp]
         getattr(lib, name).restype = i32
+    lib.mi_conv_prep_bytes.argtypes = [i32, i32, i32, i32, i32]
+    lib.mi_conv_prep_bytes.restype = C.c_longlong
     lib.mi_flash_kv_prep_bytes.argtypes = [i32, i32]
     lib.mi_flash_kv_prep_bytes.restype = C.c_longlong
     lib.mi_step_advance.argtypes = [vp, vp, i32, vp]

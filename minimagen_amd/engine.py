@@ -31,6 +31,7 @@ CONV_SPLIT8 = int(os.environ.get("MINIMAGEN_CONV_SPLIT8", "64"))        # 8-chan
 CONV_RP = int(os.environ.get("MINIMAGEN_CONV_RP", "2"))                 # 1: narrow k3 s1 convs (channels in multiples of 8, <= 64 in) on the row-paired matrix-core kernel; 2: also nearest-x2 + k3 and k4 s2
 RP_TILE = {k: int(os.environ.get("MINIMAGEN_RP_TILE_" + k, d)) for k, d in (("L", "6"), ("M", "6"), ("S", "6"))}   # tile_cfg for images > 128^2 / > 64^2 / smaller
 RP_TILE_WIDE = int(os.environ.get("MINIMAGEN_RP_TILE_WIDE", "6"))          # tile of the wide k3 s1 convs: 6 = 8x64 where the image is a multiple of 64 wide (the B fragments of a round serve twice the pixels: Unet() default 32.2 -> 31.7 ms per step), 7 = 8x32
+CONV_WIDE_GEMM = os.environ.get("MINIMAGEN_CONV_WIDE_GEMM", "1") != "0"   # wide k3 s1 convs (channels in multiples of 32 in / 128 out) on the GEMM kernel with prepared operand planes (conv_wide.hip)
 FLASH_KV_PREP = os.environ.get("MINIMAGEN_FLASH_KV_PREP", "1") != "0"     # multi-query self-attention of the wide presets: K / V prepared once per launch, LDS-DMA into the workgroups
 RP_TILE_WIDE16 = os.environ.get("MINIMAGEN_RP_TILE_WIDE16", "1") != "0"    # wide k3 s1 convs on images <= 16 wide: 16x16 tiles (an 8x32 tile is half outside such an image)
 RP_MIN_HW = int(os.environ.get("MINIMAGEN_RP_MIN_HW", "0"))             # ... for images of at least this many pixels
@@ -219,6 +220,7 @@ class UnetEngine:
         pk.freq = P.sinusoid_freq(u.dim, dev)
         pk.conv = {}
         pk.conv_rp = {}
+        pk.conv_ig = {}
         pk.attn = {}
         pk.attn_exp = {}
 
@@ -229,6 +231,8 @@ class UnetEngine:
             pk.keep.append(wp)
             if w.shape[-1] in (3, 4) and w.shape[1] % 8 == 0:
                 pk.conv_rp[id(wp)] = P.pack_conv_weight_rp(w.to(dev))
+            if CONV_WIDE_GEMM and w.shape[-1] == 3 and w.shape[1] % 32 == 0 and w.shape[0] % 128 == 0:
+                pk.conv_ig[id(wp)] = P.pack_conv_weight_ig(w.to(dev))
             return wp
 
         resblocks: List[ResnetBlock] = [m for m in u.modules() if isinstance(m, ResnetBlock)]
@@ -254,6 +258,8 @@ class UnetEngine:
                 pk.keep.append(rw)
                 if rb.res_conv.weight.shape[1] % 8 == 0:
                     pk.conv_rp[id(rw)] = P.pack_conv_weight_rp(rb.res_conv.weight)
+                if CONV_WIDE_GEMM and rb.res_conv.weight.shape[1] % 32 == 0 and rb.res_conv.weight.shape[0] % 128 == 0:
+                    pk.conv_ig[id(rw)] = P.pack_conv_weight_ig(rb.res_conv.weight)
                 pk.conv[id(rb.res_conv)] = rw
             if rb.cross_attn is not None:
                 ca: CrossAttention = rb.cross_attn.fn
@@ -361,11 +367,17 @@ class UnetEngine:
         for store16 in ((True, False) if (ws.half and STORE16) else (False,)):
             ws.store16 = store16
             ws.gv, ws.tensors, ws.prog, ws.prog_text, ws.wide_attn = {}, [], [], [], False     # (prog_text: the wide cross-attentions' text keys / values)
+            ws.ig_convs = []                 # wide GEMM convs: their operand planes share ONE buffer (the launches of a workspace are ordered)
             try:
                 self._build_program(ws, pk)
                 break
             except _Store16Unsupported:
                 continue
+        if ws.ig_convs:
+            nbytes = max(n for _, n in ws.ig_convs)
+            ws.ig_prep = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=dev)
+            for p_, _ in ws.ig_convs:
+                p_.act_prep, p_.act_prep_bytes = L.ptr(ws.ig_prep), nbytes
         self._ws[key] = ws
         return ws
 
@@ -428,7 +440,11 @@ class UnetEngine:
                 cfg = 6                  # 8 x 64 tiles for the wide k3 s1 convs
             if wide and RP_TILE_WIDE16 and stride == 1 and not up2 and Wo <= 16 and Ho > 8 and Cout >= 32 and not ws.half:
                 cfg = 10                 # 16 x 16 tiles for images no wider than 16
-            th, tw = {5: (16, 64), 6: (8, 64), 7: (8, 32), 10: (16, 16)}[cfg]
+            gemm = wide and ksize == 3 and stride == 1 and not up2 and not ws.half and cin_tot % 32 == 0 and cres % 32 == 0 and Cout % 128 == 0 \
+                and id(wpack) in pk.conv_ig and (cres == 0 or id(res[2]) in pk.conv_ig)
+            if gemm:
+                cfg = 11                 # the wide GEMM kernel (conv_wide.hip): 8 x 16 pixels x 128 channels per workgroup
+            th, tw = {5: (16, 64), 6: (8, 64), 7: (8, 32), 10: (16, 16), 11: (8, 16)}[cfg]
             nt = -(-Ho // th) * -(-Wo // tw)
         if ws.store16 and (not rp or wide):
             raise _Store16Unsupported()          # only the narrow row-paired kernels read bf16 activations
@@ -468,13 +484,17 @@ class UnetEngine:
             if not nt_knob and ws.pipelined and RP_NTILE_PIPE[cls] and batch * nt // RP_NTILE_PIPE[cls] >= 256:
                 nt_knob = RP_NTILE_PIPE[cls]        # (only while the launch still has a workgroup per CU: smaller batches keep the library's choice -- config 3 at B = 16: 39.1 K with, 40.7 K without)
             p.tile_cfg |= (nt_knob & 0xf) << 12
-            frag, p.w_rp_exp = pk.conv_rp[id(wpack)]
+            frags = pk.conv_ig if gemm else pk.conv_rp
+            frag, p.w_rp_exp = frags[id(wpack)]
             p.w_rp = L.ptr(frag)
             if res is not None and res[2] is not None:
-                rfrag, p.res_w_rp_exp = pk.conv_rp[id(res[2])]
+                rfrag, p.res_w_rp_exp = frags[id(res[2])]
                 p.res_w_rp = L.ptr(rfrag)
         if wide:
             ws.prog.append((lib.mi_gn_coef_fwd, p, "gn_coef"))
+            if gemm:
+                ws.ig_convs.append((p, lib.mi_conv_prep_bytes(batch, cin_tot, cres, Ho, Wo)))
+                ws.prog.append((lib.mi_conv_prep_fwd, p, "conv_prep"))
         ws.prog.append((lib.mi_conv_fwd, p, "conv"))
         return out
 

@@ -123,6 +123,24 @@ def pack_conv_weight_rp(w: torch.Tensor, exp=None):
     return torch.cat((hi, lo), dim=-1).contiguous().to(w.device), exp
 
 
+def pack_conv_weight_ig(w: torch.Tensor, exp=None):
+    """[Cout][Cin][3][3] (or [Cout][Cres][1][1]) fp32 -> (fragments, exponent) for csrc/conv_wide.hip (the wide presets' GEMM kernel).
+
+    B operand of v_mfma_f32_16x16x32_f16 with N = 16 output channels, K = 32 input channels of ONE tap:
+    [Cin/32][taps][Cout/16][hi | lo][64 lanes][8 halves] fp16, lane (lq, lg) holding W[co = 16 nt + lq][ci = 32 g + 8 lg + e][tap]; Cin in
+    multiples of 32, Cout of 16.  Pre-scaled by 2^exponent exactly like pack_conv_weight_rp (max|w| in [128, 256))."""
+    cout, cin, kh, kw = w.shape
+    assert (kh, kw) in ((3, 3), (1, 1)) and cin % 32 == 0 and cout % 16 == 0
+    wd = w.detach().double()
+    if exp is None:
+        exp = rp_weight_exponent(float(wd.abs().max()))
+    ws = (wd * (2.0 ** exp)).reshape(cout // 16, 16, cin // 32, 4, 8, kh * kw)          # [nt][lq][g][lg][e][tap]
+    out = ws.permute(2, 5, 0, 3, 1, 4).reshape(cin // 32, kh * kw, cout // 16, 64, 8)     # [g][tap][nt][lane = 16 lg + lq][e]
+    hi = out.float().half()
+    lo = (out - hi.double()).float().half()
+    return torch.stack((hi, lo), dim=3).contiguous().to(w.device), exp                   # [g][tap][nt][2][64][8]
+
+
 def attn_f16_exponents(mg, mv, g0, v0, cmax: float, xmax: float):
     """Power-of-two operand scalings (x_exp, g_exp, v_exp) of the fp16x3 cross-attention from magnitude BOUNDS: |x^| <= xmax,
     |g_j| <= max_row sum_b |mg| * cmax (context rows bounded by cmax), likewise vw; each scaled bound lands at <= 2^12, which leaves a

@@ -171,7 +171,8 @@ def test_conv_row_paired_path(backend, case):
     if C1:
         p.in1 = L.MiAct(d("x1", x1).data_ptr(), C1, d("s1", chan_stats(x1)).data_ptr(), 1, sk, 0)
     p.Cout, p.ksize, p.stride, p.up2 = Cout, 3, 1, 0
-    wf, wexp = P.pack_conv_weight_rp(w)
+    pack = P.pack_conv_weight_ig if tcfg == 11 else P.pack_conv_weight_rp
+    wf, wexp = pack(w)
     p.w_rp, p.w_rp_exp, p.bias = d("wf", wf).data_ptr(), wexp, d("b", bias).data_ptr()
     if gn:
         p.gn_groups, p.gn_gamma, p.gn_beta, p.gn_eps = 8, d("g", gamma).data_ptr(), d("be", beta).data_ptr(), 1e-5
@@ -244,7 +245,8 @@ def test_conv_row_paired_bf16_storage(backend, case):
     if C1:
         p.in1 = L.MiAct(d("x1", x1).data_ptr(), C1, d("s1", chan_stats(x1.float())).data_ptr(), 1, sk, 0, 1)
     p.Cout, p.ksize, p.stride, p.up2 = Cout, 3, 1, 0
-    wf, wexp = P.pack_conv_weight_rp(w)
+    pack = P.pack_conv_weight_ig if tcfg == 11 else P.pack_conv_weight_rp
+    wf, wexp = pack(w)
     p.w_rp, p.w_rp_exp, p.bias = d("wf", wf).data_ptr(), wexp, d("b", bias).data_ptr()
     p.gn_groups, p.gn_gamma, p.gn_beta, p.gn_eps = 8, d("g", gamma).data_ptr(), d("be", beta).data_ptr(), 1e-5
     if res != 'none':
@@ -303,7 +305,8 @@ def test_conv_row_paired_resampling(backend, case):
     p.B, p.H, p.W = B, H, W
     p.in0 = L.MiAct(d("x0", x0).data_ptr(), Cin, d("s0", chan_stats(x0)).data_ptr(), 1, 1.0, 0)
     p.Cout, p.ksize, p.stride, p.up2 = Cout, ks, stride, up2
-    wf, wexp = P.pack_conv_weight_rp(w)
+    pack = P.pack_conv_weight_ig if tcfg == 11 else P.pack_conv_weight_rp
+    wf, wexp = pack(w)
     p.w_rp, p.w_rp_exp, p.bias = d("wf", wf).data_ptr(), wexp, d("b", bias).data_ptr()
     nt = tile_nt(lib, cfg, H, W)
     out = torch.full((B, Cout, H, W), float('nan'), device=dev)
@@ -332,6 +335,9 @@ WIDE_CASES = [
     (2, 96, 64, 72, 8, 64, 3, 1, 0, False, False, 'conv', 6),     # ... concat input, 1x1 residual over the concat, ragged N tiles, no GroupNorm
     (2, 128, 0, 64, 16, 16, 3, 1, 0, True, True, 'id', 10),       # 16 x 16 tiles (tile_cfg 10: images no wider than 16)
     (1, 96, 64, 72, 24, 12, 3, 1, 0, True, False, 'conv', 10),    # ... ragged in both directions, concat input + 1x1 residual, ragged N tiles
+    (2, 128, 0, 128, 16, 16, 3, 1, 0, True, True, 'id', 11),      # the wide GEMM kernel (conv_wide.hip: prepared operand planes, 8 x 16 x 128-channel tiles)
+    (1, 96, 64, 128, 24, 12, 3, 1, 0, True, False, 'conv', 11),   # ... ragged in both directions, concat input, 1x1 residual over a concat
+    (2, 64, 0, 256, 8, 32, 3, 1, 0, False, False, 'none', 11),    # ... no GroupNorm, two tiles across, two channel groups
 ]
 
 
@@ -389,7 +395,8 @@ def test_conv_wide_regime(backend, case):
     if C1:
         p.in1 = L.MiAct(d("x1", x1).data_ptr(), C1, d("s1", chan_stats(x1)).data_ptr(), 1, sk, 0)
     p.Cout, p.ksize, p.stride, p.up2 = Cout, ks, stride, up2
-    wf, wexp = P.pack_conv_weight_rp(w)
+    pack = P.pack_conv_weight_ig if tcfg == 11 else P.pack_conv_weight_rp
+    wf, wexp = pack(w)
     p.w_rp, p.w_rp_exp, p.bias = d("wf", wf).data_ptr(), wexp, d("b", bias).data_ptr()
     if gn:
         p.gn_groups, p.gn_gamma, p.gn_beta, p.gn_eps = 8, d("g", gamma).data_ptr(), d("be", beta).data_ptr(), 1e-5
@@ -407,7 +414,7 @@ def test_conv_wide_regime(backend, case):
         p.res0 = L.MiAct(d("r0", r0).data_ptr(), 96, d("rs0", chan_stats(r0)).data_ptr(), 1, 1.0, 0)
         p.res1 = L.MiAct(d("r1", r1).data_ptr(), 64, d("rs1", chan_stats(r1)).data_ptr(), 1, sk, 0)
         p.res_w = 1
-        rwf, p.res_w_rp_exp = P.pack_conv_weight_rp(rw)
+        rwf, p.res_w_rp_exp = pack(rw)
         p.res_w_rp, p.res_b = d("rwf", rwf).data_ptr(), d("rb", rb).data_ptr()
     coef = torch.zeros(B, Cin, 4, device=dev)
     exps = torch.zeros(B, 2, dtype=torch.int32, device=dev)
@@ -417,6 +424,13 @@ def test_conv_wide_regime(backend, case):
     ost = torch.zeros(B, Cout, nt, 2, dtype=torch.float64, device=dev)
     p.out, p.out_stats, p.tile_cfg = out.data_ptr(), ost.data_ptr(), tcfg
     L.check(lib.mi_gn_coef_fwd(C.byref(p), L.current_stream()), "gn coef")
+    if tcfg == 11:
+        nbytes = lib.mi_conv_prep_bytes(B, Cin, 160 if res == 'conv' else 0, H, W)
+        prep = torch.full((nbytes // 4,), float('nan'), device=dev)
+        p.act_prep, p.act_prep_bytes = prep.data_ptr(), nbytes - 16
+        assert lib.mi_conv_prep_fwd(C.byref(p), L.current_stream()) != 0 and b"too small" in lib.mi_last_error()
+        p.act_prep_bytes = nbytes
+        L.check(lib.mi_conv_prep_fwd(C.byref(p), L.current_stream()), "conv prep")
     L.check(lib.mi_conv_fwd(C.byref(p), L.current_stream()), "conv wide")
     scale = max(1.0, ref.abs().max().item() / 8.0)
     err = (out.cpu().double() - ref).abs().max().item()

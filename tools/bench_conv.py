@@ -40,8 +40,10 @@ def run(B, C0, Cout, H, W, gn, res, path, C1=0, reps=20, nt_in=None):
     wide = path.startswith("w")
     if wide:
         path = "rp" + path[1:]
+    gemm = path == "rp11"                      # the wide GEMM kernel (conv_wide.hip)
+    pack_w = P.pack_conv_weight_ig if gemm else P.pack_conv_weight_rp
     if path.startswith("rp"):
-        wf, p.w_rp_exp = P.pack_conv_weight_rp(w)
+        wf, p.w_rp_exp = pack_w(w)
         wf = wf.to(dev); keep.append(wf)
         p.w_rp = wf.data_ptr()
         cfg = int(path[2:]) | (int(os.environ.get("NTILE", "0")) << 12)
@@ -65,7 +67,7 @@ def run(B, C0, Cout, H, W, gn, res, path, C1=0, reps=20, nt_in=None):
         rw = torch.randn(Cout, Cin, 1, 1, generator=g) * 0.3
         p.res_w = 1
         if path.startswith("rp"):
-            rwf, p.res_w_rp_exp = P.pack_conv_weight_rp(rw); rwf = rwf.to(dev); keep.append(rwf); p.res_w_rp = rwf.data_ptr()
+            rwf, p.res_w_rp_exp = pack_w(rw); rwf = rwf.to(dev); keep.append(rwf); p.res_w_rp = rwf.data_ptr()
         else:
             rwp = P.pack_conv_weight(rw, lib.mi_conv_cout_tile(Cout)).reshape(Cin, -1).contiguous().to(dev); keep.append(rwp); p.res_w = rwp.data_ptr()
     th, tw = C.c_int(), C.c_int()
@@ -79,6 +81,17 @@ def run(B, C0, Cout, H, W, gn, res, path, C1=0, reps=20, nt_in=None):
         coef = torch.zeros(B, Cin, 4, device=dev); exps = torch.zeros(B, 2, dtype=torch.int32, device=dev); keep += [coef, exps]
         p.gn_coef, p.gn_exps = coef.data_ptr(), exps.data_ptr()
         L.check(lib.mi_gn_coef_fwd(C.byref(p), st), "gn_coef")
+        if gemm:
+            nbytes = lib.mi_conv_prep_bytes(B, Cin, Cin if res == "conv" else 0, H, W)
+            prep = torch.empty(nbytes // 4, device=dev); keep.append(prep)
+            p.act_prep, p.act_prep_bytes = prep.data_ptr(), nbytes
+            L.check(lib.mi_conv_prep_fwd(C.byref(p), st), "conv_prep")
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                L.check(lib.mi_conv_prep_fwd(C.byref(p), st), "conv_prep")
+            e1.record(); torch.cuda.synchronize()
+            print(f"      conv_prep: {e0.elapsed_time(e1) / reps * 1e3:7.1f} us ({nbytes / 1e6:.0f} MB written)")
     for _ in range(3):
         L.check(lib.mi_conv_fwd(C.byref(p), st), "conv")
     torch.cuda.synchronize()
