@@ -315,7 +315,7 @@ __global__ __launch_bounds__(64 * NW) void flash_attn_f16x3_kernel(const mi_flas
 constexpr int FW_CP = 9, FW_CHUNK16 = 4 * 64 * FW_CP;         // 16-byte chunks of one prepared context chunk (36 864 bytes)
 
 __global__ __launch_bounds__(256) void flash_kv_prep_kernel(const mi_flash_attn_params p, const int nchunk) {
-    constexpr int D = 64, CP = FW_CP, EPT = 16, PPR = 4;
+    constexpr int CP = FW_CP, EPT = 16, PPR = 4;
     __shared__ __attribute__((aligned(16))) uint4 img[FW_CHUNK16];          // KsH | KsL | VtH | VtL
     __shared__ float smax[2][4];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -550,6 +550,12 @@ __global__ __launch_bounds__(64 * NW, WPS) void flash_attn_mq_kernel(const mi_fl
         }
     }
 }
+
+// (Tried and removed, in the git history: the same kernel with the two waves of every SIMD half a chunk apart -- waves 0-3 in the matrix block
+// [PV(i - 1), QK^T(i)] while waves 4-7 run the softmax of chunk i - 1, a barrier at every hand-over, bit-identical.  3.23 ms against 3.19 ms per
+// 4096-token launch: on this machine the matrix time and the VALU issue time of a SIMD's waves add up whichever wave they come from
+// (96 matrix instructions x 16 cycles + ~270 VALU x 4 per wave and chunk = the measured 6 000 cycles per chunk and wave pair);
+// profiles/r05_wide_flash_kv_prep_ab.txt.)
 
 // ---- tokens [B][HW][C] -> NCHW, with an optional LayerNorm over C (gamma, beta) in front, a residual NCHW tensor added and the next
 // GroupNorm's partial statistics (64-token tiles) emitted: to_out.1 + residual of both attentions, and the tail of ChanFeedForward
