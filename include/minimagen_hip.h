@@ -98,7 +98,7 @@ typedef struct mi_conv_params {
        BEFORE mi_conv_fwd(p); non-NULL gn_coef selects the wide kernel (output channels tiled over the grid) */
     float* gn_coef;         /* [B][Cin][4] = {A 2^ka, B 2^ka, -log2(e) A, -log2(e) B} */
     int* gn_exps;           /* [B][2] = {ka, largest safe exponent of the 1x1-residual input} */
-    /* wide GEMM kernel (conv_wide.hip; tile_cfg 11, k3 s1, input / residual channels in multiples of 32, output channels of 128): the conv input after
+    /* wide GEMM kernel (conv_wide.hip; tile_cfg 11, k3 s1, input / residual channels in multiples of 32, output channels of 64): the conv input after
        GroupNorm / scale-shift / SiLU (and the 1x1-residual input) as fp16 hi / lo operand planes, written once per layer by mi_conv_prep_fwd(p) --
        after mi_gn_coef_fwd(p), before mi_conv_fwd(p); mi_conv_prep_bytes() bytes; w_rp / res_w_rp then hold packing.pack_conv_weight_ig fragments
        ([Cin/32][taps][Cout/16][hi | lo][64 lanes][8 halves]: lane (lq, lg) = W[16 nt + lq][32 g + 8 lg .. + 7][tap]) */

@@ -16,6 +16,7 @@
 // brought into the fp16 range by exact powers of two (weights at pack time, activations per image by mi_gn_coef_fwd) and undone in the epilogue.
 #include "common.hip.h"
 #include <type_traits>
+#include <cstdlib>
 
 namespace {
 
@@ -26,8 +27,7 @@ typedef float cw_f32x2 __attribute__((ext_vector_type(2)));
 constexpr int CW_TH = 8, CW_TW = 16, CW_IH = CW_TH + 2, CW_UW = CW_TW + 2;
 constexpr int CW_WIN = 4 * 2 * CW_IH * CW_UW;       // 16-byte chunks of one 32-channel window: [octet 4][hi | lo][row][column] = 1440
 constexpr int CW_WIN_INSTR = 23;                     // ... copied by 23 wave-wide LDS-DMA instructions (6 per wave, 5 for the last; the last 32 lanes land in padding)
-constexpr int CW_NT = 8;                             // 16-channel N tiles per workgroup (128 output channels)
-constexpr int CW_BCH = CW_NT * 2 * 64;               // chunks of one step's B fragments: [N tile][hi | lo][lane] = 16 KB
+// NF: 16-channel N fragments per wave (4: 128 output channels per workgroup; 2: 64 -- for launches that would otherwise leave CUs with one workgroup)
 
 __device__ __forceinline__ void cw_split8(const float (&y)[8], uint4& hi, uint4& lo) {
     unsigned h[4], l[4];
@@ -92,13 +92,16 @@ __global__ __launch_bounds__(256) void conv_prep_kernel(const mi_conv_params p, 
 }
 
 // ---- the GEMM loop
+template <int NF>
 __global__ __launch_bounds__(256, 2) void conv_wide_kernel(const mi_conv_params p, const uint4* __restrict__ wf, const uint4* __restrict__ rwf,
                                                            const uint4* __restrict__ prep) {
+    constexpr int CW_NT = 2 * NF;                          // N tiles per workgroup
+    constexpr int CW_BCH = CW_NT * 2 * 64;                 // chunks of one step's B fragments: [N tile][hi | lo][lane] (16 / 8 KB)
     __shared__ __attribute__((aligned(16))) uint4 aw[2][CW_WIN_INSTR * 64];
     __shared__ __attribute__((aligned(16))) uint4 bw[2][CW_BCH];
-    // 2 x 23 552 + 2 x 16 384 = 79 872 bytes: two workgroups per CU (the epilogue's 4 KB of partial statistics reuse bw)
+    // NF = 4: 2 x 23 552 + 2 x 16 384 = 79 872 bytes: two workgroups per CU (the epilogue's partial statistics reuse bw)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lq = lane & 15, lg = lane >> 4;
-    const int wm = wave & 1, wn = wave >> 1;               // the wave's 4 rows / 4 N tiles of the workgroup's 8 x 8
+    const int wm = wave & 1, wn = wave >> 1;               // the wave's 4 rows / NF N tiles of the workgroup's 8 x 2 NF
     const int H = p.H, W = p.W, Hp = cw_hp(H), Wp = cw_wp(W), plane = Hp * Wp;
     const int tiles_x = (W + CW_TW - 1) / CW_TW, tiles = tiles_x * ((H + CW_TH - 1) / CW_TH);
     // XCD-aware placement as in conv_rp.hip: workgroup L runs on XCD L % 8; whole images per XCD
@@ -147,9 +150,9 @@ __global__ __launch_bounds__(256, 2) void conv_wide_kernel(const mi_conv_params 
     auto issue_b = [&](int g, int tap, int buf) {
         const uint4* src = g < G ? wf + (((size_t)g * 9 + tap) * njt + nt0) * 128 : rwf + ((size_t)(g - G) * njt + nt0) * 128;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint4* gp = src + (wave * 4 + i) * 64 + lane;
-            uint4* l = &bw[buf][(wave * 4 + i) * 64];
+        for (int i = 0; i < NF; ++i) {
+            const uint4* gp = src + (wave * NF + i) * 64 + lane;
+            uint4* l = &bw[buf][(wave * NF + i) * 64];
 #if defined(HIPEMU)
             l[lane] = *gp;
 #else
@@ -158,11 +161,11 @@ __global__ __launch_bounds__(256, 2) void conv_wide_kernel(const mi_conv_params 
         }
     };
 
-    f32x4 acc[4][4];
+    f32x4 acc[4][NF];
 #pragma unroll
     for (int mf = 0; mf < 4; ++mf)
 #pragma unroll
-        for (int nf = 0; nf < 4; ++nf) acc[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int nf = 0; nf < NF; ++nf) acc[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     issue_a(0, 0);
     issue_b(0, 0, 0);
@@ -186,18 +189,18 @@ __global__ __launch_bounds__(256, 2) void conv_wide_kernel(const mi_conv_params 
         const uint4* const ab = aw[g & 1];
         const uint4* const bb = bw[kb];
         constexpr int dy = tap / 3, dx = tap % 3;
-        cw_f16x8 bh[4], bl[4];
+        cw_f16x8 bh[NF], bl[NF];
 #pragma unroll
-        for (int nf = 0; nf < 4; ++nf) {
-            bh[nf] = __builtin_bit_cast(cw_f16x8, bb[((wn * 4 + nf) * 2) * 64 + lane]);
-            bl[nf] = __builtin_bit_cast(cw_f16x8, bb[((wn * 4 + nf) * 2 + 1) * 64 + lane]);
+        for (int nf = 0; nf < NF; ++nf) {
+            bh[nf] = __builtin_bit_cast(cw_f16x8, bb[((wn * NF + nf) * 2) * 64 + lane]);
+            bl[nf] = __builtin_bit_cast(cw_f16x8, bb[((wn * NF + nf) * 2 + 1) * 64 + lane]);
         }
 #pragma unroll
         for (int mf = 0; mf < 4; ++mf) {
             const int idx = (lg * 2 * CW_IH + wm * 4 + mf + dy) * CW_UW + dx + lq;
             const cw_f16x8 ah = __builtin_bit_cast(cw_f16x8, ab[idx]), al = __builtin_bit_cast(cw_f16x8, ab[idx + CW_IH * CW_UW]);
 #pragma unroll
-            for (int nf = 0; nf < 4; ++nf) {
+            for (int nf = 0; nf < NF; ++nf) {
                 acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[nf], acc[mf][nf], 0, 0, 0);
                 acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[nf], acc[mf][nf], 0, 0, 0);
                 acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[nf], acc[mf][nf], 0, 0, 0);
@@ -237,8 +240,8 @@ __global__ __launch_bounds__(256, 2) void conv_wide_kernel(const mi_conv_params 
         for (int mf = 0; mf < 4; ++mf) wcnt += (ty0 + wm * 4 + mf < H) ? nx : 0;
     }
 #pragma unroll
-    for (int nf = 0; nf < 4; ++nf) {
-        const int col = (wn * 4 + nf) * 16 + lq, co = nt0 * 16 + col;
+    for (int nf = 0; nf < NF; ++nf) {
+        const int col = (wn * NF + nf) * 16 + lq, co = nt0 * 16 + col;
         float bv = p.bias ? p.bias[co] : 0.0f;
         if (Cres && p.res_b) bv += p.res_b[co];
         float4 yv[4];
@@ -275,7 +278,8 @@ __global__ __launch_bounds__(256, 2) void conv_wide_kernel(const mi_conv_params 
     }
     if (p.out_stats) {
         __syncthreads();
-        p.out_stats[((size_t)(b * p.Cout + nt0 * 16 + (tid >> 1)) * tiles + tile) * 2 + (tid & 1)] = red[0][tid] + red[1][tid];
+        if (tid < CW_NT * 16 * 2)
+            p.out_stats[((size_t)(b * p.Cout + nt0 * 16 + (tid >> 1)) * tiles + tile) * 2 + (tid & 1)] = red[0][tid] + red[1][tid];
     }
 }
 
@@ -289,8 +293,8 @@ static int cw_check(const mi_conv_params& p, const char* who) {
     const int C0 = p.in0.C, C1 = p.in1.data ? p.in1.C : 0, Cin = C0 + C1;
     const int Cr0 = (p.res0.data && p.res_w_rp) ? p.res0.C : 0, Cr1 = (Cr0 && p.res1.data) ? p.res1.C : 0, Cres = Cr0 + Cr1;
     if (p.ksize != 3 || p.stride != 1 || p.up2) { mi_set_error("%s: the wide GEMM kernel is k3 s1", who); return MI_ERR_UNSUPPORTED; }
-    if ((C0 & 7) || (C1 & 7) || (Cr0 & 7) || (Cr1 & 7) || (Cin & 31) || (Cres & 31) || Cin <= 0 || (p.Cout & 127) || (p.W & 3) || p.B <= 0 || p.H <= 0) {
-        mi_set_error("%s: the wide GEMM kernel needs input / residual channels in multiples of 32 (each concat part of 8), output channels of 128, W %% 4 == 0", who);
+    if ((C0 & 7) || (C1 & 7) || (Cr0 & 7) || (Cr1 & 7) || (Cin & 31) || (Cres & 31) || Cin <= 0 || (p.Cout & 63) || (p.W & 3) || p.B <= 0 || p.H <= 0) {
+        mi_set_error("%s: the wide GEMM kernel needs input / residual channels in multiples of 32 (each concat part of 8), output channels of 64, W %% 4 == 0", who);
         return MI_ERR_UNSUPPORTED;
     }
     if (!p.gn_coef || !p.gn_exps || !p.act_prep || !p.w_rp) { mi_set_error("%s: gn_coef / gn_exps (mi_gn_coef_fwd), act_prep and w_rp are required", who); return MI_ERR_INVALID; }
@@ -315,7 +319,12 @@ int mi_conv_wide_launch(const mi_conv_params& p, hipStream_t st) {
     if (p.res0.data && !p.res_w_rp && p.res0.C != p.Cout) { mi_set_error("mi_conv_fwd: identity residual needs Cres == Cout"); return MI_ERR_INVALID; }
     if (p.res0.data && !p.res_w_rp && p.res0.st) { mi_set_error("mi_conv_fwd: fp32 residual only"); return MI_ERR_UNSUPPORTED; }
     const int tiles = ((p.H + CW_TH - 1) / CW_TH) * ((p.W + CW_TW - 1) / CW_TW);
-    hipLaunchKernelGGL(conv_wide_kernel, dim3(tiles * p.B, p.Cout / 128), dim3(256), 0, st, p, (const uint4*)p.w_rp,
-                       (const uint4*)(p.res0.data ? p.res_w_rp : nullptr), (const uint4*)p.act_prep);
+    // 128 output channels per workgroup where that still gives every CU two workgroups (or the layer has no 64-channel remainder to spare), else 64:
+    // the results do not depend on the choice (the K order of an output is the same)
+    const bool n128 = (p.Cout & 127) == 0 && ((long long)tiles * p.B * (p.Cout / 128) >= 512 || getenv("MI_CONV_WIDE_N128"));
+    if (n128) hipLaunchKernelGGL(conv_wide_kernel<4>, dim3(tiles * p.B, p.Cout / 128), dim3(256), 0, st, p, (const uint4*)p.w_rp,
+                                 (const uint4*)(p.res0.data ? p.res_w_rp : nullptr), (const uint4*)p.act_prep);
+    else hipLaunchKernelGGL(conv_wide_kernel<2>, dim3(tiles * p.B, p.Cout / 64), dim3(256), 0, st, p, (const uint4*)p.w_rp,
+                            (const uint4*)(p.res0.data ? p.res_w_rp : nullptr), (const uint4*)p.act_prep);
     return mi_check_launch("conv_wide_kernel");
 }

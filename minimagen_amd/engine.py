@@ -31,7 +31,7 @@ CONV_SPLIT8 = int(os.environ.get("MINIMAGEN_CONV_SPLIT8", "64"))        # 8-chan
 CONV_RP = int(os.environ.get("MINIMAGEN_CONV_RP", "2"))                 # 1: narrow k3 s1 convs (channels in multiples of 8, <= 64 in) on the row-paired matrix-core kernel; 2: also nearest-x2 + k3 and k4 s2
 RP_TILE = {k: int(os.environ.get("MINIMAGEN_RP_TILE_" + k, d)) for k, d in (("L", "6"), ("M", "6"), ("S", "6"))}   # tile_cfg for images > 128^2 / > 64^2 / smaller
 RP_TILE_WIDE = int(os.environ.get("MINIMAGEN_RP_TILE_WIDE", "6"))          # tile of the wide k3 s1 convs: 6 = 8x64 where the image is a multiple of 64 wide (the B fragments of a round serve twice the pixels: Unet() default 32.2 -> 31.7 ms per step), 7 = 8x32
-CONV_WIDE_GEMM = os.environ.get("MINIMAGEN_CONV_WIDE_GEMM", "1") != "0"   # wide k3 s1 convs (channels in multiples of 32 in / 128 out) on the GEMM kernel with prepared operand planes (conv_wide.hip)
+CONV_WIDE_GEMM = os.environ.get("MINIMAGEN_CONV_WIDE_GEMM", "1") != "0"   # wide k3 s1 convs (channels in multiples of 32 in / 64 out) on the GEMM kernel with prepared operand planes (conv_wide.hip)
 FLASH_KV_PREP = os.environ.get("MINIMAGEN_FLASH_KV_PREP", "1") != "0"     # multi-query self-attention of the wide presets: K / V prepared once per launch, LDS-DMA into the workgroups
 RP_TILE_WIDE16 = os.environ.get("MINIMAGEN_RP_TILE_WIDE16", "1") != "0"    # wide k3 s1 convs on images <= 16 wide: 16x16 tiles (an 8x32 tile is half outside such an image)
 RP_MIN_HW = int(os.environ.get("MINIMAGEN_RP_MIN_HW", "0"))             # ... for images of at least this many pixels
@@ -231,7 +231,7 @@ class UnetEngine:
             pk.keep.append(wp)
             if w.shape[-1] in (3, 4) and w.shape[1] % 8 == 0:
                 pk.conv_rp[id(wp)] = P.pack_conv_weight_rp(w.to(dev))
-            if CONV_WIDE_GEMM and w.shape[-1] == 3 and w.shape[1] % 32 == 0 and w.shape[0] % 128 == 0:
+            if CONV_WIDE_GEMM and w.shape[-1] == 3 and w.shape[1] % 32 == 0 and w.shape[0] % 64 == 0:
                 pk.conv_ig[id(wp)] = P.pack_conv_weight_ig(w.to(dev))
             return wp
 
@@ -258,7 +258,7 @@ class UnetEngine:
                 pk.keep.append(rw)
                 if rb.res_conv.weight.shape[1] % 8 == 0:
                     pk.conv_rp[id(rw)] = P.pack_conv_weight_rp(rb.res_conv.weight)
-                if CONV_WIDE_GEMM and rb.res_conv.weight.shape[1] % 32 == 0 and rb.res_conv.weight.shape[0] % 128 == 0:
+                if CONV_WIDE_GEMM and rb.res_conv.weight.shape[1] % 32 == 0 and rb.res_conv.weight.shape[0] % 64 == 0:
                     pk.conv_ig[id(rw)] = P.pack_conv_weight_ig(rb.res_conv.weight)
                 pk.conv[id(rb.res_conv)] = rw
             if rb.cross_attn is not None:
@@ -440,10 +440,10 @@ class UnetEngine:
                 cfg = 6                  # 8 x 64 tiles for the wide k3 s1 convs
             if wide and RP_TILE_WIDE16 and stride == 1 and not up2 and Wo <= 16 and Ho > 8 and Cout >= 32 and not ws.half:
                 cfg = 10                 # 16 x 16 tiles for images no wider than 16
-            gemm = wide and ksize == 3 and stride == 1 and not up2 and not ws.half and cin_tot % 32 == 0 and cres % 32 == 0 and Cout % 128 == 0 \
+            gemm = wide and ksize == 3 and stride == 1 and not up2 and not ws.half and cin_tot % 32 == 0 and cres % 32 == 0 and Cout % 64 == 0 \
                 and id(wpack) in pk.conv_ig and (cres == 0 or id(res[2]) in pk.conv_ig)
             if gemm:
-                cfg = 11                 # the wide GEMM kernel (conv_wide.hip): 8 x 16 pixels x 128 channels per workgroup
+                cfg = 11                 # the wide GEMM kernel (conv_wide.hip): 8 x 16 pixels x 128 (or 64) channels per workgroup
             th, tw = {5: (16, 64), 6: (8, 64), 7: (8, 32), 10: (16, 16), 11: (8, 16)}[cfg]
             nt = -(-Ho // th) * -(-Wo // tw)
         if ws.store16 and (not rp or wide):

@@ -2,6 +2,7 @@
 (the arithmetic spec the reference itself uses).  Tolerances: fp32, op-level atol 2e-5 (+4e-6 relative for
 the long k15 sums); bit-exact for the quantile selection and the elementwise sampler math."""
 import ctypes as C
+import os
 
 import pytest
 import torch
@@ -338,6 +339,7 @@ WIDE_CASES = [
     (2, 128, 0, 128, 16, 16, 3, 1, 0, True, True, 'id', 11),      # the wide GEMM kernel (conv_wide.hip: prepared operand planes, 8 x 16 x 128-channel tiles)
     (1, 96, 64, 128, 24, 12, 3, 1, 0, True, False, 'conv', 11),   # ... ragged in both directions, concat input, 1x1 residual over a concat
     (2, 64, 0, 256, 8, 32, 3, 1, 0, False, False, 'none', 11),    # ... no GroupNorm, two tiles across, two channel groups
+    (1, 64, 0, 192, 16, 16, 3, 1, 0, True, True, 'none', 11),     # ... 192 output channels: three 64-channel workgroups
 ]
 
 
@@ -432,6 +434,16 @@ def test_conv_wide_regime(backend, case):
         p.act_prep_bytes = nbytes
         L.check(lib.mi_conv_prep_fwd(C.byref(p), L.current_stream()), "conv prep")
     L.check(lib.mi_conv_fwd(C.byref(p), L.current_stream()), "conv wide")
+    if tcfg == 11 and Cout % 128 == 0:
+        # small launches take 64 output channels per workgroup; the 128-channel form (forced here) gives the same bits
+        out64, ost64 = out.clone(), ost.clone()
+        out.fill_(float('nan')); ost.zero_()
+        os.environ["MI_CONV_WIDE_N128"] = "1"
+        try:
+            L.check(lib.mi_conv_fwd(C.byref(p), L.current_stream()), "conv wide (128 channels per workgroup)")
+        finally:
+            del os.environ["MI_CONV_WIDE_N128"]
+        assert torch.equal(out.cpu(), out64.cpu()) and torch.equal(ost.cpu(), ost64.cpu())
     scale = max(1.0, ref.abs().max().item() / 8.0)
     err = (out.cpu().double() - ref).abs().max().item()
     print(f"wide conv {case}: max|d| = {err:.2e} (gate {2e-5 * scale:.2e}, exps {exps.cpu().tolist()})")
