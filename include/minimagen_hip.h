@@ -403,9 +403,9 @@ typedef struct mi_flash_attn_params {
     const float* k0; const float* v0; int n0, ld0; long long bs0;
     const float* k1; const float* v1; int n1, ld1; long long bs1;
     float* out;                     /* [B][HW][heads*64] */
-    /* optional workspace of mi_flash_kv_prep_bytes(B, J) bytes (J = context rows incl. the null row); with it the multi-query form (kv_heads == 1,
-       heads % 4 == 0) prepares its K / V operands once per launch (a small kernel) and streams them global -> LDS by LDS-DMA instead of every
-       workgroup re-staging the whole context; NULL: the self-staging kernel */
+    /* optional workspace of mi_flash_kv_prep_bytes(B * kv_heads, J) bytes (J = context rows incl. the null row); with it the K / V operands are prepared
+       once per launch (a small kernel) and streamed global -> LDS by LDS-DMA instead of every workgroup re-staging the whole context (multi-query
+       form with heads % 4 == 0, or one k / v head per head); NULL: the self-staging kernels */
     void* kv_prep; long long kv_prep_bytes;
 } mi_flash_attn_params;
 int mi_flash_attn_fwd(const mi_flash_attn_params* p, void* stream);

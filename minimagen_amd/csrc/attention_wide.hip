@@ -319,7 +319,8 @@ __global__ __launch_bounds__(256) void flash_kv_prep_kernel(const mi_flash_attn_
     __shared__ __attribute__((aligned(16))) uint4 img[FW_CHUNK16];          // KsH | KsL | VtH | VtL
     __shared__ float smax[2][4];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int c = blockIdx.x, b = blockIdx.z, j0 = 64 * c;
+    const int c = blockIdx.x, kvh = blockIdx.y, b = blockIdx.z, j0 = 64 * c;       // kvh: which k / v head (0 for the multi-query form)
+    const int KVH = gridDim.y;
     const int nnull = p.null_k ? 1 : 0, J = nnull + p.n0 + p.n1;
     const int srow = tid / PPR, sd0 = (tid % PPR) * EPT;
     const int spos = (srow & 32) | (((srow >> 2) & 3) << 3) | (((srow >> 4) & 1) << 2) | (srow & 3);
@@ -330,8 +331,8 @@ __global__ __launch_bounds__(256) void flash_kv_prep_kernel(const mi_flash_attn_
         const float* vsrc = nullptr;
         if (jj < J) {
             if (jj < nnull) { ksrc = p.null_k; vsrc = p.null_v; }
-            else if (jj - nnull < p.n0) { const size_t o_ = (size_t)b * p.bs0 + (size_t)(jj - nnull) * p.ld0; ksrc = p.k0 + o_; vsrc = p.v0 + o_; }
-            else { const size_t o_ = (size_t)b * p.bs1 + (size_t)(jj - nnull - p.n0) * p.ld1; ksrc = p.k1 + o_; vsrc = p.v1 + o_; }
+            else if (jj - nnull < p.n0) { const size_t o_ = (size_t)b * p.bs0 + (size_t)(jj - nnull) * p.ld0 + kvh * 64; ksrc = p.k0 + o_; vsrc = p.v0 + o_; }
+            else { const size_t o_ = (size_t)b * p.bs1 + (size_t)(jj - nnull - p.n0) * p.ld1 + kvh * 64; ksrc = p.k1 + o_; vsrc = p.v1 + o_; }
         }
 #pragma unroll
         for (int e = 0; e < EPT; e += 4) {
@@ -378,26 +379,30 @@ __global__ __launch_bounds__(256) void flash_kv_prep_kernel(const mi_flash_attn_
         }
     }
     __syncthreads();
-    uint4* dst = reinterpret_cast<uint4*>(p.kv_prep) + ((size_t)b * nchunk + c) * FW_CHUNK16;
+    const size_t img_i = ((size_t)b * KVH + kvh) * nchunk + c;
+    uint4* dst = reinterpret_cast<uint4*>(p.kv_prep) + img_i * FW_CHUNK16;
     for (int i = tid; i < FW_CHUNK16; i += 256) dst[i] = img[i];
     if (tid == 0) {
-        int* ex = reinterpret_cast<int*>(reinterpret_cast<uint4*>(p.kv_prep) + (size_t)p.B * nchunk * FW_CHUNK16) + ((size_t)b * nchunk + c) * 2;
+        int* ex = reinterpret_cast<int*>(reinterpret_cast<uint4*>(p.kv_prep) + (size_t)p.B * KVH * nchunk * FW_CHUNK16) + img_i * 2;
         ex[0] = ek; ex[1] = ev;
     }
 }
 
-template <int NW, int QT, int WPS>
+// PERHEAD (k / v per head, the wide presets' cross-attention): a workgroup = NW x QT x 16 queries of ONE head, which share that head's chunks
+template <int NW, int QT, int WPS, bool PERHEAD = false>
 __global__ __launch_bounds__(64 * NW, WPS) void flash_attn_mq_kernel(const mi_flash_attn_params p, const int nchunk) {
     // a workgroup = 64 queries x NH heads; a wave = QT 16-query tiles of one head: every K / V fragment read from LDS feeds QT x 3 matrix
     // instructions (with QT = 1 and 16 waves the LDS reads -- each wave reads the whole 36 KB chunk -- took longer than the matrix work)
     constexpr int D = 64, CP = FW_CP, WPH = 4 / QT, NH = NW / WPH;
     __shared__ __attribute__((aligned(16))) uint4 kv[2][FW_CHUNK16];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lq = lane & 15, lg = lane >> 4;
-    const int h = blockIdx.y * NH + wave / WPH, b = blockIdx.z;
+    const int h = PERHEAD ? (int)blockIdx.y : (int)blockIdx.y * NH + wave / WPH, b = blockIdx.z;
     const int inner = p.heads * D;
     const int nnull = p.null_k ? 1 : 0, J = nnull + p.n0 + p.n1;
-    const uint4* const prep = reinterpret_cast<const uint4*>(p.kv_prep) + (size_t)b * nchunk * FW_CHUNK16;
-    const int* const exps = reinterpret_cast<const int*>(reinterpret_cast<const uint4*>(p.kv_prep) + (size_t)p.B * nchunk * FW_CHUNK16) + (size_t)b * nchunk * 2;
+    const int KVH = PERHEAD ? p.heads : 1;
+    const size_t img0 = ((size_t)b * KVH + (PERHEAD ? h : 0)) * nchunk;
+    const uint4* const prep = reinterpret_cast<const uint4*>(p.kv_prep) + img0 * FW_CHUNK16;
+    const int* const exps = reinterpret_cast<const int*>(reinterpret_cast<const uint4*>(p.kv_prep) + (size_t)p.B * KVH * nchunk * FW_CHUNK16) + img0 * 2;
     auto issue_chunk = [&](int c, int buf) {
         for (int r = wave; r < FW_CHUNK16 / 64; r += NW) {           // one 1 KB row (64 lanes x 16 bytes) per instruction
             const uint4* src = prep + (size_t)c * FW_CHUNK16 + r * 64 + lane;
@@ -414,7 +419,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void flash_attn_mq_kernel(const mi_fl
     int eq[QT], tok[QT];
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
-        tok[t] = (blockIdx.x * 4 + (wave % WPH) * QT + t) * 16 + lq;
+        tok[t] = (PERHEAD ? (int)blockIdx.x * (NW * QT) + wave * QT + t : (int)blockIdx.x * 4 + (wave % WPH) * QT + t) * 16 + lq;
         const int tokc = tok[t] < p.HW ? tok[t] : p.HW - 1;
         const float* qr = p.q + ((size_t)b * p.HW + tokc) * inner + h * D;
         float qv[2][8];
@@ -586,7 +591,11 @@ __global__ __launch_bounds__(256) void tokens_to_nchw_kernel(const mi_tokens_to_
     const int br = p.res.data ? mi_row_of(b, p.res.bmod) : 0;
     const int tok = tok0 + lane;
     const bool ok = tok < p.HW;
-    for (int c0 = 0; c0 < p.C; c0 += 64) {
+    // blockIdx.z: which share of the 64-channel blocks (small token counts -- 16 x 16 images -- would otherwise leave half of the CUs without a
+    // workgroup: 4 tiles x 32 images); every share computes the token moments for itself
+    const int nblk = (p.C + 63) / 64, per = (nblk + (int)gridDim.z - 1) / (int)gridDim.z;
+    const int c_lo = (int)blockIdx.z * per * 64, c_hi = c_lo + per * 64 < p.C ? c_lo + per * 64 : p.C;
+    for (int c0 = c_lo; c0 < c_hi; c0 += 64) {
         __syncthreads();                                  // moments published / the previous block's reads are done
 #pragma unroll 4
         for (int i = 0; i < 16; ++i) {
@@ -649,14 +658,19 @@ extern "C" int mi_flash_attn_fwd(const mi_flash_attn_params* p, void* stream) {
     static const bool exact = getenv("MI_FLASH_EXACT_F32") != nullptr;
     static const bool one_head = getenv("MI_FLASH_ONE_HEAD") != nullptr;
     if (exact) hipLaunchKernelGGL(flash_attn_kernel, dim3((p->HW + 63) / 64, p->heads, p->B), dim3(256), 0, (hipStream_t)stream, *p);
-    else if (p->kv_heads == 1 && (p->heads & 3) == 0 && !one_head && p->kv_prep) {       // multi-query with prepared K / V (see flash_kv_prep_kernel)
+    else if (p->kv_prep && !one_head && ((p->kv_heads == 1 && (p->heads & 3) == 0) || p->kv_heads == p->heads)) {
+        // prepared K / V (flash_kv_prep_kernel): multi-query (four heads of 64 queries per workgroup) or one k / v head per head (256 queries of a head)
         const int nnull = p->null_k ? 1 : 0, nchunk = (nnull + p->n0 + p->n1 + 63) / 64;
-        if (p->kv_prep_bytes < mi_flash_kv_prep_bytes(p->B, nnull + p->n0 + p->n1)) { mi_set_error("mi_flash_attn_fwd: kv_prep buffer too small"); return MI_ERR_INVALID; }
-        hipLaunchKernelGGL(flash_kv_prep_kernel, dim3(nchunk, 1, p->B), dim3(256), 0, (hipStream_t)stream, *p, nchunk);
+        if (p->kv_prep_bytes < mi_flash_kv_prep_bytes(p->B * p->kv_heads, nnull + p->n0 + p->n1)) { mi_set_error("mi_flash_attn_fwd: kv_prep buffer too small"); return MI_ERR_INVALID; }
+        hipLaunchKernelGGL(flash_kv_prep_kernel, dim3(nchunk, p->kv_heads, p->B), dim3(256), 0, (hipStream_t)stream, *p, nchunk);
         static const int qt = getenv("MI_FLASH_MQ_QT") ? atoi(getenv("MI_FLASH_MQ_QT")) : 2;         // 16-query tiles per wave (A/B knob: 1 = 16 waves of one tile each)
-        const dim3 grid((p->HW + 63) / 64, p->heads / 4, p->B);
-        if (qt == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(flash_attn_mq_kernel<16, 1, 4>), grid, dim3(1024), 0, (hipStream_t)stream, *p, nchunk);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(flash_attn_mq_kernel<8, 2, 2>), grid, dim3(512), 0, (hipStream_t)stream, *p, nchunk);
+        if (!(p->kv_heads == 1 && (p->heads & 3) == 0)) {
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(flash_attn_mq_kernel<8, 2, 2, true>), dim3((p->HW + 255) / 256, p->heads, p->B), dim3(512), 0, (hipStream_t)stream, *p, nchunk);
+        } else {
+            const dim3 grid((p->HW + 63) / 64, p->heads / 4, p->B);
+            if (qt == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(flash_attn_mq_kernel<16, 1, 4>), grid, dim3(1024), 0, (hipStream_t)stream, *p, nchunk);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(flash_attn_mq_kernel<8, 2, 2>), grid, dim3(512), 0, (hipStream_t)stream, *p, nchunk);
+        }
     }
     else if (p->kv_heads == 1 && (p->heads & 3) == 0 && !one_head) {    // multi-query: heads of the same 64 queries share every staged K / V chunk
         static const int two_heads = getenv("MI_FLASH_TWO_HEADS") ? atoi(getenv("MI_FLASH_TWO_HEADS")) : 0;
@@ -674,7 +688,10 @@ extern "C" long long mi_flash_kv_prep_bytes(int B, int J) {
 
 extern "C" int mi_tokens_to_nchw_fwd(const mi_tokens_to_nchw_params* p, void* stream) {
     if (p->B <= 0 || p->HW <= 0 || p->C <= 0) { mi_set_error("mi_tokens_to_nchw_fwd: empty problem"); return MI_ERR_INVALID; }
-    hipLaunchKernelGGL(tokens_to_nchw_kernel, dim3((p->HW + 63) / 64, p->B), dim3(256), 0, (hipStream_t)stream, *p);
+    const int nt = (p->HW + 63) / 64, nblk = (p->C + 63) / 64;
+    int split = 1;
+    while (split < nblk && (long long)nt * p->B * split < 512) split *= 2;
+    hipLaunchKernelGGL(tokens_to_nchw_kernel, dim3(nt, p->B, split), dim3(256), 0, (hipStream_t)stream, *p);
     return mi_check_launch("tokens_to_nchw_kernel");
 }
 

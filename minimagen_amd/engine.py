@@ -567,6 +567,10 @@ class UnetEngine:
         if ws.has_text:
             p.k1, p.v1, p.n1, p.ld1, p.bs1 = L.ptr(kv_text), L.ptr(kv_text) + 4 * inner, MAX_TEXT_LEN, 2 * inner, MAX_TEXT_LEN * 2 * inner
         p.out = L.ptr(o)
+        if FLASH_KV_PREP:
+            nbytes = lib.mi_flash_kv_prep_bytes(B2 * ca.heads, 1 + ws.ntot + (MAX_TEXT_LEN if ws.has_text else 0))
+            prep = self._buf(ws, (nbytes + 3) // 4)
+            p.kv_prep, p.kv_prep_bytes = L.ptr(prep), nbytes
         ws.prog.append((lib.mi_flash_attn_fwd, p, "flash_attn"))
         ws.prog.append(self._call(lib.mi_gemm_f32, "gemm_out", L.ptr(o), L.ptr(ca.to_out[0].weight), 0, 0, L.ptr(t), B2 * HW, Cc, inner, 0))
         ws.wide_attn = True

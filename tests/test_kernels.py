@@ -779,11 +779,11 @@ def test_flash_attention_unfolded(backend, case):
     gate = 2e-5 * max(1.0, ref.abs().max().item())
     print(f"flash attention {case}: max|d| = {err:.2e} (gate {gate:.2e})")
     assert torch.isfinite(out).all() and err < gate
-    if kvh == 1 and heads % 4 == 0:
+    if (kvh == 1 and heads % 4 == 0) or kvh == heads:
         # the same launch with its K / V operands prepared once (flash_kv_prep_kernel + LDS-DMA): the same arithmetic, the same bits
         J = (1 if has_null else 0) + n0 + n1
-        nbytes = lib.mi_flash_kv_prep_bytes(B, J)
-        assert nbytes == B * ((J + 63) // 64) * (4 * 64 * 9 * 16 + 8)
+        nbytes = lib.mi_flash_kv_prep_bytes(B * kvh, J)
+        assert nbytes == B * kvh * ((J + 63) // 64) * (4 * 64 * 9 * 16 + 8)
         prep = torch.full(((nbytes + 3) // 4,), float('nan'), device=dev)
         out2 = torch.full((B, HW, inner), float('nan'), device=dev)
         p.out, p.kv_prep, p.kv_prep_bytes = L.ptr(out2), L.ptr(prep), nbytes
