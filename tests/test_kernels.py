@@ -172,8 +172,7 @@ def test_conv_row_paired_path(backend, case):
     if C1:
         p.in1 = L.MiAct(d("x1", x1).data_ptr(), C1, d("s1", chan_stats(x1)).data_ptr(), 1, sk, 0)
     p.Cout, p.ksize, p.stride, p.up2 = Cout, 3, 1, 0
-    pack = P.pack_conv_weight_ig if tcfg == 11 else P.pack_conv_weight_rp
-    wf, wexp = pack(w)
+    wf, wexp = P.pack_conv_weight_rp(w)
     p.w_rp, p.w_rp_exp, p.bias = d("wf", wf).data_ptr(), wexp, d("b", bias).data_ptr()
     if gn:
         p.gn_groups, p.gn_gamma, p.gn_beta, p.gn_eps = 8, d("g", gamma).data_ptr(), d("be", beta).data_ptr(), 1e-5
@@ -246,8 +245,7 @@ def test_conv_row_paired_bf16_storage(backend, case):
     if C1:
         p.in1 = L.MiAct(d("x1", x1).data_ptr(), C1, d("s1", chan_stats(x1.float())).data_ptr(), 1, sk, 0, 1)
     p.Cout, p.ksize, p.stride, p.up2 = Cout, 3, 1, 0
-    pack = P.pack_conv_weight_ig if tcfg == 11 else P.pack_conv_weight_rp
-    wf, wexp = pack(w)
+    wf, wexp = P.pack_conv_weight_rp(w)
     p.w_rp, p.w_rp_exp, p.bias = d("wf", wf).data_ptr(), wexp, d("b", bias).data_ptr()
     p.gn_groups, p.gn_gamma, p.gn_beta, p.gn_eps = 8, d("g", gamma).data_ptr(), d("be", beta).data_ptr(), 1e-5
     if res != 'none':
@@ -306,8 +304,7 @@ def test_conv_row_paired_resampling(backend, case):
     p.B, p.H, p.W = B, H, W
     p.in0 = L.MiAct(d("x0", x0).data_ptr(), Cin, d("s0", chan_stats(x0)).data_ptr(), 1, 1.0, 0)
     p.Cout, p.ksize, p.stride, p.up2 = Cout, ks, stride, up2
-    pack = P.pack_conv_weight_ig if tcfg == 11 else P.pack_conv_weight_rp
-    wf, wexp = pack(w)
+    wf, wexp = P.pack_conv_weight_rp(w)
     p.w_rp, p.w_rp_exp, p.bias = d("wf", wf).data_ptr(), wexp, d("b", bias).data_ptr()
     nt = tile_nt(lib, cfg, H, W)
     out = torch.full((B, Cout, H, W), float('nan'), device=dev)
