@@ -463,11 +463,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void flash_attn_mq_kernel(const mi_fl
         if (c + 1 < nchunk) issue_chunk(c + 1, buf ^ 1);
         const uint4* const KsH = kv[buf], * const KsL = kv[buf] + 64 * CP, * const VtH = kv[buf] + 2 * 64 * CP, * const VtL = kv[buf] + 3 * 64 * CP;
         const int ek = exps[2 * c], ev = exps[2 * c + 1];
-        float uvv = ldexpf(1.0f, -ev);
-#if !defined(HIPEMU)
-        asm volatile("" : "+v"(uvv));                      // (VGPR operand for the packed accumulator update below, as for `us`)
-#endif
-        const mi_f32x2 uv2 = {uvv, uvv};
+        const float uv = ldexpf(1.0f, -ev);
         f32x4 s[QT][4];
 #pragma unroll
         for (int jt = 0; jt < 4; ++jt) {
@@ -488,13 +484,6 @@ __global__ __launch_bounds__(64 * NW, WPS) void flash_attn_mq_kernel(const mi_fl
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
             const float us = ldexpf(1.0f, -(ek + eq[t]));
-            // exponent arguments on packed fp32 pairs (one issue slot for two elements).  The scale is wave-uniform: held in a VGPR pair on purpose --
-            // a packed fp32 instruction with a scalar operand is the round-3 hazard (Makefile, tools/check_code_objects.py)
-            float usv = us;
-#if !defined(HIPEMU)
-            asm volatile("" : "+v"(usv));
-#endif
-            const mi_f32x2 us2 = {usv, usv};
             float mx = -INFINITY;
 #pragma unroll
             for (int jt = 0; jt < 4; ++jt)
@@ -516,19 +505,13 @@ __global__ __launch_bounds__(64 * NW, WPS) void flash_attn_mq_kernel(const mi_fl
 #pragma unroll
                     for (int r = 0; r < 4; ++r) o[t][dt][r] *= alpha;
             }
-            const mi_f32x2 nm2 = {-mn, -mn};
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
                 float pe[8];
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const f32x4 sv = s[t][2 * hf + u];
-                    const mi_f32x2 a01 = mi_pk_fma((mi_f32x2){sv[0], sv[1]}, us2, nm2), a23 = mi_pk_fma((mi_f32x2){sv[2], sv[3]}, us2, nm2);
-                    pe[4 * u] = __builtin_amdgcn_exp2f(a01[0]); pe[4 * u + 1] = __builtin_amdgcn_exp2f(a01[1]);
-                    pe[4 * u + 2] = __builtin_amdgcn_exp2f(a23[0]); pe[4 * u + 3] = __builtin_amdgcn_exp2f(a23[1]);
+                for (int u = 0; u < 2; ++u)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) l[t] += pe[4 * u + r];        // (sequential: the self-staging kernel's summation order)
-                }
+                    for (int r = 0; r < 4; ++r) { pe[4 * u + r] = __builtin_amdgcn_exp2f(fmaf(s[t][2 * hf + u][r], us, -mn)); l[t] += pe[4 * u + r]; }
                 uint4 hi, lo;
                 fw_split8(pe, hi, lo);
                 ph[t][hf] = __builtin_bit_cast(fw_f16x8, hi);
@@ -551,11 +534,9 @@ __global__ __launch_bounds__(64 * NW, WPS) void flash_attn_mq_kernel(const mi_fl
                 }
             }
 #pragma unroll
-            for (int t = 0; t < QT; ++t) {
-                const mi_f32x2 o01 = mi_pk_fma((mi_f32x2){sl[t][0], sl[t][1]}, uv2, (mi_f32x2){o[t][dt][0], o[t][dt][1]});
-                const mi_f32x2 o23 = mi_pk_fma((mi_f32x2){sl[t][2], sl[t][3]}, uv2, (mi_f32x2){o[t][dt][2], o[t][dt][3]});
-                o[t][dt] = (f32x4){o01[0], o01[1], o23[0], o23[1]};
-            }
+            for (int t = 0; t < QT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[t][dt][r] = fmaf(sl[t][r], uv, o[t][dt][r]);
         }
     };
     for (int c = 0; c + 1 < nchunk; ++c) chunk(c, std::false_type{});
