@@ -200,98 +200,6 @@ __global__ __launch_bounds__(256) void gemm_f16x3_kernel(const float* __restrict
             }
 }
 
-// ---- the same GEMM for large problems (the projections of the wide presets' attention blocks: M = batch x tokens up to 131072): a workgroup takes
-// 128 x 128 of the output as FOUR of gemm_f16x3_kernel's 64 x 64 tiles -- each of its four waves one whole tile (4 x 4 accumulator fragments instead of
-// 2 x 2: an operand fragment read from LDS feeds twelve matrix instructions instead of six, and a slice's barriers are amortised over four times the
-// matrix work), with the staging shared: half the global traffic per flop.  Block scaling stays per 64 x 32 operand tile and the K order is the same,
-// so every output element is computed exactly as in gemm_f16x3_kernel: the same bits (tests/test_t5.py::test_gemm_large_tiles_match).
-__global__ __launch_bounds__(256) void gemm_f16x3_wide_kernel(const float* __restrict__ A, const float* __restrict__ W, const float* __restrict__ R,
-                                                              float* __restrict__ Cout, int M, int N, int K, int act) {
-    constexpr int BK = 32, PITCH = 5;
-    __shared__ __attribute__((aligned(16))) uint4 Ah[128 * PITCH], Al[128 * PITCH], Wh[128 * PITCH], Wl[128 * PITCH];
-    __shared__ float smax[4][4];                          // [A half 0, A half 1, W half 0, W half 1][wave]
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int wm = wave >> 1, wn = wave & 1;             // the wave's 64-row half of A / of W
-    const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
-    const int lr = tid >> 2, lc = tid & 3;                // staging: row within a half, 8-float chunk
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto amax8 = [](const float4& u, const float4& v) {
-        return fmaxf(fmaxf(fmaxf(fabsf(u.x), fabsf(u.y)), fmaxf(fabsf(u.z), fabsf(u.w))), fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
-    };
-    float4 a[2][2], w[2][2];
-    auto load_slice = [&](int k0) {
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-            a[hf][0] = z4; a[hf][1] = z4; w[hf][0] = z4; w[hf][1] = z4;
-            if (m0 + 64 * hf + lr < M) { const float4* pa = reinterpret_cast<const float4*>(A + (size_t)(m0 + 64 * hf + lr) * K + k0 + 8 * lc); a[hf][0] = pa[0]; a[hf][1] = pa[1]; }
-            if (n0 + 64 * hf + lr < N) { const float4* pw = reinterpret_cast<const float4*>(W + (size_t)(n0 + 64 * hf + lr) * K + k0 + 8 * lc); w[hf][0] = pw[0]; w[hf][1] = pw[1]; }
-        }
-    };
-    load_slice(0);
-    for (int k0 = 0; k0 < K; k0 += BK) {
-        float mx[4];
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf) { mx[hf] = mi_wave_max(amax8(a[hf][0], a[hf][1])); mx[2 + hf] = mi_wave_max(amax8(w[hf][0], w[hf][1])); }
-        __syncthreads();                                      // the previous slice's fragments and maxima are consumed
-        if (lane == 0) { smax[0][wave] = mx[0]; smax[1][wave] = mx[1]; smax[2][wave] = mx[2]; smax[3][wave] = mx[3]; }
-        __syncthreads();
-        int ex[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) ex[q] = t5_scale_exp(fmaxf(fmaxf(smax[q][0], smax[q][1]), fmaxf(smax[q][2], smax[q][3])));
-        uint4 hi, lo;
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-            t5_split8(a[hf][0], a[hf][1], ldexpf(1.0f, ex[hf]), hi, lo); Ah[(64 * hf + lr) * PITCH + lc] = hi; Al[(64 * hf + lr) * PITCH + lc] = lo;
-            t5_split8(w[hf][0], w[hf][1], ldexpf(1.0f, ex[2 + hf]), hi, lo); Wh[(64 * hf + lr) * PITCH + lc] = hi; Wl[(64 * hf + lr) * PITCH + lc] = lo;
-        }
-        if (k0 + BK < K) load_slice(k0 + BK);
-        __syncthreads();
-        const float un = ldexpf(1.0f, -((wm ? ex[1] : ex[0]) + (wn ? ex[3] : ex[2])));
-        t5_f16x8 ah[4], al[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int o = (wm * 64 + i * 16 + (lane & 15)) * PITCH + (lane >> 4);
-            ah[i] = __builtin_bit_cast(t5_f16x8, Ah[o]);
-            al[i] = __builtin_bit_cast(t5_f16x8, Al[o]);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int o = (wn * 64 + j * 16 + (lane & 15)) * PITCH + (lane >> 4);
-            const t5_f16x8 bh = __builtin_bit_cast(t5_f16x8, Wh[o]), bl = __builtin_bit_cast(t5_f16x8, Wl[o]);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                f32x4 sl = (f32x4){0.f, 0.f, 0.f, 0.f};
-                sl = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh, sl, 0, 0, 0);
-                sl = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl, sl, 0, 0, 0);
-                sl = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh, sl, 0, 0, 0);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[i][j][r] = fmaf(sl[r], un, acc[i][j][r]);
-            }
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m0 + wm * 64 + i * 16 + 4 * (lane >> 4) + r, n = n0 + wn * 64 + j * 16 + (lane & 15);
-                if (m < M && n < N) {
-                    float v = acc[i][j][r];
-                    if (act == 1) v = fmaxf(v, 0.0f);
-                    else if (act == 2) v = gelu_new(v);
-                    else if (act == 3) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
-                    if (R) v += R[(size_t)m * N + n];
-                    Cout[(size_t)m * N + n] = v;
-                }
-            }
-}
-
 __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* x, const float* w, float* y, int rows, int dim, float eps, const uint8_t* zero_mask) {
     __shared__ float red[4];
     const int row = blockIdx.x, tid = threadIdx.x;
@@ -397,12 +305,6 @@ extern "C" int mi_gemm_f32(const float* A, const float* W, const float* gate, co
     // otherwise (and with MI_GEMM_EXACT_F32 set in the environment, for A/B measurements) the exact-fp32 MFMA kernel
     static const bool exact = getenv("MI_GEMM_EXACT_F32") != nullptr;
     if ((K % 32) == 0 && !exact) {
-        // large problems: four 64 x 64 tiles per workgroup (the same bits; MI_GEMM_SMALL_TILES in the environment: A/B measurements)
-        const bool small_only = getenv("MI_GEMM_SMALL_TILES") != nullptr;
-        if (!gate && !small_only && (long long)((M + 127) / 128) * ((N + 127) / 128) >= 512) {
-            hipLaunchKernelGGL(gemm_f16x3_wide_kernel, dim3((N + 127) / 128, (M + 127) / 128), dim3(256), 0, (hipStream_t)stream, A, W, R, Cout, M, N, K, act);
-            return mi_check_launch("gemm_f16x3_wide_kernel");
-        }
         if (gate) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_f16x3_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, A, W, gate, R, Cout, M, N, K, act);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_f16x3_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, A, W, gate, R, Cout, M, N, K, act);
         return mi_check_launch("gemm_f16x3_kernel");

@@ -81,39 +81,6 @@ def test_gemm_f16x3_block_scaled(backend, case):
     assert torch.isfinite(out).all() and bool((err <= tol).all()), (err / tol).max()
 
 
-@pytest.mark.parametrize("backend", BACKENDS)
-@pytest.mark.parametrize("case", [(2900, 2900, 32, 0), (4096, 2080, 64, 3)])
-def test_gemm_large_tiles_match(backend, case):
-    """large problems run four 64 x 64 tiles per workgroup (gemm_f16x3_wide_kernel: the wide presets' attention projections); block scaling and K order
-    are per 64 x 32 operand tile as in the small kernel, so the two give the same bits -- ragged M / N included"""
-    import ctypes as C
-    import os
-    from minimagen_amd import _lib as L
-    dev = setup(backend)
-    lib = L.lib()
-    M, N, K, act = case
-    g = torch.Generator().manual_seed(9)
-    A, W, Rm = torch.randn(M, K, generator=g) * 3.0, torch.randn(N, K, generator=g) * 0.2, torch.randn(M, N, generator=g)
-    A[::5] *= 2.0 ** -6
-    Ad, Wd, Rd = A.to(dev), W.to(dev), Rm.to(dev)
-    assert ((M + 127) // 128) * ((N + 127) // 128) >= 512          # the launcher's rule for the large-tile kernel
-    outs = []
-    for small in (False, True):
-        out = torch.full((M, N), float("nan"), device=dev)
-        if small:
-            os.environ["MI_GEMM_SMALL_TILES"] = "1"
-        try:
-            L.check(lib.mi_gemm_f32(L.ptr(Ad), L.ptr(Wd), None, L.ptr(Rd), L.ptr(out), M, N, K, act, L.current_stream()), "mi_gemm_f32")
-        finally:
-            os.environ.pop("MI_GEMM_SMALL_TILES", None)
-        outs.append(out.cpu())
-    pre = A.double() @ W.double().t()
-    ref = (torch.nn.functional.gelu(pre) if act == 3 else pre) + Rm.double()
-    tol = 4e-6 * (A.abs().double() @ W.abs().double().t()) + 1e-6 * ref.abs() + 1e-30
-    assert bool(((outs[0].double() - ref).abs() <= tol).all())
-    assert torch.equal(outs[0], outs[1])
-
-
 @pytest.mark.gpu
 def test_t5_encoder_bench_shape():
     """the shape bench.py's t5_encode leg runs: T5Config() = t5-small, 6 layers, B=32, L=64, ragged masks"""
