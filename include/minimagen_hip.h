@@ -186,6 +186,8 @@ typedef struct mi_cond_step_params {
     float* ss;                      /* out [B2][R] */
     float* c_time;                  /* out [B2][ntok_total][cd], ntok_total = ntok * (1 + lowres) */
     float* t_out;                   /* out [B2][tcd] or NULL */
+    float* silu_out;                /* out [B2][tcd] or NULL: SiLU(t), the input of every time_mlp -- for callers that run the stacked time-MLP as one GEMM
+                                       (ss == NULL skips it here: the wide presets, where it is [~10 K][512] per row) */
 } mi_cond_step_params;
 int mi_cond_step_fwd(const mi_cond_step_params* p, void* stream);
 

@@ -70,7 +70,7 @@ class MiCondStepParams(C.Structure):
         ("time", C.c_void_p), ("lowres_time", C.c_void_p), ("freq", C.c_void_p),
         ("th", MiLinear), ("tc", MiLinear), ("tt", MiLinear), ("lth", MiLinear), ("ltc", MiLinear), ("ltt", MiLinear),
         ("text_hiddens", C.c_void_p), ("norm_w", C.c_void_p), ("norm_b", C.c_void_p), ("time_mlps", MiLinear),
-        ("ss", C.c_void_p), ("c_time", C.c_void_p), ("t_out", C.c_void_p),
+        ("ss", C.c_void_p), ("c_time", C.c_void_p), ("t_out", C.c_void_p), ("silu_out", C.c_void_p),
     ]
 
 

@@ -126,6 +126,7 @@ __global__ __launch_bounds__(256) void cond_step_kernel(const mi_cond_step_param
         if (p.text_hiddens) v += p.text_hiddens[(size_t)bb * p.tcd + o];
         if (p.t_out) p.t_out[(size_t)bb * p.tcd + o] = v;
         hid[o] = mi_silu(v);          // SiLU(t), input of every time_mlp
+        if (p.silu_out) p.silu_out[(size_t)bb * p.tcd + o] = hid[o];
     }
     // norm_cond over each time-token row
     for (int r = tid; r < ntot; r += NT) {

@@ -50,7 +50,8 @@ __global__ __launch_bounds__(256) void conv_prep_kernel(const mi_conv_params p, 
     const int H = p.H, W = p.W, Hp = cw_hp(H), Wp = cw_wp(W), plane = Hp * Wp;
     const int b = blockIdx.z, o = blockIdx.y, q = blockIdx.x * 256 + threadIdx.x;
     if (q >= plane) return;
-    const int yy = q / Wp, xx = q - yy * Wp, y = yy - 1, x = xx - 1;
+    const int yy = q / Wp, xx = q - yy * Wp, y = yy - 1, x = xx - 1;      // output-resolution pixel; with up2 (nearest x2 in front of the conv,
+    const int Hs = p.up2 ? H / 2 : H, Ws = p.up2 ? W / 2 : W;             // layers.py:512-515) the planes are written up-sampled: source (y >> 1, x >> 1)
     const int C0 = p.in0.C, C1 = p.in1.data ? p.in1.C : 0, Cin = C0 + C1;
     const int Cr0 = (p.res0.data && p.res_w_rp) ? p.res0.C : 0, Cr1 = (Cr0 && p.res1.data) ? p.res1.C : 0;
     const int KO = Cin >> 3, NO = KO + ((Cr0 + Cr1) >> 3);
@@ -62,8 +63,8 @@ __global__ __launch_bounds__(256) void conv_prep_kernel(const mi_conv_params p, 
         const bool second = c0 >= Ca;
         const mi_act& t = isres ? (second ? p.res1 : p.res0) : (second ? p.in1 : p.in0);
         const int bb = mi_row_of(b, t.bmod);
-        const size_t HW = (size_t)H * W;
-        const float* src = t.data + ((size_t)bb * (second ? Cb : Ca) + (second ? c0 - Ca : c0)) * HW + (size_t)y * W + x;
+        const size_t HW = (size_t)Hs * Ws;
+        const float* src = t.data + ((size_t)bb * (second ? Cb : Ca) + (second ? c0 - Ca : c0)) * HW + (p.up2 ? (size_t)(y >> 1) * Ws + (x >> 1) : (size_t)y * Ws + x);
         float v[8];
         if (isres) {
             const float rsc = ldexpf(t.scale, p.gn_exps[2 * b + 1]);
@@ -292,7 +293,8 @@ extern "C" long long mi_conv_prep_bytes(int B, int Cin, int Cres, int H, int W) 
 static int cw_check(const mi_conv_params& p, const char* who) {
     const int C0 = p.in0.C, C1 = p.in1.data ? p.in1.C : 0, Cin = C0 + C1;
     const int Cr0 = (p.res0.data && p.res_w_rp) ? p.res0.C : 0, Cr1 = (Cr0 && p.res1.data) ? p.res1.C : 0, Cres = Cr0 + Cr1;
-    if (p.ksize != 3 || p.stride != 1 || p.up2) { mi_set_error("%s: the wide GEMM kernel is k3 s1", who); return MI_ERR_UNSUPPORTED; }
+    if (p.ksize != 3 || p.stride != 1) { mi_set_error("%s: the wide GEMM kernel is k3 s1 (optionally behind a nearest x2 up-sampling)", who); return MI_ERR_UNSUPPORTED; }
+    if (p.up2 && (((p.H | p.W) & 1) || p.res0.data)) { mi_set_error("%s: up2 needs an even output size and takes no residual", who); return MI_ERR_INVALID; }
     if ((C0 & 7) || (C1 & 7) || (Cr0 & 7) || (Cr1 & 7) || (Cin & 31) || (Cres & 31) || Cin <= 0 || (p.Cout & 63) || (p.W & 3) || p.B <= 0 || p.H <= 0) {
         mi_set_error("%s: the wide GEMM kernel needs input / residual channels in multiples of 32 (each concat part of 8), output channels of 64, W %% 4 == 0", who);
         return MI_ERR_UNSUPPORTED;

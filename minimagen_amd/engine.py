@@ -32,6 +32,7 @@ CONV_RP = int(os.environ.get("MINIMAGEN_CONV_RP", "2"))                 # 1: nar
 RP_TILE = {k: int(os.environ.get("MINIMAGEN_RP_TILE_" + k, d)) for k, d in (("L", "6"), ("M", "6"), ("S", "6"))}   # tile_cfg for images > 128^2 / > 64^2 / smaller
 RP_TILE_WIDE = int(os.environ.get("MINIMAGEN_RP_TILE_WIDE", "6"))          # tile of the wide k3 s1 convs: 6 = 8x64 where the image is a multiple of 64 wide (the B fragments of a round serve twice the pixels: Unet() default 32.2 -> 31.7 ms per step), 7 = 8x32
 CONV_WIDE_GEMM = os.environ.get("MINIMAGEN_CONV_WIDE_GEMM", "1") != "0"   # wide k3 s1 convs (channels in multiples of 32 in / 64 out) on the GEMM kernel with prepared operand planes (conv_wide.hip)
+COND_GEMM = int(os.environ.get("MINIMAGEN_COND_GEMM", "2048"))           # stacked time-MLPs with at least this many rows run as one GEMM per step (0 = always inside cond_step_kernel)
 FLASH_KV_PREP = os.environ.get("MINIMAGEN_FLASH_KV_PREP", "1") != "0"     # multi-query self-attention of the wide presets: K / V prepared once per launch, LDS-DMA into the workgroups
 RP_TILE_WIDE16 = os.environ.get("MINIMAGEN_RP_TILE_WIDE16", "1") != "0"    # wide k3 s1 convs on images <= 16 wide: 16x16 tiles (an 8x32 tile is half outside such an image)
 RP_MIN_HW = int(os.environ.get("MINIMAGEN_RP_MIN_HW", "0"))             # ... for images of at least this many pixels
@@ -440,7 +441,7 @@ class UnetEngine:
                 cfg = 6                  # 8 x 64 tiles for the wide k3 s1 convs
             if wide and RP_TILE_WIDE16 and stride == 1 and not up2 and Wo <= 16 and Ho > 8 and Cout >= 32 and not ws.half:
                 cfg = 10                 # 16 x 16 tiles for images no wider than 16
-            gemm = wide and ksize == 3 and stride == 1 and not up2 and not ws.half and cin_tot % 32 == 0 and cres % 32 == 0 and Cout % 64 == 0 \
+            gemm = wide and ksize == 3 and stride == 1 and (not up2 or res is None) and not ws.half and cin_tot % 32 == 0 and cres % 32 == 0 and Cout % 64 == 0 \
                 and id(wpack) in pk.conv_ig and (cres == 0 or id(res[2]) in pk.conv_ig)
             if gemm:
                 cfg = 11                 # the wide GEMM kernel (conv_wide.hip): 8 x 16 pixels x 128 (or 64) channels per workgroup
@@ -745,6 +746,16 @@ class UnetEngine:
         # the sampling loop (prepare_step_tables / ws.prog_stage)
         ws.cond_params = cp
         ws.prog_cond = [(lib.mi_cond_step_fwd, cp, "cond_step")]
+        if COND_GEMM and pk.R >= COND_GEMM and u.time_cond_dim % 32 == 0:
+            # wide nets: the stacked time-MLPs are a [R ~ 10 K][tcd] matrix -- one mat-vec per batch row inside cond_step_kernel (one workgroup per
+            # row, a weight row per work-item) took 0.54 ms per step of Unet(); as ONE GEMM over all rows the weights are read once
+            cg = L.MiCondStepParams.from_buffer_copy(cp)
+            ws.silu_t = self._buf(ws, B2, u.time_cond_dim)
+            ws.tm_bias = pk.tm_b.unsqueeze(0).expand(B2, -1).contiguous()
+            ws.tensors.append(ws.tm_bias)
+            cg.ss, cg.silu_out = 0, L.ptr(ws.silu_t)
+            ws.prog_cond = [(lib.mi_cond_step_fwd, cg, "cond_step"),
+                            self._call(lib.mi_gemm_f32, "gemm_time_mlps", L.ptr(ws.silu_t), L.ptr(pk.tm_w), 0, L.ptr(ws.tm_bias), L.ptr(ws.ss), B2, pk.R, u.time_cond_dim, 0)]
 
         # ---- K3: init conv.  For super-resolution U-Nets the low-res conditioning image is constant over the T steps and
         # the convolution is linear, so conv(cat(x, lr)) = conv_x(x) + conv_lr(lr): the lr half runs once per sample()

@@ -337,6 +337,7 @@ WIDE_CASES = [
     (1, 96, 64, 128, 24, 12, 3, 1, 0, True, False, 'conv', 11),   # ... ragged in both directions, concat input, 1x1 residual over a concat
     (2, 64, 0, 256, 8, 32, 3, 1, 0, False, False, 'none', 11),    # ... no GroupNorm, two tiles across, two channel groups
     (1, 64, 0, 192, 16, 16, 3, 1, 0, True, True, 'none', 11),     # ... 192 output channels: three 64-channel workgroups
+    (2, 128, 0, 64, 16, 32, 3, 1, 1, False, False, 'none', 11),   # ... nearest x2 + conv: the operand planes are written up-sampled
 ]
 
 
@@ -349,6 +350,10 @@ WIDE_REAL_CASES = [
     (1, 256, 0, 256, 64, 64, 3, 1, 0, True, True, 'id'),
     (1, 128, 0, 256, 64, 64, 4, 2, 0, False, False, 'none'),
     (1, 256, 0, 128, 128, 128, 3, 1, 1, False, False, 'none'),
+    (1, 128, 0, 128, 128, 128, 3, 1, 0, True, True, 'id', 11),    # the same shapes on the wide GEMM kernel (tile_cfg 11)
+    (1, 96, 64, 128, 128, 128, 3, 1, 0, True, True, 'conv', 11),
+    (1, 256, 0, 256, 64, 64, 3, 1, 0, True, True, 'id', 11),
+    (1, 256, 0, 128, 128, 128, 3, 1, 1, False, False, 'none', 11),
 ]
 
 
