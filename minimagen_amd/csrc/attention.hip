@@ -646,7 +646,11 @@ __global__ __launch_bounds__(256) void ln_tokens_kernel(const mi_act x, int HW, 
     __syncthreads();
     const float rstd = sRstd[tl];
     const int orow = tid >> 2, oseg = (tid & 3) * 16;               // output role: token row, 16-channel segment of the 64-channel block
-    for (int c0 = 0; c0 < C; c0 += 64) {
+    // blockIdx.z: which share of the 64-channel blocks (few tokens per image -- 16 x 16 -- would otherwise leave half of the CUs without a workgroup);
+    // every share computes the token moments for itself
+    const int nblk = (C + 63) / 64, per = (nblk + (int)gridDim.z - 1) / (int)gridDim.z;
+    const int c_lo = (int)blockIdx.z * per * 64, c_hi = c_lo + per * 64 < C ? c_lo + per * 64 : C;
+    for (int c0 = c_lo; c0 < c_hi; c0 += 64) {
         for (int cc = cq; cc < 64; cc += 4) {
             const int c = c0 + cc;
             if (c < C) T[tl * 65 + cc] = (xb[(size_t)c * HW] * x.scale - mean) * rstd * gamma[c] + beta[c];
@@ -876,7 +880,10 @@ __global__ __launch_bounds__(256) void chan_ff_kernel(const mi_chan_ff_params p,
 
 extern "C" int mi_ln_tokens_fwd(const mi_act* x, int B, int HW, const float* gamma, const float* beta, float* out, void* stream) {
     if (B <= 0 || HW <= 0) { mi_set_error("mi_ln_tokens_fwd: empty"); return MI_ERR_INVALID; }
-    hipLaunchKernelGGL(ln_tokens_kernel, dim3((HW + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, *x, HW, gamma, beta, out);
+    const int nt = (HW + 63) / 64, nblk = (x->C + 63) / 64;
+    int split = 1;
+    while (split < nblk && (long long)nt * B * split < 512) split *= 2;
+    hipLaunchKernelGGL(ln_tokens_kernel, dim3(nt, B, split), dim3(256), 0, (hipStream_t)stream, *x, HW, gamma, beta, out);
     return mi_check_launch("ln_tokens_kernel");
 }
 

@@ -470,7 +470,8 @@ def test_conv_rejects_bad_arguments():
 
 CE_CASES = [(2, 3, 0, 64, 64, (3, 7, 15), (4, 2, 2), 0, 0), (2, 3, 3, 40, 72, (3, 7, 15), (4, 2, 2), 1, 0),
             (4, 3, 3, 16, 32, (3, 7, 15), (4, 2, 2), 2, 2), (1, 3, 0, 24, 40, (3, 7, 15), (8, 4, 4), 2, 0),
-            (1, 3, 3, 16, 64, (3, 5), (4, 4), 0, 0)]
+            (1, 3, 3, 16, 64, (3, 5), (4, 4), 0, 0),
+            (2, 3, 3, 24, 40, (3, 7, 15), (16, 8, 8), 2, 1), (1, 3, 0, 16, 64, (3, 7), (24, 8), 0, 0)]      # members in multiples of 8: eight channels per work-item
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
@@ -1050,6 +1051,27 @@ def test_resize_and_lowres_augment(backend):
     a, b = float(sched.sqrt_alphas_cumprod[20]), float(sched.sqrt_one_minus_alphas_cumprod[20])
     lib.mi_lowres_augment(up.data_ptr(), noise.to(dev).data_ptr(), out.data_ptr(), up.numel(), a, b, 1, L.current_stream())
     assert torch.equal(out.cpu(), sched.q_sample(ref, 20, noise) * 2 - 1)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("case", [(2, 100, 96, 1.0), (1, 256, 512, 0.7071), (3, 37, 40, 1.0)])
+def test_ln_tokens(backend, case):
+    """mi_ln_tokens_fwd (the LayerNorm in front of the wide attention blocks, layers.py:322-343 / 14-104): NCHW activation (x its scale) -> per-token
+    LayerNorm over the channels -> token rows; ragged token / channel counts, few-token launches (channel blocks split over the grid) vs torch fp64"""
+    dev = setup(backend)
+    lib = L.lib()
+    B, HW, Cc, scale = case
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(B, Cc, HW, generator=g) * 2.0 + 0.5
+    gamma, beta = 1 + 0.2 * torch.randn(Cc, generator=g), 0.1 * torch.randn(Cc, generator=g)
+    xs = x.double().permute(0, 2, 1) * scale
+    mean, var = xs.mean(-1, keepdim=True), xs.var(-1, unbiased=False, keepdim=True)
+    ref = (xs - mean) / torch.sqrt(var + 1e-5) * gamma.double() + beta.double()
+    xd, gd, bd = x.to(dev).contiguous(), gamma.to(dev), beta.to(dev)
+    out = torch.full((B, HW, Cc), float('nan'), device=dev)
+    a = L.MiAct(xd.data_ptr(), Cc, 0, 0, scale, 0)
+    L.check(lib.mi_ln_tokens_fwd(C.byref(a), B, HW, gd.data_ptr(), bd.data_ptr(), out.data_ptr(), L.current_stream()), "mi_ln_tokens_fwd")
+    assert (out.cpu().double() - ref).abs().max().item() < 2e-5
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
