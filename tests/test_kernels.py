@@ -1054,6 +1054,25 @@ def test_resize_and_lowres_augment(backend):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("case", [(130, 128, True), (7, 200, False), (64, 512, True)])
+def test_ln_rows(backend, case):
+    """mi_ln_rows_fwd (ChanLayerNorm of ChanFeedForward in token layout, layers.py:148-161, 322-343): LayerNorm over the last dimension of [rows][dim],
+    a wave per row; ragged row counts and widths, with and without beta, vs torch fp64"""
+    dev = setup(backend)
+    lib = L.lib()
+    rows, dim, has_beta = case
+    g = torch.Generator().manual_seed(23)
+    x = torch.randn(rows, dim, generator=g) * 3.0 - 1.0
+    gamma, beta = 1 + 0.2 * torch.randn(dim, generator=g), 0.1 * torch.randn(dim, generator=g)
+    xd = x.double()
+    ref = (xd - xd.mean(-1, keepdim=True)) / torch.sqrt(xd.var(-1, unbiased=False, keepdim=True) + 1e-5) * gamma.double() + (beta.double() if has_beta else 0.0)
+    xg, gg, bg = x.to(dev), gamma.to(dev), beta.to(dev)
+    out = torch.full((rows, dim), float('nan'), device=dev)
+    L.check(lib.mi_ln_rows_fwd(xg.data_ptr(), gg.data_ptr(), bg.data_ptr() if has_beta else None, out.data_ptr(), rows, dim, 1e-5, L.current_stream()), "mi_ln_rows_fwd")
+    assert (out.cpu().double() - ref).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
 @pytest.mark.parametrize("case", [(2, 100, 96, 1.0), (1, 256, 512, 0.7071), (3, 37, 40, 1.0)])
 def test_ln_tokens(backend, case):
     """mi_ln_tokens_fwd (the LayerNorm in front of the wide attention blocks, layers.py:322-343 / 14-104): NCHW activation (x its scale) -> per-token
