@@ -407,6 +407,46 @@ def train_step_leg():
         return {"error": repr(exc)[:400]}
 
 
+def wide_step_leg():
+    """SURVEY 8(f) rank 2 (not the headline): sampling with the reference's default ``Unet()`` (dim 128, channels 128 / 256 / 512, self- and
+    cross-attention at every level: the wide regime of the kernels) at 64 x 64, B = 16 with guidance, T = 25: ms per denoising step through
+    Imagen.sample's captured graphs.  Runs in a fresh process (`--wide-step-only`)."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--wide-step-only"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=300)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        return json.loads(lines[-1]) if (r.returncode == 0 and lines) else {"error": (r.stderr or r.stdout)[-400:]}
+    except Exception as exc:                      # never let the secondary leg take the driver line down
+        return {"error": repr(exc)[:400]}
+
+
+def wide_step_only():
+    from minimagen_amd.Imagen import Imagen
+    from minimagen_amd.Unet import Unet
+    dev = torch.device("cuda:0")
+    B, T = 16, 25
+    torch.manual_seed(6)
+    im = Imagen((Unet(),), text_encoder_name="t5_small", image_sizes=(64,), timesteps=T, cond_drop_prob=0.1).to(dev).eval()
+    emb, mask = synthetic_text(B)
+    emb, mask = emb.to(dev), mask.to(dev)
+    for k in range(2):
+        im.sample(text_embeds=emb, text_masks=mask, cond_scale=3., _seed=k)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 3
+    for k in range(n):
+        out = im.sample(text_embeds=emb, text_masks=mask, cond_scale=3., _seed=10 + k)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    im.check_device_status()
+    print(json.dumps({"config": f"Unet() default (dim 128, dim_mults (1, 2, 4), attention at every level) @64x64, B={B}, cond_scale 3 (2 U-Net evaluations per step in one "
+                                f"{2 * B}-row batch), T={T}, fp32 (3-term fp16-split MFMA products); 2 warm-up + {n} timed sample() calls",
+                      "ms_per_denoising_step": dt / T * 1e3, "denoising_steps_per_s": B * T / dt, "finite": bool(torch.isfinite(out).all()),
+                      "parameters_M": sum(p.numel() for p in im.parameters()) / 1e6}))
+
+
 def train_step_only():
     from minimagen_amd import train_ops
     dev = torch.device("cuda:0")
@@ -463,6 +503,8 @@ def train_step_only():
 def main():
     if "--train-step-only" in sys.argv:
         return train_step_only()
+    if "--wide-step-only" in sys.argv:
+        return wide_step_only()
     pmc_child_mode = "--pmc-child" in sys.argv
     if pmc_child_mode:
         sys.argv.remove("--pmc-child")
@@ -725,6 +767,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_secondary and args.workload == "cascade64_256" and args.precision == "fp32":
         res["secondary"] = secondary_lines(args.timesteps, args.cond_scale)
         res["secondary"]["train_step_sr_unet_B32"] = train_step_leg()
+        res["secondary"]["wide_unet_default_B16"] = wide_step_leg()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline()
     if rank == 0:
