@@ -338,6 +338,7 @@ WIDE_CASES = [
     (2, 64, 0, 256, 8, 32, 3, 1, 0, False, False, 'none', 11),    # ... no GroupNorm, two tiles across, two channel groups
     (1, 64, 0, 192, 16, 16, 3, 1, 0, True, True, 'none', 11),     # ... 192 output channels: three 64-channel workgroups
     (2, 128, 0, 64, 16, 32, 3, 1, 1, False, False, 'none', 11),   # ... nearest x2 + conv: the operand planes are written up-sampled
+    (8, 32, 32, 64, 8, 32, 3, 1, 0, True, True, 'id', 11),        # ... a batch of eight: the XCD-aware workgroup -> image map
 ]
 
 
