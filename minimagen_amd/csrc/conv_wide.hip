@@ -25,8 +25,11 @@ typedef _Float16 cw_f16x2 __attribute__((ext_vector_type(2)));
 typedef float cw_f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int CW_TH = 8, CW_TW = 16, CW_IH = CW_TH + 2, CW_UW = CW_TW + 2;
-constexpr int CW_WIN = 4 * 2 * CW_IH * CW_UW;       // 16-byte chunks of one 32-channel window: [octet 4][hi | lo][row][column] = 1440
-constexpr int CW_WIN_INSTR = 23;                     // ... copied by 23 wave-wide LDS-DMA instructions (6 per wave, 5 for the last; the last 32 lanes land in padding)
+// one 32-channel window in LDS: [octet 4][hi | lo][row][column] 16-byte chunks, the octets CW_OCT = 368 chunks apart (360 used).  The stride is a
+// multiple of 16 chunks on purpose: a ds_read_b128 is served in lane groups like {0-3, 12-15, 20-27} -- lanes of two neighbouring octets (lane / 16) in
+// one group --, so with the octets 360 chunks apart (= 8 mod 16) every A read was a 2-way bank conflict (33-40 % of the LDS cycles, PMC)
+constexpr int CW_OCT = 368, CW_OCT_USED = 2 * CW_IH * CW_UW;
+constexpr int CW_WIN_INSTR = 4 * CW_OCT / 64;        // copied by 23 wave-wide LDS-DMA instructions (6 per wave, 5 for the last)
 // NF: 16-channel N fragments per wave (4: 128 output channels per workgroup; 2: 64 -- for launches that would otherwise leave CUs with one workgroup)
 
 __device__ __forceinline__ void cw_split8(const float (&y)[8], uint4& hi, uint4& lo) {
@@ -101,6 +104,7 @@ __global__ __launch_bounds__(256, 2) void conv_wide_kernel(const mi_conv_params 
     __shared__ __attribute__((aligned(16))) uint4 aw[2][CW_WIN_INSTR * 64];
     __shared__ __attribute__((aligned(16))) uint4 bw[2][CW_BCH];
     // NF = 4: 2 x 23 552 + 2 x 16 384 = 79 872 bytes: two workgroups per CU (the epilogue's partial statistics reuse bw)
+    static_assert(CW_OCT % 16 == 0 && CW_OCT >= CW_OCT_USED && (4 * CW_OCT) % 64 == 0, "window layout");
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lq = lane & 15, lg = lane >> 4;
     const int wm = wave & 1, wn = wave >> 1;               // the wave's 4 rows / NF N tiles of the workgroup's 8 x 2 NF
     const int H = p.H, W = p.W, Hp = cw_hp(H), Wp = cw_wp(W), plane = Hp * Wp;
@@ -126,8 +130,10 @@ __global__ __launch_bounds__(256, 2) void conv_wide_kernel(const mi_conv_params 
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
         int q = (wave * 6 + i) * 64 + lane;                 // (instruction 23 does not exist: wave 3 copies five)
-        q = q < CW_WIN ? q : CW_WIN - 1;                    // (padding lanes re-fetch the last chunk)
-        const int oc = q / (2 * CW_IH * CW_UW), r1 = q - oc * (2 * CW_IH * CW_UW);
+        q = q < 4 * CW_OCT ? q : 4 * CW_OCT - 1;
+        const int oc = q / CW_OCT;
+        int r1 = q - oc * CW_OCT;
+        r1 = r1 < CW_OCT_USED ? r1 : CW_OCT_USED - 1;       // (the 8 padding lanes of an octet re-fetch its last chunk)
         const int pl = r1 / (CW_IH * CW_UW), r2 = r1 - pl * (CW_IH * CW_UW);
         const int iy = r2 / CW_UW, c = r2 - iy * CW_UW;
         aoff[i] = (unsigned)(((oc * 2 + pl) * Hp + ty0 + iy) * Wp + tx0 + c);
@@ -198,7 +204,7 @@ __global__ __launch_bounds__(256, 2) void conv_wide_kernel(const mi_conv_params 
         }
 #pragma unroll
         for (int mf = 0; mf < 4; ++mf) {
-            const int idx = (lg * 2 * CW_IH + wm * 4 + mf + dy) * CW_UW + dx + lq;
+            const int idx = lg * CW_OCT + (wm * 4 + mf + dy) * CW_UW + dx + lq;
             const cw_f16x8 ah = __builtin_bit_cast(cw_f16x8, ab[idx]), al = __builtin_bit_cast(cw_f16x8, ab[idx + CW_IH * CW_UW]);
 #pragma unroll
             for (int nf = 0; nf < NF; ++nf) {
