@@ -307,15 +307,18 @@ __global__ __launch_bounds__(64 * NW) void flash_attn_f16x3_kernel(const mi_flas
 }
 
 // ---- multi-query attention with the K / V operands prepared ONCE per launch (p.kv_prep): flash_kv_prep_kernel splits, scales and transposes
-// every 64-row context chunk into the exact LDS image flash_attn_f16x3_kernel builds for itself -- [K hi | K lo | V^T hi | V^T lo], 4 x 64 x 9
+// every 64-row context chunk into the operand image the matrix loop reads -- flash_attn_f16x3_kernel's values, octet-major (below): [K hi | K lo | V^T hi | V^T lo], 4 x 8 x 64
 // 16-byte chunks, plus the chunk's two block-scaling exponents -- and flash_attn_mq_kernel copies a chunk global -> LDS by LDS-DMA into a
 // double buffer, the next chunk under the current one's matrix work, one barrier per chunk.  In the staged form every workgroup (64 queries)
 // re-did that preparation for all 65 chunks of a 4096-token context: two reductions, the split, 2-byte scattered LDS writes and three barriers
 // per chunk, 64 times per image -- 11.5 us per chunk and workgroup against ~3 us of LDS reads + matrix work.  Same arithmetic, same bits.
-constexpr int FW_CP = 9, FW_CHUNK16 = 4 * 64 * FW_CP;         // 16-byte chunks of one prepared context chunk (36 864 bytes)
+// the prepared image of a 64-row chunk: four operand arrays [K hi | K lo | V^T hi | V^T lo], each [octet of the contracted index 8][row 64] 16-byte chunks
+// (octet-major: the lanes of two neighbouring octets that a ds_read_b128 serves together -- {0-3, 12-15, 20-27}, ... -- then fall on disjoint banks;
+// the row-major pitch-9 layout of the self-staging kernel is a 2-way conflict on this machine's lane groups: 46 % of the LDS cycles, PMC)
+constexpr int FW_PL = 8 * 64, FW_CHUNK16 = 4 * FW_PL;          // 16-byte chunks per array / per prepared context chunk (32 768 bytes)
 
 __global__ __launch_bounds__(256) void flash_kv_prep_kernel(const mi_flash_attn_params p, const int nchunk) {
-    constexpr int CP = FW_CP, EPT = 16, PPR = 4;
+    constexpr int EPT = 16, PPR = 4;
     __shared__ __attribute__((aligned(16))) uint4 img[FW_CHUNK16];          // KsH | KsL | VtH | VtL
     __shared__ float smax[2][4];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -354,9 +357,9 @@ __global__ __launch_bounds__(256) void flash_kv_prep_kernel(const mi_flash_attn_
     {
         const float sk = ldexpf(1.0f, ek), sv = ldexpf(1.0f, ev);
         _Float16* ksh = reinterpret_cast<_Float16*>(img);
-        _Float16* ksl = reinterpret_cast<_Float16*>(img + 64 * CP);
-        _Float16* vth = reinterpret_cast<_Float16*>(img + 2 * 64 * CP);
-        _Float16* vtl = reinterpret_cast<_Float16*>(img + 3 * 64 * CP);
+        _Float16* ksl = reinterpret_cast<_Float16*>(img + FW_PL);
+        _Float16* vth = reinterpret_cast<_Float16*>(img + 2 * FW_PL);
+        _Float16* vtl = reinterpret_cast<_Float16*>(img + 3 * FW_PL);
 #pragma unroll
         for (int e = 0; e < EPT; e += 4) {
             unsigned hb[2], lb[2];
@@ -367,15 +370,17 @@ __global__ __launch_bounds__(256) void flash_kv_prep_kernel(const mi_flash_attn_
                 hb[q] = __builtin_bit_cast(unsigned, h2);
                 lb[q] = mi_split_lo2(hb[q], x0, x1);
             }
-            *reinterpret_cast<uint2*>(ksh + srow * (8 * CP) + sd0 + e) = make_uint2(hb[0], hb[1]);
-            *reinterpret_cast<uint2*>(ksl + srow * (8 * CP) + sd0 + e) = make_uint2(lb[0], lb[1]);
+            const int ko = ((((sd0 + e) >> 3) * 64 + srow) << 3) + ((sd0 + e) & 7);       // chunk (octet of d, row), halves within
+            *reinterpret_cast<uint2*>(ksh + ko) = make_uint2(hb[0], hb[1]);
+            *reinterpret_cast<uint2*>(ksl + ko) = make_uint2(lb[0], lb[1]);
         }
 #pragma unroll
         for (int e = 0; e < EPT; ++e) {
             const float x = vf[e] * sv;
             const _Float16 hi = (_Float16)x, lo = (_Float16)(x - (float)hi);
-            vth[(sd0 + e) * (8 * CP) + spos] = hi;
-            vtl[(sd0 + e) * (8 * CP) + spos] = lo;
+            const int vo = (((spos >> 3) * 64 + sd0 + e) << 3) + (spos & 7);             // chunk (octet of the permuted context row, d)
+            vth[vo] = hi;
+            vtl[vo] = lo;
         }
     }
     __syncthreads();
@@ -392,8 +397,8 @@ __global__ __launch_bounds__(256) void flash_kv_prep_kernel(const mi_flash_attn_
 template <int NW, int QT, int WPS, bool PERHEAD = false>
 __global__ __launch_bounds__(64 * NW, WPS) void flash_attn_mq_kernel(const mi_flash_attn_params p, const int nchunk) {
     // a workgroup = 64 queries x NH heads; a wave = QT 16-query tiles of one head: every K / V fragment read from LDS feeds QT x 3 matrix
-    // instructions (with QT = 1 and 16 waves the LDS reads -- each wave reads the whole 36 KB chunk -- took longer than the matrix work)
-    constexpr int D = 64, CP = FW_CP, WPH = 4 / QT, NH = NW / WPH;
+    // instructions (with QT = 1 and 16 waves the LDS reads -- each wave reads the whole chunk -- took longer than the matrix work)
+    constexpr int D = 64, WPH = 4 / QT, NH = NW / WPH;
     __shared__ __attribute__((aligned(16))) uint4 kv[2][FW_CHUNK16];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lq = lane & 15, lg = lane >> 4;
     const int h = PERHEAD ? (int)blockIdx.y : (int)blockIdx.y * NH + wave / WPH, b = blockIdx.z;
@@ -461,7 +466,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void flash_attn_mq_kernel(const mi_fl
 #endif
         __syncthreads();                                  // ... everybody's has, and nobody reads chunk c - 1's buffer any more
         if (c + 1 < nchunk) issue_chunk(c + 1, buf ^ 1);
-        const uint4* const KsH = kv[buf], * const KsL = kv[buf] + 64 * CP, * const VtH = kv[buf] + 2 * 64 * CP, * const VtL = kv[buf] + 3 * 64 * CP;
+        const uint4* const KsH = kv[buf], * const KsL = kv[buf] + FW_PL, * const VtH = kv[buf] + 2 * FW_PL, * const VtL = kv[buf] + 3 * FW_PL;
         const int ek = exps[2 * c], ev = exps[2 * c + 1];
         const float uv = ldexpf(1.0f, -ev);
         f32x4 s[QT][4];
@@ -471,7 +476,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void flash_attn_mq_kernel(const mi_fl
             for (int t = 0; t < QT; ++t) s[t][jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
-                const fw_f16x8 kh = __builtin_bit_cast(fw_f16x8, KsH[(16 * jt + lq) * CP + 4 * hf + lg]), kl = __builtin_bit_cast(fw_f16x8, KsL[(16 * jt + lq) * CP + 4 * hf + lg]);
+                const fw_f16x8 kh = __builtin_bit_cast(fw_f16x8, KsH[(4 * hf + lg) * 64 + 16 * jt + lq]), kl = __builtin_bit_cast(fw_f16x8, KsL[(4 * hf + lg) * 64 + 16 * jt + lq]);
 #pragma unroll
                 for (int t = 0; t < QT; ++t) {
                     s[t][jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl, qh[t][hf], s[t][jt], 0, 0, 0);
@@ -525,7 +530,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void flash_attn_mq_kernel(const mi_fl
             for (int t = 0; t < QT; ++t) sl[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
-                const fw_f16x8 vh = __builtin_bit_cast(fw_f16x8, VtH[(16 * dt + lq) * CP + 4 * hf + lg]), vl = __builtin_bit_cast(fw_f16x8, VtL[(16 * dt + lq) * CP + 4 * hf + lg]);
+                const fw_f16x8 vh = __builtin_bit_cast(fw_f16x8, VtH[(4 * hf + lg) * 64 + 16 * dt + lq]), vl = __builtin_bit_cast(fw_f16x8, VtL[(4 * hf + lg) * 64 + 16 * dt + lq]);
 #pragma unroll
                 for (int t = 0; t < QT; ++t) {
                     sl[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl, ph[t][hf], sl[t], 0, 0, 0);

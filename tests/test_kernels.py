@@ -787,7 +787,7 @@ def test_flash_attention_unfolded(backend, case):
         # the same launch with its K / V operands prepared once (flash_kv_prep_kernel + LDS-DMA): the same arithmetic, the same bits
         J = (1 if has_null else 0) + n0 + n1
         nbytes = lib.mi_flash_kv_prep_bytes(B * kvh, J)
-        assert nbytes == B * kvh * ((J + 63) // 64) * (4 * 64 * 9 * 16 + 8)
+        assert nbytes == B * kvh * ((J + 63) // 64) * (4 * 64 * 8 * 16 + 8)
         prep = torch.full(((nbytes + 3) // 4,), float('nan'), device=dev)
         out2 = torch.full((B, HW, inner), float('nan'), device=dev)
         p.out, p.kv_prep, p.kv_prep_bytes = L.ptr(out2), L.ptr(prep), nbytes
