@@ -16,12 +16,15 @@ CHUNK = 4096           # elements per launched workgroup
 
 
 class Adam(torch.optim.Optimizer):
-    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.):
+    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0., amsgrad: bool = False,
+                 maximize: bool = False, capturable: bool = False):
+        if amsgrad or maximize or capturable:
+            raise NotImplementedError("minimagen_amd.optim.Adam implements torch.optim.Adam's default update only (no amsgrad / maximize / capturable)")
         if not 0.0 <= lr or not 0.0 <= eps or not 0.0 <= betas[0] < 1.0 or not 0.0 <= betas[1] < 1.0 or not 0.0 <= weight_decay:
             raise ValueError("invalid Adam hyper-parameters")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._tables = {}
-        self._count = {}          # parameter -> step count as a Python int (the ``step`` tensors of the state are written on state_dict())
+        self._count = {}          # parameter -> step count as a Python int (mirrored into the state's host ``step`` tensor at every step)
 
     def _state_of(self, p):
         st = self.state[p]
@@ -41,6 +44,9 @@ class Adam(torch.optim.Optimizer):
         return super().state_dict()
 
     def load_state_dict(self, state_dict):
+        for g in state_dict.get("param_groups", ()):
+            if g.get("amsgrad") or g.get("maximize") or g.get("capturable"):
+                raise NotImplementedError("minimagen_amd.optim.Adam: a state dict with amsgrad / maximize / capturable set would be silently ignored")
         super().load_state_dict(state_dict)
         self._count = {}
         self._tables = {}
@@ -85,14 +91,16 @@ class Adam(torch.optim.Optimizer):
                     and (p.is_cuda or L.backend() == "hipemu") and p.device == p.grad.device
                 (fast if ok else slow).append(p)
             for p in fast + slow:
-                self._state_of(p)
+                st = self._state_of(p)
                 self._count[p] += 1
+                st["step"].fill_(float(self._count[p]))          # a host scalar: readers of optimizer.state[p]['step'] see the live count
             # parameters of one group share the step count in every ordinary use; groups whose counts differ are split by count
             by_step = {}
             for p in fast:
                 by_step.setdefault(float(self._count[p]), []).append(p)
-            for t, ps in by_step.items():
-                _, tens, ct, co, nchunks = self._table((gi, t if len(by_step) > 1 else None), ps)
+            # (table slots are keyed by group and position among the distinct counts, not by the count itself: nothing accumulates per step)
+            for slot, (t, ps) in enumerate(by_step.items()):
+                _, tens, ct, co, nchunks = self._table((gi, slot), ps)
                 a = L.MiAdamParams()
                 a.tensors, a.chunk_tensor, a.chunk_off, a.nchunks, a.chunk = tens.data_ptr(), ct.data_ptr(), co.data_ptr(), nchunks, CHUNK
                 a.lr, a.beta1, a.beta2, a.eps, a.weight_decay = group["lr"], b1, b2, group["eps"], group["weight_decay"]

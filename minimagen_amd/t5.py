@@ -295,19 +295,39 @@ def _tokenize(tokenizer, text, max_length):
 # rows are a pure function of (encoder, caption, max_length).  Entries hold the UNPADDED rows on the encoder's device; a call encodes only
 # its misses (one batch) and assembles the padded [B, L, dim] result from the cache.  Masked keys contribute exact zeros and every other
 # operation is per row, so a caption's rows do not depend on its batch beyond fp32 rounding (the block-scaled GEMM shares a power-of-two
-# scale among the rows of a tile): cached and fresh results agree to ~1e-6 (tests/test_t5.py).  MINIMAGEN_T5_CACHE = entries kept per
-# process (default 4096, 0 = off).
+# scale among the rows of a tile): cached and fresh results agree to ~1e-6 (tests/test_t5.py) -- so with the cache on, a caption's rows
+# depend on which call first encoded it; set MINIMAGEN_T5_CACHE=0 where bit-reproducible encodings matter.  MINIMAGEN_T5_CACHE = entries
+# kept per process (default 4096, 0 = off); MINIMAGEN_T5_CACHE_MB bounds the device memory the entries hold (default 256 MB: an entry is
+# up to 256 x d_model fp32 values, 0.8 MB for t5_base, 4 MB for the xxl encoders).  Keys carry a per-encoder serial, not id().
 import collections as _collections
 import os as _os
 
 _EMBED_CACHE = _collections.OrderedDict()
 T5_CACHE_ENTRIES = int(_os.environ.get("MINIMAGEN_T5_CACHE", "4096"))
+T5_CACHE_BYTES = int(float(_os.environ.get("MINIMAGEN_T5_CACHE_MB", "256")) * (1 << 20))
+_cache_bytes = 0
+_encoder_serial = iter(range(1, 1 << 62))
+
+
+def _serial_of(model):
+    s = getattr(model, "_cache_serial", None)
+    if s is None:
+        s = model._cache_serial = next(_encoder_serial)
+    return s
+
+
+def _cache_pop_oldest():
+    global _cache_bytes
+    _, v = _EMBED_CACHE.popitem(last=False)
+    _cache_bytes -= v.numel() * v.element_size()
 t5_cache_stats = {"hits": 0, "misses": 0}
 
 
 def _embed_cache_clear(name=None):
+    global _cache_bytes
     for k in [k for k in _EMBED_CACHE if name is None or k[0] == name]:
-        del _EMBED_CACHE[k]
+        v = _EMBED_CACHE.pop(k)
+        _cache_bytes -= v.numel() * v.element_size()
 
 
 def t5_encode_text(text, name: str = 't5_base', max_length=MAX_LENGTH, tokenizer=None):
@@ -324,7 +344,8 @@ def t5_encode_text(text, name: str = 't5_base', max_length=MAX_LENGTH, tokenizer
     prefix = bool((attention_mask.bool() == (torch.arange(Lq)[None, :] < attention_mask.sum(1, keepdim=True))).all())      # right-padded, as every T5 tokenizer pads
     if T5_CACHE_ENTRIES <= 0 or tokenizer is not None or not prefix or min(lens) == 0:
         return model.encode(input_ids, attention_mask)
-    keys = [(name, cap, max_length, id(model)) for cap in text]
+    global _cache_bytes
+    keys = [(name, cap, max_length, _serial_of(model)) for cap in text]
     rows = [None] * B
     miss = []
     for b, k in enumerate(keys):
@@ -340,9 +361,13 @@ def t5_encode_text(text, name: str = 't5_base', max_length=MAX_LENGTH, tokenizer
         lm = max(lens[b] for b in miss)                     # (re-pad the misses among themselves: a shorter launch)
         emb, _ = model.encode(input_ids[miss, :lm].contiguous(), attention_mask[miss, :lm].contiguous())
         for j, b in enumerate(miss):
-            _EMBED_CACHE[keys[b]] = emb[j, :lens[b]].clone()
-        while len(_EMBED_CACHE) > T5_CACHE_ENTRIES:
-            _EMBED_CACHE.popitem(last=False)
+            old = _EMBED_CACHE.pop(keys[b], None)
+            if old is not None:
+                _cache_bytes -= old.numel() * old.element_size()
+            v = _EMBED_CACHE[keys[b]] = emb[j, :lens[b]].clone()
+            _cache_bytes += v.numel() * v.element_size()
+        while _EMBED_CACHE and (len(_EMBED_CACHE) > T5_CACHE_ENTRIES or _cache_bytes > T5_CACHE_BYTES):
+            _cache_pop_oldest()
     out = torch.zeros(B, Lq, model.cfg["d_model"], dtype=torch.float32, device=model.dev)
     for b, k in enumerate(keys):
         r = rows[b] if rows[b] is not None else _EMBED_CACHE.get(k)

@@ -1,7 +1,10 @@
 """The reference's training driver surface (minimagen/training.py) over the device training path: command-line parser, training /
 validation loop with its on-disk layout, and the helpers train.py calls.  What is kept is the OBSERVABLE behaviour -- flag names and defaults,
 ``training_<timestamp>/{parameters,state_dicts,tmp}``, ``training_progess.txt`` [sic] and its lines, the checkpoint file names
-``minimagen_amd.generate.load_minimagen`` reads back -- so that the reference's ``train.py`` runs against this package.
+``minimagen_amd.generate.load_minimagen`` reads back.  The reference's ``train.py`` does NOT run unchanged against this package: it calls
+``ConceptualCaptions`` unconditionally (train.py:43-47; a network download, SURVEY 2: out of scope) and that raises here, and the
+reference's ``MinimagenDataset`` / ``_Rescale`` are not rebuilt.  Everything else train.py imports from ``minimagen.training`` resolves;
+``tests/test_training_loop.py::test_reference_train_flow_offline`` is that script's flow with ``SyntheticCaptions`` as the dataset.
 
 The loop body is ``imagen(images, text_embeds=..., unet_number=k).backward()``: with the U-Nets on the GPU that is the HIP training graph of
 ``minimagen_amd.train_ops`` (every convolution, CrossEmbed and the folded cross-attention core forward and backward on the kernels of
@@ -137,11 +140,12 @@ def _save_tmp(training_dir, imagen, n_unets):
             torch.save(imagen.unets[i].state_dict(), f"unet_{i}_tmp.pth")
 
 
-def MinimagenTrain(timestamp, args, unets, imagen, train_dataloader, valid_dataloader, training_dir, optimizer, timeout=60):
+def MinimagenTrain(timestamp, args, unets, imagen, train_dataloader, valid_dataloader, training_dir, optimizer, timeout=60, fail_fast=False):
     """training.py:344-478.  Per batch: for every U-Net of the cascade ``imagen(images, text_embeds, text_masks, unet_number)`` ->
     ``backward`` -> gradient-norm clip at 50 over ALL parameters; optimiser step every ACCUM_ITER batches (and at the last batch); every
     CHCKPT_NUM batches: rolling checkpoints in ``tmp/``, running / batch losses, a validation pass, best-so-far state dicts in ``state_dicts/``.
-    A batch that raises leaves a note and the latest state dicts in ``tmp/``; one that exceeds ``timeout`` seconds is skipped."""
+    A batch that raises leaves a note and the latest state dicts in ``tmp/`` and the loop goes on with the next batch, as the reference's
+    does (``fail_fast=True``, not in the reference, re-raises instead); one that exceeds ``timeout`` seconds is skipped."""
     n = len(unets)
     best = [torch.tensor(9999999.) for _ in range(n)]
     params = [p for p in imagen.parameters()]
@@ -200,8 +204,9 @@ def MinimagenTrain(timestamp, args, unets, imagen, train_dataloader, valid_datal
             except Exception as exc:
                 _progress(training_dir, f"\n\nTRAINING ABORTED AT EPOCH {epoch}, BATCH NUMBER {batch_num} with exception {exc}. MOST RECENT STATE "
                                         f"DICTS SAVED TO ./tmp IN TRAINING FOLDER")
-                _save_tmp(training_dir, imagen, n)
-                raise
+                _save_tmp(training_dir, imagen, n)          # training.py:470-478: note, tmp state dicts, then ON to the next batch
+                if fail_fast:
+                    raise
 
 
 def _parse_training_file(params_dir, keep):
