@@ -229,6 +229,8 @@ def _bind(lib):
     lib.mi_graph_launch.argtypes = [vp, vp]
     lib.mi_graph_destroy.argtypes = [vp]
     lib.mi_conv_tile_shape.argtypes = [i32, C.POINTER(i32), C.POINTER(i32)]
+    lib.mi_conv_stripe_rows.argtypes = [vp]
+    lib.mi_conv_stripe_rows.restype = i32
     lib.mi_conv_cout_tile.argtypes = [i32]
     lib.mi_conv_wgrad_workspace.argtypes = [i32, i32, i32]
     lib.mi_conv_wgrad_workspace.restype = C.c_longlong

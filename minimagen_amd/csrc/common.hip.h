@@ -382,6 +382,7 @@ __device__ __forceinline__ void mi_sleep() { __builtin_amdgcn_s_sleep(2); }
 
 int mi_conv_rp_launch(const mi_conv_params& p, hipStream_t st);     // conv_rp.hip
 int mi_conv_wide_launch(const mi_conv_params& p, hipStream_t st);   // conv_wide.hip
+int mi_conv_stripe_launch(const mi_conv_params& p, hipStream_t st); // conv_stripe.hip
 
 // host-side error plumbing (capi.hip)
 void mi_set_error(const char* fmt, ...);

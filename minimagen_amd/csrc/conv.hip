@@ -440,6 +440,7 @@ extern "C" int mi_conv_tile_shape(int tile_cfg, int* th, int* tw) {
         case 7: *th = 8; *tw = 32; return MI_OK;
         case 10: *th = 16; *tw = 16; return MI_OK;    // (wide k3 s1 member only)
         case 11: *th = 8; *tw = 16; return MI_OK;     // wide GEMM kernel (conv_wide.hip)
+        // (12: full-width stripes, conv_stripe.hip -- the statistics blocks are mi_conv_stripe_rows(p) rows x the image width, not a fixed tile)
         case 0: *th = 16; *tw = 64; return MI_OK;
         case 1: *th = 32; *tw = 32; return MI_OK;
         case 2: *th = 8; *tw = 32; return MI_OK;
@@ -463,6 +464,7 @@ extern "C" int mi_conv_fwd(const mi_conv_params* pp, void* stream) {
         if (p.res0.data && !p.res_w && p.res0.C != p.Cout) { mi_set_error("mi_conv_fwd: identity residual needs Cres == Cout"); return MI_ERR_INVALID; }
         if (p.B <= 0 || p.H <= 0 || p.W <= 0 || p.Cout <= 0) { mi_set_error("mi_conv_fwd: empty problem"); return MI_ERR_INVALID; }
         if ((p.tile_cfg & 0xff) == 11) return mi_conv_wide_launch(p, st);
+        if ((p.tile_cfg & 0xff) == 12) return mi_conv_stripe_launch(p, st);
         return mi_conv_rp_launch(p, st);
     }
     if (Cin > MI_MAX_CIN || p.gn_groups > MI_MAX_GROUPS) { mi_set_error("mi_conv_fwd: Cin %d / groups %d too large for the direct-conv family", Cin, p.gn_groups); return MI_ERR_UNSUPPORTED; }

@@ -1,0 +1,598 @@
+// Full-width-stripe, wave-specialised form of the row-paired matrix-core 3x3 convolution (conv_rp.hip) for the narrow k3 s1 layers of
+// MinImagen's U-Nets on images 32 .. 256 pixels wide: Block = GroupNorm -> [scale/shift] -> SiLU -> Conv3x3 (layers.py:131-145), the
+// identity or 1x1-conv residual of ResnetBlock (layers.py:415-439), the skip concatenation (Unet.py:445), the next GroupNorm's partial
+// statistics.  Same arithmetic as conv_rp_kernel -- the same per-channel affine, the same fp16 hi / lo operand split, the same MFMA
+// triples in the same order, the same epilogue -- so outputs are bit-identical to it; what differs is how the data moves (round 6):
+//
+//   conv_rp_kernel: 8 x 64 tiles, every wave loads, transforms, multiplies and stores in turn.  Measured (profiles/r05_conv_dma_ablation.txt):
+//   the phases of a tile ADD UP, the 10 x 66 windows re-read 29 % of the input, ~13 us of every launch is lock-step pipeline fill / drain.
+//
+//   here: a workgroup owns RS consecutive output rows of one image at FULL WIDTH (no horizontal halo; vertical halo (RS + 2) / RS) and walks
+//   them two rows per step -- the row-paired MFMA form turns 4 input rows into 2 output rows -- over a RING of 6 transformed input rows in
+//   LDS.  Waves are specialised:
+//     * loader / transform waves: a lane owns 4 consecutive pixels of one new input row and the 8 channels of one octet = 8 dwordx4
+//       loads per step, each wave-instruction a whole row run of a channel plane (1 KB at 256 wide); TWO steps in flight in registers,
+//       issued unconditionally so that the wait counts stay exact; GroupNorm affine + SiLU + fp16 split in registers; 4 pixel chunks
+//       (16 B hi + 16 B lo) written to the ring;
+//     * MFMA / epilogue waves: A fragments from the ring (16-byte reads, lane group <-> row permutation 0, 2, 1, 3: conflict-free with the
+//       pitch W + 8), B fragments from LDS (registers for the 8 -> 8 layers), identity-residual loads one step ahead, bias + residual +
+//       float4 stores in the MFMA layout, statistics accumulated in registers and flushed once per block of W / 8 rows.  Before the first
+//       multiply these waves have nothing to do, so THEY run the prologue: the producers' partial statistics -> channel totals -> (one wave)
+//       group moments + per-channel affine + operand exponents, the B fragments, and the load + transform of the stripe's first four input
+//       rows (steps -1 and 0) -- the loader waves start with steps 1 and 2 in flight.
+//   One workgroup barrier per step: a step costs max(loader, consumer) instead of their sum, and the first output rows leave ~one memory
+//   round trip after the launch instead of after the whole tile's load / transform / multiply sequence.
+//   Measured on the skeleton of this structure before it was built (tools/ubench/stripe_pipe.hip, profiles/r06_stripe_pipe_ubench.txt):
+//   8 -> 8 @256^2 + identity residual 79 us against 96 us (a plain copy of the same three streams: 78 us), @128^2 18.7 against 24.2 us.
+//
+// Statistics partition: one partial (sum, sum of squares) per channel and BLOCK of W / 8 rows (32 rows at 256 wide .. 4 at 32) -- a function
+// of the image size only, whatever the number of blocks a workgroup takes (tile_cfg bits 12..15; speed only; default one), so a sharded
+// batch reproduces the unsharded rows bit for bit.
+// Phase traces of this kernel (tools/trace_stripe.py, profiles/r06_stripe_phase_trace.txt) are why the prologue looks the way it does: with
+// one round of workgroups starting together, everything before the first multiply is exposed latency -- 22 % of a workgroup's life at 256^2,
+// 46 % at 64^2 in the first version (statistics round trip under the initial burst of row loads, moments and affine through two barriers,
+// the first two steps transformed by the loader waves alone).
+#include "rp_common.hip.h"
+
+#ifdef ST_TRACE
+// development aid (tools/trace_stripe.py; -DST_TRACE builds only): shader-clock stamps of the prologue / pipeline phases of the first 1024
+// workgroups of the last launch.  Slots 0..9: consumer wave 0 (start, totals done, barrier 1, affine done, B fragments staged, barrier 3, barrier 4,
+// first step multiplied, loop done, statistics published); 10..15: loader wave 0 (start, first rows requested, barrier 3, -, barrier 4, done)
+__device__ unsigned long long mi_trace_st_buf[1024 * 16];
+extern "C" int mi_debug_read_trace_st(void* dst, size_t bytes) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(mi_trace_st_buf), bytes); }
+#define ST_STAMP(k) do { if (lane == 0 && blockIdx.x < 1024) mi_trace_st_buf[blockIdx.x * 16 + (k)] = clock64(); } while (0)
+#else
+#define ST_STAMP(k) do { } while (0)
+#endif
+
+#ifndef ST_ABL
+#define ST_ABL 0            // timing-only ablation builds (tools/sweep_stripe.py): 1 plain workgroup -> image map, 2 no output statistics, 4 no statistics prologue
+#endif
+#ifndef ST_BREG
+#define ST_BREG 1           // one conv octet, one N tile (8 -> 8 channels): the six B fragments stay in registers instead of being re-read from LDS every step
+#endif
+#ifndef ST_HALF_OCTETS
+#define ST_HALF_OCTETS 1
+#endif
+
+namespace {
+
+// KO_ / NJ_: channel octets of the conv input / N tiles (8 output channels each).  OM_ (output mode): 0 = every channel of the N tiles is an
+// output channel, no identity residual; 1 = ... with the identity residual; 2 = fewer output channels than the N tiles hold (the final 8 -> 3 conv:
+// masked stores), no residual.  Compile-time, because a residual load or an output store inside a run-time conditional makes the compiler's wait
+// counts conservative: the wait for step it's residual then also waits for the stores of step it - 1 and for the residual loads of step it + 1
+// that were issued a moment ago (seen in the ISA of the first version: vmcnt(3) .. (0) in every step).
+// (Launches with a 1x1 residual conv stay on the tile kernel: the residual octets' ring rows would leave one workgroup per CU.)
+template <int W_, int KO_, int NJ_, bool GN_, int OM_>
+struct StCfg {
+    static constexpr int W = W_, KO = KO_, NJ = NJ_, OM = OM_;
+    static constexpr bool GN = GN_;
+    // loader units per step: 2 rows x pixel quads x octets (x 2 channel halves: HS).  A work-item owns 4 consecutive pixels of one row and the 8
+    // (HS: 4) channels of one (half) octet: that many dwordx4 loads per step, TWO steps in flight, issued unconditionally and unrolled by two so that
+    // the wait before a transform is exact.  HS below 256 wide: a step's GroupNorm / SiLU / split of 32 values per work-item was the per-step critical
+    // path there (phase trace: 2.7 us per step whatever the width); 16 values on twice the work-items halve it.  256-wide steps are paced by memory.
+    static constexpr bool HS = W_ < 256 && ST_HALF_OCTETS;
+    static constexpr int NCH = HS ? 4 : 8;
+    static constexpr int QPR = W_ / 4, UNITS = 2 * QPR * KO * (HS ? 2 : 1), NLW = (UNITS + 63) / 64;
+    static constexpr int NG = W_ / 16, NCW = NG >= 4 ? 4 : NG, GPW = NG / NCW;             // 16-pixel groups of a row pair, MFMA waves
+    static constexpr int NT = (NLW + NCW) * 64;
+    static constexpr int PW = W_ + 8, RING = 6, PLANE = KO * RING * PW;
+    static constexpr int SR0 = W_ / 8;                                                      // rows per statistics block
+    static constexpr int WCH = 3 * NJ * 128, WTOT = KO * WCH;                               // 16-byte chunks of B fragments
+    static constexpr bool BREG = ST_BREG && KO == 1 && NJ == 1;
+    // prologue units of the MFMA waves: the stripe's first 4 input rows, as half octets where that still fits one pass
+    static constexpr bool PHS = HS && 8 * QPR * KO <= NCW * 64;
+    static constexpr int PCH = PHS ? 4 : 8, PU = 4 * QPR * KO * (PHS ? 2 : 1);
+    static_assert(PU <= NCW * 64, "the MFMA waves transform the first four rows in one pass");
+};
+
+// mi_gn_totals_issue (common.hip.h) with every load UNCONDITIONAL (clamped, always legal addresses; a missing statistics pointer reads the
+// activation instead and is ignored): a load inside a run-time conditional makes the compiler's wait counts conservative, and the wait for these
+// few latency-critical values then also waits for the bulk row loads requested right behind them (phase trace: 5 of a 64^2 launch's 21 us).
+// Returns whether the loaded partials cover the problem (else the caller falls back to mi_gn_channel_totals).
+__device__ __forceinline__ bool st_totals_issue(const mi_act& in0, const mi_act& in1, int C0, int Cin, int b, int lane, int nlanes, bool have, mi_stats_regs& r) {
+    int TPC = 1;
+    while (TPC < 64 && TPC * 2 * Cin <= nlanes) TPC *= 2;
+    const int nt_max = (Cin > C0 && in1.nt > in0.nt) ? in1.nt : in0.nt;
+    const bool covers = have && TPC * Cin <= nlanes && nt_max <= MI_STATS_K * TPC;
+    const int c = lane / TPC, sub = lane % TPC;
+    const bool live = covers && c < Cin;
+    const bool second = live && c >= C0;
+    const int cc = live ? (second ? c - C0 : c) : 0;
+    const int nt = second ? in1.nt : in0.nt, CC = second ? in1.C : in0.C;
+    const double* sp = second ? in1.stats : in0.stats;
+    const int ba = mi_row_of(b, second ? in1.bmod : in0.bmod);
+    const mi_gptr<const double> st = live ? mi_global(sp) + ((size_t)(ba * CC + cc) * nt) * 2 : mi_global(reinterpret_cast<const double*>(in0.data));
+#pragma unroll
+    for (int k = 0; k < MI_STATS_K; ++k) {
+        const int t = sub + k * TPC;
+        const bool ok = live && t < nt;
+        const double x = st[2 * (ok ? t : 0)], y = st[2 * (ok ? t : 0) + 1];
+        r.v[k] = make_double2(ok ? x : 0.0, ok ? y : 0.0);
+    }
+    r.c = live ? c : -1;
+    r.tpc = TPC;
+    r.scale = second ? in1.scale : in0.scale;
+    return covers;
+}
+
+template <class CFG>
+__global__ __launch_bounds__(CFG::NT) void conv_stripe_kernel(const mi_conv_params p, const uint4* __restrict__ wrp, const int nblk) {
+    constexpr int W = CFG::W, KO = CFG::KO, NJ = CFG::NJ, QPR = CFG::QPR, UNITS = CFG::UNITS, NLW = CFG::NLW, NLT = NLW;
+    constexpr int NCW = CFG::NCW, GPW = CFG::GPW, PW = CFG::PW, RING = CFG::RING, SR0 = CFG::SR0, WCH = CFG::WCH, WTOT = CFG::WTOT, PU = CFG::PU;
+    constexpr bool GN = CFG::GN, BREG = CFG::BREG;
+    __shared__ __attribute__((aligned(16))) uint4 actH[CFG::PLANE];
+    __shared__ __attribute__((aligned(16))) uint4 actL[CFG::PLANE];
+    __shared__ __attribute__((aligned(16))) uint4 wl[BREG ? 1 : WTOT];
+    __shared__ __attribute__((aligned(16))) float4 chP[RP_MAXC];
+    __shared__ double chS[RP_MAXC], chQ[RP_MAXC];
+    __shared__ double red[NCW][2 * 8 * NJ];
+    __shared__ int sExp[4];
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lq = lane & 15, lg = lane >> 4;
+    const int H = p.H, HW = H * W;
+    const int nt = H / SR0;                            // statistics blocks per image
+    const int wgs = nt / nblk;                         // workgroups per image
+    // XCD-aware placement as in conv_rp.hip (speed only): workgroup L runs on XCD L % 8; whole images per XCD
+    int b, sidx;
+    if ((p.B & 7) == 0 && !(ST_ABL & 1)) {
+        const int L = blockIdx.x;
+        int k = L >> 3;
+        if (p.tile_cfg & MI_CONV_REVERSE) k = (int)(gridDim.x >> 3) - 1 - k;
+        b = (L & 7) + 8 * (k / wgs);
+        sidx = k % wgs;
+    } else {
+        b = blockIdx.x / wgs;
+        sidx = blockIdx.x % wgs;
+    }
+    const int blk0 = sidx * nblk, y0 = blk0 * SR0, RS = nblk * SR0, NSTEP = RS / 2;
+    const int C0 = p.in0.C, C1 = p.in1.data ? p.in1.C : 0, Cin = C0 + C1;
+    const bool have_stats = !(ST_ABL & 4) && (GN || p.in0.stats != nullptr);
+    // first element of the 8 channel planes of octet `oct` of image b (in0, then in1: the skip concatenation).  The two tensors' image bases are
+    // formed ONCE from the (scalar) kernel arguments; a work-item then selects between two computed pointers.  (Selecting the struct FIELDS per
+    // work-item -- `second ? p.in1.data : p.in0.data` -- compiles to a vector load from the kernel-argument segment with a per-lane address and a
+    // s_waitcnt vmcnt(0) right behind it: two dependent memory round trips in front of every wave's first bulk load, seen in the ISA.)
+    const float* const img0 = p.in0.data + (size_t)mi_row_of(b, p.in0.bmod) * C0 * HW;
+    const float* const img1 = C1 ? p.in1.data + (size_t)mi_row_of(b, p.in1.bmod) * C1 * HW : img0;
+    auto octet_base = [&](int oct) {
+        const int c0 = 8 * oct;
+        const float* a0 = img0 + (size_t)c0 * HW;
+        const float* a1 = img1 + (size_t)(c0 - C0) * HW;
+        return mi_global(c0 >= C0 ? a1 : a0);
+    };
+    // GroupNorm affine + scale/shift + SiLU (or the plain operand scaling) + fp16 split of 4 pixels x NC channels (an octet, or its half `half`) ->
+    // the 16-byte (8-byte) pieces of 4 pixel chunks of ring row `slot`
+    auto transform_quad = [&](auto nc_tag, const f32x4* raw, const float4* P, bool inimg, bool live, int oct, int half, int slot, int q) {
+        constexpr int NC = decltype(nc_tag)::value;
+#pragma unroll
+        for (int px = 0; px < 4; ++px) {
+            float y[NC];
+#pragma unroll
+            for (int j = 0; j < NC; ++j) {
+                const float x = raw[j][px];
+                if constexpr (GN) {
+                    const float a = fmaf(x, P[j].x, P[j].y);
+                    const float ex = __builtin_amdgcn_exp2f(fmaf(x, P[j].z, P[j].w));       // exp(-a)
+                    y[j] = a * __builtin_amdgcn_rcpf(1.0f + ex);
+                } else {
+                    y[j] = x * P[j].x;
+                }
+            }
+            unsigned h[NC / 2], l[NC / 2];
+#pragma unroll
+            for (int i = 0; i < NC / 2; ++i) {
+                const rp_f32x2 v = {y[2 * i], y[2 * i + 1]};
+                h[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, rp_f16x2));
+                l[i] = mi_split_lo2(h[i], y[2 * i], y[2 * i + 1]);
+            }
+            if (!inimg) {                                                                   // zero padding follows the activation (as in the reference)
+#pragma unroll
+                for (int i = 0; i < NC / 2; ++i) { h[i] = 0u; l[i] = 0u; }
+            }
+            if (live) {
+                const int idx = (oct * RING + slot) * PW + 1 + 4 * q + px;
+                if constexpr (NC == 8) {
+                    actH[idx] = make_uint4(h[0], h[1], h[2], h[3]);
+                    actL[idx] = make_uint4(l[0], l[1], l[2], l[3]);
+                } else {
+                    reinterpret_cast<uint2*>(&actH[idx])[half] = make_uint2(h[0], h[1]);
+                    reinterpret_cast<uint2*>(&actL[idx])[half] = make_uint2(l[0], l[1]);
+                }
+            }
+        }
+    };
+
+    if (wave < NLT) {
+        // =================================================================== loader / transform waves
+        constexpr int NCH = CFG::NCH, HSM = CFG::HS ? 2 : 1;
+        const int u = wave * 64 + lane;
+        const bool live = u < UNITS;
+        const int uu = live ? u : 0;
+        const int oct = uu / (2 * QPR * HSM), half = HSM == 2 ? (uu / (2 * QPR)) & 1 : 0, lrow = (uu / QPR) & 1, q = uu % QPR;   // octet, channel half, row of the step, pixel quad
+        const mi_gptr<const float> base = octet_base(oct) + (size_t)(NCH * half) * HW;
+        f32x4 raw[2][NCH];
+        bool inimg[2];
+        auto issue = [&](int s, auto buf_tag) {            // step s brings input rows y0 + 2 s + 1 + lrow (steps -1 and 0 are the MFMA waves' prologue)
+            constexpr int buf = decltype(buf_tag)::value;
+            int y = y0 + 2 * s + 1 + lrow;
+            y = y > y0 + RS ? y0 + RS : y;                // steps past the stripe (issued UNCONDITIONALLY: a conditional issue makes the compiler's wait counts conservative) re-read its last halo row
+            const bool ok = y < H;
+            inimg[buf] = ok;
+            const unsigned off = ok ? (unsigned)(y * W + 4 * q) : 0u;
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) raw[buf][j] = *reinterpret_cast<mi_gptr<const f32x4>>(base + (size_t)j * HW + off);
+        };
+        constexpr std::integral_constant<int, 0> B0{};
+        constexpr std::integral_constant<int, 1> B1{};
+        if (wave == 0) ST_STAMP(10);
+        issue(1, B1);
+        issue(2, B0);
+        if (wave == 0) ST_STAMP(11);
+        if (have_stats) __syncthreads();                   // (1) channel totals in LDS
+        __syncthreads();                                   // (3) chP / sExp / B fragments / pads visible
+        if (wave == 0) ST_STAMP(12);
+        float4 P[NCH];
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) P[j] = chP[8 * oct + NCH * half + j];
+        auto transform = [&](int s, auto buf_tag) {
+            constexpr int buf = decltype(buf_tag)::value;
+            transform_quad(std::integral_constant<int, NCH>{}, raw[buf], P, inimg[buf], live, oct, half, (2 * s + 2 + lrow) % RING, q);      // ring row = input row - (y0 - 1)
+        };
+        __syncthreads();                                   // (4) rows of steps -1 and 0 in the ring
+        if (wave == 0) ST_STAMP(14);
+        for (int it = 0; it < NSTEP; it += 2) {            // slot it: the MFMA waves multiply step it; this wave transforms step it + 1 and requests step it + 3
+            transform(it + 1, B1);                         // (the step past the last lands in ring rows nobody reads)
+            issue(it + 3, B1);
+            __syncthreads();
+            transform(it + 2, B0);
+            issue(it + 4, B0);
+            __syncthreads();
+        }
+        if (wave == 0) ST_STAMP(15);
+    } else {
+        // =================================================================== MFMA / epilogue waves
+        const int cw = wave - NLT, ct = tid - NLT * 64;
+        constexpr int NCT = NCW * 64;
+        if (cw == 0) ST_STAMP(0);
+        // ---- prologue, everything requested in ONE memory round trip, every load UNCONDITIONAL (null pointers read a dummy: see st_totals_issue),
+        // the short latency-critical ones first:
+        // (a) the producers' partial statistics
+        mi_stats_regs sr;
+        const bool fast = st_totals_issue(p.in0, p.in1, C0, Cin, b, ct, NCT, have_stats, sr);
+        // (b) the layer's parameters
+        // (the loaded values are only TOUCHED after the first barrier: a select or an add right here would put a wait for them -- and for every
+        //  older load -- in front of the bulk loads below)
+        float pg = 0.f, pb = 0.f, ld_s1 = 0.f, ld_s2 = 0.f, ld_b[NJ];
+        if constexpr (GN) {
+            const int c = lane < Cin ? lane : 0;
+            pg = p.gn_gamma[c];
+            pb = p.gn_beta[c];
+            const float* ss = p.scale_shift ? p.scale_shift + (size_t)b * p.ss_stride + p.ss_off : p.gn_gamma;
+            ld_s1 = ss[p.scale_shift ? c : 0];
+            ld_s2 = ss[p.scale_shift ? Cin + c : 0];
+        }
+#pragma unroll
+        for (int jt = 0; jt < NJ; ++jt) {
+            const int co = 8 * jt + (lq & 7);
+            const bool hb = p.bias != nullptr && co < p.Cout;
+            ld_b[jt] = (hb ? p.bias : p.in0.data)[hb ? co : 0];
+        }
+        // (c) the B fragments: straight into registers for the 8 -> 8 layers (global layout [tap][lane][hi | lo]), else staged for their LDS planes
+        constexpr int WPER = BREG ? 1 : (WTOT + NCT - 1) / NCT;
+        uint4 wreg[WPER];
+        rp_f16x8 breg[BREG ? 6 : 1];
+        if constexpr (BREG) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) breg[k] = __builtin_bit_cast(rp_f16x8, mi_ldg4u(wrp + 128 * (k >> 1) + 2 * lane + (k & 1)));
+        } else {
+#pragma unroll
+            for (int i = 0; i < WPER; ++i) {
+                const int k = ct + i * NCT;
+                wreg[i] = mi_ldg4u(wrp + (k < WTOT ? k : 0));
+            }
+        }
+        // (d) the stripe's first four input rows (steps -1 and 0): one pixel quad x (half) octet per work-item
+        constexpr int PCH = CFG::PCH, PHM = CFG::PHS ? 2 : 1;
+        const bool plive = ct < PU;
+        const int pu = plive ? ct : 0;
+        const int poct = pu / (4 * QPR * PHM), phalf = PHM == 2 ? (pu / (4 * QPR)) & 1 : 0, prow = (pu / QPR) & 3, pq = pu % QPR;
+        f32x4 praw[PCH];
+        const int py = y0 - 1 + prow;
+        const bool pin = py >= 0 && py < H;
+        {
+            const mi_gptr<const float> pbase = octet_base(poct) + (size_t)(PCH * phalf) * HW;
+            const unsigned off = pin ? (unsigned)(py * W + 4 * pq) : 0u;
+#pragma unroll
+            for (int j = 0; j < PCH; ++j) praw[j] = *reinterpret_cast<mi_gptr<const f32x4>>(pbase + (size_t)j * HW + off);
+        }
+        // the horizontal zero padding of the conv = a zero chunk left and right of every ring row
+        for (int k = ct; k < KO * RING * 2; k += NCT) {
+            const int r = k >> 1, c = (k & 1) ? W + 1 : 0;
+            actH[r * PW + c] = make_uint4(0u, 0u, 0u, 0u);
+            actL[r * PW + c] = make_uint4(0u, 0u, 0u, 0u);
+        }
+        double inv_n = 1.0;
+        if constexpr (GN) inv_n = 1.0 / ((double)(Cin / p.gn_groups) * (double)HW);        // (an fp64 division: dozens of instructions, done under the loads' latency)
+        if (fast) mi_gn_totals_finish(sr, ct, chS, chQ);
+        else if (have_stats) mi_gn_channel_totals(p.in0, p.in1, C0, Cin, b, ct, NCT, chS, chQ);          // (rare: more partials than the registers hold)
+        if (cw == 0) ST_STAMP(1);
+        if (have_stats) __syncthreads();                   // (1)
+        if (cw == 0) ST_STAMP(2);
+        // ---- ONE wave: group moments (each channel's lane adds up its group, in mi_gn_group_moments' order) -> per-channel affine of the fused
+        // GroupNorm / scale-shift, and the power-of-two operand scaling (conv_rp.hip's arithmetic); the other waves stage the B fragments meanwhile
+        if (cw == 0) {
+            const int c = lane;
+            const float psc = p.scale_shift ? ld_s1 + 1.0f : 1.0f, psh = p.scale_shift ? ld_s2 : 0.0f;
+            float A = 0.f, Bc = 0.f, m = 0.f;
+            if constexpr (GN) {
+                if (c < Cin) {
+                    const int cpg = Cin / p.gn_groups, g = c / cpg;
+                    float mean, rstd;
+                    if (ST_ABL & 4) { mean = 0.3f; rstd = 0.6f; }
+                    else {                                     // mi_gn_group_moments with the fp64 reciprocal of the count taken before the loads came back
+                        double gs = 0.0, gq = 0.0;
+                        for (int cc = g * cpg; cc < (g + 1) * cpg; ++cc) { gs += chS[cc]; gq += chQ[cc]; }
+                        const double mean_d = gs * inv_n;
+                        double var = gq * inv_n - mean_d * mean_d;
+                        var = var > 0.0 ? var : 0.0;
+                        mean = (float)mean_d;
+                        rstd = 1.0f / sqrtf((float)(var + (double)p.gn_eps));
+                    }
+                    float An = pg, Bn = pb;
+                    A = rstd * pg;
+                    Bc = pb - mean * A;
+                    if (p.scale_shift) {
+                        A *= psc;
+                        Bc = Bc * psc + psh;
+                        An *= psc;
+                        Bn = Bn * psc + psh;
+                    }
+                    A *= (c >= C0) ? p.in1.scale : p.in0.scale;
+                    m = 4.0f * fabsf(An) + fabsf(Bn);                    // |SiLU(a)| <= |a|; 4 sigma of the normalised input
+                }
+                m = mi_wave_max(m);
+            } else if (have_stats) {
+                double qq = (c < Cin) ? chQ[c] : 0.0;                   // rms of the raw input (the tensors' scales are already applied)
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) qq += __shfl_xor(qq, o);
+                m = 4.0f * sqrtf((float)(qq / ((double)Cin * (double)HW)));
+            }
+            const int ka = (m > 0.f) ? rp_clamp_exp(4 - rp_exponent(m)) : 0;            // scaled magnitudes land in [8, 16)
+            if (c < Cin) {
+                if constexpr (GN) chP[c] = make_float4(ldexpf(A, ka), ldexpf(Bc, ka), A * -1.44269504088896340736f, Bc * -1.44269504088896340736f);
+                else chP[c] = make_float4(ldexpf((c >= C0) ? p.in1.scale : p.in0.scale, ka), 0.f, 0.f, 0.f);
+            }
+            if (lane == 0) { sExp[0] = ka; sExp[2] = ka + p.w_rp_exp; }
+        }
+        if (cw == 0) ST_STAMP(3);
+        if constexpr (!BREG) {
+#pragma unroll
+            for (int i = 0; i < WPER; ++i) {
+                const int k = ct + i * NCT;
+                if (k < WTOT) wl[rp_wl_index(k)] = wreg[i];
+            }
+        }
+        if (cw == 0) ST_STAMP(4);
+        __syncthreads();                                   // (3)
+        if (cw == 0) ST_STAMP(5);
+        {
+            float4 PP[PCH];
+#pragma unroll
+            for (int j = 0; j < PCH; ++j) PP[j] = chP[8 * poct + PCH * phalf + j];
+            transform_quad(std::integral_constant<int, PCH>{}, praw, PP, pin, plive, poct, phalf, prow, pq);       // ring rows 0 .. 3 = input rows y0 - 1 .. y0 + 2
+        }
+
+        float bvv[NJ];
+#pragma unroll
+        for (int jt = 0; jt < NJ; ++jt) bvv[jt] = (p.bias != nullptr && 8 * jt + (lq & 7) < p.Cout) ? ld_b[jt] : 0.0f;
+        const int perm = ((lg & 1) << 1) | (lg >> 1);     // lane group -> input row (0, 2, 1, 3)
+        const int dy = lq >> 3;
+        constexpr bool idres = CFG::OM == 1, MASKC = CFG::OM == 2;
+        const mi_gptr<float> obuf = mi_global(p.out + (size_t)b * p.Cout * HW);
+        const mi_gptr<const float> rbuf = mi_global(idres ? p.res0.data + (size_t)mi_row_of(b, p.res0.bmod) * p.res0.C * HW : p.out);
+        const float unscale = ldexpf(1.0f, -sExp[2]);
+        const float rs = idres ? p.res0.scale : 0.0f;
+        f32x4 rv[2][idres ? GPW : 1][idres ? NJ : 1];
+        auto issue_res = [&](int it, auto buf_tag) {       // identity residual of step it: unconditional loads (past the stripe: its last step again)
+            constexpr int buf = decltype(buf_tag)::value;
+            if constexpr (idres) {
+                const int itc = it < NSTEP ? it : NSTEP - 1;
+#pragma unroll
+                for (int g = 0; g < GPW; ++g)
+#pragma unroll
+                    for (int jt = 0; jt < NJ; ++jt) {
+                        const int co = 8 * jt + (lq & 7);
+                        const int oy = y0 + 2 * itc + dy, ox = 16 * (cw * GPW + g) + 4 * lg;
+                        rv[buf][g][jt] = *reinterpret_cast<mi_gptr<const f32x4>>(rbuf + (unsigned)(co * HW + oy * W + ox));
+                    }
+            }
+        };
+        float csum[NJ], csq[NJ], cshift[NJ];
+        auto compute = [&](int it, auto buf_tag, bool first_of_block) {
+            constexpr int buf = decltype(buf_tag)::value;
+            f32x4 acc[GPW][NJ];
+#pragma unroll
+            for (int g = 0; g < GPW; ++g)
+#pragma unroll
+                for (int jt = 0; jt < NJ; ++jt) acc[g][jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const int slot = (2 * it + perm) % RING;
+            // D[px 16][(dy, co)] += act[px][(r, ci)] . B[(r, ci)][(dy, co)]: octets in conv_rp's round order, one instruction triple per horizontal tap
+#pragma unroll
+            for (int o = 0; o < KO; ++o) {
+#pragma unroll
+                for (int s = 0; s < 3; ++s) {
+                    rp_f16x8 bh[NJ], bl[NJ];
+#pragma unroll
+                    for (int jt = 0; jt < NJ; ++jt) {
+                        if constexpr (BREG) { bh[jt] = breg[2 * s]; bl[jt] = breg[2 * s + 1]; }
+                        else {
+                            bh[jt] = __builtin_bit_cast(rp_f16x8, wl[o * WCH + (s * NJ + jt) * 128 + lane]);
+                            bl[jt] = __builtin_bit_cast(rp_f16x8, wl[o * WCH + (s * NJ + jt) * 128 + 64 + lane]);
+                        }
+                    }
+#pragma unroll
+                    for (int g = 0; g < GPW; ++g) {
+                        const int idx = (o * RING + slot) * PW + 16 * (cw * GPW + g) + lq + s;
+                        const rp_f16x8 ah = __builtin_bit_cast(rp_f16x8, actH[idx]);
+                        const rp_f16x8 al = __builtin_bit_cast(rp_f16x8, actL[idx]);
+#pragma unroll
+                        for (int jt = 0; jt < NJ; ++jt) {
+                            acc[g][jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[jt], acc[g][jt], 0, 0, 0);
+                            acc[g][jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[jt], acc[g][jt], 0, 0, 0);
+                        }
+#pragma unroll
+                        for (int jt = 0; jt < NJ; ++jt) acc[g][jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[jt], acc[g][jt], 0, 0, 0);
+                    }
+                }
+            }
+            // epilogue: lane (lq, lg) holds pixels 4 lg .. 4 lg + 3 of channel lq & 7, row parity lq >> 3, of every group
+#pragma unroll
+            for (int jt = 0; jt < NJ; ++jt) {
+                const int co = 8 * jt + (lq & 7);
+                const float bv = bvv[jt];
+                f32x4 yv[GPW];
+#pragma unroll
+                for (int g = 0; g < GPW; ++g) {
+                    f32x4 y;
+                    y[0] = fmaf(acc[g][jt][0], unscale, bv); y[1] = fmaf(acc[g][jt][1], unscale, bv);
+                    y[2] = fmaf(acc[g][jt][2], unscale, bv); y[3] = fmaf(acc[g][jt][3], unscale, bv);
+                    if constexpr (idres) { const f32x4 r = rv[buf][g][jt]; y[0] = fmaf(r[0], rs, y[0]); y[1] = fmaf(r[1], rs, y[1]); y[2] = fmaf(r[2], rs, y[2]); y[3] = fmaf(r[3], rs, y[3]); }
+                    yv[g] = y;
+                }
+                if (first_of_block) {                      // statistics about a per-channel shift: the block's first value of the channel in this wave
+                    cshift[jt] = __shfl(yv[0][0], lq & 7);
+                    csum[jt] = 0.f; csq[jt] = 0.f;
+                }
+                const float cs_ = cshift[jt];
+                const bool ok = !MASKC || co < p.Cout;
+#pragma unroll
+                for (int g = 0; g < GPW; ++g) {
+                    const int oy = y0 + 2 * it + dy, ox = 16 * (cw * GPW + g) + 4 * lg;
+                    const f32x4 y = yv[g];
+                    if constexpr (MASKC) { if (ok) *reinterpret_cast<mi_gptr<f32x4>>(obuf + (unsigned)(co * HW + oy * W + ox)) = y; }
+                    else *reinterpret_cast<mi_gptr<f32x4>>(obuf + (unsigned)(co * HW + oy * W + ox)) = y;
+                    const float d0 = y[0] - cs_, d1 = y[1] - cs_, d2 = y[2] - cs_, d3 = y[3] - cs_;
+                    csum[jt] += ok ? (d0 + d1) + (d2 + d3) : 0.0f;
+                    csq[jt] += ok ? fmaf(d0, d0, fmaf(d1, d1, fmaf(d2, d2, d3 * d3))) : 0.0f;
+                }
+            }
+        };
+        auto flush = [&]() {                               // this wave's partial statistics of the block that just ended -> LDS (fp64)
+            if (!p.out_stats || (ST_ABL & 2)) return;
+#pragma unroll
+            for (int jt = 0; jt < NJ; ++jt) {
+                float s_ = csum[jt], q_ = csq[jt];
+                s_ += __shfl_xor(s_, 8); q_ += __shfl_xor(q_, 8);
+                s_ += __shfl_xor(s_, 16); q_ += __shfl_xor(q_, 16);
+                s_ += __shfl_xor(s_, 32); q_ += __shfl_xor(q_, 32);
+                if (lane < 8) {
+                    mi_stat_acc a; a.c = cshift[jt]; a.s = s_; a.q = q_; a.n = GPW * 16 * SR0;
+                    mi_stat_finish(a, red[cw][2 * (8 * jt + lane)], red[cw][2 * (8 * jt + lane) + 1]);
+                }
+            }
+        };
+        auto publish = [&](int blk) {                      // after the step barrier: the block's partials of all waves, added in a fixed order
+            if (!p.out_stats || cw != 0 || (ST_ABL & 2)) return;
+            if (lane < 2 * 8 * NJ && (lane >> 1) < p.Cout) {
+                double v = red[0][lane];
+                if constexpr (NCW == 2) v = red[0][lane] + red[1][lane];
+                if constexpr (NCW == 4) v = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+                p.out_stats[((size_t)(b * p.Cout + (lane >> 1)) * nt + blk) * 2 + (lane & 1)] = v;
+            }
+        };
+        issue_res(0, std::integral_constant<int, 0>{});
+        __syncthreads();                                   // (4)
+        if (cw == 0) ST_STAMP(6);
+        constexpr int SPB = SR0 / 2;                       // steps per statistics block
+        for (int kb = 0; kb < nblk; ++kb) {
+            const int it0 = kb * SPB;
+            for (int i = 0; i < SPB; i += 2) {
+                issue_res(it0 + i + 1, std::integral_constant<int, 1>{});
+                compute(it0 + i, std::integral_constant<int, 0>{}, i == 0);
+                if (cw == 0 && kb == 0 && i == 0) ST_STAMP(7);
+                __syncthreads();
+                issue_res(it0 + i + 2, std::integral_constant<int, 0>{});
+                compute(it0 + i + 1, std::integral_constant<int, 1>{}, false);
+                if (i + 2 == SPB) flush();
+                __syncthreads();
+            }
+            if (cw == 0 && kb + 1 == nblk) ST_STAMP(8);
+            publish(blk0 + kb);
+        }
+        if (cw == 0) ST_STAMP(9);
+    }
+}
+
+template <int W, int KO, int NJ, bool GN, int OM>
+int launch_stripe(const mi_conv_params& p, hipStream_t st) {
+    using CFG = StCfg<W, KO, NJ, GN, OM>;
+    const int nt = p.H / CFG::SR0;
+    // statistics blocks per workgroup (speed only): tile_cfg bits 12..15.  Default: one block (W / 8 rows) at 128 / 256 wide, two at <= 64 wide while
+    // that leaves a workgroup per CU -- measured isolated (tools/sweep_stripe.py) and in the captured SR step (64^2 level 384 -> 372 us with two,
+    // 388 with one; base stage 0.446 -> 0.428 ms per step): profiles/r06_summary.md
+    int nblk = (p.tile_cfg >> 12) & 0xf;
+    if (nblk == 0) nblk = (W <= 64 && nt % 2 == 0 && (long long)p.B * (nt / 2) >= 256) ? 2 : 1;
+    if (nblk > nt || nt % nblk) nblk = 1;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_stripe_kernel<CFG>), dim3(p.B * (nt / nblk)), dim3(CFG::NT), 0, st, p, (const uint4*)p.w_rp, nblk);
+    return mi_check_launch("conv_stripe_kernel");
+}
+
+template <int W>
+int launch_stripe_w(const mi_conv_params& p, hipStream_t st, int ko, int nj, bool gn) {
+    const int om = p.Cout < 8 * nj ? 2 : ((p.res0.data && !p.res_w) ? 1 : 0);
+#define ST_CASE(KO, NJ, GNV) if (ko == KO && nj == NJ && gn == GNV) { \
+        if (om == 0) return launch_stripe<W, KO, NJ, GNV, 0>(p, st); \
+        if constexpr (GNV) { if (om == 1) return launch_stripe<W, KO, NJ, GNV, 1>(p, st); } \
+        if constexpr (!GNV && NJ == 1) { if (om == 2) return launch_stripe<W, KO, NJ, GNV, 2>(p, st); } \
+        return MI_ERR_UNSUPPORTED; }
+    // the layer shapes of the BASELINE U-Nets: 8 / 16 / 24 / 32 input channels, 8 or 16 (or 3) output channels
+    ST_CASE(1, 1, true); ST_CASE(1, 1, false);
+    if constexpr (W <= 128) { ST_CASE(2, 1, true); }
+    if constexpr (W <= 64) { ST_CASE(2, 2, true); ST_CASE(4, 2, true); ST_CASE(1, 2, false); ST_CASE(3, 2, true); }
+#undef ST_CASE
+    return MI_ERR_UNSUPPORTED;
+}
+
+// rows per statistics block if this launch runs on the stripe kernel, else 0
+int stripe_block_rows(const mi_conv_params& p, int* ko_, int* nj_) {
+    if (!(p.ksize == 3 && p.stride == 1 && !p.up2) || !p.w_rp || p.gn_coef || (p.tile_cfg & MI_CONV_HALF) || p.out_st) return 0;
+    if (p.in0.st || (p.in1.data && p.in1.st) || (p.res0.data && p.res0.st)) return 0;
+    if (!(p.W == 32 || p.W == 64 || p.W == 128 || p.W == 256)) return 0;
+    const int sr0 = p.W / 8;
+    if (p.H % sr0 || p.H < sr0 || (size_t)p.H * p.W * 64 >= (1ull << 31)) return 0;
+    const int C0 = p.in0.C, C1 = p.in1.data ? p.in1.C : 0;
+    if ((C0 & 7) || (C1 & 7) || C0 + C1 > RP_MAXC || p.Cout > 16) return 0;
+    if (p.res0.data && (p.res_w || p.res0.C != p.Cout)) return 0;          // identity residual only: launches with a 1x1 residual conv stay on the tile kernel
+    if (p.gn_groups > MI_MAX_GROUPS || (p.gn_groups > 0 && ((C0 + C1) % p.gn_groups))) return 0;
+    if (p.gn_groups > 0 && (!p.in0.stats || (p.in1.data && !p.in1.stats))) return 0;
+    const int ko = (C0 + C1) >> 3, nj = (p.Cout + 7) >> 3;
+    const bool gn = p.gn_groups > 0;
+    const int om = p.Cout < 8 * nj ? 2 : (p.res0.data ? 1 : 0);
+    if ((om == 1 && !gn) || (om == 2 && (gn || nj != 1))) return 0;      // instantiated: identity residual behind a Block, masked channels in the final conv
+    // the instantiated (ko, nj, gn) combinations of launch_stripe_w
+    const bool common = (ko == 1 && nj == 1) || (p.W <= 128 && ko == 2 && nj == 1 && gn);
+    const bool small = p.W <= 64 && ((ko == 2 && nj == 2 && gn) || (ko == 4 && nj == 2 && gn) || (ko == 1 && nj == 2 && !gn) || (ko == 3 && nj == 2 && gn));
+    if (!common && !small) return 0;
+    if (ko_) { *ko_ = ko; *nj_ = nj; }
+    return sr0;
+}
+
+}  // namespace
+
+/* rows per statistics block (out_nt = H / rows) when mi_conv_fwd would run this launch on the full-width-stripe kernel (tile_cfg 12), else 0 */
+extern "C" int mi_conv_stripe_rows(const mi_conv_params* pp) { return stripe_block_rows(*pp, nullptr, nullptr); }
+
+int mi_conv_stripe_launch(const mi_conv_params& p, hipStream_t st) {
+    int ko = 0, nj = 0;
+    if (!stripe_block_rows(p, &ko, &nj)) { mi_set_error("mi_conv_fwd: tile_cfg 12 (full-width stripes) does not take this launch (see mi_conv_stripe_rows)"); return MI_ERR_UNSUPPORTED; }
+    const bool gn = p.gn_groups > 0;
+    int rc = MI_ERR_UNSUPPORTED;
+    switch (p.W) {
+        case 32: rc = launch_stripe_w<32>(p, st, ko, nj, gn); break;
+        case 64: rc = launch_stripe_w<64>(p, st, ko, nj, gn); break;
+        case 128: rc = launch_stripe_w<128>(p, st, ko, nj, gn); break;
+        case 256: rc = launch_stripe_w<256>(p, st, ko, nj, gn); break;
+    }
+    if (rc == MI_ERR_UNSUPPORTED) mi_set_error("mi_conv_fwd: stripe kernel not instantiated for this shape");
+    return rc;
+}

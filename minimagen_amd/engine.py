@@ -46,6 +46,12 @@ RP_NTILE_BY = {k: int(os.environ.get("MINIMAGEN_RP_NTILE_" + k, "0")) for k in (
 # at <= 64^2 and four at 128^2 give 44.1 K against 42.3 K denoising-steps/s with two lanes -- and 31.0 K against 33.5 K for synchronous calls, which
 # therefore keep the library's choice.  Speed only: the per-tile statistics (hence every bit of the result) do not depend on the strip length.
 RP_NTILE_PIPE = {k: int(os.environ.get("MINIMAGEN_RP_NTILE_PIPE_" + k, d)) for k, d in (("L", "0"), ("M", "4"), ("S", "2"))}
+# round 6: the narrow k3 s1 convs on 32 / 64 / 128 / 256-wide images as full-width row stripes with specialised loader / MFMA waves
+# (csrc/conv_stripe.hip, tile_cfg 12; same bits per output as the tile kernel, statistics per block of 8 (4) rows).  0 = the tile kernel
+# everywhere; a string of size classes ("LMS" = all, the default) selects where: L > 128^2, M > 64^2, S smaller
+CONV_STRIPE = os.environ.get("MINIMAGEN_CONV_STRIPE", "LMS").upper().replace("0", "").replace("1", "LMS")
+ST_NBLK = {k: int(os.environ.get("MINIMAGEN_ST_NBLK_" + k, "0")) for k in ("L", "M", "S")}              # statistics blocks per workgroup (0 = the library's choice; speed only)
+ST_NBLK_PIPE = {k: int(os.environ.get("MINIMAGEN_ST_NBLK_PIPE_" + k, "0")) for k in ("L", "M", "S")}    # ... for workspaces of pipelined calls
 TILE64 = int(os.environ.get("MINIMAGEN_TILE64", "-1"))                  # force a conv tile shape at 64x64 / 128x128 (experiments)
 TILE128 = int(os.environ.get("MINIMAGEN_TILE128", "-1"))       # 1: 16-channel 3x3 outputs as two 8-channel workgroups
 WEIGHT_FINGERPRINT = os.environ.get("MINIMAGEN_WEIGHT_FINGERPRINT", "1") != "0"   # content fingerprint of the weights at every public call (see pack())
@@ -395,6 +401,26 @@ class UnetEngine:
         lib.mi_conv_tile_shape(best, C.byref(th), C.byref(tw))
         return best, -(-H // th.value) * -(-W // tw.value)
 
+    def _stripe_rows(self, batch, Ho, Wo, in0, in1, Cout, gn, res) -> int:
+        """rows per statistics block if csrc/conv_stripe.hip (tile_cfg 12) takes this narrow fp32 k3 s1 launch, else 0: asked of the library
+        (mi_conv_stripe_rows) on a probe of the launch's shape -- pointers only need to be non-null where the real launch has them"""
+        q = L.MiConvParams()
+        q.B, q.H, q.W, q.Cout, q.ksize, q.stride, q.up2 = batch, Ho, Wo, Cout, 3, 1, 0
+        q.in0 = L.MiAct(1, in0.C, 1 if in0.stats is not None else 0, in0.nt, 1.0, 0)
+        if in1 is not None:
+            q.in1 = L.MiAct(1, in1.C, 1 if in1.stats is not None else 0, in1.nt, 1.0, 0)
+        q.w_rp = 1
+        if gn is not None:
+            q.gn_groups = gn.num_groups
+        if res is not None:
+            r0, r1, rw, _ = res
+            q.res0 = L.MiAct(1, r0.C, 1 if r0.stats is not None else 0, r0.nt, 1.0, 0)
+            if r1 is not None:
+                q.res1 = L.MiAct(1, r1.C, 1 if r1.stats is not None else 0, r1.nt, 1.0, 0)
+            if rw is not None:
+                q.res_w, q.res_w_rp = 1, 1
+        return int(L.lib().mi_conv_stripe_rows(C.byref(q)))
+
     def _new_act(self, ws, batch, Cc, H, W, nt, fp32: bool = False) -> Act:
         t = torch.empty(batch, Cc, H, W, dtype=torch.float32 if (fp32 or not ws.store16) else torch.bfloat16, device=ws.dev)
         st = torch.zeros(batch, Cc, max(nt, 1), 2, dtype=torch.float64, device=ws.dev) if nt else None      # fp64 partial (sum, sumsq): include/minimagen_hip.h
@@ -424,6 +450,7 @@ class UnetEngine:
             and (res is None or res[2] is None or (id(res[2]) in pk.conv_rp and res[0].C % 8 == 0 and (res[1] is None or res[1].C % 8 == 0)))
         narrow = cin_tot <= 64 and cres <= 64 and Cout <= (16 if stride == 2 else (8 if up2 else 32))
         wide = rp and not narrow
+        stripe = False
         if rp:
             cfg = RP_TILE["L"] if Ho * Wo > 128 * 128 else (RP_TILE["M"] if Ho * Wo > 64 * 64 else RP_TILE["S"])
             if Ho * Wo <= 64 * 64 and (Wo <= 32 or Cout <= 8) and "MINIMAGEN_RP_TILE_S" not in os.environ:
@@ -447,6 +474,11 @@ class UnetEngine:
                 cfg = 11                 # the wide GEMM kernel (conv_wide.hip): 8 x 16 pixels x 128 (or 64) channels per workgroup
             th, tw = {5: (16, 64), 6: (8, 64), 7: (8, 32), 10: (16, 16), 11: (8, 16)}[cfg]
             nt = -(-Ho // th) * -(-Wo // tw)
+            cls = "L" if Ho * Wo > 128 * 128 else ("M" if Ho * Wo > 64 * 64 else "S")
+            if narrow and ksize == 3 and stride == 1 and not up2 and not ws.half and cls in CONV_STRIPE:
+                rows = self._stripe_rows(batch, Ho, Wo, in0, in1, Cout, gn, res)
+                if rows:
+                    cfg, nt, stripe = 12, Ho // rows, True
         if ws.store16 and (not rp or wide):
             raise _Store16Unsupported()          # only the narrow row-paired kernels read bf16 activations
         out = self._new_act(ws, batch, Cout, Ho, Wo, nt if want_stats else 0, fp32=out_fp32)
@@ -484,6 +516,10 @@ class UnetEngine:
             nt_knob = RP_NTILE_BY[cls] or RP_NTILE
             if not nt_knob and ws.pipelined and RP_NTILE_PIPE[cls] and batch * nt // RP_NTILE_PIPE[cls] >= 256:
                 nt_knob = RP_NTILE_PIPE[cls]        # (only while the launch still has a workgroup per CU: smaller batches keep the library's choice -- config 3 at B = 16: 39.1 K with, 40.7 K without)
+            if stripe:                              # statistics blocks per workgroup of the stripe kernel (must divide the blocks of an image)
+                nt_knob = (ST_NBLK_PIPE[cls] if ws.pipelined and ST_NBLK_PIPE[cls] else ST_NBLK[cls])
+                if nt_knob and (nt % nt_knob or nt_knob > 15):
+                    nt_knob = 0
             p.tile_cfg |= (nt_knob & 0xf) << 12
             frags = pk.conv_ig if gemm else pk.conv_rp
             frag, p.w_rp_exp = frags[id(wpack)]

@@ -70,9 +70,15 @@ def run(B, C0, Cout, H, W, gn, res, path, C1=0, reps=20, nt_in=None):
             rwf, p.res_w_rp_exp = pack_w(rw); rwf = rwf.to(dev); keep.append(rwf); p.res_w_rp = rwf.data_ptr()
         else:
             rwp = P.pack_conv_weight(rw, lib.mi_conv_cout_tile(Cout)).reshape(Cin, -1).contiguous().to(dev); keep.append(rwp); p.res_w = rwp.data_ptr()
-    th, tw = C.c_int(), C.c_int()
-    lib.mi_conv_tile_shape(cfg & 0xff, C.byref(th), C.byref(tw))
-    nt = -(-H // th.value) * -(-W // tw.value)
+    if (cfg & 0xff) == 12:                         # full-width stripes (conv_stripe.hip): statistics blocks of mi_conv_stripe_rows rows
+        rows = lib.mi_conv_stripe_rows(C.byref(p))
+        if not rows:
+            raise SystemExit("the stripe kernel does not take this shape")
+        nt = H // rows
+    else:
+        th, tw = C.c_int(), C.c_int()
+        lib.mi_conv_tile_shape(cfg & 0xff, C.byref(th), C.byref(tw))
+        nt = -(-H // th.value) * -(-W // tw.value)
     out = torch.empty(B, Cout, H, W, device=dev)
     ost = torch.zeros(B, Cout, nt, 2, dtype=torch.float64, device=dev)
     p.out, p.out_stats, p.tile_cfg = out.data_ptr(), ost.data_ptr(), cfg
