@@ -311,25 +311,49 @@ __global__ __launch_bounds__(CFG::NT) void conv_stripe_kernel(const mi_conv_para
             actH[r * PW + c] = make_uint4(0u, 0u, 0u, 0u);
             actL[r * PW + c] = make_uint4(0u, 0u, 0u, 0u);
         }
+        // ---- everything of the affine that does not need the statistics is done BEFORE they are waited for (the trace showed 1.9 us between the
+        // totals and the affine in the first version): the fp64 reciprocal of the group size, the magnitude bound m = 4 |gamma'| + |beta'| of the
+        // normalised activation and its power-of-two exponent (one wave; six cross-lane steps), and the B fragments' way into LDS
         double inv_n = 1.0;
-        if constexpr (GN) inv_n = 1.0 / ((double)(Cin / p.gn_groups) * (double)HW);        // (an fp64 division: dozens of instructions, done under the loads' latency)
+        if constexpr (GN) inv_n = 1.0 / ((double)(Cin / p.gn_groups) * (double)HW);
+        float psc = 1.0f, psh = 0.0f, An = 0.f, Bn = 0.f;
+        int ka = 0;
+        if constexpr (GN) {
+            if (cw == 0) {
+                psc = p.scale_shift ? ld_s1 + 1.0f : 1.0f;
+                psh = p.scale_shift ? ld_s2 : 0.0f;
+                float m = 0.f;
+                if (lane < Cin) {
+                    An = pg; Bn = pb;
+                    if (p.scale_shift) { An *= psc; Bn = Bn * psc + psh; }
+                    m = 4.0f * fabsf(An) + fabsf(Bn);                    // |SiLU(a)| <= |a|; 4 sigma of the normalised input
+                }
+                m = mi_wave_max(m);
+                ka = (m > 0.f) ? rp_clamp_exp(4 - rp_exponent(m)) : 0;   // scaled magnitudes land in [8, 16)
+            }
+        }
+        if constexpr (!BREG) {
+#pragma unroll
+            for (int i = 0; i < WPER; ++i) {
+                const int k = ct + i * NCT;
+                if (k < WTOT) wl[rp_wl_index(k)] = wreg[i];
+            }
+        }
         if (fast) mi_gn_totals_finish(sr, ct, chS, chQ);
         else if (have_stats) mi_gn_channel_totals(p.in0, p.in1, C0, Cin, b, ct, NCT, chS, chQ);          // (rare: more partials than the registers hold)
         if (cw == 0) ST_STAMP(1);
         if (have_stats) __syncthreads();                   // (1)
         if (cw == 0) ST_STAMP(2);
         // ---- ONE wave: group moments (each channel's lane adds up its group, in mi_gn_group_moments' order) -> per-channel affine of the fused
-        // GroupNorm / scale-shift, and the power-of-two operand scaling (conv_rp.hip's arithmetic); the other waves stage the B fragments meanwhile
+        // GroupNorm / scale-shift with the power-of-two operand scaling (conv_rp.hip's arithmetic)
         if (cw == 0) {
             const int c = lane;
-            const float psc = p.scale_shift ? ld_s1 + 1.0f : 1.0f, psh = p.scale_shift ? ld_s2 : 0.0f;
-            float A = 0.f, Bc = 0.f, m = 0.f;
             if constexpr (GN) {
                 if (c < Cin) {
                     const int cpg = Cin / p.gn_groups, g = c / cpg;
                     float mean, rstd;
                     if (ST_ABL & 4) { mean = 0.3f; rstd = 0.6f; }
-                    else {                                     // mi_gn_group_moments with the fp64 reciprocal of the count taken before the loads came back
+                    else {
                         double gs = 0.0, gq = 0.0;
                         for (int cc = g * cpg; cc < (g + 1) * cpg; ++cc) { gs += chS[cc]; gq += chQ[cc]; }
                         const double mean_d = gs * inv_n;
@@ -338,40 +362,29 @@ __global__ __launch_bounds__(CFG::NT) void conv_stripe_kernel(const mi_conv_para
                         mean = (float)mean_d;
                         rstd = 1.0f / sqrtf((float)(var + (double)p.gn_eps));
                     }
-                    float An = pg, Bn = pb;
-                    A = rstd * pg;
-                    Bc = pb - mean * A;
+                    float A = rstd * pg;
+                    float Bc = pb - mean * A;
                     if (p.scale_shift) {
                         A *= psc;
                         Bc = Bc * psc + psh;
-                        An *= psc;
-                        Bn = Bn * psc + psh;
                     }
                     A *= (c >= C0) ? p.in1.scale : p.in0.scale;
-                    m = 4.0f * fabsf(An) + fabsf(Bn);                    // |SiLU(a)| <= |a|; 4 sigma of the normalised input
+                    chP[c] = make_float4(ldexpf(A, ka), ldexpf(Bc, ka), A * -1.44269504088896340736f, Bc * -1.44269504088896340736f);
                 }
-                m = mi_wave_max(m);
-            } else if (have_stats) {
-                double qq = (c < Cin) ? chQ[c] : 0.0;                   // rms of the raw input (the tensors' scales are already applied)
+            } else {
+                float m = 0.f;
+                if (have_stats) {
+                    double qq = (c < Cin) ? chQ[c] : 0.0;               // rms of the raw input (the tensors' scales are already applied)
 #pragma unroll
-                for (int o = 32; o > 0; o >>= 1) qq += __shfl_xor(qq, o);
-                m = 4.0f * sqrtf((float)(qq / ((double)Cin * (double)HW)));
-            }
-            const int ka = (m > 0.f) ? rp_clamp_exp(4 - rp_exponent(m)) : 0;            // scaled magnitudes land in [8, 16)
-            if (c < Cin) {
-                if constexpr (GN) chP[c] = make_float4(ldexpf(A, ka), ldexpf(Bc, ka), A * -1.44269504088896340736f, Bc * -1.44269504088896340736f);
-                else chP[c] = make_float4(ldexpf((c >= C0) ? p.in1.scale : p.in0.scale, ka), 0.f, 0.f, 0.f);
+                    for (int o = 32; o > 0; o >>= 1) qq += __shfl_xor(qq, o);
+                    m = 4.0f * sqrtf((float)(qq / ((double)Cin * (double)HW)));
+                }
+                ka = (m > 0.f) ? rp_clamp_exp(4 - rp_exponent(m)) : 0;
+                if (c < Cin) chP[c] = make_float4(ldexpf((c >= C0) ? p.in1.scale : p.in0.scale, ka), 0.f, 0.f, 0.f);
             }
             if (lane == 0) { sExp[0] = ka; sExp[2] = ka + p.w_rp_exp; }
         }
         if (cw == 0) ST_STAMP(3);
-        if constexpr (!BREG) {
-#pragma unroll
-            for (int i = 0; i < WPER; ++i) {
-                const int k = ct + i * NCT;
-                if (k < WTOT) wl[rp_wl_index(k)] = wreg[i];
-            }
-        }
         if (cw == 0) ST_STAMP(4);
         __syncthreads();                                   // (3)
         if (cw == 0) ST_STAMP(5);
