@@ -59,7 +59,8 @@ namespace {
 
 // KO_ / NJ_: channel octets of the conv input / N tiles (8 output channels each).  OM_ (output mode): 0 = every channel of the N tiles is an
 // output channel, no identity residual; 1 = ... with the identity residual; 2 = fewer output channels than the N tiles hold (the final 8 -> 3 conv:
-// masked stores), no residual.  Compile-time, because a residual load or an output store inside a run-time conditional makes the compiler's wait
+// masked stores), no residual; 3 = nearest x2 up-sampling in front of the conv (Upsample, layers.py:512-515: no GroupNorm, no residual): the ring
+// holds SOURCE rows of half the width, one new row per step, and the A-fragment indices go through (v >> 1) as in conv_rp's MODE 1.  Compile-time, because a residual load or an output store inside a run-time conditional makes the compiler's wait
 // counts conservative: the wait for step it's residual then also waits for the stores of step it - 1 and for the residual loads of step it + 1
 // that were issued a moment ago (seen in the ISA of the first version: vmcnt(3) .. (0) in every step).
 // (Launches with a 1x1 residual conv stay on the tile kernel: the residual octets' ring rows would leave one workgroup per CU.)
@@ -71,18 +72,20 @@ struct StCfg {
     // (HS: 4) channels of one (half) octet: that many dwordx4 loads per step, TWO steps in flight, issued unconditionally and unrolled by two so that
     // the wait before a transform is exact.  HS below 256 wide: a step's GroupNorm / SiLU / split of 32 values per work-item was the per-step critical
     // path there (phase trace: 2.7 us per step whatever the width); 16 values on twice the work-items halve it.  256-wide steps are paced by memory.
+    static constexpr bool UP = OM_ == 3;
+    static constexpr int WS = UP ? W_ / 2 : W_, RPS = UP ? 1 : 2, NPR = UP ? 3 : 4;       // source width, new source rows per step, rows of the prologue
     static constexpr bool HS = W_ < 256 && ST_HALF_OCTETS;
     static constexpr int NCH = HS ? 4 : 8;
-    static constexpr int QPR = W_ / 4, UNITS = 2 * QPR * KO * (HS ? 2 : 1), NLW = (UNITS + 63) / 64;
+    static constexpr int QPR = WS / 4, UNITS = RPS * QPR * KO * (HS ? 2 : 1), NLW = (UNITS + 63) / 64;
     static constexpr int NG = W_ / 16, NCW = NG >= 4 ? 4 : NG, GPW = NG / NCW;             // 16-pixel groups of a row pair, MFMA waves
     static constexpr int NT = (NLW + NCW) * 64;
-    static constexpr int PW = W_ + 8, RING = 6, PLANE = KO * RING * PW;
+    static constexpr int PW = WS + 8, RING = 6, PLANE = KO * RING * PW;
     static constexpr int SR0 = W_ / 8;                                                      // rows per statistics block
     static constexpr int WCH = 3 * NJ * 128, WTOT = KO * WCH;                               // 16-byte chunks of B fragments
     static constexpr bool BREG = ST_BREG && KO == 1 && NJ == 1;
     // prologue units of the MFMA waves: the stripe's first 4 input rows, as half octets where that still fits one pass
-    static constexpr bool PHS = HS && 8 * QPR * KO <= NCW * 64;
-    static constexpr int PCH = PHS ? 4 : 8, PU = 4 * QPR * KO * (PHS ? 2 : 1);
+    static constexpr bool PHS = HS && 2 * NPR * QPR * KO <= NCW * 64;
+    static constexpr int PCH = PHS ? 4 : 8, PU = NPR * QPR * KO * (PHS ? 2 : 1);
     static_assert(PU <= NCW * 64, "the MFMA waves transform the first four rows in one pass");
 };
 
@@ -120,7 +123,8 @@ template <class CFG>
 __global__ __launch_bounds__(CFG::NT) void conv_stripe_kernel(const mi_conv_params p, const uint4* __restrict__ wrp, const int nblk) {
     constexpr int W = CFG::W, KO = CFG::KO, NJ = CFG::NJ, QPR = CFG::QPR, UNITS = CFG::UNITS, NLW = CFG::NLW, NLT = NLW;
     constexpr int NCW = CFG::NCW, GPW = CFG::GPW, PW = CFG::PW, RING = CFG::RING, SR0 = CFG::SR0, WCH = CFG::WCH, WTOT = CFG::WTOT, PU = CFG::PU;
-    constexpr bool GN = CFG::GN, BREG = CFG::BREG;
+    constexpr bool GN = CFG::GN, BREG = CFG::BREG, UP = CFG::UP;
+    constexpr int WS = CFG::WS, RPS = CFG::RPS, NPR = CFG::NPR;
     __shared__ __attribute__((aligned(16))) uint4 actH[CFG::PLANE];
     __shared__ __attribute__((aligned(16))) uint4 actL[CFG::PLANE];
     __shared__ __attribute__((aligned(16))) uint4 wl[BREG ? 1 : WTOT];
@@ -131,6 +135,7 @@ __global__ __launch_bounds__(CFG::NT) void conv_stripe_kernel(const mi_conv_para
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lq = lane & 15, lg = lane >> 4;
     const int H = p.H, HW = H * W;
+    const int Hs = UP ? H / 2 : H, HWs = UP ? HW / 4 : HW;           // source image
     const int nt = H / SR0;                            // statistics blocks per image
     const int wgs = nt / nblk;                         // workgroups per image
     // XCD-aware placement as in conv_rp.hip (speed only): workgroup L runs on XCD L % 8; whole images per XCD
@@ -152,12 +157,12 @@ __global__ __launch_bounds__(CFG::NT) void conv_stripe_kernel(const mi_conv_para
     // formed ONCE from the (scalar) kernel arguments; a work-item then selects between two computed pointers.  (Selecting the struct FIELDS per
     // work-item -- `second ? p.in1.data : p.in0.data` -- compiles to a vector load from the kernel-argument segment with a per-lane address and a
     // s_waitcnt vmcnt(0) right behind it: two dependent memory round trips in front of every wave's first bulk load, seen in the ISA.)
-    const float* const img0 = p.in0.data + (size_t)mi_row_of(b, p.in0.bmod) * C0 * HW;
-    const float* const img1 = C1 ? p.in1.data + (size_t)mi_row_of(b, p.in1.bmod) * C1 * HW : img0;
+    const float* const img0 = p.in0.data + (size_t)mi_row_of(b, p.in0.bmod) * C0 * HWs;
+    const float* const img1 = C1 ? p.in1.data + (size_t)mi_row_of(b, p.in1.bmod) * C1 * HWs : img0;
     auto octet_base = [&](int oct) {
         const int c0 = 8 * oct;
-        const float* a0 = img0 + (size_t)c0 * HW;
-        const float* a1 = img1 + (size_t)(c0 - C0) * HW;
+        const float* a0 = img0 + (size_t)c0 * HWs;
+        const float* a1 = img1 + (size_t)(c0 - C0) * HWs;
         return mi_global(c0 >= C0 ? a1 : a0);
     };
     // GroupNorm affine + scale/shift + SiLU (or the plain operand scaling) + fp16 split of 4 pixels x NC channels (an octet, or its half `half`) ->
@@ -208,19 +213,20 @@ __global__ __launch_bounds__(CFG::NT) void conv_stripe_kernel(const mi_conv_para
         const int u = wave * 64 + lane;
         const bool live = u < UNITS;
         const int uu = live ? u : 0;
-        const int oct = uu / (2 * QPR * HSM), half = HSM == 2 ? (uu / (2 * QPR)) & 1 : 0, lrow = (uu / QPR) & 1, q = uu % QPR;   // octet, channel half, row of the step, pixel quad
-        const mi_gptr<const float> base = octet_base(oct) + (size_t)(NCH * half) * HW;
+        const int oct = uu / (RPS * QPR * HSM), half = HSM == 2 ? (uu / (RPS * QPR)) & 1 : 0, lrow = RPS == 2 ? (uu / QPR) & 1 : 0, q = uu % QPR;   // octet, channel half, row of the step, pixel quad
+        const mi_gptr<const float> base = octet_base(oct) + (size_t)(NCH * half) * HWs;
         f32x4 raw[2][NCH];
         bool inimg[2];
-        auto issue = [&](int s, auto buf_tag) {            // step s brings input rows y0 + 2 s + 1 + lrow (steps -1 and 0 are the MFMA waves' prologue)
+        auto issue = [&](int s, auto buf_tag) {            // step s brings input rows y0 + 2 s + 1 + lrow (UP: source row y0 / 2 + s + 1); steps -1 and 0 are the MFMA waves' prologue
             constexpr int buf = decltype(buf_tag)::value;
-            int y = y0 + 2 * s + 1 + lrow;
-            y = y > y0 + RS ? y0 + RS : y;                // steps past the stripe (issued UNCONDITIONALLY: a conditional issue makes the compiler's wait counts conservative) re-read its last halo row
-            const bool ok = y < H;
+            int y = UP ? y0 / 2 + s + 1 : y0 + 2 * s + 1 + lrow;
+            const int ylast = UP ? (y0 + RS) / 2 : y0 + RS;
+            y = y > ylast ? ylast : y;                    // steps past the stripe (issued UNCONDITIONALLY: a conditional issue makes the compiler's wait counts conservative) re-read its last halo row
+            const bool ok = y < Hs;
             inimg[buf] = ok;
-            const unsigned off = ok ? (unsigned)(y * W + 4 * q) : 0u;
+            const unsigned off = ok ? (unsigned)(y * WS + 4 * q) : 0u;
 #pragma unroll
-            for (int j = 0; j < NCH; ++j) raw[buf][j] = *reinterpret_cast<mi_gptr<const f32x4>>(base + (size_t)j * HW + off);
+            for (int j = 0; j < NCH; ++j) raw[buf][j] = *reinterpret_cast<mi_gptr<const f32x4>>(base + (size_t)j * HWs + off);
         };
         constexpr std::integral_constant<int, 0> B0{};
         constexpr std::integral_constant<int, 1> B1{};
@@ -236,7 +242,7 @@ __global__ __launch_bounds__(CFG::NT) void conv_stripe_kernel(const mi_conv_para
         for (int j = 0; j < NCH; ++j) P[j] = chP[8 * oct + NCH * half + j];
         auto transform = [&](int s, auto buf_tag) {
             constexpr int buf = decltype(buf_tag)::value;
-            transform_quad(std::integral_constant<int, NCH>{}, raw[buf], P, inimg[buf], live, oct, half, (2 * s + 2 + lrow) % RING, q);      // ring row = input row - (y0 - 1)
+            transform_quad(std::integral_constant<int, NCH>{}, raw[buf], P, inimg[buf], live, oct, half, (UP ? s + 2 : 2 * s + 2 + lrow) % RING, q);      // ring row = source row - (first source row of the stripe - 1)
         };
         __syncthreads();                                   // (4) rows of steps -1 and 0 in the ring
         if (wave == 0) ST_STAMP(14);
@@ -295,19 +301,19 @@ __global__ __launch_bounds__(CFG::NT) void conv_stripe_kernel(const mi_conv_para
         constexpr int PCH = CFG::PCH, PHM = CFG::PHS ? 2 : 1;
         const bool plive = ct < PU;
         const int pu = plive ? ct : 0;
-        const int poct = pu / (4 * QPR * PHM), phalf = PHM == 2 ? (pu / (4 * QPR)) & 1 : 0, prow = (pu / QPR) & 3, pq = pu % QPR;
+        const int poct = pu / (NPR * QPR * PHM), phalf = PHM == 2 ? (pu / (NPR * QPR)) & 1 : 0, prow = (pu / QPR) % NPR, pq = pu % QPR;
         f32x4 praw[PCH];
-        const int py = y0 - 1 + prow;
-        const bool pin = py >= 0 && py < H;
+        const int py = (UP ? y0 / 2 : y0) - 1 + prow;
+        const bool pin = py >= 0 && py < Hs;
         {
-            const mi_gptr<const float> pbase = octet_base(poct) + (size_t)(PCH * phalf) * HW;
-            const unsigned off = pin ? (unsigned)(py * W + 4 * pq) : 0u;
+            const mi_gptr<const float> pbase = octet_base(poct) + (size_t)(PCH * phalf) * HWs;
+            const unsigned off = pin ? (unsigned)(py * WS + 4 * pq) : 0u;
 #pragma unroll
-            for (int j = 0; j < PCH; ++j) praw[j] = *reinterpret_cast<mi_gptr<const f32x4>>(pbase + (size_t)j * HW + off);
+            for (int j = 0; j < PCH; ++j) praw[j] = *reinterpret_cast<mi_gptr<const f32x4>>(pbase + (size_t)j * HWs + off);
         }
         // the horizontal zero padding of the conv = a zero chunk left and right of every ring row
         for (int k = ct; k < KO * RING * 2; k += NCT) {
-            const int r = k >> 1, c = (k & 1) ? W + 1 : 0;
+            const int r = k >> 1, c = (k & 1) ? WS + 1 : 0;
             actH[r * PW + c] = make_uint4(0u, 0u, 0u, 0u);
             actL[r * PW + c] = make_uint4(0u, 0u, 0u, 0u);
         }
@@ -377,7 +383,7 @@ __global__ __launch_bounds__(CFG::NT) void conv_stripe_kernel(const mi_conv_para
                     double qq = (c < Cin) ? chQ[c] : 0.0;               // rms of the raw input (the tensors' scales are already applied)
 #pragma unroll
                     for (int o = 32; o > 0; o >>= 1) qq += __shfl_xor(qq, o);
-                    m = 4.0f * sqrtf((float)(qq / ((double)Cin * (double)HW)));
+                    m = 4.0f * sqrtf((float)(qq / ((double)Cin * (double)HWs)));
                 }
                 ka = (m > 0.f) ? rp_clamp_exp(4 - rp_exponent(m)) : 0;
                 if (c < Cin) chP[c] = make_float4(ldexpf((c >= C0) ? p.in1.scale : p.in0.scale, ka), 0.f, 0.f, 0.f);
@@ -428,7 +434,7 @@ __global__ __launch_bounds__(CFG::NT) void conv_stripe_kernel(const mi_conv_para
             for (int g = 0; g < GPW; ++g)
 #pragma unroll
                 for (int jt = 0; jt < NJ; ++jt) acc[g][jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            const int slot = (2 * it + perm) % RING;
+            const int slot = (UP ? it + 1 + ((perm - 1) >> 1) : 2 * it + perm) % RING;    // UP: up-sampled rows 2 it - 1 .. 2 it + 2 = source rows it - 1, it, it, it + 1
             // D[px 16][(dy, co)] += act[px][(r, ci)] . B[(r, ci)][(dy, co)]: octets in conv_rp's round order, one instruction triple per horizontal tap
 #pragma unroll
             for (int o = 0; o < KO; ++o) {
@@ -445,7 +451,8 @@ __global__ __launch_bounds__(CFG::NT) void conv_stripe_kernel(const mi_conv_para
                     }
 #pragma unroll
                     for (int g = 0; g < GPW; ++g) {
-                        const int idx = (o * RING + slot) * PW + 16 * (cw * GPW + g) + lq + s;
+                        const int col = 16 * (cw * GPW + g) + lq + s;
+                        const int idx = (o * RING + slot) * PW + (UP ? ((col - 1) >> 1) + 1 : col);
                         const rp_f16x8 ah = __builtin_bit_cast(rp_f16x8, actH[idx]);
                         const rp_f16x8 al = __builtin_bit_cast(rp_f16x8, actL[idx]);
 #pragma unroll
@@ -552,23 +559,27 @@ int launch_stripe(const mi_conv_params& p, hipStream_t st) {
 
 template <int W>
 int launch_stripe_w(const mi_conv_params& p, hipStream_t st, int ko, int nj, bool gn) {
-    const int om = p.Cout < 8 * nj ? 2 : ((p.res0.data && !p.res_w) ? 1 : 0);
-#define ST_CASE(KO, NJ, GNV) if (ko == KO && nj == NJ && gn == GNV) { \
-        if (om == 0) return launch_stripe<W, KO, NJ, GNV, 0>(p, st); \
-        if constexpr (GNV) { if (om == 1) return launch_stripe<W, KO, NJ, GNV, 1>(p, st); } \
-        if constexpr (!GNV && NJ == 1) { if (om == 2) return launch_stripe<W, KO, NJ, GNV, 2>(p, st); } \
-        return MI_ERR_UNSUPPORTED; }
+    const int om = p.up2 ? 3 : (p.Cout < 8 * nj ? 2 : ((p.res0.data && !p.res_w) ? 1 : 0));
     // the layer shapes of the BASELINE U-Nets: 8 / 16 / 24 / 32 input channels, 8 or 16 (or 3) output channels
-    ST_CASE(1, 1, true); ST_CASE(1, 1, false);
-    if constexpr (W <= 128) { ST_CASE(2, 1, true); }
-    if constexpr (W <= 64) { ST_CASE(2, 2, true); ST_CASE(4, 2, true); ST_CASE(1, 2, false); ST_CASE(3, 2, true); }
-#undef ST_CASE
+#define ST_BLOCK(KO, NJ) if (gn && ko == KO && nj == NJ) return om == 1 ? launch_stripe<W, KO, NJ, true, 1>(p, st) : launch_stripe<W, KO, NJ, true, 0>(p, st)
+#define ST_PLAIN(KO, NJ, OMV) if (!gn && ko == KO && nj == NJ && om == OMV) return launch_stripe<W, KO, NJ, false, OMV>(p, st)
+    if (om <= 1) {
+        ST_BLOCK(1, 1);
+        if constexpr (W <= 128) { ST_BLOCK(2, 1); }
+        if constexpr (W <= 64) { ST_BLOCK(2, 2); ST_BLOCK(4, 2); ST_BLOCK(3, 2); }
+    }
+    ST_PLAIN(1, 1, 0);                                       // 8 -> 8 without GroupNorm
+    ST_PLAIN(1, 1, 2);                                       // the final 8 -> 3 conv
+    if constexpr (W <= 64) { ST_PLAIN(1, 2, 0); }            // the folded Parallel(3x3, 1x1) conv 8 -> 16 of the base U-Net
+    if constexpr (W >= 64 && W <= 128) { ST_PLAIN(1, 1, 3); ST_PLAIN(2, 1, 3); }      // nearest x2 + conv
+#undef ST_BLOCK
+#undef ST_PLAIN
     return MI_ERR_UNSUPPORTED;
 }
 
 // rows per statistics block if this launch runs on the stripe kernel, else 0
 int stripe_block_rows(const mi_conv_params& p, int* ko_, int* nj_) {
-    if (!(p.ksize == 3 && p.stride == 1 && !p.up2) || !p.w_rp || p.gn_coef || (p.tile_cfg & MI_CONV_HALF) || p.out_st) return 0;
+    if (!(p.ksize == 3 && p.stride == 1) || !p.w_rp || p.gn_coef || (p.tile_cfg & MI_CONV_HALF) || p.out_st) return 0;
     if (p.in0.st || (p.in1.data && p.in1.st) || (p.res0.data && p.res0.st)) return 0;
     if (!(p.W == 32 || p.W == 64 || p.W == 128 || p.W == 256)) return 0;
     const int sr0 = p.W / 8;
@@ -580,7 +591,13 @@ int stripe_block_rows(const mi_conv_params& p, int* ko_, int* nj_) {
     if (p.gn_groups > 0 && (!p.in0.stats || (p.in1.data && !p.in1.stats))) return 0;
     const int ko = (C0 + C1) >> 3, nj = (p.Cout + 7) >> 3;
     const bool gn = p.gn_groups > 0;
-    const int om = p.Cout < 8 * nj ? 2 : (p.res0.data ? 1 : 0);
+    const int om = p.up2 ? 3 : (p.Cout < 8 * nj ? 2 : (p.res0.data ? 1 : 0));
+    if (om == 3) {      // nearest x2 + conv (Upsample): 8 or 16 -> 8 channels, no GroupNorm, no residual, output at least 64 wide
+        // (256-wide outputs stay on the tile kernel: write-bound, 52 against 48 us in the captured SR step; 128 wide: 20.8 against 27.8 us)
+        if (gn || p.res0.data || nj != 1 || p.Cout != 8 || ko > 2 || p.W < 64 || p.W > 128 || (p.H & 1)) return 0;
+        if (ko_) { *ko_ = ko; *nj_ = nj; }
+        return sr0;
+    }
     if ((om == 1 && !gn) || (om == 2 && (gn || nj != 1))) return 0;      // instantiated: identity residual behind a Block, masked channels in the final conv
     // the instantiated (ko, nj, gn) combinations of launch_stripe_w
     const bool common = (ko == 1 && nj == 1) || (p.W <= 128 && ko == 2 && nj == 1 && gn);

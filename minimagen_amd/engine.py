@@ -51,7 +51,10 @@ RP_NTILE_PIPE = {k: int(os.environ.get("MINIMAGEN_RP_NTILE_PIPE_" + k, d)) for k
 # everywhere; a string of size classes ("LMS" = all, the default) selects where: L > 128^2, M > 64^2, S smaller
 CONV_STRIPE = os.environ.get("MINIMAGEN_CONV_STRIPE", "LMS").upper().replace("0", "").replace("1", "LMS")
 ST_NBLK = {k: int(os.environ.get("MINIMAGEN_ST_NBLK_" + k, "0")) for k in ("L", "M", "S")}              # statistics blocks per workgroup (0 = the library's choice; speed only)
-ST_NBLK_PIPE = {k: int(os.environ.get("MINIMAGEN_ST_NBLK_PIPE_" + k, "0")) for k in ("L", "M", "S")}    # ... for workspaces of pipelined calls
+# ... for workspaces of PIPELINED calls: four blocks (half an image) per workgroup at <= 64^2 while that leaves >= 128 workgroups -- fewer, longer
+# workgroups leave the other lane's kernels room, as with RP_NTILE_PIPE: 46.7 K against 45.8 K steps/s, same box back to back; L / M: no effect
+# (profiles/r06_summary.md)
+ST_NBLK_PIPE = {k: int(os.environ.get("MINIMAGEN_ST_NBLK_PIPE_" + k, d)) for k, d in (("L", "0"), ("M", "0"), ("S", "4"))}
 TILE64 = int(os.environ.get("MINIMAGEN_TILE64", "-1"))                  # force a conv tile shape at 64x64 / 128x128 (experiments)
 TILE128 = int(os.environ.get("MINIMAGEN_TILE128", "-1"))       # 1: 16-channel 3x3 outputs as two 8-channel workgroups
 WEIGHT_FINGERPRINT = os.environ.get("MINIMAGEN_WEIGHT_FINGERPRINT", "1") != "0"   # content fingerprint of the weights at every public call (see pack())
@@ -401,11 +404,11 @@ class UnetEngine:
         lib.mi_conv_tile_shape(best, C.byref(th), C.byref(tw))
         return best, -(-H // th.value) * -(-W // tw.value)
 
-    def _stripe_rows(self, batch, Ho, Wo, in0, in1, Cout, gn, res) -> int:
+    def _stripe_rows(self, batch, Ho, Wo, in0, in1, Cout, gn, res, up2=0) -> int:
         """rows per statistics block if csrc/conv_stripe.hip (tile_cfg 12) takes this narrow fp32 k3 s1 launch, else 0: asked of the library
         (mi_conv_stripe_rows) on a probe of the launch's shape -- pointers only need to be non-null where the real launch has them"""
         q = L.MiConvParams()
-        q.B, q.H, q.W, q.Cout, q.ksize, q.stride, q.up2 = batch, Ho, Wo, Cout, 3, 1, 0
+        q.B, q.H, q.W, q.Cout, q.ksize, q.stride, q.up2 = batch, Ho, Wo, Cout, 3, 1, int(bool(up2))
         q.in0 = L.MiAct(1, in0.C, 1 if in0.stats is not None else 0, in0.nt, 1.0, 0)
         if in1 is not None:
             q.in1 = L.MiAct(1, in1.C, 1 if in1.stats is not None else 0, in1.nt, 1.0, 0)
@@ -475,8 +478,8 @@ class UnetEngine:
             th, tw = {5: (16, 64), 6: (8, 64), 7: (8, 32), 10: (16, 16), 11: (8, 16)}[cfg]
             nt = -(-Ho // th) * -(-Wo // tw)
             cls = "L" if Ho * Wo > 128 * 128 else ("M" if Ho * Wo > 64 * 64 else "S")
-            if narrow and ksize == 3 and stride == 1 and not up2 and not ws.half and cls in CONV_STRIPE:
-                rows = self._stripe_rows(batch, Ho, Wo, in0, in1, Cout, gn, res)
+            if narrow and ksize == 3 and stride == 1 and not ws.half and cls in CONV_STRIPE:
+                rows = self._stripe_rows(batch, Ho, Wo, in0, in1, Cout, gn, res, up2)
                 if rows:
                     cfg, nt, stripe = 12, Ho // rows, True
         if ws.store16 and (not rp or wide):
@@ -517,7 +520,9 @@ class UnetEngine:
             if not nt_knob and ws.pipelined and RP_NTILE_PIPE[cls] and batch * nt // RP_NTILE_PIPE[cls] >= 256:
                 nt_knob = RP_NTILE_PIPE[cls]        # (only while the launch still has a workgroup per CU: smaller batches keep the library's choice -- config 3 at B = 16: 39.1 K with, 40.7 K without)
             if stripe:                              # statistics blocks per workgroup of the stripe kernel (must divide the blocks of an image)
-                nt_knob = (ST_NBLK_PIPE[cls] if ws.pipelined and ST_NBLK_PIPE[cls] else ST_NBLK[cls])
+                nt_knob = ST_NBLK[cls]
+                if ws.pipelined and ST_NBLK_PIPE[cls] and nt % ST_NBLK_PIPE[cls] == 0 and batch * nt // ST_NBLK_PIPE[cls] >= 128:
+                    nt_knob = ST_NBLK_PIPE[cls]
                 if nt_knob and (nt % nt_knob or nt_knob > 15):
                     nt_knob = 0
             p.tile_cfg |= (nt_knob & 0xf) << 12

@@ -145,6 +145,51 @@ def test_conv_full_width_stripes(backend, case):
     assert (s_rp.sum(2) - ost.sum(2)).abs().max().item() <= 1e-6 * s_rp.sum(2).abs().max().item()
 
 
+UP_CASES = [
+    # B, Cin, H, W (output size), xscale, wscale: nearest x2 + Conv3x3 to 8 channels (Upsample, layers.py:512-515), no GroupNorm
+    (2, 16, 32, 128, 1.0, 1.0),         # SR U-Net: 16 -> 8 up to 128^2
+    (8, 16, 16, 64, 1.0, 1.0),          # base U-Net: 16 -> 8 up to 64^2 (B % 8 == 0)
+    (1, 8, 16, 128, 300.0, 1.0 / 64),   # 8 -> 8, scaled operands
+]
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("case", UP_CASES)
+def test_conv_full_width_stripes_upsampling(backend, case):
+    """tile_cfg 12 with up2: the ring holds source rows of half the width; against torch fp64 and bit for bit against conv_rp's MODE 1"""
+    dev = setup(backend)
+    lib = L.lib()
+    B, Cin, H, W, xs, wsc = case
+    g = torch.Generator().manual_seed(hash(case) & 0xffff)
+    rn = lambda *s_: torch.randn(*s_, generator=g)
+    x = (rn(B, Cin, H // 2, W // 2) * 1.5 + 0.3) * xs
+    w, bias = rn(8, Cin, 3, 3) * 0.2 * wsc, rn(8) * wsc * xs
+    ref = F.conv2d(F.interpolate(x.double(), scale_factor=2, mode="nearest"), w.double(), bias.double(), padding=1)
+    keep = {}
+    d = lambda name, t: keep.setdefault(name, t.to(dev).contiguous())
+    p = L.MiConvParams()
+    p.B, p.H, p.W = B, H, W
+    p.in0 = L.MiAct(d("x", x).data_ptr(), Cin, d("s", chan_stats(x)).data_ptr(), 1, 1.0, 0)
+    p.Cout, p.ksize, p.stride, p.up2 = 8, 3, 1, 1
+    wf, wexp = P.pack_conv_weight_rp(w)
+    p.w_rp, p.w_rp_exp, p.bias = d("wf", wf).data_ptr(), wexp, d("b", bias).data_ptr()
+    rows = lib.mi_conv_stripe_rows(C.byref(p))
+    assert rows == W // 8
+    nt = H // rows
+    out, ost = run(lib, p, 12, nt, dev)
+    scale = max(1.0, ref.abs().max().item() / 8.0)
+    err = (out.double() - ref).abs().max().item()
+    print(f"stripe up-sampling conv {case}: max|d| = {err:.2e} (gate {2e-5 * scale:.2e})")
+    assert err < 2e-5 * scale
+    check_stats(ost, ref.float())
+    for nblk in (2, nt):
+        if nt % nblk == 0 and nblk <= 15:
+            o2, s2 = run(lib, p, 12 | (nblk << 12), nt, dev)
+            assert torch.equal(o2, out) and torch.equal(s2, ost)
+    o_rp, _ = run(lib, p, 6, tile_nt(lib, 6, H, W), dev)
+    assert torch.equal(o_rp, out), f"stripe and tile kernels differ: max|d| = {(o_rp - out).abs().max().item():.3e}"
+
+
 def test_stripe_eligibility_is_declared_by_the_library():
     """mi_conv_stripe_rows: what tile_cfg 12 takes (the engine asks before planning a launch) -- no compute, runs without a GPU"""
     setup("emu")
@@ -156,7 +201,7 @@ def test_stripe_eligibility_is_declared_by_the_library():
     assert lib.mi_conv_stripe_rows(C.byref(p)) == 8
     p.W = 32
     assert lib.mi_conv_stripe_rows(C.byref(p)) == 4
-    for field, val in (("W", 48), ("H", 60), ("stride", 2), ("up2", 1), ("Cout", 32), ("out_st", 1), ("tile_cfg", 0x400)):
+    for field, val in (("W", 48), ("H", 60), ("stride", 2), ("gn_groups", 3), ("Cout", 32), ("out_st", 1), ("tile_cfg", 0x400)):
         q = L.MiConvParams.from_buffer_copy(p)
         q.W = 64
         setattr(q, field, val)
