@@ -226,7 +226,7 @@ def pmc_traffic_live(args, dom, rows, S):
     import shutil
     import subprocess
     import tempfile
-    if dom["kernel"] != "cross_attn" or not shutil.which("rocprofv3") or os.environ.get("MINIMAGEN_BENCH_LIVE_PMC", "1") == "0":
+    if dom["kernel"] != "cross_attn" or not shutil.which("rocprofv3") or not args.live_pmc:
         return None
     grid = rows * (-(-(S // 4) * (S // 4) // 128)) * 512
     tmp = tempfile.mkdtemp(prefix="mi_pmc_", dir="/tmp")
@@ -371,9 +371,8 @@ def secondary_lines(timesteps, cond_scale):
                                                ("config5_cascade64_256_1024_B8_half", "cascade64_256_1024", 8, "half", 3)):
         cmd = [sys.executable, os.path.abspath(__file__), "--workload", workload, "--batch", str(B), "--precision", precision, "--steps", str(calls),
                "--warmup", "3" if calls > 3 else "1", "--timesteps", str(timesteps), "--cond-scale", str(cond_scale),
-               "--no-secondary", "--no-cpu-baseline", "--no-t5"] + ([] if workload == "cascade64_256_1024" else ["--no-breakdown"])
+               "--no-secondary", "--no-cpu-baseline", "--no-t5", "--no-live-pmc"] + ([] if workload == "cascade64_256_1024" else ["--no-breakdown"])      # (the secondary legs keep the committed-profile look-up: bounded run time)
         env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
-        env["MINIMAGEN_BENCH_LIVE_PMC"] = "0"          # (the secondary legs keep the committed-profile look-up: bounded run time)
         r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
         lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
         if r.returncode != 0 or not lines:
@@ -540,6 +539,7 @@ def main():
     ap.add_argument("--no-t5", action="store_true", help="skip the T5 text-embedding pass (K16) for the batch (timed by default, outside the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true")
+    ap.add_argument("--no-live-pmc", dest="live_pmc", action="store_false", help="roofline.traffic from the committed PMC profile instead of two rocprofv3 passes in this run")
     ap.add_argument("--no-pipeline", action="store_true", help="make every sample() call wait for the previous one (no cross-call stage pipelining)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short runs of the other single-GPU BASELINE configurations")
     ap.add_argument("--global-batch", type=int, default=0,
@@ -728,7 +728,7 @@ def main():
         rows = op_breakdown(im, stage, B, args.cond_scale, precision=args.precision)
         total_ms = sum(r["ms"] for r in rows)
         dom = max(rows, key=lambda r: r["ms"])
-        attn_f16 = int(os.environ.get("MINIMAGEN_ATTN_VARIANT", "6")) == 6     # engine default: fp16x3-split matrix-core attention
+        attn_f16 = True                 # the folded attention runs on the fp16x3-split matrix-core kernel (the fp32-MFMA variants are gone)
         if dom["bound"] == "hbm":
             ach, peak, unit = dom["alg_bytes"] / (dom["ms"] * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
         else:

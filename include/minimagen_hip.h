@@ -108,7 +108,7 @@ typedef struct mi_conv_params {
 #define MI_CONV_SPLIT8  0x800   /* 8-channel outputs as two 4-channel workgroups (small, latency-bound launches) */
 #define MI_CONV_HALF    0x400   /* row-paired matrix-core path: single fp16 term per product (reduced-precision configuration; parity gate 3e-2) */
 #define MI_CONV_REVERSE 0x200  /* tile_cfg | MI_CONV_REVERSE (row-paired path): workgroups take the images in reverse order (speed only) */
-#define MI_CONV_RP_FIRST 5      /* tile_cfg 5: 16x64, 6: 8x64, 7: 8x32 output tiles of the row-paired matrix-core path; 10: 16x16 (wide k3 s1 convs on images <= 16 wide); 11: 8x16 tiles of the wide GEMM kernel (conv_wide.hip) */
+#define MI_CONV_RP_FIRST 6      /* tile_cfg 6: 8x64, 7: 8x32 output tiles of the row-paired matrix-core path (5, 16x64, removed in ABI 10); 10: 16x16 (wide k3 s1 convs on images <= 16 wide); 11: 8x16 tiles of the wide GEMM kernel (conv_wide.hip) */
 
 /* tile_cfg -> output tile (th x tw) handled by one workgroup; out_nt = ceil(H/th)*ceil(W/tw) */
 int mi_conv_tile_shape(int tile_cfg, int* th, int* tw);
@@ -248,13 +248,13 @@ typedef struct mi_cross_attn_params {
     const float* gv;
     const float* n1_g; const float* n1_b;   /* CrossAttention.norm   gamma / beta */
     const float* n2_g; const float* n2_b;   /* to_out.1              gamma / beta */
-    float* out; double* out_stats;   /* [B2][C][HW]; stats [B2][C][ceil(HW/tok)][2], tok = 128 (variant 0) or 64 (variant 1) */
+    float* out; double* out_stats;   /* [B2][C][HW]; stats [B2][C][ceil(HW/tok)][2], tok = 64 tokens */
     int out_st;                     /* storage of `out` (as mi_act.st; variant 7 only) */
     int x_exp, g_exp, v_exp;        /* variants 6 / 7: LayerNorm(x) is scaled by 2^x_exp before its fp16 split, the fragments carry 2^g_exp /
                                        2^v_exp (mi_attn_fold_params); the kernel undoes all three exactly (scores, output) */
-    int variant;                    /* 0: 32 tokens per wave; 1,3,4: 16 tokens per wave (fp32 MFMA, exact); 6: 16 tokens per wave with the
-                                       contractions as 3-term fp16 splits on v_mfma_f32_16x16x16_f16 (hi*hi + hi*lo + lo*hi, ~2^-21);
-                                       7: as 6 with a single fp16 term (reduced-precision configuration, same frag_f16 fragments) */
+    int variant;                    /* 6: 16 tokens per wave with the contractions as 3-term fp16 splits on v_mfma_f32_16x16x32_f16
+                                       (hi*hi + hi*lo + lo*hi, ~2^-21: fp32-grade); 7: as 6 with a single fp16 term (reduced-precision
+                                       configuration, same frag_f16 fragments).  (0 .. 5, the exact-fp32 MFMA yardsticks of rounds 1-5, are gone: ABI 10) */
 } mi_cross_attn_params;
 int mi_cross_attn_fwd(const mi_cross_attn_params* p, void* stream);
 #define MI_ATTN_TOKENS_PER_WG 128

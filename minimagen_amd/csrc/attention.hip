@@ -1,250 +1,13 @@
-// K9: the bottleneck cross-attention of MinImagen's ResnetBlock (layers.py:220-251, 433-435) in
-// folded form (see minimagen_hip.h).  One wave owns 16*NQ image tokens; for every head it
-// computes S^T = G_h . x^^T (swapped operands, so a token's scores over all context rows j sit in
-// ONE lane's accumulators + the 3 lanes 16/32/48 away -> row max / row sum are in-register plus two
-// cross-lane steps), exponentiates in place, and feeds the accumulators straight back as the B
-// operand of O^T += VW_h^T . P^T: the C/D layout of v_mfma_f32_16x16x4_f32 (row = 4*(lane>>4)+reg)
-// IS the B layout (k = lane>>4) for the k-order j = 4k + reg, so P never moves.  The whole
-// (tokens x 261) score row lives in registers: no online-softmax rescaling, no LDS, no barriers in
-// the main loop; A fragments come pre-arranged from mi_attn_fold_rows through L2.
+// K9: the bottleneck cross-attention of MinImagen's ResnetBlock (layers.py:220-251, 433-435) in folded form (see minimagen_hip.h).
+// One wave owns 16 image tokens; for every head it computes S^T = G_h . x^^T (swapped operands, so a token's scores over all context rows j
+// sit in ONE lane's accumulators + the 3 lanes 16/32/48 away -> row max / row sum are in-register plus two cross-lane steps),
+// exponentiates in place, and feeds the accumulators straight back as the B operand of O^T += VW_h^T . P^T: the C/D layout of the score
+// tiles IS the B layout of PV, so P never moves.  The whole (tokens x 261) score row lives in registers: no online-softmax rescaling.
+// (Rounds 1-5 also carried exact-fp32 MFMA forms of this kernel -- `variant` 0 .. 5 of mi_cross_attn_fwd -- as A/B yardsticks; removed in
+//  round 6: they were reachable through an environment knob only.  git history has them.)
 #include "common.hip.h"
 
 namespace {
-
-// WPS = waves per SIMD the register allocator must leave room for (hipcc's default heuristic spends 200 registers here;
-// 118 are enough, which doubles the resident waves and lets one wave's MFMAs run under another's softmax)
-template <int C, int NQ, int JT, bool PIPE, int WPS>
-__global__ __launch_bounds__(256, WPS) void cross_attn_folded_kernel(const mi_cross_attn_params p) {
-    constexpr int KK = C / 4;                       // k-steps of QK^T
-    constexpr int NGP = KK < 4 ? 4 : KK;
-    constexpr int MT = (C + 15) / 16;               // M tiles of PV (output channels)
-    constexpr int FR = NGP + 4 * MT;
-    constexpr int TOK_WG = 4 * 16 * NQ;             // tokens per workgroup
-    __shared__ double red[4][2 * 16 * MT];
-
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int lq = lane & 15, lg = lane >> 4;
-    // XCD-aware placement: workgroup L runs on XCD L%8 (observed dispatch order); give each XCD whole samples so the
-    // folded context fragments (267 KB per sample) stay in that XCD's L2.  Pure speed: any placement is correct.
-    const int tiles = (p.HW + TOK_WG - 1) / TOK_WG;
-    int b, tile;
-    if ((p.B2 & 7) == 0) {
-        const int L = blockIdx.x, k = L >> 3;
-        b = (L & 7) + 8 * (k / tiles);
-        tile = k % tiles;
-    } else {
-        b = blockIdx.x / tiles;
-        tile = blockIdx.x % tiles;
-    }
-    const int bx = mi_row_of(b, p.x.bmod);
-    const int i0 = (tile * 4 + wave) * 16 * NQ;
-    const float* xb = p.x.data + (size_t)bx * C * p.HW;
-
-    // ---- LayerNorm(x) per token -> B operand of QK^T: lane supplies x^[a = 4kk + lg][token lq]
-    float xh[NQ][KK];
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        const int i = i0 + 16 * q + lq;
-        const bool ok = i < p.HW;
-        float s = 0.0f;
-#pragma unroll
-        for (int kk = 0; kk < KK; ++kk) {
-            xh[q][kk] = ok ? xb[(size_t)(4 * kk + lg) * p.HW + i] * p.x.scale : 0.0f;
-            s += xh[q][kk];
-        }
-        s += __shfl_xor(s, 16);
-        s += __shfl_xor(s, 32);
-        const float mean = s / (float)C;
-        float v = 0.0f;
-#pragma unroll
-        for (int kk = 0; kk < KK; ++kk) { const float d = xh[q][kk] - mean; v = fmaf(d, d, v); }
-        v += __shfl_xor(v, 16);
-        v += __shfl_xor(v, 32);
-        const float rstd = 1.0f / sqrtf(v / (float)C + 1e-5f);
-#pragma unroll
-        for (int kk = 0; kk < KK; ++kk) {
-            const int a = 4 * kk + lg;
-            xh[q][kk] = (xh[q][kk] - mean) * rstd * p.n1_g[a] + p.n1_b[a];
-        }
-    }
-
-    f32x4 oacc[NQ][MT];
-#pragma unroll
-    for (int q = 0; q < NQ; ++q)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) oacc[q][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    const float* gvb = p.gv + (size_t)b * p.heads * JT * 64 * FR + (size_t)lane * FR;
-    const int jlast = p.J - 1;
-
-    auto qk = [&](int h, f32x4 (&s)[JT][NQ]) {
-        const float* gvh = gvb + (size_t)h * JT * 64 * FR;
-        // ---- S^T tiles
-#pragma unroll
-        for (int jt = 0; jt < JT; ++jt) {
-            float g[NGP];
-#pragma unroll
-            for (int v4 = 0; v4 < NGP / 4; ++v4) {
-                const float4 t = *reinterpret_cast<const float4*>(gvh + (size_t)jt * 64 * FR + 4 * v4);
-                g[4 * v4 + 0] = t.x; g[4 * v4 + 1] = t.y; g[4 * v4 + 2] = t.z; g[4 * v4 + 3] = t.w;
-            }
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int kk = 0; kk < KK; ++kk) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(g[kk], xh[q][kk], acc, 0, 0, 0);
-                s[jt][q] = acc;
-            }
-        }
-    };
-    auto softmax_pv = [&](int h, f32x4 (&s)[JT][NQ]) {
-        const float* gvh = gvb + (size_t)h * JT * 64 * FR;
-        // ---- softmax over j (rows of S^T): this lane holds j = 16jt + 4lg + r.  P stays un-normalised; the 1/l of
-        // this head is applied to its 16*MT-row PV result instead of to the 272 probabilities.
-        float linv[NQ];
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            float m = -INFINITY;
-#pragma unroll
-            for (int jt = 0; jt < JT; ++jt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (jt == JT - 1 && (16 * jt + 4 * lg + r) > jlast) s[jt][q][r] = -INFINITY;   // padded context rows
-                    m = fmaxf(m, s[jt][q][r]);
-                }
-            m = fmaxf(m, __shfl_xor(m, 16));
-            m = fmaxf(m, __shfl_xor(m, 32));
-            float l = 0.0f;
-#pragma unroll
-            for (int jt = 0; jt < JT; ++jt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float e = __builtin_amdgcn_exp2f(s[jt][q][r] - m);
-                    s[jt][q][r] = e;
-                    l += e;
-                }
-            l += __shfl_xor(l, 16);
-            l += __shfl_xor(l, 32);
-            linv[q] = 1.0f / l;
-        }
-        // ---- O_h^T = VW_h^T . P^T
-        f32x4 oh[NQ][MT];
-#pragma unroll
-        for (int q = 0; q < NQ; ++q)
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) oh[q][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int jt = 0; jt < JT; ++jt) {
-            float vw[4 * MT];
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const float4 t = *reinterpret_cast<const float4*>(gvh + (size_t)jt * 64 * FR + NGP + 4 * mt);
-                vw[4 * mt + 0] = t.x; vw[4 * mt + 1] = t.y; vw[4 * mt + 2] = t.z; vw[4 * mt + 3] = t.w;
-            }
-#pragma unroll
-            for (int q = 0; q < NQ; ++q)
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        oh[q][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vw[4 * mt + r], s[jt][q][r], oh[q][mt], 0, 0, 0);
-        }
-#pragma unroll
-        for (int q = 0; q < NQ; ++q)
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) oacc[q][mt][r] = fmaf(oh[q][mt][r], linv[q], oacc[q][mt][r]);
-    };
-    if constexpr (PIPE) {
-        // two score sets: the QK^T MFMAs of head h+1 are issued before head h's softmax so the matrix pipe works under
-        // the exponentials of the same wave (named arrays, static indices only)
-        f32x4 sA[JT][NQ], sB[JT][NQ];
-        qk(0, sA);
-        for (int h = 0; h < p.heads; h += 2) {
-            if (h + 1 < p.heads) qk(h + 1, sB);
-            softmax_pv(h, sA);
-            if (h + 1 < p.heads) {
-                if (h + 2 < p.heads) qk(h + 2, sA);
-                softmax_pv(h + 1, sB);
-            }
-        }
-    } else {
-        for (int h = 0; h < p.heads; ++h) {
-            f32x4 s[JT][NQ];
-            qk(h, s);
-            softmax_pv(h, s);
-        }
-    }
-
-    // ---- to_out.1 LayerNorm over channels, + residual, store, statistics.
-    // This lane holds channels a = 16mt + 4lg + r of token lq (rows >= C are exact zeros).
-    double csum[4 * MT], csq[4 * MT];         // (sum, sum of squares) per channel in fp64, valid at lq == 0 (common.hip.h)
-#pragma unroll
-    for (int e = 0; e < 4 * MT; ++e) { csum[e] = 0.0; csq[e] = 0.0; }
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        const int i = i0 + 16 * q + lq;
-        const bool ok = i < p.HW;
-        float s1 = 0.0f;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) s1 += oacc[q][mt][r];
-        s1 += __shfl_xor(s1, 16);
-        s1 += __shfl_xor(s1, 32);
-        const float mean = s1 / (float)C;
-        float v = 0.0f;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int a = 16 * mt + 4 * lg + r;
-                const float d = (a < C) ? oacc[q][mt][r] - mean : 0.0f;
-                v = fmaf(d, d, v);
-            }
-        v += __shfl_xor(v, 16);
-        v += __shfl_xor(v, 32);
-        const float rstd = 1.0f / sqrtf(v / (float)C + 1e-5f);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int a = 16 * mt + 4 * lg + r;
-                float y = 0.0f;
-                if (a < C && ok) {
-                    const float res = xb[(size_t)a * p.HW + i] * p.x.scale;
-                    y = (oacc[q][mt][r] - mean) * rstd * p.n2_g[a] + p.n2_b[a] + res;
-                    p.out[((size_t)b * C + a) * p.HW + i] = y;
-                }
-                if (p.out_stats) {          // over the 16 tokens held by the lanes with the same lg
-                    double S, Q;
-                    mi_stat_reduce16(y, a < C && ok, lane, S, Q);
-                    csum[4 * mt + r] += S;
-                    csq[4 * mt + r] += Q;
-                }
-            }
-    }
-    if (p.out_stats) {
-        // ... then over the 4 waves
-        if (lq == 0) {
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int a = 16 * mt + 4 * lg + r;
-                    red[wave][2 * a] = csum[4 * mt + r];
-                    red[wave][2 * a + 1] = csq[4 * mt + r];
-                }
-        }
-        __syncthreads();
-        if (tid < 2 * C) {
-            const double a4 = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
-            p.out_stats[((size_t)(b * C + (tid >> 1)) * tiles + tile) * 2 + (tid & 1)] = a4;
-        }
-    }
-}
-
 
 // ---- variant 6: the same algorithm with both contractions as 3-term fp16 splits on the real matrix cores.
 // Measured on MI355X (profiles/r01_mfma_valu_overlap_ubench.txt): v_mfma_f32_16x16x4_f32 does not overlap with VALU work
@@ -276,7 +39,7 @@ __device__ __forceinline__ void split_f16(const float (&x)[4], f16x4& hi, f16x4&
 // L2 -> LDS traffic (1.1 GB per SR launch at 4 waves); statistics stay per 64-token tile (4 waves)
 template <int C, int JT, int WPS, bool HALF, int NWV>
 __global__ __launch_bounds__(64 * NWV, WPS) void cross_attn_f16x3_kernel(const mi_cross_attn_params p) {
-    constexpr int KC = (C + 15) / 16, MT = (C + 15) / 16, FRH = 8 * KC + 8 * MT, TOK_WG = 16 * NWV, NT = 64 * NWV;
+    constexpr int KC = (C + 15) / 16, MT = (C + 15) / 16, FRH = 8 * KC + 8 * MT, TOK_WG = 16 * NWV;
     constexpr int JP = (JT + 1) / 2;
     __shared__ double red[NWV][2 * 16 * MT];
     // One head's context fragments as they lie in global memory, [tile][chunk q][lane] 16 bytes: q < KC: G {4 hi | 4 lo}; q >= KC: the V
@@ -540,10 +303,9 @@ extern "C" int mi_cross_attn_fwd(const mi_cross_attn_params* pp, void* stream) {
     const int JT = (p.J + 15) / 16;
     // MinImagen's contexts: null + time tokens + 256 text rows (17 tiles), or null + time tokens only when the U-Net is called
     // without text (Unet.py:572: text is optional; 1 tile, fp16 kernel only)
-    if (JT != 17 && !(JT == 1 && (p.variant == 6 || p.variant == 7))) { mi_set_error("mi_cross_attn_fwd: context of %d rows (%d tiles) not instantiated (MinImagen: 1 + time tokens [+ 256])", p.J, JT); return MI_ERR_UNSUPPORTED; }
+    if (JT != 17 && JT != 1) { mi_set_error("mi_cross_attn_fwd: context of %d rows (%d tiles) not instantiated (MinImagen: 1 + time tokens [+ 256])", p.J, JT); return MI_ERR_UNSUPPORTED; }
     if (p.B2 <= 0 || p.HW <= 0) { mi_set_error("mi_cross_attn_fwd: empty problem"); return MI_ERR_INVALID; }
     if ((p.x.st || p.out_st) && p.variant != 7) { mi_set_error("mi_cross_attn_fwd: bf16 activation storage is variant 7 only"); return MI_ERR_UNSUPPORTED; }
-    // out_stats tiles are MI_ATTN_TOKENS_PER_WG tokens (NQ = 2); p.variant = 1 selects NQ = 1 (64-token tiles)
     if (p.variant == 6 || p.variant == 7) {      // fp16 MFMA (fragments from mi_attn_fold_rows with frag_f16 = 1): 6 = 3-term split (fp32-grade), 7 = single term
         // waves per workgroup (measured on MI355X): 8 for the SR bottleneck (4096 tokens: 0.53 -> 0.47 ms per pair of launches),
         // 16 for up to 1024 tokens (base U-Net)
@@ -552,13 +314,13 @@ extern "C" int mi_cross_attn_fwd(const mi_cross_attn_params* pp, void* stream) {
         const dim3 g6(((p.HW + 16 * nwv - 1) / (16 * nwv)) * p.B2);
 #define MI_ATTN16_LAUNCH(CC) \
         if (JT == 1) { \
-            if (p.variant == 6) hipLaunchKernelGGL(HIP_KERNEL_NAME(cross_attn_f16x3_kernel<CC, 1, 4, false, 8>), dim3(((p.HW + 127) / 128) * p.B2), dim3(512), 0, st, p); \
-            else hipLaunchKernelGGL(HIP_KERNEL_NAME(cross_attn_f16x3_kernel<CC, 1, 4, true, 8>), dim3(((p.HW + 127) / 128) * p.B2), dim3(512), 0, st, p); \
+            if (p.variant == 6) hipLaunchKernelGGL(HIP_KERNEL_NAME(cross_attn_f16x3_kernel<CC, 1, (CC <= 16 ? 4 : 2), false, 8>), dim3(((p.HW + 127) / 128) * p.B2), dim3(512), 0, st, p); \
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(cross_attn_f16x3_kernel<CC, 1, (CC <= 16 ? 4 : 2), true, 8>), dim3(((p.HW + 127) / 128) * p.B2), dim3(512), 0, st, p); \
         } else \
-        if (p.variant == 6 && nwv == 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(cross_attn_f16x3_kernel<CC, 17, 4, false, 8>), g6, dim3(512), 0, st, p); \
-        else if (p.variant == 6) hipLaunchKernelGGL(HIP_KERNEL_NAME(cross_attn_f16x3_kernel<CC, 17, 4, false, 16>), g6, dim3(1024), 0, st, p); \
-        else if (nwv == 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(cross_attn_f16x3_kernel<CC, 17, 4, true, 8>), g6, dim3(512), 0, st, p); \
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(cross_attn_f16x3_kernel<CC, 17, 4, true, 16>), g6, dim3(1024), 0, st, p);
+        if (p.variant == 6 && nwv == 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(cross_attn_f16x3_kernel<CC, 17, (CC <= 16 ? 4 : 2), false, 8>), g6, dim3(512), 0, st, p); \
+        else if (p.variant == 6) hipLaunchKernelGGL(HIP_KERNEL_NAME(cross_attn_f16x3_kernel<CC, 17, (CC <= 16 ? 4 : 2), false, 16>), g6, dim3(1024), 0, st, p); \
+        else if (nwv == 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(cross_attn_f16x3_kernel<CC, 17, (CC <= 16 ? 4 : 2), true, 8>), g6, dim3(512), 0, st, p); \
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(cross_attn_f16x3_kernel<CC, 17, (CC <= 16 ? 4 : 2), true, 16>), g6, dim3(1024), 0, st, p);
         switch (p.C) {
             case 8: MI_ATTN16_LAUNCH(8) break;
             case 16: MI_ATTN16_LAUNCH(16) break;
@@ -568,49 +330,8 @@ extern "C" int mi_cross_attn_fwd(const mi_cross_attn_params* pp, void* stream) {
 #undef MI_ATTN16_LAUNCH
         return mi_check_launch("cross_attn_f16x3_kernel");
     }
-    if (p.variant >= 3 && p.variant <= 5) {      // 16 / 32 tokens per wave with a register cap for 3, 4 / 2 waves per SIMD
-        const int tok3 = p.variant == 5 ? 128 : 64;
-        const dim3 g3(((p.HW + tok3 - 1) / tok3) * p.B2);
-        if (p.C != 16 && p.C != 8 && p.C != 32) { mi_set_error("mi_cross_attn_fwd: folded path instantiated for C in {8,16,32}, got %d", p.C); return MI_ERR_UNSUPPORTED; }
-#define MI_ATTN_LAUNCH(CC) \
-        if (p.C == CC) { \
-            if (p.variant == 3) hipLaunchKernelGGL(HIP_KERNEL_NAME(cross_attn_folded_kernel<CC, 1, 17, false, 3>), g3, dim3(256), 0, st, p); \
-            else if (p.variant == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(cross_attn_folded_kernel<CC, 1, 17, false, 4>), g3, dim3(256), 0, st, p); \
-            else hipLaunchKernelGGL(HIP_KERNEL_NAME(cross_attn_folded_kernel<CC, 2, 17, false, 2>), g3, dim3(256), 0, st, p); \
-        }
-        MI_ATTN_LAUNCH(8) MI_ATTN_LAUNCH(16) MI_ATTN_LAUNCH(32)
-#undef MI_ATTN_LAUNCH
-        return mi_check_launch("cross_attn_folded_kernel");
-    }
-    if (p.variant == 2) {      // 16 tokens per wave, QK^T of the next head software-pipelined under the softmax
-        const dim3 g2(((p.HW + 63) / 64) * p.B2);
-        switch (p.C) {
-            case 8: hipLaunchKernelGGL(HIP_KERNEL_NAME(cross_attn_folded_kernel<8, 1, 17, true, 1>), g2, dim3(256), 0, st, p); break;
-            case 16: hipLaunchKernelGGL(HIP_KERNEL_NAME(cross_attn_folded_kernel<16, 1, 17, true, 1>), g2, dim3(256), 0, st, p); break;
-            case 32: hipLaunchKernelGGL(HIP_KERNEL_NAME(cross_attn_folded_kernel<32, 1, 17, true, 1>), g2, dim3(256), 0, st, p); break;
-            default: mi_set_error("mi_cross_attn_fwd: folded path instantiated for C in {8,16,32}, got %d", p.C); return MI_ERR_UNSUPPORTED;
-        }
-        return mi_check_launch("cross_attn_folded_kernel");
-    }
-    const int nq = p.variant == 1 ? 1 : 2;
-    const int tok = 64 * nq;
-    const dim3 grid(((p.HW + tok - 1) / tok) * p.B2);
-    if (nq == 1) {
-        switch (p.C) {
-            case 8: hipLaunchKernelGGL(HIP_KERNEL_NAME(cross_attn_folded_kernel<8, 1, 17, false, 2>), grid, dim3(256), 0, st, p); break;
-            case 16: hipLaunchKernelGGL(HIP_KERNEL_NAME(cross_attn_folded_kernel<16, 1, 17, false, 2>), grid, dim3(256), 0, st, p); break;
-            case 32: hipLaunchKernelGGL(HIP_KERNEL_NAME(cross_attn_folded_kernel<32, 1, 17, false, 2>), grid, dim3(256), 0, st, p); break;
-            default: mi_set_error("mi_cross_attn_fwd: folded path instantiated for C in {8,16,32}, got %d", p.C); return MI_ERR_UNSUPPORTED;
-        }
-        return mi_check_launch("cross_attn_folded_kernel");
-    }
-    switch (p.C) {
-        case 8: hipLaunchKernelGGL(HIP_KERNEL_NAME(cross_attn_folded_kernel<8, 2, 17, false, 1>), grid, dim3(256), 0, st, p); break;
-        case 16: hipLaunchKernelGGL(HIP_KERNEL_NAME(cross_attn_folded_kernel<16, 2, 17, false, 1>), grid, dim3(256), 0, st, p); break;
-        case 32: hipLaunchKernelGGL(HIP_KERNEL_NAME(cross_attn_folded_kernel<32, 2, 17, false, 1>), grid, dim3(256), 0, st, p); break;
-        default: mi_set_error("mi_cross_attn_fwd: folded path instantiated for C in {8,16,32}, got %d", p.C); return MI_ERR_UNSUPPORTED;
-    }
-    return mi_check_launch("cross_attn_folded_kernel");
+    mi_set_error("mi_cross_attn_fwd: variant %d (6 = 3-term fp16 split, fp32-grade; 7 = single fp16 term: the reduced-precision configuration)", p.variant);
+    return MI_ERR_UNSUPPORTED;
 }
 
 // =====================================================================================================

@@ -435,8 +435,7 @@ int dispatch_tile(const mi_conv_params& p, hipStream_t st) {
 
 extern "C" int mi_conv_tile_shape(int tile_cfg, int* th, int* tw) {
     switch (tile_cfg & 0xff) {
-        case 5: *th = 16; *tw = 64; return MI_OK;     // row-paired matrix-core path (conv_rp.hip)
-        case 6: *th = 8; *tw = 64; return MI_OK;
+        case 6: *th = 8; *tw = 64; return MI_OK;      // row-paired matrix-core path (conv_rp.hip)
         case 7: *th = 8; *tw = 32; return MI_OK;
         case 10: *th = 16; *tw = 16; return MI_OK;    // (wide k3 s1 member only)
         case 11: *th = 8; *tw = 16; return MI_OK;     // wide GEMM kernel (conv_wide.hip)

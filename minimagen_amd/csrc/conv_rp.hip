@@ -82,7 +82,16 @@ struct RpCfg {
     // back to back: the 17 conv launches of the SR U-Net's 64^2 level 423 -> 383 us, SR step 1.461 -> 1.425 ms (profiles/r05_summary.md)
     // (the wide regime's four-N-tile kernels also spill at three, 39 registers, but measured no better at two: 32.9 vs 32.5 ms per step of Unet())
     // (16 x 64 tiles at 256^2, with or without their 17 spills: 285 / 327 us against 270-277 us for the four launches on 8 x 64 tiles)
-    static constexpr int WPS = (NJ_ == 1 && TH_ * TW_ <= 512 && (KO_ + RO_ == 1 || TH_ * TW_ <= 256)) ? 4 : ((NJ_ >= 2 && TH_ * TW_ == 512) ? 2 : 3);
+    static constexpr int WPS_BASE = (NJ_ == 1 && TH_ * TW_ <= 512 && (KO_ + RO_ == 1 || TH_ * TW_ <= 256)) ? 4 : ((NJ_ >= 2 && TH_ * TW_ == 512) ? 2 : 3);
+    // (round 6, tools/check_code_objects.py: the members with a 1x1 residual conv -- more rounds of raw registers in flight -- and the single-term
+    //  k4 s2 members spilled 12 .. 84 bytes at these targets: one wave per SIMD less for them)
+    static constexpr int WPS_REG = ((RO_ > 0 || (MODE_ == 2 && HALF_)) && WPS_BASE > 2) ? WPS_BASE - 1 : WPS_BASE;
+    // ... and never more than the LDS of a CU holds workgroups (one wave per SIMD each): asking for an occupancy the LDS forbids only costs
+    // registers (spills) -- 12 "failed to meet occupancy target" build warnings until round 6
+    static constexpr int WCH_ = NSTEP * NJ_ * 128, WTOT_ = KO_ >= 0 ? KO_ * WCH_ + RO_ * NJ_ * 128 : WCH_;
+    static constexpr int LDS_EST = PLANE * 16 * (HALF_ ? 1 : 2) + (HALF_ ? 16 : 0) + WTOT_ * 16 + 64 * 16 + 4 * 64 * 8 + 2 * 32 * 4 + 4 * NJ_ * (MODE_ == 2 ? 32 : 16) * 8 + 16;
+    static constexpr int WPS_LDS = 163840 / LDS_EST < 1 ? 1 : 163840 / LDS_EST;
+    static constexpr int WPS = WPS_REG < WPS_LDS ? WPS_REG : WPS_LDS;
 };
 
 template <class CFG>
@@ -832,10 +841,9 @@ int mi_conv_rp_launch(const mi_conv_params& p, hipStream_t st) {
         return MI_ERR_INVALID;
     }
     switch (p.tile_cfg & 0xff) {
-        case 5: return launch_rp_nj<16, 64, 0>(p, st);
         case 6: return launch_rp_nj<8, 64, 0>(p, st);
         case 7: return launch_rp_nj<8, 32, 0>(p, st);
     }
-    mi_set_error("mi_conv_fwd: row-paired path uses tile_cfg 5 (16x64), 6 (8x64) or 7 (8x32)");
+    mi_set_error("mi_conv_fwd: row-paired path uses tile_cfg 6 (8x64) or 7 (8x32) (5, 16x64 tiles, was removed in round 6: measured slower, profiles/r05_summary.md r05l)");
     return MI_ERR_INVALID;
 }

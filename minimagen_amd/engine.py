@@ -25,19 +25,12 @@ from .layers import Attention, CrossAttention, EinopsToAndFrom, Identity, Parall
 
 MAX_TEXT_LEN = 256
 # kernel-shape tuning knobs (A/B measurements; the defaults are what profiles/ was measured with)
-ATTN_VARIANT = int(os.environ.get("MINIMAGEN_ATTN_VARIANT", "6"))       # 6: fp16x3 MFMA (default); 0/1/3/4/5: exact-fp32 MFMA shapes
-CONV_SPLIT16 = int(os.environ.get("MINIMAGEN_CONV_SPLIT16", "1"))
 CONV_SPLIT8 = int(os.environ.get("MINIMAGEN_CONV_SPLIT8", "64"))        # 8-channel outputs of images up to SPLIT8^2 pixels as two 4-channel workgroups (0 = off)
 CONV_RP = int(os.environ.get("MINIMAGEN_CONV_RP", "2"))                 # 1: narrow k3 s1 convs (channels in multiples of 8, <= 64 in) on the row-paired matrix-core kernel; 2: also nearest-x2 + k3 and k4 s2
-RP_TILE = {k: int(os.environ.get("MINIMAGEN_RP_TILE_" + k, d)) for k, d in (("L", "6"), ("M", "6"), ("S", "6"))}   # tile_cfg for images > 128^2 / > 64^2 / smaller
-RP_TILE_WIDE = int(os.environ.get("MINIMAGEN_RP_TILE_WIDE", "6"))          # tile of the wide k3 s1 convs: 6 = 8x64 where the image is a multiple of 64 wide (the B fragments of a round serve twice the pixels: Unet() default 32.2 -> 31.7 ms per step), 7 = 8x32
 CONV_WIDE_GEMM = os.environ.get("MINIMAGEN_CONV_WIDE_GEMM", "1") != "0"   # wide k3 s1 convs (channels in multiples of 32 in / 64 out) on the GEMM kernel with prepared operand planes (conv_wide.hip)
 COND_GEMM = int(os.environ.get("MINIMAGEN_COND_GEMM", "2048"))           # stacked time-MLPs with at least this many rows run as one GEMM per step (0 = always inside cond_step_kernel)
 FLASH_KV_PREP = os.environ.get("MINIMAGEN_FLASH_KV_PREP", "1") != "0"     # multi-query self-attention of the wide presets: K / V prepared once per launch, LDS-DMA into the workgroups
-RP_TILE_WIDE16 = os.environ.get("MINIMAGEN_RP_TILE_WIDE16", "1") != "0"    # wide k3 s1 convs on images <= 16 wide: 16x16 tiles (an 8x32 tile is half outside such an image)
-RP_MIN_HW = int(os.environ.get("MINIMAGEN_RP_MIN_HW", "0"))             # ... for images of at least this many pixels
 CE_MFMA = os.environ.get("MINIMAGEN_CE_MFMA", "1") != "0"                  # CrossEmbed on the matrix cores (0: the fp32 VALU kernel)
-STORE16 = os.environ.get("MINIMAGEN_STORE16", "1") != "0"                  # reduced-precision configuration: bf16 activation storage
 CONV_REVERSE = int(os.environ.get("MINIMAGEN_CONV_REVERSE", "1"))        # a row-paired conv walks the image groups opposite to its producer (0 = off)
 RP_NTILE = int(os.environ.get("MINIMAGEN_RP_NTILE", "0"))               # tiles per workgroup of the row-paired kernel (0 = the library's choice)
 RP_NTILE_BY = {k: int(os.environ.get("MINIMAGEN_RP_NTILE_" + k, "0")) for k in ("L", "M", "S")}     # ... per image-size class (> 128^2 / > 64^2 / smaller)
@@ -55,8 +48,6 @@ ST_NBLK = {k: int(os.environ.get("MINIMAGEN_ST_NBLK_" + k, "0")) for k in ("L", 
 # workgroups leave the other lane's kernels room, as with RP_NTILE_PIPE: 46.7 K against 45.8 K steps/s, same box back to back; L / M: no effect
 # (profiles/r06_summary.md)
 ST_NBLK_PIPE = {k: int(os.environ.get("MINIMAGEN_ST_NBLK_PIPE_" + k, d)) for k, d in (("L", "0"), ("M", "0"), ("S", "4"))}
-TILE64 = int(os.environ.get("MINIMAGEN_TILE64", "-1"))                  # force a conv tile shape at 64x64 / 128x128 (experiments)
-TILE128 = int(os.environ.get("MINIMAGEN_TILE128", "-1"))       # 1: 16-channel 3x3 outputs as two 8-channel workgroups
 WEIGHT_FINGERPRINT = os.environ.get("MINIMAGEN_WEIGHT_FINGERPRINT", "1") != "0"   # content fingerprint of the weights at every public call (see pack())
 JT = 17     # context tiles of 16 rows: 1 null + (2|4) time tokens + 256 text rows <= 272
 
@@ -374,7 +365,7 @@ class UnetEngine:
         ws.text_L = None
         # reduced-precision configuration: activations in bf16 (BASELINE configs 3-5) when every layer runs on a kernel that reads them
         # (row-paired convs, matrix-core CrossEmbed, fp16 cross-attention: the BASELINE U-Nets); otherwise fp32 storage
-        for store16 in ((True, False) if (ws.half and STORE16) else (False,)):
+        for store16 in ((True, False) if ws.half else (False,)):
             ws.store16 = store16
             ws.gv, ws.tensors, ws.prog, ws.prog_text, ws.wide_attn = {}, [], [], [], False     # (prog_text: the wide cross-attentions' text keys / values)
             ws.ig_convs = []                 # wide GEMM convs: their operand planes share ONE buffer (the launches of a workspace are ordered)
@@ -396,10 +387,6 @@ class UnetEngine:
         batch is, so that a sharded batch reproduces the unsharded rows bit for bit."""
         lib = L.lib()
         best = 0 if (W >= 64 and H * W > 64 * 64) else 2
-        if H * W == 64 * 64 and TILE64 >= 0:
-            best = TILE64
-        if H * W == 128 * 128 and TILE128 >= 0:
-            best = TILE128
         th, tw = C.c_int(), C.c_int()
         lib.mi_conv_tile_shape(best, C.byref(th), C.byref(tw))
         return best, -(-H // th.value) * -(-W // tw.value)
@@ -448,34 +435,32 @@ class UnetEngine:
         # tiled over the grid, GroupNorm affine + operand exponents from a small per-image launch (mi_gn_coef_fwd) ahead of the conv
         cres = 0 if (res is None or res[2] is None) else res[0].C + (res[1].C if res[1] is not None else 0)
         rp = bool(CONV_RP) and ((ksize == 3 and stride == 1) or (ksize == 4 and stride == 2 and not up2 and CONV_RP >= 2)) \
-            and (not up2 or CONV_RP >= 2) and Wo % 4 == 0 and id(wpack) in pk.conv_rp and Ho * Wo >= RP_MIN_HW \
+            and (not up2 or CONV_RP >= 2) and Wo % 4 == 0 and id(wpack) in pk.conv_rp \
             and in0.C % 8 == 0 and (in1 is None or in1.C % 8 == 0) \
             and (res is None or res[2] is None or (id(res[2]) in pk.conv_rp and res[0].C % 8 == 0 and (res[1] is None or res[1].C % 8 == 0)))
         narrow = cin_tot <= 64 and cres <= 64 and Cout <= (16 if stride == 2 else (8 if up2 else 32))
         wide = rp and not narrow
         stripe = False
         if rp:
-            cfg = RP_TILE["L"] if Ho * Wo > 128 * 128 else (RP_TILE["M"] if Ho * Wo > 64 * 64 else RP_TILE["S"])
-            if Ho * Wo <= 64 * 64 and (Wo <= 32 or Cout <= 8) and "MINIMAGEN_RP_TILE_S" not in os.environ:
+            cfg = 6                      # 8 x 64 tiles
+            if Ho * Wo <= 64 * 64 and (Wo <= 32 or Cout <= 8):
                 cfg = 7                  # measured: 8x32 tiles for 8-channel layers at <= 64^2 (twice the workgroups) and for images no
                                          # wider than a tile; 16 output channels at 64^2 stay on 8x64 (B fragments staged per workgroup)
-            if Cout > 8 and cfg == 5:
-                cfg = 6
             if Cout > 16:
                 cfg = 7                  # four N tiles are only instantiated for the 8x32 tile
             if up2:
                 cfg = 6                  # the up- / down-sampling members have one tile shape each
             if stride == 2 or wide:
                 cfg = 7
-            if wide and RP_TILE_WIDE == 6 and stride == 1 and not up2 and Wo % 64 == 0 and Cout >= 32 and not ws.half:
+            if wide and stride == 1 and not up2 and Wo % 64 == 0 and Cout >= 32 and not ws.half:
                 cfg = 6                  # 8 x 64 tiles for the wide k3 s1 convs
-            if wide and RP_TILE_WIDE16 and stride == 1 and not up2 and Wo <= 16 and Ho > 8 and Cout >= 32 and not ws.half:
+            if wide and stride == 1 and not up2 and Wo <= 16 and Ho > 8 and Cout >= 32 and not ws.half:
                 cfg = 10                 # 16 x 16 tiles for images no wider than 16
             gemm = wide and ksize == 3 and stride == 1 and (not up2 or res is None) and not ws.half and cin_tot % 32 == 0 and cres % 32 == 0 and Cout % 64 == 0 \
                 and id(wpack) in pk.conv_ig and (cres == 0 or id(res[2]) in pk.conv_ig)
             if gemm:
                 cfg = 11                 # the wide GEMM kernel (conv_wide.hip): 8 x 16 pixels x 128 (or 64) channels per workgroup
-            th, tw = {5: (16, 64), 6: (8, 64), 7: (8, 32), 10: (16, 16), 11: (8, 16)}[cfg]
+            th, tw = {6: (8, 64), 7: (8, 32), 10: (16, 16), 11: (8, 16)}[cfg]
             nt = -(-Ho // th) * -(-Wo // tw)
             cls = "L" if Ho * Wo > 128 * 128 else ("M" if Ho * Wo > 64 * 64 else "S")
             if narrow and ksize == 3 and stride == 1 and not ws.half and cls in CONV_STRIPE:
@@ -503,7 +488,7 @@ class UnetEngine:
                 p.res1 = r1.c(batch, skip_scale)
             p.res_w, p.res_b = L.ptr(rw), L.ptr(rb)
         p.out_st = out.st
-        p.out, p.out_stats, p.tile_cfg = L.ptr(out.t), L.ptr(out.stats), cfg | (0x100 if CONV_SPLIT16 else 0) | (0x400 if ws.half else 0) | (0x800 if (CONV_SPLIT8 and Ho * Wo <= CONV_SPLIT8 * CONV_SPLIT8) else 0)
+        p.out, p.out_stats, p.tile_cfg = L.ptr(out.t), L.ptr(out.stats), cfg | 0x100 | (0x400 if ws.half else 0) | (0x800 if (CONV_SPLIT8 and Ho * Wo <= CONV_SPLIT8 * CONV_SPLIT8) else 0)
         if wide:
             coef = torch.zeros(batch, cin_tot, 4, dtype=torch.float32, device=ws.dev)
             exps = torch.zeros(batch, 2, dtype=torch.int32, device=ws.dev)
@@ -666,13 +651,11 @@ class UnetEngine:
         Cc, HW = h.C, h.H * h.W
         if Cc not in (8, 16, 32):
             return self._emit_cross_attn_wide(ws, ca, h)
-        if ws.store16 and ATTN_VARIANT != 6:
-            raise _Store16Unsupported()
         FR = lib.mi_attn_fragment_floats(Cc)
-        jts = ws.JT + (ws.JT & 1) if ATTN_VARIANT == 6 else ws.JT            # fp16 fragments: V chunks live per PAIR of context tiles
+        jts = ws.JT + (ws.JT & 1)            # fp16 fragments: V chunks live per PAIR of context tiles
         gv = torch.zeros(ws.B2, ca.heads, jts, 64, FR, dtype=torch.float32, device=ws.dev)        # zero-filled: padded context rows must read as finite
         ws.gv[id(ca)] = gv
-        nt = -(-HW // (128 if ATTN_VARIANT in (0, 5) else 64))
+        nt = -(-HW // 64)
         out = self._new_act(ws, ws.B2, Cc, h.H, h.W, nt)
         p = L.MiCrossAttnParams()
         p.B2, p.C, p.HW, p.heads, p.J = ws.B2, Cc, HW, ca.heads, ws.J
@@ -681,9 +664,8 @@ class UnetEngine:
         p.n1_g, p.n1_b = L.ptr(ca.norm.gamma), L.ptr(ca.norm.beta)
         p.n2_g, p.n2_b = L.ptr(ca.to_out[1].gamma), L.ptr(ca.to_out[1].beta)
         p.out_st = out.st
-        p.out, p.out_stats, p.variant = L.ptr(out.t), L.ptr(out.stats), (7 if (ws.half and ATTN_VARIANT == 6) else ATTN_VARIANT)
-        if ATTN_VARIANT == 6:
-            p.x_exp, p.g_exp, p.v_exp = pk.attn_exp[id(ca)]
+        p.out, p.out_stats, p.variant = L.ptr(out.t), L.ptr(out.stats), (7 if ws.half else 6)       # 3-term fp16 split (fp32-grade) / single term
+        p.x_exp, p.g_exp, p.v_exp = pk.attn_exp[id(ca)]
         ws.prog.append((lib.mi_cross_attn_fwd, p, "cross_attn"))
         return out
 
@@ -757,12 +739,11 @@ class UnetEngine:
                 p = L.MiAttnFoldParams()
                 p.B2, p.C, p.cd, p.heads, p.JT = ws.B2, ca0.to_q.in_features, self.unet.cond_dim, ca0.heads, ws.JT
                 p.c_rows, p.c_stride_b, p.row0, p.nrows, p.write_null = L.ptr(rows_t), stride_b, row0, nrows, write_null
-                p.frag_f16 = 1 if ATTN_VARIANT == 6 else 0
+                p.frag_f16 = 1
                 p.n_blocks = len(chunk)
                 for k, cid in enumerate(chunk):
                     mg, mv, g0, v0 = pk.attn[cid]
-                    if ATTN_VARIANT == 6:
-                        _, p.blk[k].g_exp, p.blk[k].v_exp = pk.attn_exp[cid]
+                    _, p.blk[k].g_exp, p.blk[k].v_exp = pk.attn_exp[cid]
                     p.blk[k].mg, p.blk[k].mv, p.blk[k].g0, p.blk[k].v0 = L.ptr(mg), L.ptr(mv), L.ptr(g0), L.ptr(v0)
                     p.blk[k].gv = L.ptr(ws.gv[cid])
                 calls.append((lib.mi_attn_fold_rows, p, "fold"))

@@ -114,11 +114,11 @@ def test_conv_family(backend, case):
 
 RP_CASES = [
     # B, C0, C1, Cout, H, W, gn, ss, res, tile_cfg, xscale, wscale
-    (2, 8, 0, 8, 16, 64, True, True, 'id', 5, 1.0, 1.0),
-    (1, 8, 8, 8, 24, 72, True, True, 'conv2', 5, 1.0, 1.0),          # ragged tile edges, concat input, 1x1 residual over a concat
+    (2, 8, 0, 8, 16, 64, True, True, 'id', 6, 1.0, 1.0),
+    (1, 8, 8, 8, 24, 72, True, True, 'conv2', 6, 1.0, 1.0),          # ragged tile edges, concat input, 1x1 residual over a concat
     (8, 16, 0, 16, 16, 32, True, True, 'id', 7, 1.0, 1.0),           # B % 8 == 0: the XCD-aware workgroup -> image map
     (1, 16, 16, 16, 20, 64, True, False, 'conv', 6, 1.0, 1.0),
-    (1, 8, 0, 3, 16, 64, False, False, 'none', 5, 1.0, 1.0),          # final conv (Cout 3 -> one padded N tile)
+    (1, 8, 0, 3, 16, 64, False, False, 'none', 6, 1.0, 1.0),          # final conv (Cout 3 -> one padded N tile)
     (1, 32, 0, 32, 8, 32, True, True, 'none', 7, 1.0, 1.0),           # four N tiles
     (1, 8, 0, 8, 16, 64, True, True, 'id', 6, 256.0, 256.0),          # range safety of the fp16 split: large / small operands
     (1, 8, 8, 8, 16, 32, True, False, 'conv', 7, 1.0 / 256, 1.0 / 256),
@@ -614,9 +614,7 @@ def test_crossembed_bf16_output(backend, case):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
-@pytest.mark.parametrize("case", [(2, 16, 256, 8, 2, 0), (1, 16, 200, 8, 4, 0), (1, 8, 128, 8, 2, 0), (1, 32, 128, 16, 2, 0),
-                                  (8, 16, 200, 8, 4, 1), (1, 8, 128, 8, 2, 1), (2, 16, 256, 8, 4, 2), (2, 16, 256, 8, 4, 3), (1, 8, 200, 8, 2, 4), (1, 16, 256, 8, 4, 5),
-                                  (2, 16, 200, 8, 4, 6), (1, 8, 128, 8, 2, 6), (1, 32, 128, 16, 2, 6),
+@pytest.mark.parametrize("case", [(2, 16, 256, 8, 2, 6), (8, 16, 200, 8, 4, 6), (2, 16, 200, 8, 4, 6), (1, 8, 128, 8, 2, 6), (1, 8, 200, 8, 2, 6), (1, 32, 128, 16, 2, 6),
                                   # range safety of the fp16 split (variant 6): checkpoint weights / context rows far from unit scale
                                   (1, 16, 128, 8, 2, 6, 256.0, 1.0 / 256, 1.0), (1, 16, 128, 8, 2, 6, 1.0 / 64, 300.0, 40.0), (1, 8, 128, 8, 4, 6, 30.0, 30.0, 0.01)])
 def test_cross_attention_folded(backend, case):

@@ -1,6 +1,6 @@
 """Development aid: time ONE conv launch shape of the SR / base U-Net in isolation on the GPU (HIP events, back to back) and, with the
 -DMI_TRACE build of the library (MINIMAGEN_HIP_LIB=.../libminimagen_hip_trace.so), print the per-phase shader-clock breakdown of
-conv_rp.hip.   python tools/bench_conv.py B Cin Cout H W gn res(none|id|conv) path(rp5|rp6|rp7|old|w6|w7|w10: the wide regime) [C1]"""
+conv_rp.hip.   python tools/bench_conv.py B Cin Cout H W gn res(none|id|conv) path(rp6|rp7|rp12: full-width stripes|old|w6|w7|w10: the wide regime) [C1]"""
 import ctypes as C
 import os
 import sys
@@ -151,7 +151,7 @@ if __name__ == "__main__":
         for nt in (1, 2, 4, 8):
             os.environ["NTILE"] = str(nt)
             print("NTILE", nt)
-            for path in ("rp5", "rp6"):
+            for path in ("rp12", "rp6"):
                 run(64, 8, 8, 256, 256, True, "id", path)
             run(64, 8, 3, 256, 256, False, "none", "rp6")
             for path in ("rp6", "rp7"):
