@@ -506,7 +506,8 @@ class UnetEngine:
                 nt_knob = RP_NTILE_PIPE[cls]        # (only while the launch still has a workgroup per CU: smaller batches keep the library's choice -- config 3 at B = 16: 39.1 K with, 40.7 K without)
             if stripe:                              # statistics blocks per workgroup of the stripe kernel (must divide the blocks of an image)
                 nt_knob = ST_NBLK[cls]
-                if ws.pipelined and ST_NBLK_PIPE[cls] and nt % ST_NBLK_PIPE[cls] == 0 and batch * nt // ST_NBLK_PIPE[cls] >= 128:
+                if ws.pipelined and ST_NBLK_PIPE[cls] and nt % ST_NBLK_PIPE[cls] == 0 and batch * nt // ST_NBLK_PIPE[cls] >= 128 \
+                        and self.unet.lowres_cond:       # (super-resolution U-Nets only: on the base U-Net it costs the base stage 7 %: 97.1 against 104.8 K steps/s, and gives the cascade nothing)
                     nt_knob = ST_NBLK_PIPE[cls]
                 if nt_knob and (nt % nt_knob or nt_knob > 15):
                     nt_knob = 0

@@ -343,6 +343,40 @@ with red.no_sync():                         # an accumulation step: no collectiv
     local = [p.grad.clone() for p in im.unets[0].parameters()]
 assert red.finish() == 0 and all(torch.equal(a, p.grad) for a, p in zip(local, im.unets[0].parameters()))
 red.remove()
+# ---- a FULL data-parallel training step on the two ranks (train.py:99-102 / training.py:344-478 semantics: backward -> gradient-norm clip at 50 ->
+# Adam): shard backward with the hook-overlapped reduction, clip, minimagen_amd.optim.Adam.step -- against the same step taken on the whole batch by
+# one process' worth of arithmetic; afterwards both ranks hold the same parameters
+import copy
+from minimagen_amd.optim import Adam
+params = list(im.unets[0].parameters())
+start = [p.detach().clone() for p in params]
+def one_step(shard):
+    for p, s0 in zip(params, start):
+        p.data.copy_(s0)
+    opt = Adam(params, lr=1e-2, eps=1e-3)          # (a large eps: with Adam's default a gradient of ~1e-12 whose rounding noise flips sign moves its parameter by +-lr)
+    r2 = GradientBucketReducer(params, bucket_mb=0.01) if shard else None
+    for it in range(2):                      # two steps: the second sees the first one's moments
+        im.zero_grad(set_to_none=True)
+        if shard:
+            (loss_of(slice(lo, hi)).sum() / (hi - lo)).backward()
+            r2.finish()
+        else:
+            loss_of(slice(0, B)).mean().backward()
+        torch.nn.utils.clip_grad_norm_(params, 50)
+        opt.step()
+    if r2 is not None:
+        r2.remove()
+    return [p.detach().clone() for p in params]
+after_dp = one_step(True)
+after_full = one_step(False)
+for a, f, s0 in zip(after_dp, after_full, start):
+    assert (a - f).abs().max() < 1e-5 * max(1.0, float(f.abs().max())), "the two-rank step differs from the full-batch step"
+assert any((a - s0).abs().max() > 1e-4 for a, s0 in zip(after_dp, start)), "the step did not move the parameters"
+flat = torch.cat([a.reshape(-1).double() for a in after_dp]).cpu()
+both = [torch.zeros_like(flat) for _ in range(2)]
+dist.all_gather(both, flat) if backend == "gloo" else dist.all_gather([b.to(dev) for b in both], flat.to(dev))
+if backend == "gloo":
+    assert torch.equal(both[0], both[1]), "the ranks' parameters diverged after a data-parallel step"
 dist.barrier()
 dist.destroy_process_group()
 print("ok")
@@ -350,8 +384,9 @@ print("ok")
 
 
 def test_allreduce_gradients_world_size_2_gloo(tmp_path):
-    """data-parallel training step on two ranks: each differentiates its contiguous shard, allreduce_gradients (bucketed, averaged) leaves
-    every rank with the gradient of the whole batch"""
+    """data-parallel training on two ranks: each differentiates its contiguous shard, allreduce_gradients (bucketed, averaged) leaves every rank
+    with the gradient of the whole batch; the hook-overlapped GradientBucketReducer gives the same gradients; and two FULL steps (backward ->
+    overlapped reduction -> clip -> Adam) move the parameters exactly as the full-batch step does, identically on both ranks"""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
