@@ -64,9 +64,11 @@ namespace {
 // counts conservative: the wait for step it's residual then also waits for the stores of step it - 1 and for the residual loads of step it + 1
 // that were issued a moment ago (seen in the ISA of the first version: vmcnt(3) .. (0) in every step).
 // (Launches with a 1x1 residual conv stay on the tile kernel: the residual octets' ring rows would leave one workgroup per CU.)
-template <int W_, int KO_, int NJ_, bool GN_, int OM_>
+// RO_: channel octets of a 1x1 residual conv's input (ResnetBlock.res_conv over the block's input, layers.py:415,439): extra loader waves bring the two
+// rows of the step's own output positions (no halo: the centre tap only) into a 4-row ring of their own; one more MFMA triple per octet and group.
+template <int W_, int KO_, int NJ_, bool GN_, int OM_, int RO_ = 0>
 struct StCfg {
-    static constexpr int W = W_, KO = KO_, NJ = NJ_, OM = OM_;
+    static constexpr int W = W_, KO = KO_, NJ = NJ_, OM = OM_, RO = RO_;
     static constexpr bool GN = GN_;
     // loader units per step: 2 rows x pixel quads x octets (x 2 channel halves: HS).  A work-item owns 4 consecutive pixels of one row and the 8
     // (HS: 4) channels of one (half) octet: that many dwordx4 loads per step, TWO steps in flight, issued unconditionally and unrolled by two so that
@@ -76,13 +78,18 @@ struct StCfg {
     static constexpr int WS = UP ? W_ / 2 : W_, RPS = UP ? 1 : 2, NPR = UP ? 3 : 4;       // source width, new source rows per step, rows of the prologue
     static constexpr bool HS = W_ < 256 && ST_HALF_OCTETS;
     static constexpr int NCH = HS ? 4 : 8;
-    static constexpr int QPR = WS / 4, UNITS = RPS * QPR * KO * (HS ? 2 : 1), NLW = (UNITS + 63) / 64;
+    static constexpr int QPR = WS / 4, UNITS = RPS * QPR * KO * (HS ? 2 : 1), NLWC = (UNITS + 63) / 64;
+    static constexpr int UNITS_R = 2 * QPR * RO, NLWR = (UNITS_R + 63) / 64, NLW = NLWC + NLWR;      // residual rows: whole octets (a plain scaling: cheap)
     static constexpr int NG = W_ / 16, NCW = NG >= 4 ? 4 : NG, GPW = NG / NCW;             // 16-pixel groups of a row pair, MFMA waves
     static constexpr int NT = (NLW + NCW) * 64;
-    static constexpr int PW = WS + 8, RING = 6, PLANE = KO * RING * PW;
+    static constexpr int PW = WS + 8, RING = 6, RINGR = 4, PLANE = (KO * RING + RO * RINGR) * PW;
     static constexpr int SR0 = W_ / 8;                                                      // rows per statistics block
-    static constexpr int WCH = 3 * NJ * 128, WTOT = KO * WCH;                               // 16-byte chunks of B fragments
-    static constexpr bool BREG = ST_BREG && KO == 1 && NJ == 1;
+    static constexpr int WCH = 3 * NJ * 128, WTOT = KO * WCH + RO * NJ * 128;               // 16-byte chunks of B fragments
+    static constexpr bool BREG = ST_BREG && KO == 1 && NJ == 1 && RO == 0;
+    static_assert(RO == 0 || (OM_ == 0 && GN_), "a 1x1 residual conv comes with a Block and replaces the identity residual");
+    // waves per SIMD the register allocation must leave room for: the 128-wide residual-conv member has eight waves per workgroup and LDS for two
+    // workgroups per CU -- 136 registers would leave one
+    static constexpr int WPE = (RO > 0 && W_ == 128) ? 4 : 1;
     // prologue units of the MFMA waves: the stripe's first 4 input rows, as half octets where that still fits one pass
     static constexpr bool PHS = HS && 2 * NPR * QPR * KO <= NCW * 64;
     static constexpr int PCH = PHS ? 4 : 8, PU = NPR * QPR * KO * (PHS ? 2 : 1);
@@ -120,8 +127,8 @@ __device__ __forceinline__ bool st_totals_issue(const mi_act& in0, const mi_act&
 }
 
 template <class CFG>
-__global__ __launch_bounds__(CFG::NT) void conv_stripe_kernel(const mi_conv_params p, const uint4* __restrict__ wrp, const int nblk) {
-    constexpr int W = CFG::W, KO = CFG::KO, NJ = CFG::NJ, QPR = CFG::QPR, UNITS = CFG::UNITS, NLW = CFG::NLW, NLT = NLW;
+__global__ __launch_bounds__(CFG::NT, CFG::WPE) void conv_stripe_kernel(const mi_conv_params p, const uint4* __restrict__ wrp, const uint4* __restrict__ rwrp, const int nblk) {
+    constexpr int W = CFG::W, KO = CFG::KO, NJ = CFG::NJ, QPR = CFG::QPR, UNITS = CFG::UNITS, NLT = CFG::NLW, NLWC = CFG::NLWC, RO = CFG::RO, RINGR = CFG::RINGR;
     constexpr int NCW = CFG::NCW, GPW = CFG::GPW, PW = CFG::PW, RING = CFG::RING, SR0 = CFG::SR0, WCH = CFG::WCH, WTOT = CFG::WTOT, PU = CFG::PU;
     constexpr bool GN = CFG::GN, BREG = CFG::BREG, UP = CFG::UP;
     constexpr int WS = CFG::WS, RPS = CFG::RPS, NPR = CFG::NPR;
@@ -129,7 +136,7 @@ __global__ __launch_bounds__(CFG::NT) void conv_stripe_kernel(const mi_conv_para
     __shared__ __attribute__((aligned(16))) uint4 actL[CFG::PLANE];
     __shared__ __attribute__((aligned(16))) uint4 wl[BREG ? 1 : WTOT];
     __shared__ __attribute__((aligned(16))) float4 chP[RP_MAXC];
-    __shared__ double chS[RP_MAXC], chQ[RP_MAXC];
+    __shared__ double chS[RP_MAXC], chQ[RP_MAXC], chS2[RO ? RP_MAXC : 1], chQ2[RO ? RP_MAXC : 1];
     __shared__ double red[NCW][2 * 8 * NJ];
     __shared__ int sExp[4];
 
@@ -153,6 +160,8 @@ __global__ __launch_bounds__(CFG::NT) void conv_stripe_kernel(const mi_conv_para
     const int blk0 = sidx * nblk, y0 = blk0 * SR0, RS = nblk * SR0, NSTEP = RS / 2;
     const int C0 = p.in0.C, C1 = p.in1.data ? p.in1.C : 0, Cin = C0 + C1;
     const bool have_stats = !(ST_ABL & 4) && (GN || p.in0.stats != nullptr);
+    const int Cr0 = RO ? p.res0.C : 0, Cr1 = (RO && p.res1.data) ? p.res1.C : 0, Cres = Cr0 + Cr1;
+    const bool res_stats = RO > 0 && p.res0.stats != nullptr && (Cr1 == 0 || p.res1.stats != nullptr);
     // first element of the 8 channel planes of octet `oct` of image b (in0, then in1: the skip concatenation).  The two tensors' image bases are
     // formed ONCE from the (scalar) kernel arguments; a work-item then selects between two computed pointers.  (Selecting the struct FIELDS per
     // work-item -- `second ? p.in1.data : p.in0.data` -- compiles to a vector load from the kernel-argument segment with a per-lane address and a
@@ -207,7 +216,69 @@ __global__ __launch_bounds__(CFG::NT) void conv_stripe_kernel(const mi_conv_para
         }
     };
 
-    if (wave < NLT) {
+    if (RO > 0 && wave >= NLWC && wave < NLT) {
+        // =================================================================== residual-row loader waves (1x1 residual conv input, centre tap only)
+        const int u = (wave - NLWC) * 64 + lane;
+        const bool live = u < CFG::UNITS_R;
+        const int uu = live ? u : 0;
+        const int oct = uu / (2 * QPR), lrow = (uu / QPR) & 1, q = uu % QPR;
+        const float* const rimg0 = p.res0.data + (size_t)mi_row_of(b, p.res0.bmod) * Cr0 * HW;
+        const float* const rimg1 = Cr1 ? p.res1.data + (size_t)mi_row_of(b, p.res1.bmod) * Cr1 * HW : rimg0;
+        const bool second = 8 * oct >= Cr0;
+        const mi_gptr<const float> base = mi_global(second ? rimg1 + (size_t)(8 * oct - Cr0) * HW : rimg0 + (size_t)(8 * oct) * HW);
+        f32x4 raw[2][8];
+        auto issue = [&](int s, auto buf_tag) {            // step s: the rows of its two output rows (steps past the stripe re-read the last one)
+            constexpr int buf = decltype(buf_tag)::value;
+            const int y = y0 + 2 * (s < NSTEP ? s : NSTEP - 1) + lrow;
+            const unsigned off = (unsigned)(y * W + 4 * q);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) raw[buf][j] = *reinterpret_cast<mi_gptr<const f32x4>>(base + (size_t)j * HW + off);
+        };
+        constexpr std::integral_constant<int, 0> B0{};
+        constexpr std::integral_constant<int, 1> B1{};
+        // these waves also add up the residual input's statistics (its magnitude sets the 1x1 conv's operand exponent) -- FIRST, and their rows
+        // after that: the rows are not needed before the first multiply, two memory round trips later, and the partials' 32 registers are free
+        // again when the 64 of the two steps in flight are taken (together they spilled under the 128-register budget of two workgroups per CU)
+        {
+            mi_stats_regs sr2;
+            const int rt = (wave - NLWC) * 64 + lane;
+            const bool fast2 = st_totals_issue(p.res0, p.res1, Cr0, Cres, b, rt, CFG::NLWR * 64, res_stats, sr2);
+            if (fast2) mi_gn_totals_finish(sr2, rt, chS2, chQ2);
+            else if (res_stats) mi_gn_channel_totals(p.res0, p.res1, Cr0, Cres, b, rt, CFG::NLWR * 64, chS2, chQ2);
+        }
+        issue(0, B0);
+        issue(1, B1);
+        if (have_stats) __syncthreads();                   // (1)
+        __syncthreads();                                   // (3)
+        const float rsc = ldexpf(second ? p.res1.scale : p.res0.scale, sExp[1]);
+        // (one base address per plane and compile-time offsets from it: buffer b always holds a step of parity b, so the ring row is a constant per call
+        //  site and the 16 LDS addresses of a step fold into the instructions' offset fields -- the first version kept them in registers and spilled)
+        uint4* const dstH = &actH[(KO * RING + oct * RINGR + lrow) * PW + 1 + 4 * q];
+        uint4* const dstL = &actL[(KO * RING + oct * RINGR + lrow) * PW + 1 + 4 * q];
+        auto transform = [&](auto buf_tag) {               // buffer 0: even steps (ring rows 0, 1 of the octet), buffer 1: odd steps (rows 2, 3)
+            constexpr int buf = decltype(buf_tag)::value;
+#pragma unroll
+            for (int px = 0; px < 4; ++px) {
+                float y[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) y[j] = raw[buf][j][px] * rsc;
+                uint4 hv, lv;
+                rp_split8(y, hv, lv);
+                if (live) { dstH[2 * buf * PW + px] = hv; dstL[2 * buf * PW + px] = lv; }
+            }
+        };
+        transform(B0);                                     // step 0
+        issue(2, B0);
+        __syncthreads();                                   // (4)
+        for (int it = 0; it < NSTEP; it += 2) {
+            transform(B1);                                 // step it + 1
+            issue(it + 3, B1);
+            __syncthreads();
+            transform(B0);                                 // step it + 2
+            issue(it + 4, B0);
+            __syncthreads();
+        }
+    } else if (wave < NLT) {
         // =================================================================== loader / transform waves
         constexpr int NCH = CFG::NCH, HSM = CFG::HS ? 2 : 1;
         const int u = wave * 64 + lane;
@@ -268,7 +339,7 @@ __global__ __launch_bounds__(CFG::NT) void conv_stripe_kernel(const mi_conv_para
         // (b) the layer's parameters
         // (the loaded values are only TOUCHED after the first barrier: a select or an add right here would put a wait for them -- and for every
         //  older load -- in front of the bulk loads below)
-        float pg = 0.f, pb = 0.f, ld_s1 = 0.f, ld_s2 = 0.f, ld_b[NJ];
+        float pg = 0.f, pb = 0.f, ld_s1 = 0.f, ld_s2 = 0.f, ld_b[NJ], ld_rb[RO ? NJ : 1];
         if constexpr (GN) {
             const int c = lane < Cin ? lane : 0;
             pg = p.gn_gamma[c];
@@ -282,6 +353,7 @@ __global__ __launch_bounds__(CFG::NT) void conv_stripe_kernel(const mi_conv_para
             const int co = 8 * jt + (lq & 7);
             const bool hb = p.bias != nullptr && co < p.Cout;
             ld_b[jt] = (hb ? p.bias : p.in0.data)[hb ? co : 0];
+            if constexpr (RO > 0) { const bool hr = p.res_b != nullptr && co < p.Cout; ld_rb[jt] = (hr ? p.res_b : p.in0.data)[hr ? co : 0]; }
         }
         // (c) the B fragments: straight into registers for the 8 -> 8 layers (global layout [tap][lane][hi | lo]), else staged for their LDS planes
         constexpr int WPER = BREG ? 1 : (WTOT + NCT - 1) / NCT;
@@ -294,7 +366,8 @@ __global__ __launch_bounds__(CFG::NT) void conv_stripe_kernel(const mi_conv_para
 #pragma unroll
             for (int i = 0; i < WPER; ++i) {
                 const int k = ct + i * NCT;
-                wreg[i] = mi_ldg4u(wrp + (k < WTOT ? k : 0));
+                const int kc = k < WTOT ? k : 0;
+                wreg[i] = (RO > 0 && kc >= KO * WCH) ? mi_ldg4u(rwrp + (kc - KO * WCH)) : mi_ldg4u(wrp + kc);
             }
         }
         // (d) the stripe's first four input rows (steps -1 and 0): one pixel quad x (half) octet per work-item
@@ -352,8 +425,25 @@ __global__ __launch_bounds__(CFG::NT) void conv_stripe_kernel(const mi_conv_para
         if (cw == 0) ST_STAMP(2);
         // ---- ONE wave: group moments (each channel's lane adds up its group, in mi_gn_group_moments' order) -> per-channel affine of the fused
         // GroupNorm / scale-shift with the power-of-two operand scaling (conv_rp.hip's arithmetic)
+        int kr = 0, Eall = 0;
         if (cw == 0) {
             const int c = lane;
+            if constexpr (RO > 0) {      // one accumulator for the conv and the 1x1 residual conv: both products carry 2^E; lowering a scale is always safe (conv_rp.hip)
+                float mr = 4.0f;
+                if (res_stats) {
+                    double qq = (c < Cres) ? chQ2[c] : 0.0;
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) qq += __shfl_xor(qq, o);
+                    mr = 4.0f * sqrtf((float)(qq / ((double)Cres * (double)HW)));
+                }
+                const int kr_max = (mr > 0.f) ? rp_clamp_exp(4 - rp_exponent(mr)) : 0;
+                int E = ka + p.w_rp_exp;
+                const int Er = kr_max + p.res_w_rp_exp;
+                if (Er < E) E = Er;
+                ka = E - p.w_rp_exp;
+                kr = E - p.res_w_rp_exp;
+                Eall = E;
+            }
             if constexpr (GN) {
                 if (c < Cin) {
                     const int cpg = Cin / p.gn_groups, g = c / cpg;
@@ -388,7 +478,7 @@ __global__ __launch_bounds__(CFG::NT) void conv_stripe_kernel(const mi_conv_para
                 ka = (m > 0.f) ? rp_clamp_exp(4 - rp_exponent(m)) : 0;
                 if (c < Cin) chP[c] = make_float4(ldexpf((c >= C0) ? p.in1.scale : p.in0.scale, ka), 0.f, 0.f, 0.f);
             }
-            if (lane == 0) { sExp[0] = ka; sExp[2] = ka + p.w_rp_exp; }
+            if (lane == 0) { sExp[0] = ka; sExp[1] = kr; sExp[2] = RO > 0 ? Eall : ka + p.w_rp_exp; }
         }
         if (cw == 0) ST_STAMP(3);
         if (cw == 0) ST_STAMP(4);
@@ -403,7 +493,10 @@ __global__ __launch_bounds__(CFG::NT) void conv_stripe_kernel(const mi_conv_para
 
         float bvv[NJ];
 #pragma unroll
-        for (int jt = 0; jt < NJ; ++jt) bvv[jt] = (p.bias != nullptr && 8 * jt + (lq & 7) < p.Cout) ? ld_b[jt] : 0.0f;
+        for (int jt = 0; jt < NJ; ++jt) {
+            bvv[jt] = (p.bias != nullptr && 8 * jt + (lq & 7) < p.Cout) ? ld_b[jt] : 0.0f;
+            if constexpr (RO > 0) bvv[jt] += (p.res_b != nullptr && 8 * jt + (lq & 7) < p.Cout) ? ld_rb[jt] : 0.0f;
+        }
         const int perm = ((lg & 1) << 1) | (lg >> 1);     // lane group -> input row (0, 2, 1, 3)
         const int dy = lq >> 3;
         constexpr bool idres = CFG::OM == 1, MASKC = CFG::OM == 2;
@@ -453,6 +546,31 @@ __global__ __launch_bounds__(CFG::NT) void conv_stripe_kernel(const mi_conv_para
                     for (int g = 0; g < GPW; ++g) {
                         const int col = 16 * (cw * GPW + g) + lq + s;
                         const int idx = (o * RING + slot) * PW + (UP ? ((col - 1) >> 1) + 1 : col);
+                        const rp_f16x8 ah = __builtin_bit_cast(rp_f16x8, actH[idx]);
+                        const rp_f16x8 al = __builtin_bit_cast(rp_f16x8, actL[idx]);
+#pragma unroll
+                        for (int jt = 0; jt < NJ; ++jt) {
+                            acc[g][jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[jt], acc[g][jt], 0, 0, 0);
+                            acc[g][jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[jt], acc[g][jt], 0, 0, 0);
+                        }
+#pragma unroll
+                        for (int jt = 0; jt < NJ; ++jt) acc[g][jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[jt], acc[g][jt], 0, 0, 0);
+                    }
+                }
+            }
+            if constexpr (RO > 0) {      // the 1x1 residual conv = the centre tap over the residual octets' own two rows (lane groups 0 / 3 multiply zero weights)
+                const int rslot = 2 * (it & 1) + (perm >> 1);
+#pragma unroll
+                for (int o = 0; o < RO; ++o) {
+                    rp_f16x8 bh[NJ], bl[NJ];
+#pragma unroll
+                    for (int jt = 0; jt < NJ; ++jt) {
+                        bh[jt] = __builtin_bit_cast(rp_f16x8, wl[KO * WCH + (o * NJ + jt) * 128 + lane]);
+                        bl[jt] = __builtin_bit_cast(rp_f16x8, wl[KO * WCH + (o * NJ + jt) * 128 + 64 + lane]);
+                    }
+#pragma unroll
+                    for (int g = 0; g < GPW; ++g) {
+                        const int idx = (KO * RING + o * RINGR + rslot) * PW + 16 * (cw * GPW + g) + lq + 1;
                         const rp_f16x8 ah = __builtin_bit_cast(rp_f16x8, actH[idx]);
                         const rp_f16x8 al = __builtin_bit_cast(rp_f16x8, actL[idx]);
 #pragma unroll
@@ -543,17 +661,17 @@ __global__ __launch_bounds__(CFG::NT) void conv_stripe_kernel(const mi_conv_para
     }
 }
 
-template <int W, int KO, int NJ, bool GN, int OM>
+template <int W, int KO, int NJ, bool GN, int OM, int RO = 0>
 int launch_stripe(const mi_conv_params& p, hipStream_t st) {
-    using CFG = StCfg<W, KO, NJ, GN, OM>;
+    using CFG = StCfg<W, KO, NJ, GN, OM, RO>;
     const int nt = p.H / CFG::SR0;
     // statistics blocks per workgroup (speed only): tile_cfg bits 12..15.  Default: one block (W / 8 rows) at 128 / 256 wide, two at <= 64 wide while
     // that leaves a workgroup per CU -- measured isolated (tools/sweep_stripe.py) and in the captured SR step (64^2 level 384 -> 372 us with two,
     // 388 with one; base stage 0.446 -> 0.428 ms per step): profiles/r06_summary.md
     int nblk = (p.tile_cfg >> 12) & 0xf;
-    if (nblk == 0) nblk = (W <= 64 && nt % 2 == 0 && (long long)p.B * (nt / 2) >= 256) ? 2 : 1;
+    if (nblk == 0) nblk = ((W <= 64 || OM == 2) && nt % 2 == 0 && (long long)p.B * (nt / 2) >= 256) ? 2 : 1;      // (OM 2: the final 8 -> 3 conv, 42 -> 38 us isolated at 256^2)
     if (nblk > nt || nt % nblk) nblk = 1;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_stripe_kernel<CFG>), dim3(p.B * (nt / nblk)), dim3(CFG::NT), 0, st, p, (const uint4*)p.w_rp, nblk);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_stripe_kernel<CFG>), dim3(p.B * (nt / nblk)), dim3(CFG::NT), 0, st, p, (const uint4*)p.w_rp, (const uint4*)p.res_w_rp, nblk);
     return mi_check_launch("conv_stripe_kernel");
 }
 
@@ -563,6 +681,9 @@ int launch_stripe_w(const mi_conv_params& p, hipStream_t st, int ko, int nj, boo
     // the layer shapes of the BASELINE U-Nets: 8 / 16 / 24 / 32 input channels, 8 or 16 (or 3) output channels
 #define ST_BLOCK(KO, NJ) if (gn && ko == KO && nj == NJ) return om == 1 ? launch_stripe<W, KO, NJ, true, 1>(p, st) : launch_stripe<W, KO, NJ, true, 0>(p, st)
 #define ST_PLAIN(KO, NJ, OMV) if (!gn && ko == KO && nj == NJ && om == OMV) return launch_stripe<W, KO, NJ, false, OMV>(p, st)
+    if constexpr (W == 64 || W == 128) {      // 8 -> 8 behind a Block with the 1x1 residual conv over 16 channels (ups.1 of both U-Nets)
+        if (gn && ko == 1 && nj == 1 && om == 0 && p.res0.data && p.res_w) return launch_stripe<W, 1, 1, true, 0, 2>(p, st);
+    }
     if (om <= 1) {
         ST_BLOCK(1, 1);
         if constexpr (W <= 128) { ST_BLOCK(2, 1); }
@@ -586,12 +707,16 @@ int stripe_block_rows(const mi_conv_params& p, int* ko_, int* nj_) {
     if (p.H % sr0 || p.H < sr0 || (size_t)p.H * p.W * 64 >= (1ull << 31)) return 0;
     const int C0 = p.in0.C, C1 = p.in1.data ? p.in1.C : 0;
     if ((C0 & 7) || (C1 & 7) || C0 + C1 > RP_MAXC || p.Cout > 16) return 0;
-    if (p.res0.data && (p.res_w || p.res0.C != p.Cout)) return 0;          // identity residual only: launches with a 1x1 residual conv stay on the tile kernel
+    const bool rconv = p.res0.data && p.res_w;
+    if (rconv) {        // 1x1 residual conv: instantiated for 8 -> 8 over 16 residual channels at 64 / 128 wide (bigger ones leave one workgroup per CU: tile kernel)
+        const int cres = p.res0.C + (p.res1.data ? p.res1.C : 0);
+        if (!p.res_w_rp || (p.res0.C & 7) || (p.res1.data && (p.res1.C & 7)) || (p.res1.data && p.res1.st) || cres != 16 || C0 + C1 != 8 || p.Cout != 8 || !p.gn_groups || p.up2 || !(p.W == 64 || p.W == 128)) return 0;
+    } else if (p.res0.data && p.res0.C != p.Cout) return 0;
     if (p.gn_groups > MI_MAX_GROUPS || (p.gn_groups > 0 && ((C0 + C1) % p.gn_groups))) return 0;
     if (p.gn_groups > 0 && (!p.in0.stats || (p.in1.data && !p.in1.stats))) return 0;
     const int ko = (C0 + C1) >> 3, nj = (p.Cout + 7) >> 3;
     const bool gn = p.gn_groups > 0;
-    const int om = p.up2 ? 3 : (p.Cout < 8 * nj ? 2 : (p.res0.data ? 1 : 0));
+    const int om = p.up2 ? 3 : (p.Cout < 8 * nj ? 2 : ((p.res0.data && !rconv) ? 1 : 0));
     if (om == 3) {      // nearest x2 + conv (Upsample): 8 or 16 -> 8 channels, no GroupNorm, no residual, output at least 64 wide
         // (256-wide outputs stay on the tile kernel: write-bound, 52 against 48 us in the captured SR step; 128 wide: 20.8 against 27.8 us)
         if (gn || p.res0.data || nj != 1 || p.Cout != 8 || ko > 2 || p.W < 64 || p.W > 128 || (p.H & 1)) return 0;

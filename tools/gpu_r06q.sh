@@ -1,4 +1,4 @@
-out=gpurun_out/r06q; mkdir -p $out
+out=gpurun_out/r06u; mkdir -p $out
 python -m pytest tests/test_conv_stripe.py tests/test_unet.py tests/test_sampler.py -x -q -m gpu > $out/pytest.log 2>&1; tail -3 $out/pytest.log
 run() { name=$1; shift; env "$@" python bench.py --steps 8 --warmup 2 --no-secondary --no-cpu-baseline --no-t5 --breakdown-out $out/bd_$name.json > $out/bench_$name.json 2> $out/bench_$name.err
 python - <<P
