@@ -433,10 +433,18 @@ int mi_ln_rows_fwd(const float* x, const float* gamma, const float* beta, float*
 /* C[M][N] = act(A[M][K] . W[N][K]^T) + R[M][N]   (R may be NULL; act: 0 none, 1 ReLU, 2 gelu_new (tanh form), 3 exact GELU (erf form, nn.GELU))
  * gate != NULL (gated-gelu FF of T5 v1.1): C = act(A.W^T) * (A.gate^T).   K % 16 == 0 (N % 64 == 0 for the gated form). */
 int mi_gemm_f32(const float* A, const float* W, const float* gate, const float* R, float* Cout, int M, int N, int K, int act, void* stream);
+/* The same product with T5's RMSNorm folded in (round 6: 44 -> 32 launches per encode): rowsq_in [M][nparts] (may be NULL) holds partial sums of
+ * squares of A's rows; row m of A.W^T is scaled by rsqrt(sum_p rowsq_in[m][p] / K + eps) before the activation -- with the norm's weight folded into W
+ * by the caller this is act(RMSNorm(A) . W0^T).  rowsq_out [M][ceil(N/64)] (may be NULL) receives, per 64-column tile, the sum of squares of every
+ * output row after the residual: the next projection's rowsq_in.  K % 32 == 0. */
+int mi_gemm_rms_f32(const float* A, const float* W, const float* gate, const float* R, float* Cout, int M, int N, int K, int act,
+                    const float* rowsq_in, int nparts, float eps, float* rowsq_out, void* stream);
 /* y = x * rsqrt(mean(x^2) + eps) * w per row (T5LayerNorm); zero_mask != NULL: rows with zero_mask[row]==0 are zeroed (t5.py:82) */
 int mi_rmsnorm(const float* x, const float* w, float* y, int rows, int dim, float eps, const uint8_t* zero_mask, void* stream);
 /* out[row][:] = table[ids[row]][:] */
 int mi_embed_rows(const int64_t* ids, const float* table, float* out, int rows, int dim, void* stream);
+/* ... and rowsq[row][0] = sum of squares of the row, rowsq[row][1 .. nparts-1] = 0 (the record mi_gemm_rms_f32 reads) */
+int mi_embed_rows_sq(const int64_t* ids, const float* table, float* out, float* rowsq, int nparts, int rows, int dim, void* stream);
 /* T5 self-attention core for one layer: qkv [B*L][3*inner] (q | k | v, head h at columns h*64), unscaled q.k^T
  * + bias_tab[heads][2L-1] (relative position bias indexed by (j - i) + L-1) + key mask, softmax, .v -> ctx [B*L][inner] */
 int mi_t5_attention(const float* qkv, const float* bias_tab, const uint8_t* key_mask, float* ctx, int B, int L, int heads, void* stream);

@@ -221,6 +221,8 @@ def _bind(lib):
     lib.mi_gemm_f32.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
     lib.mi_rmsnorm.argtypes = [vp, vp, vp, i32, i32, f32, vp, vp]
     lib.mi_embed_rows.argtypes = [vp, vp, vp, i32, i32, vp]
+    lib.mi_embed_rows_sq.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp]
+    lib.mi_gemm_rms_f32.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, i32, f32, vp, vp]
     lib.mi_t5_attention.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp]
     lib.mi_ln_tokens_fwd.argtypes = [vp, i32, i32, vp, vp, vp, vp]
     lib.mi_ln_rows_fwd.argtypes = [vp, vp, vp, vp, i32, i32, f32, vp]

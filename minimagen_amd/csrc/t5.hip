@@ -100,9 +100,13 @@ __device__ __forceinline__ void t5_split8(const float4& u, const float4& v, floa
     hi = make_uint4(h[0], h[1], h[2], h[3]);
     lo = make_uint4(l[0], l[1], l[2], l[3]);
 }
+// rowsq_in [M][nparts] (may be NULL): partial sums of squares of A's rows -> row m of the product is scaled by rsqrt(sum / K + eps) before the
+// activation: T5's RMSNorm in front of a projection, y = (x rsqrt(mean x^2 + eps) w) W^T = rsqrt(..) (x (W diag w)^T), with w folded into W by the host.
+// rowsq_out [M][gridDim.x] (may be NULL): this tile's sum of squares of every output row (after the residual) -- what the NEXT projection's RMSNorm needs.
 template <bool GATED>
 __global__ __launch_bounds__(256) void gemm_f16x3_kernel(const float* __restrict__ A, const float* __restrict__ W, const float* __restrict__ G,
-                                                         const float* __restrict__ R, float* __restrict__ Cout, int M, int N, int K, int act) {
+                                                         const float* __restrict__ R, float* __restrict__ Cout, int M, int N, int K, int act,
+                                                         const float* __restrict__ rowsq_in, int nparts, float eps, float* __restrict__ rowsq_out) {
     constexpr int BM = 64, BN = 64, BK = 32, PITCH = 5;      // rows of 4 16-byte chunks (8 halves each) + 1 pad chunk: conflict-free ds_read_b128
     __shared__ __attribute__((aligned(16))) uint4 Ah[BM * PITCH], Al[BM * PITCH], Wh[BN * PITCH], Wl[BN * PITCH];
     __shared__ __attribute__((aligned(16))) uint4 Gh[GATED ? BN * PITCH : 1], Gl[GATED ? BN * PITCH : 1];
@@ -181,23 +185,42 @@ __global__ __launch_bounds__(256) void gemm_f16x3_kernel(const float* __restrict
         }
     }
     // D layout as in the fp32 kernel above: row (m) = 4 * (lane >> 4) + r, column (n) = lane & 15
+    __shared__ float sq[2][BM];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int r = 0; r < 4; ++r) {
+            const int ml = wm * 32 + i * 16 + 4 * (lane >> 4) + r, m = m0 + ml;
+            float rs = 1.0f;
+            if (rowsq_in && m < M) {
+                float t = 0.0f;
+                for (int q = 0; q < nparts; ++q) t += rowsq_in[(size_t)m * nparts + q];
+                rs = 1.0f / sqrtf(t / (float)K + eps);
+            }
+            float part = 0.0f;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m0 + wm * 32 + i * 16 + 4 * (lane >> 4) + r, n = n0 + wn * 32 + j * 16 + (lane & 15);
+            for (int j = 0; j < 2; ++j) {
+                const int n = n0 + wn * 32 + j * 16 + (lane & 15);
                 if (m < M && n < N) {
-                    float v = acc[i][j][r];
+                    float v = acc[i][j][r] * rs;
                     if (act == 1) v = fmaxf(v, 0.0f);
                     else if (act == 2) v = gelu_new(v);
                     else if (act == 3) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
-                    if (GATED) v *= accg[i][j][r];
+                    if (GATED) v *= accg[i][j][r] * rs;
                     if (R) v += R[(size_t)m * N + n];
                     Cout[(size_t)m * N + n] = v;
+                    part = fmaf(v, v, part);
                 }
             }
+            if (rowsq_out) {                                   // (wave-uniform) the 16 lanes of a row group hold its 32 columns of this wave
+                part += __shfl_xor(part, 1); part += __shfl_xor(part, 2); part += __shfl_xor(part, 4); part += __shfl_xor(part, 8);
+                if ((lane & 15) == 0) sq[wn][ml] = part;
+            }
+        }
+    if (rowsq_out) {
+        __syncthreads();
+        if (tid < BM && m0 + tid < M) rowsq_out[(size_t)(m0 + tid) * gridDim.x + blockIdx.x] = sq[0][tid] + sq[1][tid];
+    }
 }
 
 __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* x, const float* w, float* y, int rows, int dim, float eps, const uint8_t* zero_mask) {
@@ -215,10 +238,18 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* x, const floa
     for (int i = tid; i < dim; i += 256) y[(size_t)row * dim + i] = zero ? 0.0f : xr[i] * rs * w[i];
 }
 
-__global__ __launch_bounds__(256) void embed_rows_kernel(const long long* ids, const float* table, float* out, int rows, int dim) {
+__global__ __launch_bounds__(256) void embed_rows_kernel(const long long* ids, const float* table, float* out, int rows, int dim, float* rowsq, int nparts) {
+    __shared__ float red[4];
     const int row = blockIdx.x;
     const float* src = table + (size_t)ids[row] * dim;
-    for (int i = threadIdx.x; i < dim; i += 256) out[(size_t)row * dim + i] = src[i];
+    float s = 0.0f;
+    for (int i = threadIdx.x; i < dim; i += 256) { const float v = src[i]; out[(size_t)row * dim + i] = v; s = fmaf(v, v, s); }
+    if (rowsq) {                    // the row's sum of squares in part 0 of its rowsq record (the layout mi_gemm_rms_f32 reads), the other parts zero
+        s = mi_wave_sum(s);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+        __syncthreads();
+        if (threadIdx.x < nparts) rowsq[(size_t)row * nparts + threadIdx.x] = threadIdx.x == 0 ? (red[0] + red[1]) + (red[2] + red[3]) : 0.0f;
+    }
 }
 
 // one wave = 16 queries of one (batch, head); the whole (<=256)-key score row lives in registers like K9
@@ -305,13 +336,22 @@ extern "C" int mi_gemm_f32(const float* A, const float* W, const float* gate, co
     // otherwise (and with MI_GEMM_EXACT_F32 set in the environment, for A/B measurements) the exact-fp32 MFMA kernel
     static const bool exact = getenv("MI_GEMM_EXACT_F32") != nullptr;
     if ((K % 32) == 0 && !exact) {
-        if (gate) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_f16x3_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, A, W, gate, R, Cout, M, N, K, act);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_f16x3_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, A, W, gate, R, Cout, M, N, K, act);
+        if (gate) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_f16x3_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, A, W, gate, R, Cout, M, N, K, act, (const float*)nullptr, 0, 0.0f, (float*)nullptr);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_f16x3_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, A, W, gate, R, Cout, M, N, K, act, (const float*)nullptr, 0, 0.0f, (float*)nullptr);
         return mi_check_launch("gemm_f16x3_kernel");
     }
     if (gate) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_f32_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, A, W, gate, R, Cout, M, N, K, act);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_f32_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, A, W, gate, R, Cout, M, N, K, act);
     return mi_check_launch("gemm_f32_kernel");
+}
+
+extern "C" int mi_gemm_rms_f32(const float* A, const float* W, const float* gate, const float* R, float* Cout, int M, int N, int K, int act,
+                               const float* rowsq_in, int nparts, float eps, float* rowsq_out, void* stream) {
+    if (M <= 0 || N <= 0 || (gate && (N % 64) != 0) || (K % 32) != 0 || (rowsq_in && nparts <= 0)) { mi_set_error("mi_gemm_rms_f32: need M>0, K%%32==0, nparts>0 with rowsq_in (and N%%64==0 when gated) (got %d,%d,%d)", M, N, K); return MI_ERR_INVALID; }
+    const dim3 grid((N + 63) / 64, (M + 63) / 64);
+    if (gate) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_f16x3_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, A, W, gate, R, Cout, M, N, K, act, rowsq_in, nparts, eps, rowsq_out);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_f16x3_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, A, W, gate, R, Cout, M, N, K, act, rowsq_in, nparts, eps, rowsq_out);
+    return mi_check_launch("gemm_f16x3_kernel (rms)");
 }
 
 extern "C" int mi_rmsnorm(const float* x, const float* w, float* y, int rows, int dim, float eps, const uint8_t* zero_mask, void* stream) {
@@ -322,7 +362,13 @@ extern "C" int mi_rmsnorm(const float* x, const float* w, float* y, int rows, in
 
 extern "C" int mi_embed_rows(const int64_t* ids, const float* table, float* out, int rows, int dim, void* stream) {
     if (rows <= 0) { mi_set_error("mi_embed_rows: empty"); return MI_ERR_INVALID; }
-    hipLaunchKernelGGL(embed_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, (const long long*)ids, table, out, rows, dim);
+    hipLaunchKernelGGL(embed_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, (const long long*)ids, table, out, rows, dim, (float*)nullptr, 0);
+    return mi_check_launch("embed_rows_kernel");
+}
+
+extern "C" int mi_embed_rows_sq(const int64_t* ids, const float* table, float* out, float* rowsq, int nparts, int rows, int dim, void* stream) {
+    if (rows <= 0 || nparts <= 0 || nparts > 256 || !rowsq) { mi_set_error("mi_embed_rows_sq: empty / bad rowsq record"); return MI_ERR_INVALID; }
+    hipLaunchKernelGGL(embed_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, (const long long*)ids, table, out, rows, dim, rowsq, nparts);
     return mi_check_launch("embed_rows_kernel");
 }
 

@@ -67,11 +67,14 @@ class T5EncoderHIP:
         for i in range(num_layers):
             p = f"encoder.block.{i}.layer."
             ff = p + "1.DenseReluDense."
+            # T5LayerNorm's weight is folded into the projection behind it (y = rsqrt(mean x^2 + eps) * (x . (W diag w)^T)): the norm itself is the
+            # row scaling of mi_gemm_rms_f32's epilogue, fed by the sums of squares the previous projection's epilogue left (no rmsnorm launches)
+            ln0, ln1 = f(p + "0.layer_norm.weight"), f(p + "1.layer_norm.weight")
             self.layers.append(dict(
-                ln0=f(p + "0.layer_norm.weight"),
-                wqkv=torch.cat([f(p + f"0.SelfAttention.{n}.weight") for n in "qkv"], 0).contiguous(),
-                wo=f(p + "0.SelfAttention.o.weight"), ln1=f(p + "1.layer_norm.weight"),
-                wi=f(ff + ("wi_0.weight" if self.gated else "wi.weight")), wg=f(ff + "wi_1.weight") if self.gated else None,
+                wqkv=(torch.cat([f(p + f"0.SelfAttention.{n}.weight") for n in "qkv"], 0) * ln0[None, :]).contiguous(),
+                wo=f(p + "0.SelfAttention.o.weight"),
+                wi=(f(ff + ("wi_0.weight" if self.gated else "wi.weight")) * ln1[None, :]).contiguous(),
+                wg=(f(ff + "wi_1.weight") * ln1[None, :]).contiguous() if self.gated else None,
                 wo2=f(ff + "wo.weight")))
         self.final_ln = f("encoder.final_layer_norm.weight")
         self.dev = dev
@@ -92,7 +95,7 @@ class T5EncoderHIP:
         return self.rel_emb_cpu[b].t().contiguous().to(self.dev)
 
     def _plan(self, B: int, Lq: int):
-        """static buffers + (later) the captured HIP graph of one (batch, length) shape: 42 launches become one replay"""
+        """static buffers + (later) the captured HIP graph of one (batch, length) shape: 32 launches become one replay"""
         plans = self.__dict__.setdefault("_plans", {})
         pl = plans.get((B, Lq))
         if pl is None:
@@ -100,7 +103,7 @@ class T5EncoderHIP:
             M, d, inner = B * Lq, c["d_model"], c["heads"] * c["d_kv"]
             e = lambda *s: torch.empty(*s, dtype=torch.float32, device=self.dev)
             pl = dict(ids=torch.zeros(B, Lq, dtype=torch.int64, device=self.dev), mask=torch.ones(B, Lq, dtype=torch.uint8, device=self.dev),
-                      h=e(M, d), x=e(M, d), qkv=e(M, 3 * inner), ctx=e(M, inner), ff=e(M, c["d_ff"]), h2=e(M, d), out=e(M, d),
+                      h=e(M, d), sq=e(M, -(-d // 64)), sq2=e(M, -(-d // 64)), qkv=e(M, 3 * inner), ctx=e(M, inner), ff=e(M, c["d_ff"]), h2=e(M, d), out=e(M, d),
                       bias=self.bias_table(Lq), graph=None)
             while len(plans) >= 8:                         # bounded: one plan per shape
                 old = plans.pop(next(iter(plans)))
@@ -114,16 +117,16 @@ class T5EncoderHIP:
     def _launch(self, pl, B: int, Lq: int, st):
         lib, c = L.lib(), self.cfg
         M, d, inner = B * Lq, c["d_model"], c["heads"] * c["d_kv"]
-        h, x, qkv, ctx, ff, h2, bias, mask = pl["h"], pl["x"], pl["qkv"], pl["ctx"], pl["ff"], pl["h2"], pl["bias"], pl["mask"]
-        L.check(lib.mi_embed_rows(L.ptr(pl["ids"]), L.ptr(self.emb), L.ptr(h), M, d, st), "mi_embed_rows")
-        for ly in self.layers:
-            L.check(lib.mi_rmsnorm(L.ptr(h), L.ptr(ly["ln0"]), L.ptr(x), M, d, c["eps"], None, st), "mi_rmsnorm")
-            L.check(lib.mi_gemm_f32(L.ptr(x), L.ptr(ly["wqkv"]), None, None, L.ptr(qkv), M, 3 * inner, d, 0, st), "mi_gemm_f32 qkv")
+        h, qkv, ctx, ff, h2, bias, mask = pl["h"], pl["qkv"], pl["ctx"], pl["ff"], pl["h2"], pl["bias"], pl["mask"]
+        sq, sq2, np_ = pl["sq"], pl["sq2"], -(-d // 64)           # per-row sums of squares of h / h2, one partial per 64-column tile of their producer
+        eps = c["eps"]
+        L.check(lib.mi_embed_rows_sq(L.ptr(pl["ids"]), L.ptr(self.emb), L.ptr(h), L.ptr(sq), np_, M, d, st), "mi_embed_rows_sq")
+        for ly in self.layers:        # five launches per layer: RMSNorm + QKV, attention, O + residual, RMSNorm + FF-in (+ gate, activation), FF-out + residual
+            L.check(lib.mi_gemm_rms_f32(L.ptr(h), L.ptr(ly["wqkv"]), None, None, L.ptr(qkv), M, 3 * inner, d, 0, L.ptr(sq), np_, eps, None, st), "mi_gemm_rms_f32 qkv")
             L.check(lib.mi_t5_attention(L.ptr(qkv), L.ptr(bias), L.ptr(mask), L.ptr(ctx), B, Lq, c["heads"], st), "mi_t5_attention")
-            L.check(lib.mi_gemm_f32(L.ptr(ctx), L.ptr(ly["wo"]), None, L.ptr(h), L.ptr(h2), M, d, inner, 0, st), "mi_gemm_f32 o")
-            L.check(lib.mi_rmsnorm(L.ptr(h2), L.ptr(ly["ln1"]), L.ptr(x), M, d, c["eps"], None, st), "mi_rmsnorm")
-            L.check(lib.mi_gemm_f32(L.ptr(x), L.ptr(ly["wi"]), L.ptr(ly["wg"]), None, L.ptr(ff), M, c["d_ff"], d, self.act, st), "mi_gemm_f32 wi")
-            L.check(lib.mi_gemm_f32(L.ptr(ff), L.ptr(ly["wo2"]), None, L.ptr(h2), L.ptr(h), M, d, c["d_ff"], 0, st), "mi_gemm_f32 wo")
+            L.check(lib.mi_gemm_rms_f32(L.ptr(ctx), L.ptr(ly["wo"]), None, L.ptr(h), L.ptr(h2), M, d, inner, 0, None, 0, 0.0, L.ptr(sq2), st), "mi_gemm_rms_f32 o")
+            L.check(lib.mi_gemm_rms_f32(L.ptr(h2), L.ptr(ly["wi"]), L.ptr(ly["wg"]), None, L.ptr(ff), M, c["d_ff"], d, self.act, L.ptr(sq2), np_, eps, None, st), "mi_gemm_rms_f32 wi")
+            L.check(lib.mi_gemm_rms_f32(L.ptr(ff), L.ptr(ly["wo2"]), None, L.ptr(h2), L.ptr(h), M, d, c["d_ff"], 0, None, 0, 0.0, L.ptr(sq), st), "mi_gemm_rms_f32 wo")
         L.check(lib.mi_rmsnorm(L.ptr(h), L.ptr(self.final_ln), L.ptr(pl["out"]), M, d, c["eps"], L.ptr(mask), st), "mi_rmsnorm final")
 
     @torch.no_grad()
