@@ -185,18 +185,22 @@ __global__ __launch_bounds__(256) void gemm_f16x3_kernel(const float* __restrict
         }
     }
     // D layout as in the fp32 kernel above: row (m) = 4 * (lane >> 4) + r, column (n) = lane & 15
-    __shared__ float sq[2][BM];
+    __shared__ float sq[2][BM], rsc[BM];
+    if (rowsq_in) {                                        // one work-item per row of the tile adds up the row's partials: rsqrt(mean x^2 + eps)
+        if (tid < BM) {
+            float t = 0.0f;
+            if (m0 + tid < M)
+                for (int q = 0; q < nparts; ++q) t += rowsq_in[(size_t)(m0 + tid) * nparts + q];
+            rsc[tid] = 1.0f / sqrtf(t / (float)K + eps);
+        }
+        __syncthreads();
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int ml = wm * 32 + i * 16 + 4 * (lane >> 4) + r, m = m0 + ml;
-            float rs = 1.0f;
-            if (rowsq_in && m < M) {
-                float t = 0.0f;
-                for (int q = 0; q < nparts; ++q) t += rowsq_in[(size_t)m * nparts + q];
-                rs = 1.0f / sqrtf(t / (float)K + eps);
-            }
+            const float rs = rowsq_in ? rsc[ml] : 1.0f;
             float part = 0.0f;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
