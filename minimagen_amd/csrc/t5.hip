@@ -103,18 +103,20 @@ __device__ __forceinline__ void t5_split8(const float4& u, const float4& v, floa
 // rowsq_in [M][nparts] (may be NULL): partial sums of squares of A's rows -> row m of the product is scaled by rsqrt(sum / K + eps) before the
 // activation: T5's RMSNorm in front of a projection, y = (x rsqrt(mean x^2 + eps) w) W^T = rsqrt(..) (x (W diag w)^T), with w folded into W by the host.
 // rowsq_out [M][gridDim.x] (may be NULL): this tile's sum of squares of every output row (after the residual) -- what the NEXT projection's RMSNorm needs.
-template <bool GATED>
+// KS = K steps of 32 per slice (round 6: 2 where K % 64 == 0 -- the slice loop is paced by its barriers and cross-lane maxima, ~1 us per slice
+// whatever it multiplies: half the slices for the same work)
+template <bool GATED, int KS>
 __global__ __launch_bounds__(256) void gemm_f16x3_kernel(const float* __restrict__ A, const float* __restrict__ W, const float* __restrict__ G,
                                                          const float* __restrict__ R, float* __restrict__ Cout, int M, int N, int K, int act,
                                                          const float* __restrict__ rowsq_in, int nparts, float eps, float* __restrict__ rowsq_out) {
-    constexpr int BM = 64, BN = 64, BK = 32, PITCH = 5;      // rows of 4 16-byte chunks (8 halves each) + 1 pad chunk: conflict-free ds_read_b128
+    constexpr int BM = 64, BN = 64, BK = 32 * KS, PITCH = 4 * KS + 1;      // rows of 4 KS 16-byte chunks (8 halves each) + 1 pad chunk: conflict-free ds_read_b128
     __shared__ __attribute__((aligned(16))) uint4 Ah[BM * PITCH], Al[BM * PITCH], Wh[BN * PITCH], Wl[BN * PITCH];
     __shared__ __attribute__((aligned(16))) uint4 Gh[GATED ? BN * PITCH : 1], Gl[GATED ? BN * PITCH : 1];
     __shared__ float smax[3][4];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int lr = tid >> 2, lc = tid & 3;                    // staging: row, 8-float chunk
+    const int lr = tid >> 2, lc = tid & 3;                    // staging: row, 8-float chunk (+ 4 per K step)
     f32x4 acc[2][2], accg[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -126,17 +128,26 @@ __global__ __launch_bounds__(256) void gemm_f16x3_kernel(const float* __restrict
     };
     // the next slice's global loads are issued right after this slice's values have been split into LDS: they fly under the MFMA section
     // (and under the other resident workgroups) instead of in front of every slice
-    float4 a0 = z4, a1 = z4, w0 = z4, w1 = z4, g0 = z4, g1 = z4;
+    float4 a0[KS], a1[KS], w0[KS], w1[KS], g0[KS], g1[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) { a0[ks] = z4; a1[ks] = z4; w0[ks] = z4; w1[ks] = z4; g0[ks] = z4; g1[ks] = z4; }
     auto load_slice = [&](int k0) {
-        if (m0 + lr < M) { const float4* pa = reinterpret_cast<const float4*>(A + (size_t)(m0 + lr) * K + k0 + 8 * lc); a0 = pa[0]; a1 = pa[1]; }
-        if (n0 + lr < N) {
-            const float4* pw = reinterpret_cast<const float4*>(W + (size_t)(n0 + lr) * K + k0 + 8 * lc); w0 = pw[0]; w1 = pw[1];
-            if (GATED) { const float4* pg = reinterpret_cast<const float4*>(G + (size_t)(n0 + lr) * K + k0 + 8 * lc); g0 = pg[0]; g1 = pg[1]; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int kk = k0 + 32 * ks + 8 * lc;
+            if (m0 + lr < M) { const float4* pa = reinterpret_cast<const float4*>(A + (size_t)(m0 + lr) * K + kk); a0[ks] = pa[0]; a1[ks] = pa[1]; }
+            if (n0 + lr < N) {
+                const float4* pw = reinterpret_cast<const float4*>(W + (size_t)(n0 + lr) * K + kk); w0[ks] = pw[0]; w1[ks] = pw[1];
+                if (GATED) { const float4* pg = reinterpret_cast<const float4*>(G + (size_t)(n0 + lr) * K + kk); g0[ks] = pg[0]; g1[ks] = pg[1]; }
+            }
         }
     };
     load_slice(0);
     for (int k0 = 0; k0 < K; k0 += BK) {
-        const float ma = mi_wave_max(amax8(a0, a1)), mw = mi_wave_max(amax8(w0, w1)), mg = GATED ? mi_wave_max(amax8(g0, g1)) : 0.0f;
+        float ma = 0.f, mw = 0.f, mg = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) { ma = fmaxf(ma, amax8(a0[ks], a1[ks])); mw = fmaxf(mw, amax8(w0[ks], w1[ks])); if (GATED) mg = fmaxf(mg, amax8(g0[ks], g1[ks])); }
+        ma = mi_wave_max(ma); mw = mi_wave_max(mw); mg = GATED ? mi_wave_max(mg) : 0.0f;
         __syncthreads();                                      // the previous slice's fragments and maxima are consumed
         if (lane == 0) { smax[0][wave] = ma; smax[1][wave] = mw; smax[2][wave] = mg; }
         __syncthreads();
@@ -144,45 +155,60 @@ __global__ __launch_bounds__(256) void gemm_f16x3_kernel(const float* __restrict
         const int ew = t5_scale_exp(fmaxf(fmaxf(smax[1][0], smax[1][1]), fmaxf(smax[1][2], smax[1][3])));
         const int eg = GATED ? t5_scale_exp(fmaxf(fmaxf(smax[2][0], smax[2][1]), fmaxf(smax[2][2], smax[2][3]))) : 0;
         uint4 hi, lo;
-        t5_split8(a0, a1, ldexpf(1.0f, ea), hi, lo); Ah[lr * PITCH + lc] = hi; Al[lr * PITCH + lc] = lo;
-        t5_split8(w0, w1, ldexpf(1.0f, ew), hi, lo); Wh[lr * PITCH + lc] = hi; Wl[lr * PITCH + lc] = lo;
-        if (GATED) { t5_split8(g0, g1, ldexpf(1.0f, eg), hi, lo); Gh[lr * PITCH + lc] = hi; Gl[lr * PITCH + lc] = lo; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int o = lr * PITCH + lc + 4 * ks;
+            t5_split8(a0[ks], a1[ks], ldexpf(1.0f, ea), hi, lo); Ah[o] = hi; Al[o] = lo;
+            t5_split8(w0[ks], w1[ks], ldexpf(1.0f, ew), hi, lo); Wh[o] = hi; Wl[o] = lo;
+            if (GATED) { t5_split8(g0[ks], g1[ks], ldexpf(1.0f, eg), hi, lo); Gh[o] = hi; Gl[o] = lo; }
+        }
         if (k0 + BK < K) load_slice(k0 + BK);
         __syncthreads();
-        t5_f16x8 ah[2], al[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int o = (wm * 32 + i * 16 + (lane & 15)) * PITCH + (lane >> 4);
-            ah[i] = __builtin_bit_cast(t5_f16x8, Ah[o]);
-            al[i] = __builtin_bit_cast(t5_f16x8, Al[o]);
-        }
         const float un = ldexpf(1.0f, -(ea + ew)), ung = ldexpf(1.0f, -(ea + eg));
+        f32x4 sl[2][2], slg[2][2];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int o = (wn * 32 + j * 16 + (lane & 15)) * PITCH + (lane >> 4);
-            const t5_f16x8 bh = __builtin_bit_cast(t5_f16x8, Wh[o]), bl = __builtin_bit_cast(t5_f16x8, Wl[o]);
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) { sl[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; slg[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            t5_f16x8 ah[2], al[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                f32x4 sl = (f32x4){0.f, 0.f, 0.f, 0.f};
-                sl = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh, sl, 0, 0, 0);
-                sl = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl, sl, 0, 0, 0);
-                sl = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh, sl, 0, 0, 0);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[i][j][r] = fmaf(sl[r], un, acc[i][j][r]);
+                const int o = (wm * 32 + i * 16 + (lane & 15)) * PITCH + (lane >> 4) + 4 * ks;
+                ah[i] = __builtin_bit_cast(t5_f16x8, Ah[o]);
+                al[i] = __builtin_bit_cast(t5_f16x8, Al[o]);
             }
-            if (GATED) {
-                const t5_f16x8 gh = __builtin_bit_cast(t5_f16x8, Gh[o]), gl = __builtin_bit_cast(t5_f16x8, Gl[o]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int o = (wn * 32 + j * 16 + (lane & 15)) * PITCH + (lane >> 4) + 4 * ks;
+                const t5_f16x8 bh = __builtin_bit_cast(t5_f16x8, Wh[o]), bl = __builtin_bit_cast(t5_f16x8, Wl[o]);
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    f32x4 sl = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    sl = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], gh, sl, 0, 0, 0);
-                    sl = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], gl, sl, 0, 0, 0);
-                    sl = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], gh, sl, 0, 0, 0);
+                    sl[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh, sl[i][j], 0, 0, 0);
+                    sl[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl, sl[i][j], 0, 0, 0);
+                    sl[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh, sl[i][j], 0, 0, 0);
+                }
+                if (GATED) {
+                    const t5_f16x8 gh = __builtin_bit_cast(t5_f16x8, Gh[o]), gl = __builtin_bit_cast(t5_f16x8, Gl[o]);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) accg[i][j][r] = fmaf(sl[r], ung, accg[i][j][r]);
+                    for (int i = 0; i < 2; ++i) {
+                        slg[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], gh, slg[i][j], 0, 0, 0);
+                        slg[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], gl, slg[i][j], 0, 0, 0);
+                        slg[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], gh, slg[i][j], 0, 0, 0);
+                    }
                 }
             }
         }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    acc[i][j][r] = fmaf(sl[i][j][r], un, acc[i][j][r]);
+                    if (GATED) accg[i][j][r] = fmaf(slg[i][j][r], ung, accg[i][j][r]);
+                }
     }
     // D layout as in the fp32 kernel above: row (m) = 4 * (lane >> 4) + r, column (n) = lane & 15
     __shared__ float sq[2][BM], rsc[BM];
@@ -333,6 +359,18 @@ __global__ __launch_bounds__(256) void t5_attention_kernel(const float* __restri
 
 }  // namespace
 
+static int gemm_f16x3_launch(const float* A, const float* W, const float* gate, const float* R, float* Cout, int M, int N, int K, int act,
+                             const float* rowsq_in, int nparts, float eps, float* rowsq_out, hipStream_t st) {
+    const dim3 grid((N + 63) / 64, (M + 63) / 64);
+#define MI_GEMM_GO(GATED, KS) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_f16x3_kernel<GATED, KS>), grid, dim3(256), 0, st, A, W, gate, R, Cout, M, N, K, act, rowsq_in, nparts, eps, rowsq_out)
+    static const bool ks1 = getenv("MI_GEMM_KS1") != nullptr;       // A/B knob: 32-wide slices everywhere
+    // (128-wide slices, measured: wo 54 -> 47 us but qkv 31 -> 35 and wi 37 -> 41: two workgroups per CU instead of three; not kept)
+    if ((K % 64) == 0 && !ks1) { if (gate) MI_GEMM_GO(true, 2); else MI_GEMM_GO(false, 2); }
+    else { if (gate) MI_GEMM_GO(true, 1); else MI_GEMM_GO(false, 1); }
+#undef MI_GEMM_GO
+    return mi_check_launch("gemm_f16x3_kernel");
+}
+
 extern "C" int mi_gemm_f32(const float* A, const float* W, const float* gate, const float* R, float* Cout, int M, int N, int K, int act, void* stream) {
     if (M <= 0 || N <= 0 || (gate && (N % 64) != 0) || (K % 16) != 0) { mi_set_error("mi_gemm_f32: need M>0, K%%16==0 (and N%%64==0 when gated) (got %d,%d,%d)", M, N, K); return MI_ERR_INVALID; }
     const dim3 grid((N + 63) / 64, (M + 63) / 64);
@@ -340,9 +378,7 @@ extern "C" int mi_gemm_f32(const float* A, const float* W, const float* gate, co
     // otherwise (and with MI_GEMM_EXACT_F32 set in the environment, for A/B measurements) the exact-fp32 MFMA kernel
     static const bool exact = getenv("MI_GEMM_EXACT_F32") != nullptr;
     if ((K % 32) == 0 && !exact) {
-        if (gate) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_f16x3_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, A, W, gate, R, Cout, M, N, K, act, (const float*)nullptr, 0, 0.0f, (float*)nullptr);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_f16x3_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, A, W, gate, R, Cout, M, N, K, act, (const float*)nullptr, 0, 0.0f, (float*)nullptr);
-        return mi_check_launch("gemm_f16x3_kernel");
+        return gemm_f16x3_launch(A, W, gate, R, Cout, M, N, K, act, nullptr, 0, 0.0f, nullptr, (hipStream_t)stream);
     }
     if (gate) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_f32_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, A, W, gate, R, Cout, M, N, K, act);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_f32_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, A, W, gate, R, Cout, M, N, K, act);
@@ -352,10 +388,7 @@ extern "C" int mi_gemm_f32(const float* A, const float* W, const float* gate, co
 extern "C" int mi_gemm_rms_f32(const float* A, const float* W, const float* gate, const float* R, float* Cout, int M, int N, int K, int act,
                                const float* rowsq_in, int nparts, float eps, float* rowsq_out, void* stream) {
     if (M <= 0 || N <= 0 || (gate && (N % 64) != 0) || (K % 32) != 0 || (rowsq_in && nparts <= 0)) { mi_set_error("mi_gemm_rms_f32: need M>0, K%%32==0, nparts>0 with rowsq_in (and N%%64==0 when gated) (got %d,%d,%d)", M, N, K); return MI_ERR_INVALID; }
-    const dim3 grid((N + 63) / 64, (M + 63) / 64);
-    if (gate) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_f16x3_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, A, W, gate, R, Cout, M, N, K, act, rowsq_in, nparts, eps, rowsq_out);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_f16x3_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, A, W, gate, R, Cout, M, N, K, act, rowsq_in, nparts, eps, rowsq_out);
-    return mi_check_launch("gemm_f16x3_kernel (rms)");
+    return gemm_f16x3_launch(A, W, gate, R, Cout, M, N, K, act, rowsq_in, nparts, eps, rowsq_out, (hipStream_t)stream);
 }
 
 extern "C" int mi_rmsnorm(const float* x, const float* w, float* y, int rows, int dim, float eps, const uint8_t* zero_mask, void* stream) {
