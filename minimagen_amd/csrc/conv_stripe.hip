@@ -38,9 +38,9 @@
 // development aid (tools/trace_stripe.py; -DST_TRACE builds only): shader-clock stamps of the prologue / pipeline phases of the first 1024
 // workgroups of the last launch.  Slots 0..9: consumer wave 0 (start, totals done, barrier 1, affine done, B fragments staged, barrier 3, barrier 4,
 // first step multiplied, loop done, statistics published); 10..15: loader wave 0 (start, first rows requested, barrier 3, -, barrier 4, done)
-__device__ unsigned long long mi_trace_st_buf[1024 * 16];
+__device__ unsigned long long mi_trace_st_buf[1024 * 32];
 extern "C" int mi_debug_read_trace_st(void* dst, size_t bytes) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(mi_trace_st_buf), bytes); }
-#define ST_STAMP(k) do { if (lane == 0 && blockIdx.x < 1024) mi_trace_st_buf[blockIdx.x * 16 + (k)] = clock64(); } while (0)
+#define ST_STAMP(k) do { if (lane == 0 && blockIdx.x < 1024) mi_trace_st_buf[blockIdx.x * 32 + (k)] = clock64(); } while (0)
 #else
 #define ST_STAMP(k) do { } while (0)
 #endif
@@ -53,6 +53,15 @@ extern "C" int mi_debug_read_trace_st(void* dst, size_t bytes) { return (int)hip
 #endif
 #ifndef ST_HALF_OCTETS
 #define ST_HALF_OCTETS 1
+#endif
+#ifndef ST_NB_HS
+#define ST_NB_HS 2
+#endif
+#ifndef ST_LDG2
+#define ST_LDG2 1
+#endif
+#ifndef ST_LOOKAHEAD
+#define ST_LOOKAHEAD 2
 #endif
 
 namespace {
@@ -78,18 +87,31 @@ struct StCfg {
     static constexpr int WS = UP ? W_ / 2 : W_, RPS = UP ? 1 : 2, NPR = UP ? 3 : 4;       // source width, new source rows per step, rows of the prologue
     static constexpr bool HS = W_ < 256 && ST_HALF_OCTETS;
     static constexpr int NCH = HS ? 4 : 8;
+    // steps of rows in flight per loader work-item: the step time of the pipeline cannot be shorter than (load latency) / NB.  Half-octet units hold 4
+    // dwordx4 per step, so four steps cost the registers two steps of whole octets do
+    static constexpr int NB = (HS && W_ >= 64) ? ST_NB_HS : 2;
     static constexpr int QPR = WS / 4, UNITS = RPS * QPR * KO * (HS ? 2 : 1), NLWC = (UNITS + 63) / 64;
-    static constexpr int UNITS_R = 2 * QPR * RO, NLWR = (UNITS_R + 63) / 64, NLW = NLWC + NLWR;      // residual rows: whole octets (a plain scaling: cheap)
+    // loader GROUPS: with one or two loader waves next to four MFMA waves, two of the CU's four SIMDs carry a loader wave AND an MFMA wave, the other
+    // two an MFMA wave only -- and the transform (two transcendentals per value) costs about what the step's MFMAs do, so the step is paced by the
+    // loaded SIMDs.  Two groups of loader waves take alternate steps (each with NB of ITS steps in flight): a loader wave on every SIMD, each
+    // transforming every other step.  GroupNorm members only (a plain scaling is cheap), where the step count is a multiple of NB * LDG.
+    // stages of LDS operands requested ahead of the MFMAs that use them (0 = the plain source-order loop: 256 wide, where the step is paced by memory
+    // and the registers are taken by four pixel groups per wave)
+    // (one stage for the member whose two accumulators, identity-residual prefetch and two stages of six fragments do not fit 128 registers)
+    static constexpr int LA = W_ <= 128 ? ((OM_ == 1 && NJ_ == 2 && KO_ == 2 && ST_LOOKAHEAD > 1) ? 1 : ST_LOOKAHEAD) : 0;
+    static constexpr int LDG = (ST_LDG2 && GN_ && RO_ == 0 && W_ >= 64 && W_ <= 128 && NLWC <= 2) ? 2 : 1;
+    static constexpr int NLC = NLWC * LDG;                                                  // conv loader waves
+    static constexpr int UNITS_R = 2 * QPR * RO, NLWR = (UNITS_R + 63) / 64, NLW = NLC + NLWR;      // residual rows: whole octets (a plain scaling: cheap)
     static constexpr int NG = W_ / 16, NCW = NG >= 4 ? 4 : NG, GPW = NG / NCW;             // 16-pixel groups of a row pair, MFMA waves
     static constexpr int NT = (NLW + NCW) * 64;
     static constexpr int PW = WS + 8, RING = 6, RINGR = 4, PLANE = (KO * RING + RO * RINGR) * PW;
     static constexpr int SR0 = W_ / 8;                                                      // rows per statistics block
     static constexpr int WCH = 3 * NJ * 128, WTOT = KO * WCH + RO * NJ * 128;               // 16-byte chunks of B fragments
-    static constexpr bool BREG = ST_BREG && KO == 1 && NJ == 1 && RO == 0;
+    static constexpr bool BREG = ST_BREG && KO == 1 && NJ == 1 && RO == 0 && !(LDG == 2 && OM_ == 1);      // (with the identity residual prefetch they do not fit the 128 registers of two 8-wave workgroups per CU)
     static_assert(RO == 0 || (OM_ == 0 && GN_), "a 1x1 residual conv comes with a Block and replaces the identity residual");
     // waves per SIMD the register allocation must leave room for: the 128-wide residual-conv member has eight waves per workgroup and LDS for two
     // workgroups per CU -- 136 registers would leave one
-    static constexpr int WPE = (RO > 0 && W_ == 128) ? 4 : 1;
+    static constexpr int WPE = ((RO > 0 && W_ == 128) || LDG == 2) ? 4 : 1;
     // prologue units of the MFMA waves: the stripe's first 4 input rows, as half octets where that still fits one pass
     static constexpr bool PHS = HS && 2 * NPR * QPR * KO <= NCW * 64;
     static constexpr int PCH = PHS ? 4 : 8, PU = NPR * QPR * KO * (PHS ? 2 : 1);
@@ -128,7 +150,7 @@ __device__ __forceinline__ bool st_totals_issue(const mi_act& in0, const mi_act&
 
 template <class CFG>
 __global__ __launch_bounds__(CFG::NT, CFG::WPE) void conv_stripe_kernel(const mi_conv_params p, const uint4* __restrict__ wrp, const uint4* __restrict__ rwrp, const int nblk) {
-    constexpr int W = CFG::W, KO = CFG::KO, NJ = CFG::NJ, QPR = CFG::QPR, UNITS = CFG::UNITS, NLT = CFG::NLW, NLWC = CFG::NLWC, RO = CFG::RO, RINGR = CFG::RINGR;
+    constexpr int W = CFG::W, KO = CFG::KO, NJ = CFG::NJ, QPR = CFG::QPR, UNITS = CFG::UNITS, NLT = CFG::NLW, NLWC = CFG::NLWC, NLC = CFG::NLC, LDG = CFG::LDG, RO = CFG::RO, RINGR = CFG::RINGR;
     constexpr int NCW = CFG::NCW, GPW = CFG::GPW, PW = CFG::PW, RING = CFG::RING, SR0 = CFG::SR0, WCH = CFG::WCH, WTOT = CFG::WTOT, PU = CFG::PU;
     constexpr bool GN = CFG::GN, BREG = CFG::BREG, UP = CFG::UP;
     constexpr int WS = CFG::WS, RPS = CFG::RPS, NPR = CFG::NPR;
@@ -216,9 +238,9 @@ __global__ __launch_bounds__(CFG::NT, CFG::WPE) void conv_stripe_kernel(const mi
         }
     };
 
-    if (RO > 0 && wave >= NLWC && wave < NLT) {
+    if (RO > 0 && wave >= NLC && wave < NLT) {
         // =================================================================== residual-row loader waves (1x1 residual conv input, centre tap only)
-        const int u = (wave - NLWC) * 64 + lane;
+        const int u = (wave - NLC) * 64 + lane;
         const bool live = u < CFG::UNITS_R;
         const int uu = live ? u : 0;
         const int oct = uu / (2 * QPR), lrow = (uu / QPR) & 1, q = uu % QPR;
@@ -241,7 +263,7 @@ __global__ __launch_bounds__(CFG::NT, CFG::WPE) void conv_stripe_kernel(const mi
         // again when the 64 of the two steps in flight are taken (together they spilled under the 128-register budget of two workgroups per CU)
         {
             mi_stats_regs sr2;
-            const int rt = (wave - NLWC) * 64 + lane;
+            const int rt = (wave - NLC) * 64 + lane;
             const bool fast2 = st_totals_issue(p.res0, p.res1, Cr0, Cres, b, rt, CFG::NLWR * 64, res_stats, sr2);
             if (fast2) mi_gn_totals_finish(sr2, rt, chS2, chQ2);
             else if (res_stats) mi_gn_channel_totals(p.res0, p.res1, Cr0, Cres, b, rt, CFG::NLWR * 64, chS2, chQ2);
@@ -281,13 +303,15 @@ __global__ __launch_bounds__(CFG::NT, CFG::WPE) void conv_stripe_kernel(const mi
     } else if (wave < NLT) {
         // =================================================================== loader / transform waves
         constexpr int NCH = CFG::NCH, HSM = CFG::HS ? 2 : 1;
-        const int u = wave * 64 + lane;
+        const int grp = LDG > 1 ? wave / NLWC : 0;         // loader group (wave-uniform): takes the steps s with (s - 1) % LDG == grp
+        const int u = (wave - grp * NLWC) * 64 + lane;
         const bool live = u < UNITS;
         const int uu = live ? u : 0;
         const int oct = uu / (RPS * QPR * HSM), half = HSM == 2 ? (uu / (RPS * QPR)) & 1 : 0, lrow = RPS == 2 ? (uu / QPR) & 1 : 0, q = uu % QPR;   // octet, channel half, row of the step, pixel quad
         const mi_gptr<const float> base = octet_base(oct) + (size_t)(NCH * half) * HWs;
-        f32x4 raw[2][NCH];
-        bool inimg[2];
+        constexpr int NB = CFG::NB;
+        f32x4 raw[NB][NCH];
+        bool inimg[NB];
         auto issue = [&](int s, auto buf_tag) {            // step s brings input rows y0 + 2 s + 1 + lrow (UP: source row y0 / 2 + s + 1); steps -1 and 0 are the MFMA waves' prologue
             constexpr int buf = decltype(buf_tag)::value;
             int y = UP ? y0 / 2 + s + 1 : y0 + 2 * s + 1 + lrow;
@@ -299,32 +323,42 @@ __global__ __launch_bounds__(CFG::NT, CFG::WPE) void conv_stripe_kernel(const mi
 #pragma unroll
             for (int j = 0; j < NCH; ++j) raw[buf][j] = *reinterpret_cast<mi_gptr<const f32x4>>(base + (size_t)j * HWs + off);
         };
-        constexpr std::integral_constant<int, 0> B0{};
-        constexpr std::integral_constant<int, 1> B1{};
-        if (wave == 0) ST_STAMP(10);
-        issue(1, B1);
-        issue(2, B0);
-        if (wave == 0) ST_STAMP(11);
-        if (have_stats) __syncthreads();                   // (1) channel totals in LDS
-        __syncthreads();                                   // (3) chP / sExp / B fragments / pads visible
-        if (wave == 0) ST_STAMP(12);
         float4 P[NCH];
-#pragma unroll
-        for (int j = 0; j < NCH; ++j) P[j] = chP[8 * oct + NCH * half + j];
         auto transform = [&](int s, auto buf_tag) {
             constexpr int buf = decltype(buf_tag)::value;
             transform_quad(std::integral_constant<int, NCH>{}, raw[buf], P, inimg[buf], live, oct, half, (UP ? s + 2 : 2 * s + 2 + lrow) % RING, q);      // ring row = source row - (first source row of the stripe - 1)
         };
-        __syncthreads();                                   // (4) rows of steps -1 and 0 in the ring
-        if (wave == 0) ST_STAMP(14);
-        for (int it = 0; it < NSTEP; it += 2) {            // slot it: the MFMA waves multiply step it; this wave transforms step it + 1 and requests step it + 3
-            transform(it + 1, B1);                         // (the step past the last lands in ring rows nobody reads)
-            issue(it + 3, B1);
-            __syncthreads();
-            transform(it + 2, B0);
-            issue(it + 4, B0);
-            __syncthreads();
-        }
+        // one copy of the loop per group (a group's steps are issued unconditionally WITHIN its copy); every copy passes the same barriers
+        auto run = [&](auto grp_tag) {
+            constexpr int g = decltype(grp_tag)::value;
+            if (wave == 0) ST_STAMP(10);
+            rp_for_rounds(std::make_integer_sequence<int, NB>{}, [&](auto j) { issue(1 + g + LDG * decltype(j)::value, j); });       // the group's first NB steps: its k-th step sits in buffer k % NB
+            if (wave == 0) ST_STAMP(11);
+            if (have_stats) __syncthreads();               // (1) channel totals in LDS
+            __syncthreads();                               // (3) chP / sExp / B fragments / pads visible
+            if (wave == 0) ST_STAMP(12);
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) P[j] = chP[8 * oct + NCH * half + j];
+            __syncthreads();                               // (4) rows of steps -1 and 0 in the ring
+            if (wave == 0) ST_STAMP(14);
+            for (int it = 0; it < NSTEP; it += NB * LDG) { // slot t: the MFMA waves multiply step t; the group with (t % LDG) == g transforms step t + 1 and requests its step t + 1 + NB LDG
+                rp_for_rounds(std::make_integer_sequence<int, NB * LDG>{}, [&](auto jh) {
+                    constexpr int j = decltype(jh)::value / LDG, h = decltype(jh)::value % LDG;
+                    if constexpr (h == g) {
+                        const int t = it + j * LDG + h;
+                        if (wave == 0 && t == 2) ST_STAMP(20);
+                        transform(t + 1, std::integral_constant<int, j>{});       // (the step past the last lands in ring rows nobody reads)
+                        if (wave == 0 && t == 2) ST_STAMP(21);
+                        issue(t + 1 + NB * LDG, std::integral_constant<int, j>{});
+                        if (wave == 0 && t == 2) ST_STAMP(22);
+                    }
+                    __syncthreads();
+                    if (wave == 0 && it + j * LDG + h == 2) ST_STAMP(23);
+                });
+            }
+        };
+        if (LDG == 1 || grp == 0) run(std::integral_constant<int, 0>{});
+        else run(std::integral_constant<int, LDG - 1>{});
         if (wave == 0) ST_STAMP(15);
     } else {
         // =================================================================== MFMA / epilogue waves
@@ -527,63 +561,141 @@ __global__ __launch_bounds__(CFG::NT, CFG::WPE) void conv_stripe_kernel(const mi
             for (int g = 0; g < GPW; ++g)
 #pragma unroll
                 for (int jt = 0; jt < NJ; ++jt) acc[g][jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (cw == 0 && it == 2) ST_STAMP(16);
             const int slot = (UP ? it + 1 + ((perm - 1) >> 1) : 2 * it + perm) % RING;    // UP: up-sampled rows 2 it - 1 .. 2 it + 2 = source rows it - 1, it, it, it + 1
             // D[px 16][(dy, co)] += act[px][(r, ci)] . B[(r, ci)][(dy, co)]: octets in conv_rp's round order, one instruction triple per horizontal tap
+            if constexpr (CFG::LA > 0) {
+                // software pipeline over the step's STAGES (octet x horizontal tap, then the residual octets): the operands of stage st + LA are
+                // requested from LDS before stage st is multiplied.  Written in source order the compiler requests a stage's six fragments right in
+                // front of their first use -- a step of the 16 -> 16 @64^2 member then carried 21 exposed LDS waits, 1.9 of its 2.1 us (phase
+                // trace, profiles/r06_stripe_phase_trace.txt) with 36 MFMAs = 0.25 us of matrix-core time.  Every accumulator still takes its
+                // terms in the order (lo.hi, hi.lo, hi.hi) per stage: the bits do not change.
+                constexpr int LA = CFG::LA, NS = 3 * KO + RO, NBUF = LA + 1;
+                rp_f16x8 sah[NBUF][GPW], sal[NBUF][GPW], sbh[NBUF][NJ], sbl[NBUF][NJ];
+                const int rslot = RO > 0 ? 2 * (it & 1) + (perm >> 1) : 0;
+                auto load = [&](auto st_tag) {
+                    constexpr int st = decltype(st_tag)::value, bi = st % NBUF;
+                    if constexpr (st < 3 * KO) {
+                        constexpr int o = st / 3, t = st % 3;
+                        if constexpr (!BREG) {
 #pragma unroll
-            for (int o = 0; o < KO; ++o) {
+                            for (int jt = 0; jt < NJ; ++jt) {
+                                sbh[bi][jt] = __builtin_bit_cast(rp_f16x8, wl[o * WCH + (t * NJ + jt) * 128 + lane]);
+                                sbl[bi][jt] = __builtin_bit_cast(rp_f16x8, wl[o * WCH + (t * NJ + jt) * 128 + 64 + lane]);
+                            }
+                        }
 #pragma unroll
-                for (int s = 0; s < 3; ++s) {
+                        for (int g = 0; g < GPW; ++g) {
+                            const int col = 16 * (cw * GPW + g) + lq + t;
+                            const int idx = (o * RING + slot) * PW + (UP ? ((col - 1) >> 1) + 1 : col);
+                            sah[bi][g] = __builtin_bit_cast(rp_f16x8, actH[idx]);
+                            sal[bi][g] = __builtin_bit_cast(rp_f16x8, actL[idx]);
+                        }
+                    } else {                               // the 1x1 residual conv = the centre tap over the residual octets' own two rows (lane groups 0 / 3 multiply zero weights)
+                        constexpr int o = st - 3 * KO;
+#pragma unroll
+                        for (int jt = 0; jt < NJ; ++jt) {
+                            sbh[bi][jt] = __builtin_bit_cast(rp_f16x8, wl[KO * WCH + (o * NJ + jt) * 128 + lane]);
+                            sbl[bi][jt] = __builtin_bit_cast(rp_f16x8, wl[KO * WCH + (o * NJ + jt) * 128 + 64 + lane]);
+                        }
+#pragma unroll
+                        for (int g = 0; g < GPW; ++g) {
+                            const int idx = (KO * RING + o * RINGR + rslot) * PW + 16 * (cw * GPW + g) + lq + 1;
+                            sah[bi][g] = __builtin_bit_cast(rp_f16x8, actH[idx]);
+                            sal[bi][g] = __builtin_bit_cast(rp_f16x8, actL[idx]);
+                        }
+                    }
+                };
+                auto mult = [&](auto st_tag) {
+                    constexpr int st = decltype(st_tag)::value, bi = st % NBUF;
                     rp_f16x8 bh[NJ], bl[NJ];
 #pragma unroll
                     for (int jt = 0; jt < NJ; ++jt) {
-                        if constexpr (BREG) { bh[jt] = breg[2 * s]; bl[jt] = breg[2 * s + 1]; }
-                        else {
-                            bh[jt] = __builtin_bit_cast(rp_f16x8, wl[o * WCH + (s * NJ + jt) * 128 + lane]);
-                            bl[jt] = __builtin_bit_cast(rp_f16x8, wl[o * WCH + (s * NJ + jt) * 128 + 64 + lane]);
-                        }
+                        if constexpr (BREG) { bh[jt] = breg[2 * (st % 3)]; bl[jt] = breg[2 * (st % 3) + 1]; }
+                        else { bh[jt] = sbh[bi][jt]; bl[jt] = sbl[bi][jt]; }
                     }
+                    // term by term over all accumulators: consecutive MFMAs go to different accumulators wherever the wave has more than one
 #pragma unroll
-                    for (int g = 0; g < GPW; ++g) {
-                        const int col = 16 * (cw * GPW + g) + lq + s;
-                        const int idx = (o * RING + slot) * PW + (UP ? ((col - 1) >> 1) + 1 : col);
-                        const rp_f16x8 ah = __builtin_bit_cast(rp_f16x8, actH[idx]);
-                        const rp_f16x8 al = __builtin_bit_cast(rp_f16x8, actL[idx]);
+                    for (int g = 0; g < GPW; ++g)
 #pragma unroll
+                        for (int jt = 0; jt < NJ; ++jt) acc[g][jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(sal[bi][g], bh[jt], acc[g][jt], 0, 0, 0);
+#pragma unroll
+                    for (int g = 0; g < GPW; ++g)
+#pragma unroll
+                        for (int jt = 0; jt < NJ; ++jt) acc[g][jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(sah[bi][g], bl[jt], acc[g][jt], 0, 0, 0);
+#pragma unroll
+                    for (int g = 0; g < GPW; ++g)
+#pragma unroll
+                        for (int jt = 0; jt < NJ; ++jt) acc[g][jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(sah[bi][g], bh[jt], acc[g][jt], 0, 0, 0);
+                };
+                rp_for_rounds(std::make_integer_sequence<int, (LA < NS ? LA : NS)>{}, load);
+                rp_for_rounds(std::make_integer_sequence<int, NS>{}, [&](auto st_tag) {
+                    constexpr int st = decltype(st_tag)::value;
+                    if constexpr (st + LA < NS) load(std::integral_constant<int, st + LA>{});
+                    __builtin_amdgcn_sched_barrier(0);     // (the machine scheduler otherwise sinks every request back to its first use)
+                    mult(st_tag);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            } else {
+    #pragma unroll
+                for (int o = 0; o < KO; ++o) {
+    #pragma unroll
+                    for (int s = 0; s < 3; ++s) {
+                        rp_f16x8 bh[NJ], bl[NJ];
+    #pragma unroll
                         for (int jt = 0; jt < NJ; ++jt) {
-                            acc[g][jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[jt], acc[g][jt], 0, 0, 0);
-                            acc[g][jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[jt], acc[g][jt], 0, 0, 0);
+                            if constexpr (BREG) { bh[jt] = breg[2 * s]; bl[jt] = breg[2 * s + 1]; }
+                            else {
+                                bh[jt] = __builtin_bit_cast(rp_f16x8, wl[o * WCH + (s * NJ + jt) * 128 + lane]);
+                                bl[jt] = __builtin_bit_cast(rp_f16x8, wl[o * WCH + (s * NJ + jt) * 128 + 64 + lane]);
+                            }
                         }
-#pragma unroll
-                        for (int jt = 0; jt < NJ; ++jt) acc[g][jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[jt], acc[g][jt], 0, 0, 0);
+    #pragma unroll
+                        for (int g = 0; g < GPW; ++g) {
+                            const int col = 16 * (cw * GPW + g) + lq + s;
+                            const int idx = (o * RING + slot) * PW + (UP ? ((col - 1) >> 1) + 1 : col);
+                            const rp_f16x8 ah = __builtin_bit_cast(rp_f16x8, actH[idx]);
+                            const rp_f16x8 al = __builtin_bit_cast(rp_f16x8, actL[idx]);
+    #pragma unroll
+                            for (int jt = 0; jt < NJ; ++jt) {
+                                acc[g][jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[jt], acc[g][jt], 0, 0, 0);
+                                acc[g][jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[jt], acc[g][jt], 0, 0, 0);
+                            }
+    #pragma unroll
+                            for (int jt = 0; jt < NJ; ++jt) acc[g][jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[jt], acc[g][jt], 0, 0, 0);
+                        }
                     }
                 }
-            }
-            if constexpr (RO > 0) {      // the 1x1 residual conv = the centre tap over the residual octets' own two rows (lane groups 0 / 3 multiply zero weights)
-                const int rslot = 2 * (it & 1) + (perm >> 1);
-#pragma unroll
-                for (int o = 0; o < RO; ++o) {
-                    rp_f16x8 bh[NJ], bl[NJ];
-#pragma unroll
-                    for (int jt = 0; jt < NJ; ++jt) {
-                        bh[jt] = __builtin_bit_cast(rp_f16x8, wl[KO * WCH + (o * NJ + jt) * 128 + lane]);
-                        bl[jt] = __builtin_bit_cast(rp_f16x8, wl[KO * WCH + (o * NJ + jt) * 128 + 64 + lane]);
-                    }
-#pragma unroll
-                    for (int g = 0; g < GPW; ++g) {
-                        const int idx = (KO * RING + o * RINGR + rslot) * PW + 16 * (cw * GPW + g) + lq + 1;
-                        const rp_f16x8 ah = __builtin_bit_cast(rp_f16x8, actH[idx]);
-                        const rp_f16x8 al = __builtin_bit_cast(rp_f16x8, actL[idx]);
-#pragma unroll
+                if constexpr (RO > 0) {      // the 1x1 residual conv = the centre tap over the residual octets' own two rows (lane groups 0 / 3 multiply zero weights)
+                    const int rslot = 2 * (it & 1) + (perm >> 1);
+    #pragma unroll
+                    for (int o = 0; o < RO; ++o) {
+                        rp_f16x8 bh[NJ], bl[NJ];
+    #pragma unroll
                         for (int jt = 0; jt < NJ; ++jt) {
-                            acc[g][jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[jt], acc[g][jt], 0, 0, 0);
-                            acc[g][jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[jt], acc[g][jt], 0, 0, 0);
+                            bh[jt] = __builtin_bit_cast(rp_f16x8, wl[KO * WCH + (o * NJ + jt) * 128 + lane]);
+                            bl[jt] = __builtin_bit_cast(rp_f16x8, wl[KO * WCH + (o * NJ + jt) * 128 + 64 + lane]);
                         }
-#pragma unroll
-                        for (int jt = 0; jt < NJ; ++jt) acc[g][jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[jt], acc[g][jt], 0, 0, 0);
+    #pragma unroll
+                        for (int g = 0; g < GPW; ++g) {
+                            const int idx = (KO * RING + o * RINGR + rslot) * PW + 16 * (cw * GPW + g) + lq + 1;
+                            const rp_f16x8 ah = __builtin_bit_cast(rp_f16x8, actH[idx]);
+                            const rp_f16x8 al = __builtin_bit_cast(rp_f16x8, actL[idx]);
+    #pragma unroll
+                            for (int jt = 0; jt < NJ; ++jt) {
+                                acc[g][jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[jt], acc[g][jt], 0, 0, 0);
+                                acc[g][jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[jt], acc[g][jt], 0, 0, 0);
+                            }
+    #pragma unroll
+                            for (int jt = 0; jt < NJ; ++jt) acc[g][jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[jt], acc[g][jt], 0, 0, 0);
+                        }
                     }
                 }
             }
             // epilogue: lane (lq, lg) holds pixels 4 lg .. 4 lg + 3 of channel lq & 7, row parity lq >> 3, of every group
+#ifdef ST_TRACE
+            if (cw == 0 && it == 2) { if (acc[0][0][0] == 123.456f) ST_STAMP(31); ST_STAMP(17); }       // (the comparison makes the stamp wait for the accumulators)
+#endif
 #pragma unroll
             for (int jt = 0; jt < NJ; ++jt) {
                 const int co = 8 * jt + (lq & 7);
@@ -614,6 +726,7 @@ __global__ __launch_bounds__(CFG::NT, CFG::WPE) void conv_stripe_kernel(const mi
                     csq[jt] += ok ? fmaf(d0, d0, fmaf(d1, d1, fmaf(d2, d2, d3 * d3))) : 0.0f;
                 }
             }
+            if (cw == 0 && it == 2) ST_STAMP(18);
         };
         auto flush = [&]() {                               // this wave's partial statistics of the block that just ended -> LDS (fp64)
             if (!p.out_stats || (ST_ABL & 2)) return;
@@ -642,13 +755,16 @@ __global__ __launch_bounds__(CFG::NT, CFG::WPE) void conv_stripe_kernel(const mi
         __syncthreads();                                   // (4)
         if (cw == 0) ST_STAMP(6);
         constexpr int SPB = SR0 / 2;                       // steps per statistics block
+#pragma unroll 1
         for (int kb = 0; kb < nblk; ++kb) {
             const int it0 = kb * SPB;
+#pragma unroll 1
             for (int i = 0; i < SPB; i += 2) {
                 issue_res(it0 + i + 1, std::integral_constant<int, 1>{});
                 compute(it0 + i, std::integral_constant<int, 0>{}, i == 0);
                 if (cw == 0 && kb == 0 && i == 0) ST_STAMP(7);
                 __syncthreads();
+                if (cw == 0 && it0 + i == 2) ST_STAMP(19);
                 issue_res(it0 + i + 2, std::integral_constant<int, 0>{});
                 compute(it0 + i + 1, std::integral_constant<int, 1>{}, false);
                 if (i + 2 == SPB) flush();
