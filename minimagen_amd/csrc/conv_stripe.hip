@@ -98,7 +98,7 @@ struct StCfg {
     // stages of LDS operands requested ahead of the MFMAs that use them (0 = the plain source-order loop: 256 wide, where the step is paced by memory
     // and the registers are taken by four pixel groups per wave)
     // (one stage for the member whose two accumulators, identity-residual prefetch and two stages of six fragments do not fit 128 registers)
-    static constexpr int LA = W_ <= 128 ? ((OM_ == 1 && NJ_ == 2 && KO_ == 2 && ST_LOOKAHEAD > 1) ? 1 : ST_LOOKAHEAD) : 0;
+    static constexpr int LA = W_ <= 128 ? ((NJ_ == 2 && KO_ == 2 && OM_ == 1 && ST_LOOKAHEAD > 1) ? 1 : ST_LOOKAHEAD) : 0;
     static constexpr int LDG = (ST_LDG2 && GN_ && RO_ == 0 && W_ >= 64 && W_ <= 128 && NLWC <= 2) ? 2 : 1;
     static constexpr int NLC = NLWC * LDG;                                                  // conv loader waves
     static constexpr int UNITS_R = 2 * QPR * RO, NLWR = (UNITS_R + 63) / 64, NLW = NLC + NLWR;      // residual rows: whole octets (a plain scaling: cheap)
