@@ -105,12 +105,11 @@ __device__ __forceinline__ void t5_split8(const float4& u, const float4& v, floa
 // rowsq_out [M][gridDim.x] (may be NULL): this tile's sum of squares of every output row (after the residual) -- what the NEXT projection's RMSNorm needs.
 // KS = K steps of 32 per slice (round 6: 2 where K % 64 == 0 -- the slice loop is paced by its barriers and cross-lane maxima, ~1 us per slice
 // whatever it multiplies: half the slices for the same work)
-// MI: 16-row tiles per wave in M (2: 64 x 64 output tiles; 1: 32 x 64 -- twice the workgroups for the launches that would leave CUs idle)
-template <bool GATED, int KS, int MI>
+template <bool GATED, int KS>
 __global__ __launch_bounds__(256) void gemm_f16x3_kernel(const float* __restrict__ A, const float* __restrict__ W, const float* __restrict__ G,
                                                          const float* __restrict__ R, float* __restrict__ Cout, int M, int N, int K, int act,
                                                          const float* __restrict__ rowsq_in, int nparts, float eps, float* __restrict__ rowsq_out) {
-    constexpr int BM = 32 * MI, BN = 64, BK = 32 * KS, PITCH = 4 * KS + 1;      // rows of 4 KS 16-byte chunks (8 halves each) + 1 pad chunk: conflict-free ds_read_b128
+    constexpr int BM = 64, BN = 64, BK = 32 * KS, PITCH = 4 * KS + 1;      // rows of 4 KS 16-byte chunks (8 halves each) + 1 pad chunk: conflict-free ds_read_b128
     __shared__ __attribute__((aligned(16))) uint4 Ah[BM * PITCH], Al[BM * PITCH], Wh[BN * PITCH], Wl[BN * PITCH];
     __shared__ __attribute__((aligned(16))) uint4 Gh[GATED ? BN * PITCH : 1], Gl[GATED ? BN * PITCH : 1];
     __shared__ float smax[3][4];
@@ -118,9 +117,9 @@ __global__ __launch_bounds__(256) void gemm_f16x3_kernel(const float* __restrict
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     const int lr = tid >> 2, lc = tid & 3;                    // staging: row, 8-float chunk (+ 4 per K step)
-    f32x4 acc[MI][2], accg[MI][2];
+    f32x4 acc[2][2], accg[2][2];
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) { acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; accg[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -136,7 +135,7 @@ __global__ __launch_bounds__(256) void gemm_f16x3_kernel(const float* __restrict
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const int kk = k0 + 32 * ks + 8 * lc;
-            if (lr < BM && m0 + lr < M) { const float4* pa = reinterpret_cast<const float4*>(A + (size_t)(m0 + lr) * K + kk); a0[ks] = pa[0]; a1[ks] = pa[1]; }
+            if (m0 + lr < M) { const float4* pa = reinterpret_cast<const float4*>(A + (size_t)(m0 + lr) * K + kk); a0[ks] = pa[0]; a1[ks] = pa[1]; }
             if (n0 + lr < N) {
                 const float4* pw = reinterpret_cast<const float4*>(W + (size_t)(n0 + lr) * K + kk); w0[ks] = pw[0]; w1[ks] = pw[1];
                 if (GATED) { const float4* pg = reinterpret_cast<const float4*>(G + (size_t)(n0 + lr) * K + kk); g0[ks] = pg[0]; g1[ks] = pg[1]; }
@@ -159,24 +158,24 @@ __global__ __launch_bounds__(256) void gemm_f16x3_kernel(const float* __restrict
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const int o = lr * PITCH + lc + 4 * ks;
-            if (lr < BM) { t5_split8(a0[ks], a1[ks], ldexpf(1.0f, ea), hi, lo); Ah[o] = hi; Al[o] = lo; }
+            t5_split8(a0[ks], a1[ks], ldexpf(1.0f, ea), hi, lo); Ah[o] = hi; Al[o] = lo;
             t5_split8(w0[ks], w1[ks], ldexpf(1.0f, ew), hi, lo); Wh[o] = hi; Wl[o] = lo;
             if (GATED) { t5_split8(g0[ks], g1[ks], ldexpf(1.0f, eg), hi, lo); Gh[o] = hi; Gl[o] = lo; }
         }
         if (k0 + BK < K) load_slice(k0 + BK);
         __syncthreads();
         const float un = ldexpf(1.0f, -(ea + ew)), ung = ldexpf(1.0f, -(ea + eg));
-        f32x4 sl[MI][2], slg[MI][2];
+        f32x4 sl[2][2], slg[2][2];
 #pragma unroll
-        for (int i = 0; i < MI; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) { sl[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; slg[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            t5_f16x8 ah[MI], al[MI];
+            t5_f16x8 ah[2], al[2];
 #pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                const int o = (wm * 16 * MI + i * 16 + (lane & 15)) * PITCH + (lane >> 4) + 4 * ks;
+            for (int i = 0; i < 2; ++i) {
+                const int o = (wm * 32 + i * 16 + (lane & 15)) * PITCH + (lane >> 4) + 4 * ks;
                 ah[i] = __builtin_bit_cast(t5_f16x8, Ah[o]);
                 al[i] = __builtin_bit_cast(t5_f16x8, Al[o]);
             }
@@ -185,7 +184,7 @@ __global__ __launch_bounds__(256) void gemm_f16x3_kernel(const float* __restrict
                 const int o = (wn * 32 + j * 16 + (lane & 15)) * PITCH + (lane >> 4) + 4 * ks;
                 const t5_f16x8 bh = __builtin_bit_cast(t5_f16x8, Wh[o]), bl = __builtin_bit_cast(t5_f16x8, Wl[o]);
 #pragma unroll
-                for (int i = 0; i < MI; ++i) {
+                for (int i = 0; i < 2; ++i) {
                     sl[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh, sl[i][j], 0, 0, 0);
                     sl[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl, sl[i][j], 0, 0, 0);
                     sl[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh, sl[i][j], 0, 0, 0);
@@ -193,7 +192,7 @@ __global__ __launch_bounds__(256) void gemm_f16x3_kernel(const float* __restrict
                 if (GATED) {
                     const t5_f16x8 gh = __builtin_bit_cast(t5_f16x8, Gh[o]), gl = __builtin_bit_cast(t5_f16x8, Gl[o]);
 #pragma unroll
-                    for (int i = 0; i < MI; ++i) {
+                    for (int i = 0; i < 2; ++i) {
                         slg[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], gh, slg[i][j], 0, 0, 0);
                         slg[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], gl, slg[i][j], 0, 0, 0);
                         slg[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], gh, slg[i][j], 0, 0, 0);
@@ -202,7 +201,7 @@ __global__ __launch_bounds__(256) void gemm_f16x3_kernel(const float* __restrict
             }
         }
 #pragma unroll
-        for (int i = 0; i < MI; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -223,10 +222,10 @@ __global__ __launch_bounds__(256) void gemm_f16x3_kernel(const float* __restrict
         __syncthreads();
     }
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int ml = wm * 16 * MI + i * 16 + 4 * (lane >> 4) + r, m = m0 + ml;
+            const int ml = wm * 32 + i * 16 + 4 * (lane >> 4) + r, m = m0 + ml;
             const float rs = rowsq_in ? rsc[ml] : 1.0f;
             float part = 0.0f;
 #pragma unroll
@@ -362,13 +361,8 @@ __global__ __launch_bounds__(256) void t5_attention_kernel(const float* __restri
 
 static int gemm_f16x3_launch(const float* A, const float* W, const float* gate, const float* R, float* Cout, int M, int N, int K, int act,
                              const float* rowsq_in, int nparts, float eps, float* rowsq_out, hipStream_t st) {
-    // 32-row tiles while 64-row ones would leave fewer than two workgroups per CU (T5 at M = 2048: the o / wo projections, N = 512 -> 256 tiles):
-    // a slice costs a workgroup about the same whatever it multiplies (§13.5), so twice the workgroups is nearly twice the rate there
-    static const bool bm64 = getenv("MI_GEMM_BM64") != nullptr;     // A/B knob: 64-row tiles everywhere
-    const bool small = !bm64 && (long long)((N + 63) / 64) * ((M + 63) / 64) < 512;
-    const dim3 grid((N + 63) / 64, small ? (M + 31) / 32 : (M + 63) / 64);
-#define MI_GEMM_GO(GATED, KS) do { if (small) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_f16x3_kernel<GATED, KS, 1>), grid, dim3(256), 0, st, A, W, gate, R, Cout, M, N, K, act, rowsq_in, nparts, eps, rowsq_out); \
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_f16x3_kernel<GATED, KS, 2>), grid, dim3(256), 0, st, A, W, gate, R, Cout, M, N, K, act, rowsq_in, nparts, eps, rowsq_out); } while (0)
+    const dim3 grid((N + 63) / 64, (M + 63) / 64);
+#define MI_GEMM_GO(GATED, KS) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_f16x3_kernel<GATED, KS>), grid, dim3(256), 0, st, A, W, gate, R, Cout, M, N, K, act, rowsq_in, nparts, eps, rowsq_out)
     static const bool ks1 = getenv("MI_GEMM_KS1") != nullptr;       // A/B knob: 32-wide slices everywhere
     // (128-wide slices, measured: wo 54 -> 47 us but qkv 31 -> 35 and wi 37 -> 41: two workgroups per CU instead of three; not kept)
     if ((K % 64) == 0 && !ks1) { if (gate) MI_GEMM_GO(true, 2); else MI_GEMM_GO(false, 2); }
