@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MI_ABI_VERSION 10
+#define MI_ABI_VERSION 11
 
 enum mi_status {
     MI_OK = 0,
@@ -490,6 +490,16 @@ typedef struct mi_block_bwd_params {
 int mi_block_bwd(const mi_block_bwd_params* p, void* stream);
 /* per-(image, channel) sum and sum of squares of x [rows][HW] -> stats [rows][2] (a tensor no HIP producer left statistics for) */
 int mi_chan_stats_fwd(const float* x, double* stats, int rows, int HW, void* stream);
+/* LayerNorm over the last dimension in the training graph (ABI 11) -- the reference's `LayerNorm` (layers.py:333-343: the token norms around the
+ * bottleneck cross-attention, 131 072 rows of 16 channels at B = 32) and the nn.LayerNorm members of the conditioning stack (Unet.py:107-112,
+ * layers.py:137):  y = (x - mean) rstd gamma + beta (beta may be NULL), biased variance, dim <= 1024; stat [rows][2] = (mean, rstd) is what the
+ * backward reads (may be NULL when no backward follows).
+ * Backward: dx = rstd (g - mean(g) - xh mean(g xh)) with g = dy gamma, xh = (x - mean) rstd; dgamma = sum_rows dy xh, dbeta = sum_rows dy through
+ * `partial` ([mi_layernorm_bwd_nwg(rows, dim)][2][dim] floats), added in workgroup order by a second launch: deterministic.  dgamma == NULL: dx only. */
+int mi_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stat, int rows, int dim, float eps, void* stream);
+int mi_layernorm_bwd_nwg(int rows, int dim);
+int mi_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* stat, float* dx, float* partial, float* dgamma, float* dbeta,
+                     int rows, int dim, void* stream);
 /* a [Cout][Cin][3][3] weight (adjoint != 0: its adjoint W'[ci][co][ky][kx] = W[co][ci][2-ky][2-kx]) times 2^exp -> the row-paired fp16 hi|lo
  * fragments of mi_conv_params.w_rp and the direct-conv layout [Cin'][3][3][cout_pad] of mi_conv_params.w, in one launch on the device
  * (the training path re-packs after every optimiser step).  mi_pack_conv3_floats(…, which): element counts (0: fp16 fragments, 1: fp32). */

@@ -13,7 +13,7 @@ from torch import nn
 
 from . import train_ops
 from .helpers import default, exists, cast_tuple, prob_mask_like
-from .layers import (Attention, CrossEmbedLayer, Downsample, EinopsToAndFrom, Identity, Parallel, Residual, ResnetBlock,
+from .layers import (AffineLayerNorm, Attention, CrossEmbedLayer, Downsample, EinopsToAndFrom, Identity, Parallel, Residual, ResnetBlock,
                      SinusoidalPosEmb, TransformerBlock, Upsample)
 from .t5 import get_encoded_dim
 
@@ -104,11 +104,11 @@ class Unet(nn.Module):
         for prefix in ("",) + (("lowres_",) if lowres_cond else ()):
             for name, module in self._time_trio().items():
                 setattr(self, f"to_{prefix}{name}", module)
-        self.norm_cond = nn.LayerNorm(self.cond_dim)
+        self.norm_cond = AffineLayerNorm(self.cond_dim)
         self.text_to_cond = nn.Linear(text_embed_dim, self.cond_dim)
         self.null_text_embed = nn.Parameter(torch.randn(1, MAX_TEXT_LEN, self.cond_dim))
         self.null_text_hidden = nn.Parameter(torch.randn(1, self.time_cond_dim))
-        self.to_text_non_attn_cond = nn.Sequential(nn.LayerNorm(self.cond_dim), nn.Linear(self.cond_dim, self.time_cond_dim), nn.SiLU(),
+        self.to_text_non_attn_cond = nn.Sequential(AffineLayerNorm(self.cond_dim), nn.Linear(self.cond_dim, self.time_cond_dim), nn.SiLU(),
                                                    nn.Linear(self.time_cond_dim, self.time_cond_dim))
 
         # ---- trunk, generated from the level table: stem, the way down, the middle, the way up (mirror of the table), head

@@ -239,6 +239,10 @@ def _bind(lib):
     lib.mi_crossembed_wgrad_workspace.argtypes = [i32, i32, i32]
     lib.mi_crossembed_wgrad_workspace.restype = C.c_longlong
     lib.mi_chan_stats_fwd.argtypes = [vp, vp, i32, i32, vp]
+    lib.mi_layernorm_fwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, C.c_float, vp]
+    lib.mi_layernorm_bwd_nwg.argtypes = [i32, i32]
+    lib.mi_layernorm_bwd_nwg.restype = i32
+    lib.mi_layernorm_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]
     lib.mi_pack_conv3_floats.argtypes = [i32, i32, i32, i32, i32]
     lib.mi_pack_conv3_floats.restype = C.c_longlong
     lib.mi_pack_conv3.argtypes = [vp, i32, i32, i32, i32, vp, vp, i32, vp]

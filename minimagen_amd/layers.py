@@ -52,7 +52,18 @@ class LayerNorm(_Container):
         self.register_buffer('beta', torch.zeros(dim))
 
     def forward(self, x):
+        if torch.is_grad_enabled() and train_ops.layer_norm_supported(x, self.gamma):       # training on the device: train_ln.hip forward + backward
+            return train_ops.layer_norm(x, self.gamma, self.beta)
         return F.layer_norm(x, x.shape[-1:], self.gamma, self.beta)
+
+
+class AffineLayerNorm(nn.LayerNorm):
+    """nn.LayerNorm (same parameters, same state-dict keys) whose training forward / backward runs on the HIP kernels (train_ops.layer_norm)"""
+
+    def forward(self, x):
+        if torch.is_grad_enabled() and self.elementwise_affine and len(self.normalized_shape) == 1 and train_ops.layer_norm_supported(x, self.weight):
+            return train_ops.layer_norm(x, self.weight, self.bias, self.eps)
+        return super().forward(x)
 
 
 class ChanLayerNorm(_Container):
@@ -134,7 +145,7 @@ class Attention(_Container):
         self.null_kv = nn.Parameter(torch.randn(2, dim_head))
         self.to_q = nn.Linear(dim, inner_dim, bias=False)
         self.to_kv = nn.Linear(dim, dim_head * 2, bias=False)
-        self.to_context = nn.Sequential(nn.LayerNorm(context_dim), nn.Linear(context_dim, dim_head * 2)) if exists(context_dim) else None
+        self.to_context = nn.Sequential(AffineLayerNorm(context_dim), nn.Linear(context_dim, dim_head * 2)) if exists(context_dim) else None
         self.to_out = nn.Sequential(nn.Linear(inner_dim, dim, bias=False), LayerNorm(dim))
 
     def forward(self, x, context=None, mask=None, attn_bias=None):

@@ -465,6 +465,56 @@ def folded_attention(q: torch.Tensor, kf: torch.Tensor, vf: torch.Tensor, mask) 
     return _FoldedAttnFn.apply(q, kf, vf, mask)
 
 
+def layer_norm_supported(x: torch.Tensor, weight) -> bool:
+    """mi_layernorm_fwd / _bwd: fp32, last dimension <= 1024, an affine weight"""
+    return (ENABLED and torch.is_grad_enabled() and x.dtype == torch.float32 and (x.is_cuda or FORCE) and weight is not None and x.dim() >= 2
+            and 0 < x.shape[-1] <= 1024 and x.numel() > 0)
+
+
+class _LayerNormFn(torch.autograd.Function):
+    """LayerNorm over the last dimension (the reference's LayerNorm, layers.py:333-343, and the nn.LayerNorm members of the conditioning stack) on
+    train_ln.hip, forward and backward; saved for the backward: the input and (mean, rstd) per row -- not the normalised tensor"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        lib = L.lib()
+        x2 = x.contiguous().view(-1, x.shape[-1])
+        L.require_device(x2)
+        rows, dim = x2.shape
+        y = torch.empty_like(x2)
+        stat = torch.empty(rows, 2, dtype=torch.float32, device=x.device)
+        w = weight.detach().contiguous()
+        b = None if bias is None else bias.detach().contiguous()
+        L.check(lib.mi_layernorm_fwd(x2.data_ptr(), w.data_ptr(), L.ptr(b), y.data_ptr(), stat.data_ptr(), rows, dim, float(eps), L.current_stream()), "mi_layernorm_fwd")
+        ctx.save_for_backward(x2, w, stat)
+        ctx.has_bias = bias is not None
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = L.lib()
+        x2, w, stat = ctx.saved_tensors
+        rows, dim = x2.shape
+        dy2 = dy.contiguous().view(rows, dim)
+        dx = torch.empty_like(x2)
+        need_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
+        partial = dgamma = dbeta = None
+        if need_w:
+            partial = torch.empty(lib.mi_layernorm_bwd_nwg(rows, dim), 2, dim, dtype=torch.float32, device=x2.device)
+            dgamma = torch.empty(dim, dtype=torch.float32, device=x2.device)
+            dbeta = torch.empty(dim, dtype=torch.float32, device=x2.device) if ctx.has_bias else None
+        L.check(lib.mi_layernorm_bwd(dy2.data_ptr(), x2.data_ptr(), w.data_ptr(), stat.data_ptr(), dx.data_ptr(), L.ptr(partial), L.ptr(dgamma), L.ptr(dbeta),
+                                     rows, dim, L.current_stream()), "mi_layernorm_bwd")
+        return dx.view(dy.shape), dgamma, dbeta, None
+
+
+def layer_norm(x: torch.Tensor, weight, bias, eps: float = 1e-5) -> torch.Tensor:
+    """``F.layer_norm(x, x.shape[-1:], weight, bias, eps)`` on the HIP kernels where they apply (training on the device), else torch's"""
+    if layer_norm_supported(x, weight):
+        return _LayerNormFn.apply(x, weight, bias, eps)
+    return torch.nn.functional.layer_norm(x, x.shape[-1:], weight, bias, eps)
+
+
 def block_forward(block, x: torch.Tensor, scale_shift=None) -> torch.Tensor:
     """``Block.forward`` (layers.py:131-145) through _BlockFn"""
     gnm = block.groupnorm

@@ -242,6 +242,42 @@ def test_block_function_gradients(backend, case):
         assert (a - b).abs().max() <= 2e-5 * max(1e-6, float(b.abs().max())), (case, float((a - b).abs().max()), float(b.abs().max()))
 
 
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("case", [((2, 300, 16), True), ((3, 77, 8), False), ((5, 32), True), ((2, 33, 512), True), ((1, 700, 16), False), ((4, 9, 100), True),
+                                  ((2, 3, 1024), True)])
+def test_layernorm_kernels_forward_and_backward(backend, case):
+    """train_ln.hip through train_ops.layer_norm (the reference's LayerNorm, layers.py:333-343, and nn.LayerNorm of the conditioning stack): output,
+    dx, dgamma, dbeta against torch's F.layer_norm in fp64 -- the work-item-per-row form (dim 8 / 16 / 32), the wave-per-row form, ragged row
+    counts, with and without a bias, rows with a large common offset; run-to-run bit equality of the parameter gradients (fixed-order reduction)"""
+    from minimagen_amd import train_ops
+    shape, with_bias = case
+    dev = setup(backend)
+    torch.manual_seed(3)
+    dim = shape[-1]
+    x = (torch.randn(*shape, device=dev) * 2.0 + torch.randn(*shape[:-1], 1, device=dev) * 30.0).requires_grad_()
+    w = (1.0 + 0.3 * torch.randn(dim, device=dev)).requires_grad_()
+    b = (0.2 * torch.randn(dim, device=dev)).requires_grad_() if with_bias else None
+    gy = torch.randn(*shape, device=dev)
+    train_ops.FORCE, train_ops.ENABLED = True, True
+    try:
+        assert train_ops.layer_norm_supported(x, w)
+        outs = []
+        for rep in range(2):
+            y = train_ops.layer_norm(x, w, b, 1e-5)
+            g = torch.autograd.grad(y, [x, w] + ([b] if with_bias else []), gy)
+            outs.append((y.detach(),) + g)
+    finally:
+        train_ops.FORCE, train_ops.ENABLED = False, True
+    x64, w64 = x.detach().double().requires_grad_(), w.detach().double().requires_grad_()
+    b64 = b.detach().double().requires_grad_() if with_bias else None
+    y64 = torch.nn.functional.layer_norm(x64, (dim,), w64, b64, 1e-5)
+    g64 = torch.autograd.grad(y64, [x64, w64] + ([b64] if with_bias else []), gy.double())
+    for a, r in zip(outs[0], (y64.detach(),) + g64):
+        assert (a.double() - r).abs().max() <= 3e-5 * max(1.0, float(r.abs().max())), (case, float((a.double() - r).abs().max()), float(r.abs().max()))
+    for a, c in zip(outs[0], outs[1]):
+        assert torch.equal(a, c)
+
+
 def _unet_loss_grads(im, imgs, emb, mask, hip, unet_number):
     from minimagen_amd import train_ops
     train_ops.FORCE, train_ops.ENABLED = hip, hip
