@@ -63,6 +63,9 @@ extern "C" int mi_debug_read_trace_st(void* dst, size_t bytes) { return (int)hip
 #ifndef ST_LOOKAHEAD
 #define ST_LOOKAHEAD 2
 #endif
+#ifndef ST_LOADER_DELAY
+#define ST_LOADER_DELAY 56        // x 64 clocks (s_sleep) before the loader waves' first requests, <= 128 wide (0 = none)
+#endif
 
 namespace {
 
@@ -332,6 +335,13 @@ __global__ __launch_bounds__(CFG::NT, CFG::WPE) void conv_stripe_kernel(const mi
         auto run = [&](auto grp_tag) {
             constexpr int g = decltype(grp_tag)::value;
             if (wave == 0) ST_STAMP(10);
+#if ST_LOADER_DELAY
+            // Every workgroup of a small launch starts at once, and what it requests in its first microsecond is half of everything the launch reads:
+            // the statistics and the first four rows -- the only requests the first multiply waits for -- queue among the loaders' two steps of rows,
+            // which nobody needs for another ~8 us.  The loaders start ~1.5 us late (timing only): 64^2 level of the SR step 360 -> 347 us, SR step
+            // -0.8 .. -1.5 % (profiles/r06_stripe_late_ab.txt; 0.4 / 0.8 us: less, 2.6 us: nothing).
+            if constexpr (W <= 128) __builtin_amdgcn_s_sleep(ST_LOADER_DELAY);
+#endif
             rp_for_rounds(std::make_integer_sequence<int, NB>{}, [&](auto j) { issue(1 + g + LDG * decltype(j)::value, j); });       // the group's first NB steps: its k-th step sits in buffer k % NB
             if (wave == 0) ST_STAMP(11);
             if (have_stats) __syncthreads();               // (1) channel totals in LDS
