@@ -335,7 +335,7 @@ __global__ __launch_bounds__(CFG::NT, CFG::WPE) void conv_stripe_kernel(const mi
         auto run = [&](auto grp_tag) {
             constexpr int g = decltype(grp_tag)::value;
             if (wave == 0) ST_STAMP(10);
-#if ST_LOADER_DELAY
+#if ST_LOADER_DELAY && !defined(HIPEMU)
             // Every workgroup of a small launch starts at once, and what it requests in its first microsecond is half of everything the launch reads:
             // the statistics and the first four rows -- the only requests the first multiply waits for -- queue among the loaders' two steps of rows,
             // which nobody needs for another ~8 us.  The loaders start ~1.5 us late (timing only): 64^2 level of the SR step 360 -> 347 us, SR step
