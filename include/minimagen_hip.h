@@ -112,9 +112,9 @@ typedef struct mi_conv_params {
 
 /* tile_cfg -> output tile (th x tw) handled by one workgroup; out_nt = ceil(H/th)*ceil(W/tw) */
 int mi_conv_tile_shape(int tile_cfg, int* th, int* tw);
-/* tile_cfg 12 (round 6, conv_stripe.hip): the narrow k3 s1 layers on images 32 / 64 / 128 / 256 pixels wide as full-width row stripes with
-   specialised loader and MFMA waves (same arithmetic and bits as tile_cfg 5..7; fp32 storage only).  Returns the rows per statistics block
-   (out_nt = H / rows: 8, or 4 on 32-wide images) when mi_conv_fwd(p) with tile_cfg 12 takes the launch described by p (every field but
+/* tile_cfg 12 (round 6, conv_stripe.hip): the narrow k3 s1 layers on images 32 / 64 / 128 / 256 pixels wide -- and the k4 s2 Downsample conv over 8
+   channels to 64 / 128 output columns -- as full-width row stripes with specialised loader and MFMA waves (same arithmetic and bits as tile_cfg 6 / 7;
+   fp32 storage only).  Returns the rows per statistics block (W / 8 of the OUTPUT: out_nt = H / rows) when mi_conv_fwd(p) with tile_cfg 12 takes the launch described by p (every field but
    tile_cfg / out / out_stats is looked at), else 0.  tile_cfg bits 12..15 = statistics blocks per workgroup (0 = the library's choice; speed only). */
 int mi_conv_stripe_rows(const mi_conv_params* p);
 int mi_conv_prep_fwd(const mi_conv_params* p, void* stream);      /* operand planes of the wide GEMM kernel (tile_cfg 11) */

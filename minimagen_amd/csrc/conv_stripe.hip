@@ -86,8 +86,13 @@ struct StCfg {
     // (HS: 4) channels of one (half) octet: that many dwordx4 loads per step, TWO steps in flight, issued unconditionally and unrolled by two so that
     // the wait before a transform is exact.  HS below 256 wide: a step's GroupNorm / SiLU / split of 32 values per work-item was the per-step critical
     // path there (phase trace: 2.7 us per step whatever the width); 16 values on twice the work-items halve it.  256-wide steps are paced by memory.
-    static constexpr bool UP = OM_ == 3;
-    static constexpr int WS = UP ? W_ / 2 : W_, RPS = UP ? 1 : 2, NPR = UP ? 3 : 4;       // source width, new source rows per step, rows of the prologue
+    // OM 4 (DS): the 4x4 stride-2 Downsample conv (layers.py:308-319) as in conv_rp's MODE 2 -- N = 16 output channels of ONE output row, K = 4 input
+    // rows x 8 channels per horizontal tap (four taps); W_ is the OUTPUT width, the ring holds source rows of twice the width as two column-parity
+    // planes (tap kx of output pixel x reads source column 2 x - 1 + kx: consecutive pixels are consecutive chunks of one plane), two new source
+    // rows and one output row per step
+    static constexpr bool UP = OM_ == 3, DS = OM_ == 4;
+    static constexpr int NTAP = DS ? 4 : 3, NCO = DS ? 16 : 8, OPS = DS ? 1 : 2;           // horizontal taps, output channels per N tile, output rows per step
+    static constexpr int WS = DS ? 2 * W_ : (UP ? W_ / 2 : W_), RPS = UP ? 1 : 2, NPR = UP ? 3 : 4;       // source width, new source rows per step, rows of the prologue
     static constexpr bool HS = W_ < 256 && ST_HALF_OCTETS;
     static constexpr int NCH = HS ? 4 : 8;
     // steps of rows in flight per loader work-item: the step time of the pipeline cannot be shorter than (load latency) / NB.  Half-octet units hold 4
@@ -107,10 +112,11 @@ struct StCfg {
     static constexpr int UNITS_R = 2 * QPR * RO, NLWR = (UNITS_R + 63) / 64, NLW = NLC + NLWR;      // residual rows: whole octets (a plain scaling: cheap)
     static constexpr int NG = W_ / 16, NCW = NG >= 4 ? 4 : NG, GPW = NG / NCW;             // 16-pixel groups of a row pair, MFMA waves
     static constexpr int NT = (NLW + NCW) * 64;
-    static constexpr int PW = WS + 8, RING = 6, RINGR = 4, PLANE = (KO * RING + RO * RINGR) * PW;
+    static constexpr int PWH = WS / 2 + 2;                                                  // DS: chunks of one column-parity plane of a ring row (a zero chunk at either end)
+    static constexpr int PW = DS ? 2 * PWH : WS + 8, RING = 6, RINGR = 4, PLANE = (KO * RING + RO * RINGR) * PW;
     static constexpr int SR0 = W_ / 8;                                                      // rows per statistics block
-    static constexpr int WCH = 3 * NJ * 128, WTOT = KO * WCH + RO * NJ * 128;               // 16-byte chunks of B fragments
-    static constexpr bool BREG = ST_BREG && KO == 1 && NJ == 1 && RO == 0 && !(LDG == 2 && OM_ == 1);      // (with the identity residual prefetch they do not fit the 128 registers of two 8-wave workgroups per CU)
+    static constexpr int WCH = NTAP * NJ * 128, WTOT = KO * WCH + RO * NJ * 128;               // 16-byte chunks of B fragments
+    static constexpr bool BREG = ST_BREG && KO == 1 && NJ == 1 && RO == 0 && !DS && !(LDG == 2 && OM_ == 1);      // (with the identity residual prefetch they do not fit the 128 registers of two 8-wave workgroups per CU)
     static_assert(RO == 0 || (OM_ == 0 && GN_), "a 1x1 residual conv comes with a Block and replaces the identity residual");
     // waves per SIMD the register allocation must leave room for: the 128-wide residual-conv member has eight waves per workgroup and LDS for two
     // workgroups per CU -- 136 registers would leave one
@@ -119,6 +125,7 @@ struct StCfg {
     static constexpr bool PHS = HS && 2 * NPR * QPR * KO <= NCW * 64;
     static constexpr int PCH = PHS ? 4 : 8, PU = NPR * QPR * KO * (PHS ? 2 : 1);
     static_assert(PU <= NCW * 64, "the MFMA waves transform the first four rows in one pass");
+    static_assert(!DS || (LA > 0 && !GN_ && RO_ == 0 && W_ <= 128), "the stride-2 member is a plain conv, at most 128 output columns");
 };
 
 // mi_gn_totals_issue (common.hip.h) with every load UNCONDITIONAL (clamped, always legal addresses; a missing statistics pointer reads the
@@ -155,19 +162,20 @@ template <class CFG>
 __global__ __launch_bounds__(CFG::NT, CFG::WPE) void conv_stripe_kernel(const mi_conv_params p, const uint4* __restrict__ wrp, const uint4* __restrict__ rwrp, const int nblk) {
     constexpr int W = CFG::W, KO = CFG::KO, NJ = CFG::NJ, QPR = CFG::QPR, UNITS = CFG::UNITS, NLT = CFG::NLW, NLWC = CFG::NLWC, NLC = CFG::NLC, LDG = CFG::LDG, RO = CFG::RO, RINGR = CFG::RINGR;
     constexpr int NCW = CFG::NCW, GPW = CFG::GPW, PW = CFG::PW, RING = CFG::RING, SR0 = CFG::SR0, WCH = CFG::WCH, WTOT = CFG::WTOT, PU = CFG::PU;
-    constexpr bool GN = CFG::GN, BREG = CFG::BREG, UP = CFG::UP;
+    constexpr bool GN = CFG::GN, BREG = CFG::BREG, UP = CFG::UP, DS = CFG::DS;
+    constexpr int NTAP = CFG::NTAP, NCO = CFG::NCO, OPS = CFG::OPS, PWH = CFG::PWH;
     constexpr int WS = CFG::WS, RPS = CFG::RPS, NPR = CFG::NPR;
     __shared__ __attribute__((aligned(16))) uint4 actH[CFG::PLANE];
     __shared__ __attribute__((aligned(16))) uint4 actL[CFG::PLANE];
     __shared__ __attribute__((aligned(16))) uint4 wl[BREG ? 1 : WTOT];
     __shared__ __attribute__((aligned(16))) float4 chP[RP_MAXC];
     __shared__ double chS[RP_MAXC], chQ[RP_MAXC], chS2[RO ? RP_MAXC : 1], chQ2[RO ? RP_MAXC : 1];
-    __shared__ double red[NCW][2 * 8 * NJ];
+    __shared__ double red[NCW][2 * NCO * NJ];
     __shared__ int sExp[4];
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lq = lane & 15, lg = lane >> 4;
     const int H = p.H, HW = H * W;
-    const int Hs = UP ? H / 2 : H, HWs = UP ? HW / 4 : HW;           // source image
+    const int Hs = UP ? H / 2 : (DS ? 2 * H : H), HWs = UP ? HW / 4 : (DS ? 4 * HW : HW);           // source image
     const int nt = H / SR0;                            // statistics blocks per image
     const int wgs = nt / nblk;                         // workgroups per image
     // XCD-aware placement as in conv_rp.hip (speed only): workgroup L runs on XCD L % 8; whole images per XCD
@@ -182,7 +190,8 @@ __global__ __launch_bounds__(CFG::NT, CFG::WPE) void conv_stripe_kernel(const mi
         b = blockIdx.x / wgs;
         sidx = blockIdx.x % wgs;
     }
-    const int blk0 = sidx * nblk, y0 = blk0 * SR0, RS = nblk * SR0, NSTEP = RS / 2;
+    const int blk0 = sidx * nblk, y0 = blk0 * SR0, RS = nblk * SR0, NSTEP = RS / OPS;
+    const int ys0 = UP ? y0 / 2 : (DS ? 2 * y0 : y0);        // first source row of the stripe's own rows
     const int C0 = p.in0.C, C1 = p.in1.data ? p.in1.C : 0, Cin = C0 + C1;
     const bool have_stats = !(ST_ABL & 4) && (GN || p.in0.stats != nullptr);
     const int Cr0 = RO ? p.res0.C : 0, Cr1 = (RO && p.res1.data) ? p.res1.C : 0, Cres = Cr0 + Cr1;
@@ -229,7 +238,7 @@ __global__ __launch_bounds__(CFG::NT, CFG::WPE) void conv_stripe_kernel(const mi
                 for (int i = 0; i < NC / 2; ++i) { h[i] = 0u; l[i] = 0u; }
             }
             if (live) {
-                const int idx = (oct * RING + slot) * PW + 1 + 4 * q + px;
+                const int idx = (oct * RING + slot) * PW + (DS ? (px & 1) * PWH + 2 * q + (px >> 1) + 1 : 1 + 4 * q + px);      // DS: source column 4 q + px -> its parity plane
                 if constexpr (NC == 8) {
                     actH[idx] = make_uint4(h[0], h[1], h[2], h[3]);
                     actL[idx] = make_uint4(l[0], l[1], l[2], l[3]);
@@ -317,8 +326,8 @@ __global__ __launch_bounds__(CFG::NT, CFG::WPE) void conv_stripe_kernel(const mi
         bool inimg[NB];
         auto issue = [&](int s, auto buf_tag) {            // step s brings input rows y0 + 2 s + 1 + lrow (UP: source row y0 / 2 + s + 1); steps -1 and 0 are the MFMA waves' prologue
             constexpr int buf = decltype(buf_tag)::value;
-            int y = UP ? y0 / 2 + s + 1 : y0 + 2 * s + 1 + lrow;
-            const int ylast = UP ? (y0 + RS) / 2 : y0 + RS;
+            int y = UP ? ys0 + s + 1 : ys0 + 2 * s + 1 + lrow;
+            const int ylast = UP ? (y0 + RS) / 2 : (DS ? 2 * (y0 + RS) : y0 + RS);
             y = y > ylast ? ylast : y;                    // steps past the stripe (issued UNCONDITIONALLY: a conditional issue makes the compiler's wait counts conservative) re-read its last halo row
             const bool ok = y < Hs;
             inimg[buf] = ok;
@@ -394,7 +403,7 @@ __global__ __launch_bounds__(CFG::NT, CFG::WPE) void conv_stripe_kernel(const mi
         }
 #pragma unroll
         for (int jt = 0; jt < NJ; ++jt) {
-            const int co = 8 * jt + (lq & 7);
+            const int co = NCO * jt + (DS ? lq : (lq & 7));
             const bool hb = p.bias != nullptr && co < p.Cout;
             ld_b[jt] = (hb ? p.bias : p.in0.data)[hb ? co : 0];
             if constexpr (RO > 0) { const bool hr = p.res_b != nullptr && co < p.Cout; ld_rb[jt] = (hr ? p.res_b : p.in0.data)[hr ? co : 0]; }
@@ -420,7 +429,7 @@ __global__ __launch_bounds__(CFG::NT, CFG::WPE) void conv_stripe_kernel(const mi
         const int pu = plive ? ct : 0;
         const int poct = pu / (NPR * QPR * PHM), phalf = PHM == 2 ? (pu / (NPR * QPR)) & 1 : 0, prow = (pu / QPR) % NPR, pq = pu % QPR;
         f32x4 praw[PCH];
-        const int py = (UP ? y0 / 2 : y0) - 1 + prow;
+        const int py = ys0 - 1 + prow;
         const bool pin = py >= 0 && py < Hs;
         {
             const mi_gptr<const float> pbase = octet_base(poct) + (size_t)(PCH * phalf) * HWs;
@@ -430,7 +439,7 @@ __global__ __launch_bounds__(CFG::NT, CFG::WPE) void conv_stripe_kernel(const mi
         }
         // the horizontal zero padding of the conv = a zero chunk left and right of every ring row
         for (int k = ct; k < KO * RING * 2; k += NCT) {
-            const int r = k >> 1, c = (k & 1) ? WS + 1 : 0;
+            const int r = k >> 1, c = DS ? ((k & 1) ? WS / 2 + 1 : PWH) : ((k & 1) ? WS + 1 : 0);      // (DS: source column -1 is chunk 0 of the odd plane, column WS the last chunk of the even one)
             actH[r * PW + c] = make_uint4(0u, 0u, 0u, 0u);
             actL[r * PW + c] = make_uint4(0u, 0u, 0u, 0u);
         }
@@ -538,12 +547,13 @@ __global__ __launch_bounds__(CFG::NT, CFG::WPE) void conv_stripe_kernel(const mi
         float bvv[NJ];
 #pragma unroll
         for (int jt = 0; jt < NJ; ++jt) {
-            bvv[jt] = (p.bias != nullptr && 8 * jt + (lq & 7) < p.Cout) ? ld_b[jt] : 0.0f;
-            if constexpr (RO > 0) bvv[jt] += (p.res_b != nullptr && 8 * jt + (lq & 7) < p.Cout) ? ld_rb[jt] : 0.0f;
+            const int cob = NCO * jt + (DS ? lq : (lq & 7));
+            bvv[jt] = (p.bias != nullptr && cob < p.Cout) ? ld_b[jt] : 0.0f;
+            if constexpr (RO > 0) bvv[jt] += (p.res_b != nullptr && cob < p.Cout) ? ld_rb[jt] : 0.0f;
         }
         const int perm = ((lg & 1) << 1) | (lg >> 1);     // lane group -> input row (0, 2, 1, 3)
-        const int dy = lq >> 3;
-        constexpr bool idres = CFG::OM == 1, MASKC = CFG::OM == 2;
+        const int dy = DS ? 0 : lq >> 3;
+        constexpr bool idres = CFG::OM == 1, MASKC = CFG::OM == 2 || DS;
         const mi_gptr<float> obuf = mi_global(p.out + (size_t)b * p.Cout * HW);
         const mi_gptr<const float> rbuf = mi_global(idres ? p.res0.data + (size_t)mi_row_of(b, p.res0.bmod) * p.res0.C * HW : p.out);
         const float unscale = ldexpf(1.0f, -sExp[2]);
@@ -572,7 +582,7 @@ __global__ __launch_bounds__(CFG::NT, CFG::WPE) void conv_stripe_kernel(const mi
 #pragma unroll
                 for (int jt = 0; jt < NJ; ++jt) acc[g][jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
             if (cw == 0 && it == 2) ST_STAMP(16);
-            const int slot = (UP ? it + 1 + ((perm - 1) >> 1) : 2 * it + perm) % RING;    // UP: up-sampled rows 2 it - 1 .. 2 it + 2 = source rows it - 1, it, it, it + 1
+            const int slot = (UP ? it + 1 + ((perm - 1) >> 1) : (DS ? 2 * it + lg : 2 * it + perm)) % RING;     // DS: lane group = vertical tap (source rows 2 y - 1 .. 2 y + 2)    // UP: up-sampled rows 2 it - 1 .. 2 it + 2 = source rows it - 1, it, it, it + 1
             // D[px 16][(dy, co)] += act[px][(r, ci)] . B[(r, ci)][(dy, co)]: octets in conv_rp's round order, one instruction triple per horizontal tap
             if constexpr (CFG::LA > 0) {
                 // software pipeline over the step's STAGES (octet x horizontal tap, then the residual octets): the operands of stage st + LA are
@@ -580,13 +590,13 @@ __global__ __launch_bounds__(CFG::NT, CFG::WPE) void conv_stripe_kernel(const mi
                 // front of their first use -- a step of the 16 -> 16 @64^2 member then carried 21 exposed LDS waits, 1.9 of its 2.1 us (phase
                 // trace, profiles/r06_stripe_phase_trace.txt) with 36 MFMAs = 0.25 us of matrix-core time.  Every accumulator still takes its
                 // terms in the order (lo.hi, hi.lo, hi.hi) per stage: the bits do not change.
-                constexpr int LA = CFG::LA, NS = 3 * KO + RO, NBUF = LA + 1;
+                constexpr int LA = CFG::LA, NS = NTAP * KO + RO, NBUF = LA + 1;
                 rp_f16x8 sah[NBUF][GPW], sal[NBUF][GPW], sbh[NBUF][NJ], sbl[NBUF][NJ];
                 const int rslot = RO > 0 ? 2 * (it & 1) + (perm >> 1) : 0;
                 auto load = [&](auto st_tag) {
                     constexpr int st = decltype(st_tag)::value, bi = st % NBUF;
-                    if constexpr (st < 3 * KO) {
-                        constexpr int o = st / 3, t = st % 3;
+                    if constexpr (st < NTAP * KO) {
+                        constexpr int o = st / NTAP, t = st % NTAP;
                         if constexpr (!BREG) {
 #pragma unroll
                             for (int jt = 0; jt < NJ; ++jt) {
@@ -597,12 +607,12 @@ __global__ __launch_bounds__(CFG::NT, CFG::WPE) void conv_stripe_kernel(const mi
 #pragma unroll
                         for (int g = 0; g < GPW; ++g) {
                             const int col = 16 * (cw * GPW + g) + lq + t;
-                            const int idx = (o * RING + slot) * PW + (UP ? ((col - 1) >> 1) + 1 : col);
+                            const int idx = (o * RING + slot) * PW + (DS ? ((t + 1) & 1) * PWH + 16 * (cw * GPW + g) + lq + ((t + 1) >> 1) : (UP ? ((col - 1) >> 1) + 1 : col));
                             sah[bi][g] = __builtin_bit_cast(rp_f16x8, actH[idx]);
                             sal[bi][g] = __builtin_bit_cast(rp_f16x8, actL[idx]);
                         }
                     } else {                               // the 1x1 residual conv = the centre tap over the residual octets' own two rows (lane groups 0 / 3 multiply zero weights)
-                        constexpr int o = st - 3 * KO;
+                        constexpr int o = st - NTAP * KO;
 #pragma unroll
                         for (int jt = 0; jt < NJ; ++jt) {
                             sbh[bi][jt] = __builtin_bit_cast(rp_f16x8, wl[KO * WCH + (o * NJ + jt) * 128 + lane]);
@@ -708,7 +718,7 @@ __global__ __launch_bounds__(CFG::NT, CFG::WPE) void conv_stripe_kernel(const mi
 #endif
 #pragma unroll
             for (int jt = 0; jt < NJ; ++jt) {
-                const int co = 8 * jt + (lq & 7);
+                const int co = NCO * jt + (DS ? lq : (lq & 7));
                 const float bv = bvv[jt];
                 f32x4 yv[GPW];
 #pragma unroll
@@ -720,14 +730,14 @@ __global__ __launch_bounds__(CFG::NT, CFG::WPE) void conv_stripe_kernel(const mi
                     yv[g] = y;
                 }
                 if (first_of_block) {                      // statistics about a per-channel shift: the block's first value of the channel in this wave
-                    cshift[jt] = __shfl(yv[0][0], lq & 7);
+                    cshift[jt] = __shfl(yv[0][0], DS ? lq : (lq & 7));
                     csum[jt] = 0.f; csq[jt] = 0.f;
                 }
                 const float cs_ = cshift[jt];
                 const bool ok = !MASKC || co < p.Cout;
 #pragma unroll
                 for (int g = 0; g < GPW; ++g) {
-                    const int oy = y0 + 2 * it + dy, ox = 16 * (cw * GPW + g) + 4 * lg;
+                    const int oy = y0 + OPS * it + dy, ox = 16 * (cw * GPW + g) + 4 * lg;
                     const f32x4 y = yv[g];
                     if constexpr (MASKC) { if (ok) *reinterpret_cast<mi_gptr<f32x4>>(obuf + (unsigned)(co * HW + oy * W + ox)) = y; }
                     else *reinterpret_cast<mi_gptr<f32x4>>(obuf + (unsigned)(co * HW + oy * W + ox)) = y;
@@ -743,18 +753,18 @@ __global__ __launch_bounds__(CFG::NT, CFG::WPE) void conv_stripe_kernel(const mi
 #pragma unroll
             for (int jt = 0; jt < NJ; ++jt) {
                 float s_ = csum[jt], q_ = csq[jt];
-                s_ += __shfl_xor(s_, 8); q_ += __shfl_xor(q_, 8);
+                if constexpr (!DS) { s_ += __shfl_xor(s_, 8); q_ += __shfl_xor(q_, 8); }       // (DS: a lane's 16 columns are 16 channels of one row)
                 s_ += __shfl_xor(s_, 16); q_ += __shfl_xor(q_, 16);
                 s_ += __shfl_xor(s_, 32); q_ += __shfl_xor(q_, 32);
-                if (lane < 8) {
+                if (lane < NCO) {
                     mi_stat_acc a; a.c = cshift[jt]; a.s = s_; a.q = q_; a.n = GPW * 16 * SR0;
-                    mi_stat_finish(a, red[cw][2 * (8 * jt + lane)], red[cw][2 * (8 * jt + lane) + 1]);
+                    mi_stat_finish(a, red[cw][2 * (NCO * jt + lane)], red[cw][2 * (NCO * jt + lane) + 1]);
                 }
             }
         };
         auto publish = [&](int blk) {                      // after the step barrier: the block's partials of all waves, added in a fixed order
             if (!p.out_stats || cw != 0 || (ST_ABL & 2)) return;
-            if (lane < 2 * 8 * NJ && (lane >> 1) < p.Cout) {
+            if (lane < 2 * NCO * NJ && (lane >> 1) < p.Cout) {
                 double v = red[0][lane];
                 if constexpr (NCW == 2) v = red[0][lane] + red[1][lane];
                 if constexpr (NCW == 4) v = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
@@ -764,7 +774,7 @@ __global__ __launch_bounds__(CFG::NT, CFG::WPE) void conv_stripe_kernel(const mi
         issue_res(0, std::integral_constant<int, 0>{});
         __syncthreads();                                   // (4)
         if (cw == 0) ST_STAMP(6);
-        constexpr int SPB = SR0 / 2;                       // steps per statistics block
+        constexpr int SPB = SR0 / OPS;                     // steps per statistics block
 #pragma unroll 1
         for (int kb = 0; kb < nblk; ++kb) {
             const int it0 = kb * SPB;
@@ -803,7 +813,7 @@ int launch_stripe(const mi_conv_params& p, hipStream_t st) {
 
 template <int W>
 int launch_stripe_w(const mi_conv_params& p, hipStream_t st, int ko, int nj, bool gn) {
-    const int om = p.up2 ? 3 : (p.Cout < 8 * nj ? 2 : ((p.res0.data && !p.res_w) ? 1 : 0));
+    const int om = p.ksize == 4 ? 4 : (p.up2 ? 3 : (p.Cout < 8 * nj ? 2 : ((p.res0.data && !p.res_w) ? 1 : 0)));
     // the layer shapes of the BASELINE U-Nets: 8 / 16 / 24 / 32 input channels, 8 or 16 (or 3) output channels
 #define ST_BLOCK(KO, NJ) if (gn && ko == KO && nj == NJ) return om == 1 ? launch_stripe<W, KO, NJ, true, 1>(p, st) : launch_stripe<W, KO, NJ, true, 0>(p, st)
 #define ST_PLAIN(KO, NJ, OMV) if (!gn && ko == KO && nj == NJ && om == OMV) return launch_stripe<W, KO, NJ, false, OMV>(p, st)
@@ -819,6 +829,7 @@ int launch_stripe_w(const mi_conv_params& p, hipStream_t st, int ko, int nj, boo
     ST_PLAIN(1, 1, 2);                                       // the final 8 -> 3 conv
     if constexpr (W <= 64) { ST_PLAIN(1, 2, 0); }            // the folded Parallel(3x3, 1x1) conv 8 -> 16 of the base U-Net
     if constexpr (W >= 64 && W <= 128) { ST_PLAIN(1, 1, 3); ST_PLAIN(2, 1, 3); }      // nearest x2 + conv
+    if constexpr (W >= 64 && W <= 128) { ST_PLAIN(1, 1, 4); }                         // 4x4 stride 2: 8 -> 8 / 16 channels (one N tile of 16)
 #undef ST_BLOCK
 #undef ST_PLAIN
     return MI_ERR_UNSUPPORTED;
@@ -826,7 +837,8 @@ int launch_stripe_w(const mi_conv_params& p, hipStream_t st, int ko, int nj, boo
 
 // rows per statistics block if this launch runs on the stripe kernel, else 0
 int stripe_block_rows(const mi_conv_params& p, int* ko_, int* nj_) {
-    if (!(p.ksize == 3 && p.stride == 1) || !p.w_rp || p.gn_coef || (p.tile_cfg & MI_CONV_HALF) || p.out_st) return 0;
+    const bool ds = p.ksize == 4 && p.stride == 2;
+    if (!((p.ksize == 3 && p.stride == 1) || ds) || !p.w_rp || p.gn_coef || (p.tile_cfg & MI_CONV_HALF) || p.out_st) return 0;
     if (p.in0.st || (p.in1.data && p.in1.st) || (p.res0.data && p.res0.st)) return 0;
     if (!(p.W == 32 || p.W == 64 || p.W == 128 || p.W == 256)) return 0;
     const int sr0 = p.W / 8;
@@ -840,8 +852,13 @@ int stripe_block_rows(const mi_conv_params& p, int* ko_, int* nj_) {
     } else if (p.res0.data && p.res0.C != p.Cout) return 0;
     if (p.gn_groups > MI_MAX_GROUPS || (p.gn_groups > 0 && ((C0 + C1) % p.gn_groups))) return 0;
     if (p.gn_groups > 0 && (!p.in0.stats || (p.in1.data && !p.in1.stats))) return 0;
-    const int ko = (C0 + C1) >> 3, nj = (p.Cout + 7) >> 3;
+    const int ko = (C0 + C1) >> 3, nj = ds ? (p.Cout + 15) >> 4 : (p.Cout + 7) >> 3;
     const bool gn = p.gn_groups > 0;
+    if (ds) {           // 4x4 stride 2 (Downsample): 8 input channels, one N tile of 16 output channels, no GroupNorm / residual / up-sampling, output 64 or 128 wide
+        if (gn || p.res0.data || p.up2 || C1 || ko != 1 || nj != 1 || !(p.W == 64 || p.W == 128)) return 0;
+        if (ko_) { *ko_ = ko; *nj_ = nj; }
+        return sr0;
+    }
     const int om = p.up2 ? 3 : (p.Cout < 8 * nj ? 2 : ((p.res0.data && !rconv) ? 1 : 0));
     if (om == 3) {      // nearest x2 + conv (Upsample): 8 or 16 -> 8 channels, no GroupNorm, no residual, output at least 64 wide
         // (256-wide outputs stay on the tile kernel: write-bound, 52 against 48 us in the captured SR step; 128 wide: 20.8 against 27.8 us)

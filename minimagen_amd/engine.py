@@ -391,11 +391,11 @@ class UnetEngine:
         lib.mi_conv_tile_shape(best, C.byref(th), C.byref(tw))
         return best, -(-H // th.value) * -(-W // tw.value)
 
-    def _stripe_rows(self, batch, Ho, Wo, in0, in1, Cout, gn, res, up2=0) -> int:
-        """rows per statistics block if csrc/conv_stripe.hip (tile_cfg 12) takes this narrow fp32 k3 s1 launch, else 0: asked of the library
+    def _stripe_rows(self, batch, Ho, Wo, in0, in1, Cout, gn, res, up2=0, ksize=3, stride=1) -> int:
+        """rows per statistics block if csrc/conv_stripe.hip (tile_cfg 12) takes this narrow fp32 k3 s1 (or k4 s2) launch, else 0: asked of the library
         (mi_conv_stripe_rows) on a probe of the launch's shape -- pointers only need to be non-null where the real launch has them"""
         q = L.MiConvParams()
-        q.B, q.H, q.W, q.Cout, q.ksize, q.stride, q.up2 = batch, Ho, Wo, Cout, 3, 1, int(bool(up2))
+        q.B, q.H, q.W, q.Cout, q.ksize, q.stride, q.up2 = batch, Ho, Wo, Cout, ksize, stride, int(bool(up2))
         q.in0 = L.MiAct(1, in0.C, 1 if in0.stats is not None else 0, in0.nt, 1.0, 0)
         if in1 is not None:
             q.in1 = L.MiAct(1, in1.C, 1 if in1.stats is not None else 0, in1.nt, 1.0, 0)
@@ -463,8 +463,8 @@ class UnetEngine:
             th, tw = {6: (8, 64), 7: (8, 32), 10: (16, 16), 11: (8, 16)}[cfg]
             nt = -(-Ho // th) * -(-Wo // tw)
             cls = "L" if Ho * Wo > 128 * 128 else ("M" if Ho * Wo > 64 * 64 else "S")
-            if narrow and ksize == 3 and stride == 1 and not ws.half and cls in CONV_STRIPE:
-                rows = self._stripe_rows(batch, Ho, Wo, in0, in1, Cout, gn, res, up2)
+            if narrow and ((ksize == 3 and stride == 1) or (ksize == 4 and stride == 2)) and not ws.half and cls in CONV_STRIPE:
+                rows = self._stripe_rows(batch, Ho, Wo, in0, in1, Cout, gn, res, up2, ksize, stride)
                 if rows:
                     cfg, nt, stripe = 12, Ho // rows, True
         if ws.store16 and (not rp or wide):

@@ -192,6 +192,52 @@ def test_conv_full_width_stripes_upsampling(backend, case):
     assert torch.equal(o_rp, out), f"stripe and tile kernels differ: max|d| = {(o_rp - out).abs().max().item():.3e}"
 
 
+DOWN_CASES = [
+    # B, Cout, H, W (OUTPUT size), xscale, wscale: Conv 4x4 stride 2 over 8 channels (Downsample, layers.py:308-319), no GroupNorm
+    (2, 8, 32, 128, 1.0, 1.0),          # SR U-Net: 8 -> 8, 256^2 -> 128^2
+    (8, 16, 16, 64, 1.0, 1.0),          # SR U-Net: 8 -> 16, 128^2 -> 64^2 (B % 8 == 0)
+    (1, 8, 24, 64, 300.0, 1.0 / 64),    # scaled operands, H not a power of two
+]
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("case", DOWN_CASES)
+def test_conv_full_width_stripes_downsampling(backend, case):
+    """tile_cfg 12 with the 4x4 stride-2 conv: the ring holds source rows of twice the width as two column-parity planes, one output row per step;
+    against torch fp64 and bit for bit against conv_rp's MODE 2"""
+    dev = setup(backend)
+    lib = L.lib()
+    B, Cout, H, W, xs, wsc = case
+    g = torch.Generator().manual_seed(hash(case) & 0xffff)
+    rn = lambda *s_: torch.randn(*s_, generator=g)
+    x = (rn(B, 8, 2 * H, 2 * W) * 1.5 + 0.3) * xs
+    w, bias = rn(Cout, 8, 4, 4) * 0.2 * wsc, rn(Cout) * wsc * xs
+    ref = F.conv2d(x.double(), w.double(), bias.double(), stride=2, padding=1)
+    keep = {}
+    d = lambda name, t: keep.setdefault(name, t.to(dev).contiguous())
+    p = L.MiConvParams()
+    p.B, p.H, p.W = B, H, W
+    p.in0 = L.MiAct(d("x", x).data_ptr(), 8, d("s", chan_stats(x)).data_ptr(), 1, 1.0, 0)
+    p.Cout, p.ksize, p.stride, p.up2 = Cout, 4, 2, 0
+    wf, wexp = P.pack_conv_weight_rp(w)
+    p.w_rp, p.w_rp_exp, p.bias = d("wf", wf).data_ptr(), wexp, d("b", bias).data_ptr()
+    rows = lib.mi_conv_stripe_rows(C.byref(p))
+    assert rows == W // 8
+    nt = H // rows
+    out, ost = run(lib, p, 12, nt, dev)
+    scale = max(1.0, ref.abs().max().item() / 8.0)
+    err = (out.double() - ref).abs().max().item()
+    print(f"stripe stride-2 conv {case}: max|d| = {err:.2e} (gate {2e-5 * scale:.2e})")
+    assert err < 2e-5 * scale
+    check_stats(ost, ref.float())
+    for nblk in (2, nt):
+        if nt % nblk == 0 and nblk <= 15:
+            o2, s2 = run(lib, p, 12 | (nblk << 12), nt, dev)
+            assert torch.equal(o2, out) and torch.equal(s2, ost)
+    o_rp, _ = run(lib, p, 7, tile_nt(lib, 7, H, W), dev)            # (the tile kernel's stride-2 member has 8 x 32 tiles)
+    assert torch.equal(o_rp, out), f"stripe and tile kernels differ: max|d| = {(o_rp - out).abs().max().item():.3e}"
+
+
 def test_stripe_eligibility_is_declared_by_the_library():
     """mi_conv_stripe_rows: what tile_cfg 12 takes (the engine asks before planning a launch) -- no compute, runs without a GPU"""
     setup("emu")
@@ -208,8 +254,15 @@ def test_stripe_eligibility_is_declared_by_the_library():
         q.W = 64
         setattr(q, field, val)
         if field == "stride":
-            q.ksize = 4
+            q.ksize, q.W = 4, 32                                     # (4x4 stride 2 is taken at 64 / 128 output columns)
         assert lib.mi_conv_stripe_rows(C.byref(q)) == 0, field
+    q = L.MiConvParams.from_buffer_copy(p)
+    q.W, q.ksize, q.stride = 64, 4, 2
+    assert lib.mi_conv_stripe_rows(C.byref(q)) == 8
+    q.Cout = 16
+    assert lib.mi_conv_stripe_rows(C.byref(q)) == 8
+    q.gn_groups = 8
+    assert lib.mi_conv_stripe_rows(C.byref(q)) == 0
     q = L.MiConvParams.from_buffer_copy(p)
     q.W, q.in0 = 256, L.MiAct(1, 16, 0, 0, 1.0, 0)                    # 16 input channels at 256 wide: not instantiated (LDS)
     assert lib.mi_conv_stripe_rows(C.byref(q)) == 0
