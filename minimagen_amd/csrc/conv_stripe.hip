@@ -63,6 +63,9 @@ extern "C" int mi_debug_read_trace_st(void* dst, size_t bytes) { return (int)hip
 #ifndef ST_LOOKAHEAD
 #define ST_LOOKAHEAD 2
 #endif
+#ifndef ST_RO4
+#define ST_RO4 1            // 0: A/B build without the 16 -> 16 + 1x1-residual-over-32 member (those launches on the tile kernel)
+#endif
 #ifndef ST_LOADER_DELAY
 #define ST_LOADER_DELAY 56        // x 64 clocks (s_sleep) before the loader waves' first requests, <= 128 wide (0 = none)
 #endif
@@ -820,6 +823,9 @@ int launch_stripe_w(const mi_conv_params& p, hipStream_t st, int ko, int nj, boo
     if constexpr (W == 64 || W == 128) {      // 8 -> 8 behind a Block with the 1x1 residual conv over 16 channels (ups.1 of both U-Nets)
         if (gn && ko == 1 && nj == 1 && om == 0 && p.res0.data && p.res_w) return launch_stripe<W, 1, 1, true, 0, 2>(p, st);
     }
+    if constexpr (W == 64) {                  // 16 -> 16 with the 1x1 residual conv over 32 channels (ups.0 of the SR U-Net): one workgroup per CU (105 KB of LDS)
+        if (gn && ko == 2 && nj == 2 && om == 0 && p.res0.data && p.res_w) return launch_stripe<W, 2, 2, true, 0, 4>(p, st);
+    }
     if (om <= 1) {
         ST_BLOCK(1, 1);
         if constexpr (W <= 128) { ST_BLOCK(2, 1); }
@@ -846,9 +852,10 @@ int stripe_block_rows(const mi_conv_params& p, int* ko_, int* nj_) {
     const int C0 = p.in0.C, C1 = p.in1.data ? p.in1.C : 0;
     if ((C0 & 7) || (C1 & 7) || C0 + C1 > RP_MAXC || p.Cout > 16) return 0;
     const bool rconv = p.res0.data && p.res_w;
-    if (rconv) {        // 1x1 residual conv: instantiated for 8 -> 8 over 16 residual channels at 64 / 128 wide (bigger ones leave one workgroup per CU: tile kernel)
+    if (rconv) {        // 1x1 residual conv: instantiated for 8 -> 8 over 16 residual channels at 64 / 128 wide and 16 -> 16 over 32 at 64 wide
         const int cres = p.res0.C + (p.res1.data ? p.res1.C : 0);
-        if (!p.res_w_rp || (p.res0.C & 7) || (p.res1.data && (p.res1.C & 7)) || (p.res1.data && p.res1.st) || cres != 16 || C0 + C1 != 8 || p.Cout != 8 || !p.gn_groups || p.up2 || !(p.W == 64 || p.W == 128)) return 0;
+        const bool m8 = cres == 16 && C0 + C1 == 8 && p.Cout == 8 && (p.W == 64 || p.W == 128), m16 = ST_RO4 && cres == 32 && C0 + C1 == 16 && p.Cout == 16 && p.W == 64;
+        if (!p.res_w_rp || (p.res0.C & 7) || (p.res1.data && (p.res1.C & 7)) || (p.res1.data && p.res1.st) || !(m8 || m16) || !p.gn_groups || p.up2) return 0;
     } else if (p.res0.data && p.res0.C != p.Cout) return 0;
     if (p.gn_groups > MI_MAX_GROUPS || (p.gn_groups > 0 && ((C0 + C1) % p.gn_groups))) return 0;
     if (p.gn_groups > 0 && (!p.in0.stats || (p.in1.data && !p.in1.stats))) return 0;

@@ -114,7 +114,8 @@ def test_conv_full_width_stripes(backend, case):
     p, ref = build(case, dev, keep)
     B, C0, C1, Cout, H, W = case[:6]
     rows = lib.mi_conv_stripe_rows(C.byref(p))
-    rconv_ok = case[8] == (8, 8) and C0 + C1 == 8 and Cout == 8 and W in (64, 128)      # the instantiated 1x1-residual member (ups.1 of both U-Nets)
+    rconv_ok = (case[8] == (8, 8) and C0 + C1 == 8 and Cout == 8 and W in (64, 128)) or \
+        (case[8] == (16, 16) and C0 + C1 == 16 and Cout == 16 and W == 64)      # the instantiated 1x1-residual members (ups.1 of both U-Nets, ups.0 of the SR U-Net)
     if (isinstance(case[8], tuple) and not rconv_ok) or (case[8] == 'id' and not case[6]):
         # launches with a bigger 1x1 residual conv, or an identity residual without a Block in front (no such layer in the U-Nets), stay on the
         # tile kernel: the library says so, the engine asks
