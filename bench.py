@@ -565,7 +565,10 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
-    if world > 1:
+    # MINIMAGEN_DIST_SINGLE=1 (tests): take the N > 1 control flow -- RCCL process group, barriers, the all_gather on its own stream, the
+    # max-over-ranks all_reduce -- with a group of ONE rank, so that the single-GPU test tier runs every RCCL call of this script
+    dist_on = world > 1 or os.environ.get("MINIMAGEN_DIST_SINGLE", "0") == "1"
+    if dist_on:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if one_gpu:
             dist.init_process_group("gloo")
@@ -591,21 +594,21 @@ def main():
     emb, mask = synthetic_text(B, row0=row0)
     emb, mask = emb.to(dev), mask.to(dev)
 
-    gstream = torch.cuda.Stream(device=dev) if (world > 1 and not one_gpu) else None
+    gstream = torch.cuda.Stream(device=dev) if (dist_on and not one_gpu) else None
 
     def one_step(k, pipelined=True, gather=True):
         # successive sample() calls are pipelined across the per-stage HIP streams (_async: the caller's stream is not made to wait; the
         # timed region ends with a device-wide synchronize, so every image is finished inside it)
         out = im.sample(text_embeds=emb, text_masks=mask, cond_scale=args.cond_scale, _seed=1234 + k, _sample_offset=row0, _precision=args.precision,
                         _async=pipelined)
-        if world > 1 and gather and one_gpu:
+        if dist_on and gather and one_gpu:
             if pipelined:
                 torch.cuda.current_stream().wait_event(im.last_sample_done)
             host = out.cpu()
             pad = [torch.empty_like(host) for _ in range(world)]
             dist.all_gather(pad, host)
             out = torch.cat(pad, 0).to(dev)
-        elif world > 1 and gather:
+        elif dist_on and gather:
             # RCCL over xGMI, the only collective of the path: one all_gather_into_tensor of the finished images, on its own stream behind
             # the last stage's event -- the caller's stream stays free, so the next call's base stage still starts under this call's SR stage
             if pipelined:
@@ -619,7 +622,7 @@ def main():
 
     def timed(steps, pipelined):
         """(max-over-ranks seconds, this rank's own seconds, last output): barrier + synchronize on both sides of exactly `steps` steps"""
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -627,11 +630,11 @@ def main():
             out = one_step(100 + k, pipelined)
         torch.cuda.synchronize()
         mine = time.perf_counter() - t0
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if dist_on:
             tt = torch.tensor([dt], device="cpu" if one_gpu else dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
@@ -674,7 +677,7 @@ def main():
             MI.SAMPLE_LANES = lanes
     per_rank = None
     gather_ms = None
-    if world > 1:
+    if dist_on:
         per_rank = [None] * world
         dist.all_gather_object(per_rank, {"rank": rank, "rows": B, "seconds": mine})
         if not one_gpu:                 # the collective alone, on its stream, with HIP events
@@ -719,7 +722,7 @@ def main():
         if dt_one is not None:
             res["value_one_lane"] = gB * steps_per_sample / dt_one
             res["ms_per_step_one_lane"] = dt_one * 1e3
-    if world > 1:
+    if dist_on:
         res["per_rank"] = [dict(r, denoising_steps_per_s=r["rows"] * steps_per_sample * args.steps / r["seconds"]) for r in per_rank]
         res["all_gather_ms"] = gather_ms
 
@@ -806,7 +809,7 @@ def main():
         res["cpu_baseline"] = cpu_baseline()
     if rank == 0:
         print(json.dumps(res))
-    if world > 1:
+    if dist_on:
         dist.barrier()               # rank 0 did the (untimed) per-kernel breakdown: leave together
         dist.destroy_process_group()
 

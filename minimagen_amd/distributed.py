@@ -7,10 +7,17 @@ Noise is keyed by the GLOBAL sample index, so the gathered result is bit-identic
 """
 from __future__ import annotations
 
+import os
 from typing import Optional, Tuple
 
 import torch
 import torch.distributed as dist
+
+
+def _alone(ws: int) -> bool:
+    """a group of one rank needs no collective -- unless MINIMAGEN_DIST_SINGLE=1 asks for them anyway (the single-GPU test tier runs the
+    RCCL calls of this module that way: same arguments, streams and dtypes as with N ranks)"""
+    return ws == 1 and os.environ.get("MINIMAGEN_DIST_SINGLE", "0") != "1"
 
 
 def shard_bounds(batch: int, world_size: int, rank: int) -> Tuple[int, int]:
@@ -23,7 +30,7 @@ def shard_bounds(batch: int, world_size: int, rank: int) -> Tuple[int, int]:
 def gather_samples(local: torch.Tensor, batch: int, group=None) -> torch.Tensor:
     """all_gather of per-rank image slices (possibly ragged by one row) into the full (batch, C, H, W) tensor."""
     ws = dist.get_world_size(group)
-    if ws == 1:
+    if _alone(ws):
         return local
     sizes = [shard_bounds(batch, ws, r) for r in range(ws)]
     maxn = max(hi - lo for lo, hi in sizes)
@@ -56,11 +63,11 @@ def sample_distributed(imagen, *, text_embeds: torch.Tensor, text_masks: Optiona
         dev = next(imagen.parameters()).device
         size = imagen.image_sizes[-1]
         local = torch.zeros(0, imagen.channels, size, size, dtype=torch.float32, device=dev)
-        return gather_samples(local, batch, group) if (gather and ws > 1) else local
+        return gather_samples(local, batch, group) if (gather and not _alone(ws)) else local
     local = imagen.sample(text_embeds=text_embeds[lo:hi].contiguous(),
                           text_masks=None if text_masks is None else text_masks[lo:hi].contiguous(),
                           _sample_offset=seed_off + lo, **sample_kwargs)
-    if not gather or ws == 1:
+    if not gather or _alone(ws):
         return local
     return gather_samples(local, batch, group)
 
@@ -73,7 +80,7 @@ def allreduce_gradients(params, *, bucket_mb: float = 64.0, group=None, average:
     contribute zeros (every rank must issue the same collectives).  Returns the number of collectives."""
     ws = dist.get_world_size(group) if dist.is_initialized() else 1
     params = [p for p in params if p.requires_grad]
-    if ws == 1 or not params:
+    if _alone(ws) or not params:
         return 0
     limit = max(1, int(bucket_mb * (1 << 20) / 4))
     buckets, cur, n = [], [], 0
@@ -134,7 +141,7 @@ class GradientBucketReducer:
         self.enabled = True
         self.launched_in_backward = 0
         self._reset()
-        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params] if self.ws > 1 else []
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params] if not _alone(self.ws) else []
 
     def _reset(self):
         self.missing = [len(b) for b in self.buckets]
@@ -173,7 +180,7 @@ class GradientBucketReducer:
     def finish(self, force: bool = False) -> int:
         """-> number of collectives of this step (0 after a ``no_sync`` backward; ``force=True`` reduces even if no hook fired on this rank --
         a rank whose step produced no gradient at all must still take part when the others reduce)"""
-        if self.ws == 1 or not self.enabled or not (self.dirty or force):
+        if _alone(self.ws) or not self.enabled or not (self.dirty or force):
             self._reset()
             return 0
         while self.next < len(self.buckets):

@@ -169,6 +169,30 @@ CE_TILES = ((0, 0), (0, 2), (1, 0), (2, 0))       # N tiles of the matrix-core C
 CE_TABLE_ROWS = 32
 
 
+def _crossembed_toeplitz(scaled, cin: int):
+    """the three (pre-scaled, channel-sliced) CrossEmbed weights laid out as pack_crossembed_mfma's table, before the hi / lo split:
+    float64 [row][h][hi|lo][co2][lg][e = 4 dx + ci] with the values in the hi plane"""
+    tab = torch.zeros(CE_TABLE_ROWS, 2, 2, 2, 4, 8, dtype=torch.float64)       # [row][h][hi|lo][co2][lg][e = 4 dx + ci]
+    w3, w7, w15 = scaled
+    for lg in range(4):
+        for dx in range(2):
+            for h in range(2):                                                   # k15: rows 16 + ky
+                kx = 2 * lg + dx + 8 * h
+                if kx < 15:
+                    tab[16:31, h, 0, :, lg, 4 * dx:4 * dx + cin] = w15[:, :, :, kx].permute(2, 0, 1)      # [ky][co2][ci]
+                kx = 2 * lg + dx + 8 * h - 4                                     # k7 on the same fragments: rows 8 + ky
+                if 0 <= kx < 7:
+                    tab[8:15, h, 0, :, lg, 4 * dx:4 * dx + cin] = w7[:, :, :, kx].permute(2, 0, 1)
+            kx = 2 * (lg & 1) + dx                                               # k3: rows 4 t + q
+            if kx < 3:
+                for t in range(2):
+                    for q in range(4):
+                        ky = q - 1 + (lg >> 1)
+                        if 0 <= ky < 3:
+                            tab[4 * t + q, 0, 0, :, lg, 4 * dx:4 * dx + cin] = w3[2 * t:2 * t + 2, :, ky, kx]  # [co2][ci]
+    return tab
+
+
 def pack_crossembed_mfma(ws, chan0: int, cin: int):
     """CrossEmbedLayer weights (dim_scales (4, 2, 2), kernel sizes (3, 7, 15); layers.py:254-305) for crossembed_mfma_kernel.
 
@@ -191,25 +215,35 @@ def pack_crossembed_mfma(ws, chan0: int, cin: int):
         e = max(-100, min(100, e))
         exps.append(e)
         scaled.append(wd * (2.0 ** e))
-    tab = torch.zeros(CE_TABLE_ROWS, 2, 2, 2, 4, 8, dtype=torch.float64)       # [row][h][hi|lo][co2][lg][e = 4 dx + ci]
-    w3, w7, w15 = scaled
-    for lg in range(4):
-        for dx in range(2):
-            for h in range(2):                                                   # k15: rows 16 + ky
-                kx = 2 * lg + dx + 8 * h
-                if kx < 15:
-                    tab[16:31, h, 0, :, lg, 4 * dx:4 * dx + cin] = w15[:, :, :, kx].permute(2, 0, 1)      # [ky][co2][ci]
-                kx = 2 * lg + dx + 8 * h - 4                                     # k7 on the same fragments: rows 8 + ky
-                if 0 <= kx < 7:
-                    tab[8:15, h, 0, :, lg, 4 * dx:4 * dx + cin] = w7[:, :, :, kx].permute(2, 0, 1)
-            kx = 2 * (lg & 1) + dx                                               # k3: rows 4 t + q
-            if kx < 3:
-                for t in range(2):
-                    for q in range(4):
-                        ky = q - 1 + (lg >> 1)
-                        if 0 <= ky < 3:
-                            tab[4 * t + q, 0, 0, :, lg, 4 * dx:4 * dx + cin] = w3[2 * t:2 * t + 2, :, ky, kx]  # [co2][ci]
+    tab = _crossembed_toeplitz(scaled, cin)
     hi = tab[:, :, 0].float().half()
     lo = (tab[:, :, 0] - hi.double()).float().half()
     out = torch.stack((hi, lo), dim=2)                                           # [row][h][hl][co2][lg][8]
     return out.reshape(CE_TABLE_ROWS, 256).contiguous().to(ws[0].device), exps
+
+
+def crossembed_mfma_gather_index(shapes, chan0: int, cin: int):
+    """pack_crossembed_mfma as a gather: int64 [32 * 2 * 2 * 4 * 8] positions into cat(w3.flatten(), w7.flatten(), w15.flatten(), [0]) for the
+    table's [row][h][co2][lg][e] elements (the appended zero for taps outside a kernel) -- depends on the weights' SHAPES only, so a training
+    step can rebuild the tables on the device from the updated weights without a host copy (pack_crossembed_mfma_device)"""
+    idx_w, off = [], 0
+    for sh in shapes:
+        n = 1
+        for d in sh:
+            n *= d
+        idx_w.append((torch.arange(n, dtype=torch.float64) + (off + 1)).reshape(sh)[:, chan0:chan0 + cin])
+        off += n
+    tab = _crossembed_toeplitz(idx_w, cin)[:, :, 0]                              # 0 where no tap, else flat position + 1
+    idx = tab.round().long() - 1
+    idx[idx < 0] = off
+    return idx.reshape(-1).contiguous()
+
+
+def pack_crossembed_mfma_device(ws, idx: torch.Tensor, exps):
+    """the table of pack_crossembed_mfma built where the weights live: scale each member by 2^exps[i] (exact), gather into the table layout
+    through crossembed_mfma_gather_index, split into fp16 hi | lo.  Same bits as the host packer for the same exponents."""
+    flat = torch.cat([w.detach().reshape(-1) * (2.0 ** e) for w, e in zip(ws, exps)] + [ws[0].new_zeros(1)])
+    t = flat[idx].reshape(CE_TABLE_ROWS, 2, 2, 4, 8)                             # [row][h][co2][lg][8] fp32
+    hi = t.half()
+    lo = (t - hi.float()).half()
+    return torch.stack((hi, lo), dim=2).reshape(CE_TABLE_ROWS, 256).contiguous()

@@ -128,3 +128,83 @@ def test_bench_two_ranks_over_rccl():
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["all_gather_ms"] > 0 and line["pipelined_equals_synchronous"]
+
+
+@pytest.mark.gpu
+def test_bench_rccl_calls_with_a_group_of_one():
+    """every RCCL call of bench.py's N > 1 control flow on the single-GPU tier: MINIMAGEN_DIST_SINGLE=1 makes a one-rank launch take it
+    (init_process_group("nccl", device_id), barriers, the all_gather_into_tensor on its own stream behind the last stage's event, the
+    device-side max-over-ranks all_reduce, all_gather_object) -- what RCCL is asked to do is the same for one rank and for eight"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MINIMAGEN_DIST_SINGLE="1")
+    env.pop("MINIMAGEN_BENCH_ONE_GPU", None)
+    port = str(25000 + os.getpid() % 1500)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", port,
+           os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "2", "--timesteps", "25",
+           "--no-breakdown", "--no-cpu-baseline", "--no-secondary", "--no-t5"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["all_gather_ms"] > 0 and line["pipelined_equals_synchronous"]
+    assert [r["rows"] for r in line["per_rank"]] == [2]
+
+
+_RCCL_ONE = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+os.environ["MINIMAGEN_DIST_SINGLE"] = "1"
+from minimagen_amd import _lib as L
+from minimagen_amd.Imagen import Imagen
+from minimagen_amd.Unet import Unet
+from minimagen_amd.distributed import sample_distributed, gather_samples, allreduce_gradients, GradientBucketReducer
+from oracle import restated as R
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{sys.argv[2]}", rank=0, world_size=1, device_id=dev)
+L.use_library(L.DEFAULT_LIB)
+torch.manual_seed(4)
+u = Unet(dim=8, dim_mults=(1, 2), num_resnet_blocks=1, layer_attns=False, layer_cross_attns=False, memory_efficient=True)
+im = Imagen([u], text_encoder_name="t5_small", image_sizes=[16], timesteps=21, cond_drop_prob=0.15).to(dev)
+emb, mask = R.synthetic_text(3, length=9, seed=3)
+emb, mask = emb.to(dev), mask.to(dev)
+whole = im.sample(text_embeds=emb, text_masks=mask, cond_scale=1., _seed=77)
+out = sample_distributed(im, text_embeds=emb, text_masks=mask, cond_scale=1., _seed=77)      # sample + all_gather_into_tensor over RCCL
+assert out.data_ptr() != whole.data_ptr() and torch.equal(out, whole)
+g = torch.randn(5, 3, 16, 16, device=dev)
+assert torch.equal(gather_samples(g, 5), g)
+# gradient all-reduce: flat buckets, asynchronous all_reduce, averaged by the world size
+ps = [torch.nn.Parameter(torch.randn(n, device=dev)) for n in (1000, 70000, 33)]
+for p in ps:
+    p.grad = torch.randn_like(p)
+want = [p.grad.clone() for p in ps]
+assert allreduce_gradients(ps, bucket_mb=0.1) == 3
+assert all(torch.equal(p.grad, w) for p, w in zip(ps, want))
+red = GradientBucketReducer(ps, bucket_mb=0.1)
+for p in ps:
+    p.grad = None
+loss = sum((p * p).sum() for p in ps)
+loss.backward()
+want = [2 * p.detach() for p in ps]
+assert red.finish() == 3 and red.launched_in_backward >= 1
+assert all(torch.equal(p.grad, w) for p, w in zip(ps, want))
+dist.barrier()
+dist.destroy_process_group()
+print("ok")
+'''
+
+
+@pytest.mark.gpu
+def test_distributed_module_over_rccl_with_a_group_of_one(tmp_path):
+    """minimagen_amd.distributed on RCCL (backend "nccl") with one rank: sample_distributed's all_gather_into_tensor, allreduce_gradients'
+    bucketed asynchronous all_reduce and GradientBucketReducer's hook-launched buckets run on the device and leave the values unchanged"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "r1.py"
+    script.write_text(_RCCL_ONE)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, str(script), root, str(23000 + os.getpid() % 1500)], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]

@@ -5,6 +5,7 @@ import os
 
 import pytest
 import torch
+import torch.nn.functional as F
 
 from minimagen_amd.Imagen import Imagen
 from minimagen_amd.Unet import Unet
@@ -619,3 +620,58 @@ def test_downsample_and_1x1_convs_on_the_hip_3x3_kernels(backend, case):
     for name, a, b in (("out", out, ref), ("dx", gx, rgx), ("dw", gw, rgw), ("db", gb, rgb)):
         err, mag = float((a - b).abs().max()), float(b.abs().max())
         assert a.shape == b.shape and err < 3e-5 * max(1.0, mag), (case, name, err, mag)
+
+
+@pytest.mark.gpu
+def test_lagged_scales_never_leave_a_stale_pack():
+    """weights on the GPU: ``begin_step`` re-packs from the CURRENT values on the device with the fragment scaling of the PREVIOUS step's maxima
+    (no host round trip per step).  Updates made behind the version counter (``p.data.mul_``) reach the very next forward; a 100-fold
+    out-of-band rescale stays inside the scale's head room; a training step agrees with the synchronous fingerprint mode."""
+    import copy
+    from minimagen_amd import train_ops
+    dev = setup("gpu")
+    assert train_ops.LAGGED
+    torch.manual_seed(21)
+    conv = torch.nn.Conv2d(8, 8, 3, padding=1).to(dev)
+    x = torch.randn(2, 8, 16, 16, device=dev)
+    for factor in (1.0, 2.0, 100.0, 0.01):
+        conv.weight.data.mul_(factor)                                   # invisible to (version, pointer)
+        train_ops.begin_step(conv)
+        a, _ = train_ops._packs(conv.weight)
+        assert torch.equal(a.generic.reshape(8, 3, 3, -1)[..., :8], conv.weight.detach().permute(1, 2, 3, 0))
+        y = train_ops.conv3x3_forward(conv, x)
+        ref = F.conv2d(x.double(), conv.weight.detach().double(), conv.bias.detach().double(), padding=1)
+        assert (y.double() - ref).abs().max() < 2e-6 * float(ref.abs().max()), factor
+    st = conv.__dict__["_mi_lagged"]
+    assert st["k"] == 4 and conv.weight._mi_fingerprint[1] == 4
+    # a whole training step, lagged against synchronous scales: same loss, same gradients (the scale is an exact power of two either way)
+    torch.manual_seed(9)
+    im = Imagen((Unet(**BASE), Unet(**SR)), text_encoder_name="t5_small", image_sizes=(32, 64), timesteps=60).train().to(dev)
+    imgs = torch.rand(2, 3, 72, 72, device=dev)
+    emb, mask = R.synthetic_text(2, length=11, seed=5)
+    emb, mask = emb.to(dev), mask.to(dev)
+    res = {}
+    for lagged in (True, False):
+        train_ops.LAGGED = lagged
+        try:
+            m = copy.deepcopy(im)
+            opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+            losses = []
+            for step in range(3):
+                for n in (1, 2):
+                    torch.manual_seed(100 + step)
+                    loss = m(imgs, text_embeds=emb, text_masks=mask, unet_number=n)
+                    opt.zero_grad(set_to_none=True)
+                    loss.backward()
+                    opt.step()
+                    losses.append(float(loss))
+            res[lagged] = (losses, [p.detach().clone() for p in m.parameters()])
+        finally:
+            train_ops.LAGGED = True
+    for la, lb in zip(*[res[k][0] for k in (True, False)]):
+        assert abs(la - lb) < 1e-5 * max(1.0, abs(lb)), (res[True][0], res[False][0])
+    # Adam normalises the update: a parameter whose gradient is tiny can move by lr in either direction -- compare where the update is well defined
+    worst = max(float((a - b).abs().max()) for a, b in zip(res[True][1], res[False][1]))
+    assert worst < 3 * 2e-3, worst
+    close = sum(int(((a - b).abs() < 2e-4).sum()) for a, b in zip(res[True][1], res[False][1])) / sum(a.numel() for a in res[True][1])
+    assert close > 0.97, close
