@@ -6,6 +6,10 @@
 // up to six 16-column blocks), K = pixels, one accumulator tile per (ky, N block); the four waves of a workgroup split the vertical taps.
 // A workgroup walks 8 x 32 pixel tiles (X window with halo and the dY tile in LDS), writes its partial G once; a second kernel adds the
 // partials in a fixed order (deterministic) straight into the members' [cout][Cin][k][k] gradients.
+// PAIR (<= 8 output channels in all, the reference's dim_scales (4, 2, 2)): the MFMA's rows 8 .. 15 would be padding, so they carry the SAME
+// channels one vertical tap further: with the X row rho as B operand, rows 0 .. 7 take dY row rho - ky (tap ky = 2 jp) and rows 8 .. 15 dY row
+// rho - ky - 1 (tap ky + 1) -- both of the tile's own dY rows, zero outside them.  A tile then costs ceil(K / 2) x (TH + 1) x N blocks matrix
+// instructions per four pixels of a row instead of K x TH (72 against 120 at K = 15); each wave keeps two tap pairs (half the accumulators).
 #include "common.hip.h"
 
 namespace {
@@ -13,6 +17,7 @@ namespace {
 constexpr int CW_TH = 8, CW_TW = 32, CW_KMAX = 15, CW_MAXC = 6, CW_NB = 6;
 constexpr int CW_ROWS = CW_TH + CW_KMAX - 1, CW_XP = CW_TW + CW_KMAX - 1 + 1;       // 22 rows, pitch 47
 constexpr int CW_DYP = CW_TH * CW_TW + 1;                                          // 257
+constexpr int CW_DYR = 34, CW_DYC = 292;      // paired form: dY row pitch = -2 and channel pitch = 4 (mod 32 banks): the 32 lanes of a pass hit 32 banks
 constexpr int CW_KY_PER_WAVE = 4;
 
 struct CeWgradArgs {
@@ -20,9 +25,10 @@ struct CeWgradArgs {
     int B, Cin, Ctot, H, W, K, nb, tiles_x, tiles_y;
 };
 
+template <bool PAIR>
 __global__ __launch_bounds__(256) void crossembed_wgrad_partial_kernel(CeWgradArgs p) {
     __shared__ float x_s[CW_MAXC * CW_ROWS * CW_XP];              // 24.8 KB
-    __shared__ float dy_s[16 * CW_DYP];                            // 16.4 KB
+    __shared__ float dy_s[PAIR ? 8 * CW_DYC : 16 * CW_DYP];        // 16.4 KB (PAIR: 9.3 KB)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lc = lane & 15, kk = lane >> 4;
     const int K = p.K, halo = K >> 1;
@@ -60,7 +66,8 @@ __global__ __launch_bounds__(256) void crossembed_wgrad_partial_kernel(CeWgradAr
 #pragma unroll
             for (int c = 0; c < 16; ++c) {
                 const float v = (in && c < p.Ctot) ? gdy[base + c * HW] : 0.f;
-                dy_s[c * CW_DYP + row * CW_TW + col] = v;
+                if (PAIR) { if (c < 8) dy_s[c * CW_DYC + row * CW_DYR + col] = v; }
+                else dy_s[c * CW_DYP + row * CW_TW + col] = v;
                 sdb[c] += v;
             }
         }
@@ -72,6 +79,30 @@ __global__ __launch_bounds__(256) void crossembed_wgrad_partial_kernel(CeWgradAr
             x_s[(c * CW_ROWS + r) * CW_XP + cc] = in ? gx[((long long)b * p.Cin + c) * HW + (long long)y * p.W + x] : 0.f;
         }
         __syncthreads();
+        if (PAIR) {
+            // this wave's tap pairs jp = 2 wave + a (a = 0, 1): X rows rho with a live dY row for either tap of a pair are 2 jp .. 2 jp + TH
+            const int half = lc >> 3, cdy = (lc & 7) * CW_DYC;
+            for (int rr = 0; rr < CW_TH + 3; ++rr) {
+                const int rho = 4 * wave + rr;
+                if (rho >= CW_TH + K - 1) break;
+#pragma unroll 2
+                for (int s = 0; s < CW_TW / 4; ++s) {
+                    const int px = 4 * s + kk;
+                    const float* row = x_s + rho * CW_XP + px;
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) {
+                        const int r0 = rr - 2 * a;                          // dY row of the even tap (wave-uniform); the odd tap's is r0 - 1
+                        if (r0 >= 0 && r0 <= CW_TH && 4 * wave + 2 * a < K) {
+                            const int r = r0 - half;
+                            const float av = (r >= 0 && r < CW_TH) ? dy_s[cdy + r * CW_DYR + px] : 0.f;
+#pragma unroll
+                            for (int nb = 0; nb < CW_NB; ++nb)
+                                if (nb < p.nb) acc[a][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, row[boff[nb]], acc[a][nb], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        } else
         for (int r = 0; r < CW_TH; ++r) {
 #pragma unroll 2
             for (int s = 0; s < CW_TW / 4; ++s) {
@@ -91,6 +122,18 @@ __global__ __launch_bounds__(256) void crossembed_wgrad_partial_kernel(CeWgradAr
     }
     // partial G of this workgroup: [ky][nb][co 16][n 16]
     float* out = p.partial + (long long)blockIdx.x * K * p.nb * 256;
+    if (PAIR) {                                                    // D rows 0 .. 7: (co, tap 2 jp), rows 8 .. 15: (co, tap 2 jp + 1); rows co >= 8 of the partial are never read
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int nb = 0; nb < CW_NB; ++nb)
+                if (nb < p.nb)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int m = 4 * kk + i, ky = 4 * wave + 2 * a + (m >> 3);
+                        if (ky < K) out[(ky * p.nb + nb) * 256 + (m & 7) * 16 + lc] = acc[a][nb][i];
+                    }
+    } else {
 #pragma unroll
     for (int a = 0; a < CW_KY_PER_WAVE; ++a)
         if (ky0 + a < K)
@@ -99,6 +142,7 @@ __global__ __launch_bounds__(256) void crossembed_wgrad_partial_kernel(CeWgradAr
                 if (nb < p.nb)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) out[((ky0 + a) * p.nb + nb) * 256 + (4 * kk + i) * 16 + lc] = acc[a][nb][i];
+    }
     __syncthreads();
     float* red = x_s;                                              // [256][17]
 #pragma unroll
@@ -193,7 +237,8 @@ extern "C" int mi_crossembed_wgrad(const mi_crossembed_wgrad_params* q, void* st
     p.partial_db = q->partial + (long long)q->nwg * K * p.nb * 256;
     if ((long long)p.B * p.tiles_x * p.tiles_y > 0x7fffffffLL) { mi_set_error("mi_crossembed_wgrad: problem too large"); return MI_ERR_INVALID; }
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(crossembed_wgrad_partial_kernel, dim3(q->nwg), dim3(256), 0, st, p);
+    if (ctot <= 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(crossembed_wgrad_partial_kernel<true>), dim3(q->nwg), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(crossembed_wgrad_partial_kernel<false>), dim3(q->nwg), dim3(256), 0, st, p);
     int rc = mi_check_launch("crossembed_wgrad_partial_kernel");
     if (rc) return rc;
     CeReduceArgs r;

@@ -35,7 +35,7 @@ from . import packing as P
 ENABLED = os.environ.get("MINIMAGEN_TRAIN_HIP", "1") != "0"
 FORCE = False                   # tests: take the HIP path for host tensors too (emulator build of the kernels)
 WGRAD_NWG = 1024         # workgroups of a conv weight-gradient launch (split-K partials are added in a fixed order)
-CE_WGRAD_NWG = 512
+CE_WGRAD_NWG = int(os.environ.get("MINIMAGEN_CE_WGRAD_NWG", "512"))      # workgroups of the CrossEmbed weight-gradient launch
 
 
 FINGERPRINT_EVERY = int(os.environ.get("MINIMAGEN_TRAIN_FINGERPRINT", "1"))     # content fingerprint of the conv weights every N-th training step (begin_step)
