@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MI_ABI_VERSION 11
+#define MI_ABI_VERSION 12
 
 enum mi_status {
     MI_OK = 0,
@@ -505,6 +505,14 @@ int mi_layernorm_bwd(const float* dy, const float* x, const float* gamma, const 
  * (the training path re-packs after every optimiser step).  mi_pack_conv3_floats(…, which): element counts (0: fp16 fragments, 1: fp32). */
 long long mi_pack_conv3_floats(int Cout, int Cin, int adjoint, int cout_pad, int which);
 int mi_pack_conv3(const float* w, int Cout, int Cin, int adjoint, int exp, void* frag, float* generic, int cout_pad, void* stream);
+/* the same for `n` weights in ONE launch (ABI 12): `descs` is a DEVICE array of n descriptors (the training step re-packs every conv weight of a
+ * U-Net in both directions after every optimiser step -- ~150 launches of a few microseconds each on a step that is bound by its launch count);
+ * `blocks` workgroups per descriptor. */
+typedef struct mi_pack_conv3_desc {
+    const float* w; void* frag; float* generic;
+    int Cout, Cin, adjoint, exp, cout_pad, reserved;
+} mi_pack_conv3_desc;
+int mi_pack_conv3_multi(const mi_pack_conv3_desc* descs, int n, int blocks, void* stream);
 
 /* weight / bias gradients of CrossEmbedLayer (layers.py:254-305; the first layer: no data gradient is needed): one correlation over the
  * largest member's taps serves every member (a smaller member's gradient is the centre window of its channels), split-K on the fp32

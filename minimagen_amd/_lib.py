@@ -178,9 +178,14 @@ class MiAdamParams(C.Structure):
                 ("grad_scale", C.c_void_p)]
 
 
+class MiPackConv3Desc(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("frag", C.c_void_p), ("generic", C.c_void_p), ("Cout", C.c_int), ("Cin", C.c_int), ("adjoint", C.c_int),
+                ("exp", C.c_int), ("cout_pad", C.c_int), ("reserved", C.c_int)]
+
+
 _STRUCTS = {0: MiAct, 1: MiConvParams, 2: MiCrossEmbedParams, 3: MiLinear, 4: MiTextCondParams, 5: MiCondStepParams,
             6: MiAttnFoldParams, 7: MiCrossAttnParams, 8: MiCfgX0Params, 9: MiQuantileParams, 10: MiPosteriorParams,
-            11: MiResizeParams, 12: MiSelfAttnParams, 13: MiChanFFParams, 14: MiFlashAttnParams, 15: MiTokensToNchwParams, 16: MiConvWgradParams, 17: MiBlockBwdParams, 18: MiCrossEmbedWgradParams, 19: MiFoldedAttnParams, 20: MiAdamTensor, 21: MiAdamParams}
+            11: MiResizeParams, 12: MiSelfAttnParams, 13: MiChanFFParams, 14: MiFlashAttnParams, 15: MiTokensToNchwParams, 16: MiConvWgradParams, 17: MiBlockBwdParams, 18: MiCrossEmbedWgradParams, 19: MiFoldedAttnParams, 20: MiAdamTensor, 21: MiAdamParams, 22: MiPackConv3Desc}
 
 _lib = None
 _backend = None
@@ -246,6 +251,7 @@ def _bind(lib):
     lib.mi_pack_conv3_floats.argtypes = [i32, i32, i32, i32, i32]
     lib.mi_pack_conv3_floats.restype = C.c_longlong
     lib.mi_pack_conv3.argtypes = [vp, i32, i32, i32, i32, vp, vp, i32, vp]
+    lib.mi_pack_conv3_multi.argtypes = [vp, i32, i32, vp]
     lib.mi_attn_fragment_floats.argtypes = [i32]
     for which, st in _STRUCTS.items():
         n = lib.mi_struct_size(which)
@@ -296,8 +302,14 @@ def ptr(t) -> int:
     return 0 if t is None else t.data_ptr()
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def current_stream() -> int:
+    """the raw HIP stream of torch's current stream on the current device (one C call: this is asked once per launch, ~1 000 times per training step)"""
     if backend() == "hip-gfx950":
+        if _RAW_STREAM is not None:
+            return _RAW_STREAM(torch.cuda.current_device())
         return torch.cuda.current_stream().cuda_stream
     return 0
 

@@ -48,6 +48,7 @@ extern "C" int mi_struct_size(int which) {
         case 19: return (int)sizeof(mi_folded_attn_params);
         case 20: return (int)sizeof(mi_adam_tensor);
         case 21: return (int)sizeof(mi_adam_params);
+        case 22: return (int)sizeof(mi_pack_conv3_desc);
     }
     return -1;
 }

@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void block_bwd_params_kernel(mi_block_bwd_para
 constexpr int PK_PERM[4] = {0, 2, 1, 3};        // packing.RP_PERM
 
 // fragments [ko][3][nj][64][8 hi | 8 lo] (packing.pack_conv_weight_rp, 3x3 form) and generic [Cin][3][3][cout_pad] of W or of its adjoint
-__global__ __launch_bounds__(256) void pack_conv3_kernel(const float* w, int Cout, int Cin, int adjoint, int exp, _Float16* frag, float* generic, int cout_pad) {
+__device__ __forceinline__ void pack_conv3_body(const float* w, int Cout, int Cin, int adjoint, int exp, _Float16* frag, float* generic, int cout_pad, int bx, int nbx) {
     // logical weight L[co][ci][ky][kx]: adjoint ? w[ci][co][2-ky][2-kx] (w stored [Cin_l = Cout_w ...]) : w[co][ci][ky][kx]
     const int LCo = adjoint ? Cin : Cout, LCi = adjoint ? Cout : Cin;      // logical output / input channels
     auto Lw = [&](int co, int ci, int ky, int kx) -> float {
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void pack_conv3_kernel(const float* w, int Cou
     const int nfrag = ko * 3 * nj * 64 * 8;
     const int ngen = LCi * 9 * cout_pad;
     const float scale = ldexpf(1.0f, exp);
-    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < nfrag + ngen; idx += gridDim.x * 256) {
+    for (int idx = bx * 256 + threadIdx.x; idx < nfrag + ngen; idx += nbx * 256) {
         if (idx < nfrag) {
             const int e = idx & 7, lane = (idx >> 3) & 63;
             int rest = idx >> 9;
@@ -204,6 +204,16 @@ __global__ __launch_bounds__(256) void pack_conv3_kernel(const float* w, int Cou
             generic[j] = Lw(co, ci, ky, kx);
         }
     }
+}
+
+__global__ __launch_bounds__(256) void pack_conv3_kernel(const float* w, int Cout, int Cin, int adjoint, int exp, _Float16* frag, float* generic, int cout_pad) {
+    pack_conv3_body(w, Cout, Cin, adjoint, exp, frag, generic, cout_pad, blockIdx.x, gridDim.x);
+}
+
+// grid (blocks, n): descriptor blockIdx.y
+__global__ __launch_bounds__(256) void pack_conv3_multi_kernel(const mi_pack_conv3_desc* descs) {
+    const mi_pack_conv3_desc d = descs[blockIdx.y];
+    pack_conv3_body(d.w, d.Cout, d.Cin, d.adjoint, d.exp, (_Float16*)d.frag, d.generic, d.cout_pad, blockIdx.x, gridDim.x);
 }
 
 }  // namespace
@@ -246,4 +256,10 @@ extern "C" int mi_pack_conv3(const float* w, int Cout, int Cin, int adjoint, int
     const int blocks = (int)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256);
     hipLaunchKernelGGL(pack_conv3_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, Cout, Cin, adjoint, exp, (_Float16*)frag, generic, cout_pad);
     return mi_check_launch("pack_conv3_kernel");
+}
+
+extern "C" int mi_pack_conv3_multi(const mi_pack_conv3_desc* descs, int n, int blocks, void* stream) {
+    if (!descs || n <= 0 || n > 65535 || blocks <= 0) { mi_set_error("mi_pack_conv3_multi: bad arguments"); return MI_ERR_INVALID; }
+    hipLaunchKernelGGL(pack_conv3_multi_kernel, dim3(blocks, n), dim3(256), 0, (hipStream_t)stream, descs);
+    return mi_check_launch("pack_conv3_multi_kernel");
 }

@@ -67,7 +67,9 @@ class Adam(torch.optim.Optimizer):
             n = -(-r[4] // CHUNK)
             ct += [k] * n
             co += list(range(n))
-        up = lambda a: torch.from_numpy(a).to(dev)
+        # through pinned memory, asynchronously: zero_grad(set_to_none=True) re-allocates the gradients, so this table is rebuilt on most steps, and a
+        # pageable host -> device copy waits for everything queued before it -- one full host / GPU synchronisation per training step
+        up = (lambda a: torch.from_numpy(a).pin_memory().to(dev, non_blocking=True)) if dev.type == "cuda" else (lambda a: torch.from_numpy(a).to(dev))
         tb = (key, up(tens.view(np.uint8).reshape(-1)), up(np.asarray(ct, dtype=np.int32)), up(np.asarray(co, dtype=np.int32)), len(ct))
         self._tables[gi] = tb
         return tb

@@ -26,6 +26,7 @@ import ctypes as C
 import math
 import os
 
+import numpy as np
 import torch
 import torch.nn.functional as F
 
@@ -55,7 +56,7 @@ class _Pack:
     fp16 hi|lo fragments + their exponent -- written by ONE launch of mi_pack_conv3 on the device"""
     __slots__ = ("generic", "frag", "exp", "cout", "cin", "rp")
 
-    def __init__(self, w: torch.Tensor, exp: int, adjoint: bool):
+    def __init__(self, w: torch.Tensor, exp: int, adjoint: bool, launch: bool = True):
         lib = L.lib()
         Cout, Cin = w.shape[0], w.shape[1]
         self.cout, self.cin = (Cin, Cout) if adjoint else (Cout, Cin)
@@ -64,8 +65,14 @@ class _Pack:
         self.generic = torch.empty(lib.mi_pack_conv3_floats(Cout, Cin, int(adjoint), pad, 1), dtype=torch.float32, device=w.device)
         self.frag = torch.empty(lib.mi_pack_conv3_floats(Cout, Cin, int(adjoint), pad, 0), dtype=torch.float16, device=w.device)
         self.exp, self.rp = exp, self.cin % 8 == 0
-        L.check(lib.mi_pack_conv3(w.data_ptr(), Cout, Cin, int(adjoint), exp, self.frag.data_ptr(), self.generic.data_ptr(), pad, L.current_stream()),
-                "mi_pack_conv3")
+        if launch:                # (launch=False: the buffers only -- begin_step's lagged mode fills every pack of a U-Net with ONE mi_pack_conv3_multi)
+            L.check(lib.mi_pack_conv3(w.data_ptr(), Cout, Cin, int(adjoint), exp, self.frag.data_ptr(), self.generic.data_ptr(), pad, L.current_stream()),
+                    "mi_pack_conv3")
+
+    def desc(self, w: torch.Tensor, adjoint: bool):
+        """this pack's row of mi_pack_conv3_multi's descriptor table"""
+        return (w.data_ptr(), self.frag.data_ptr(), self.generic.data_ptr(), w.shape[0], w.shape[1], int(adjoint), self.exp,
+                self.generic.numel() // (self.cin * 9), 0)
 
 
 def _pack_key(weight: torch.Tensor):
@@ -140,6 +147,10 @@ def begin_step(module: torch.nn.Module):
                     _packs(w, P.rp_weight_exponent(fp[k]))
 
 
+_DESC_DTYPE = np.dtype([("w", "u8"), ("frag", "u8"), ("generic", "u8"), ("Cout", "i4"), ("Cin", "i4"), ("adjoint", "i4"), ("exp", "i4"),
+                        ("cout_pad", "i4"), ("reserved", "i4")])          # mi_pack_conv3_desc
+
+
 def _begin_step_lagged(module, convs, ws):
     """begin_step without a host round trip.  Every pack is rebuilt from the weights' CURRENT values (so no update can be missed, whichever way
     it was made); what comes from the host is only the exponent of the fragment scaling, and that tolerates stale maxima: a scale taken from the
@@ -165,13 +176,37 @@ def _begin_step_lagged(module, convs, ws):
             ev.synchronize()
             known = st["host"][slot].tolist()
         st["k"] += 1
+        rows = []
+        packs = st.setdefault("packs", {})
         for m, w, mxk in zip(convs, ws, known):
             w._mi_fingerprint = (mxk, st["k"])                 # _weight_exp / _ce_tables: the scale, and a mark that is new every step
             for attr in ("_mi_train_packs", "_mi_ce_tables"):
                 if hasattr(w, attr):
                     delattr(w, attr)
             if m.kernel_size == (3, 3) and m.stride == (1, 1):
-                _packs(w, P.rp_weight_exponent(mxk))
+                exp = P.rp_weight_exponent(mxk)
+                if not w.is_contiguous():
+                    _packs(w, exp)
+                    continue
+                # the pack buffers live as long as the parameter keeps its storage: the descriptor table then only changes when an exponent does
+                pk = packs.get(id(w))
+                if pk is None or pk[0] != (w.data_ptr(), tuple(w.shape)):
+                    wd = w.detach()
+                    pk = packs[id(w)] = ((w.data_ptr(), tuple(w.shape)), _Pack(wd, exp, False, launch=False), _Pack(wd, exp, True, launch=False))
+                pk[1].exp = pk[2].exp = exp
+                rows += [pk[1].desc(w, False), pk[2].desc(w, True)]
+                w._mi_train_packs = (_pack_key(w), pk[1], pk[2])
+        if rows:
+            key = tuple(rows)
+            if st.get("desc_key") != key:                      # (first step, or an exponent moved: a small asynchronous upload through pinned memory)
+                arr = np.array(rows, dtype=_DESC_DTYPE)
+                host = torch.from_numpy(arr.view(np.uint8).reshape(-1)).pin_memory()
+                if st.get("desc_dev") is None or st["desc_dev"].numel() != host.numel():
+                    st["desc_dev"] = torch.empty(host.numel(), dtype=torch.uint8, device=ws[0].device)
+                st["desc_dev"].copy_(host, non_blocking=True)
+                st["desc_key"] = key
+            L.require_device(ws[0])
+            L.check(L.lib().mi_pack_conv3_multi(st["desc_dev"].data_ptr(), len(rows), 16, L.current_stream()), "mi_pack_conv3_multi")
 
 
 def invalidate(module: torch.nn.Module):
@@ -632,13 +667,27 @@ def conv4x4s2_forward(conv: torch.nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
     (16 slices of a [Cout, Cin, 4, 4] tensor)."""
     w = conv.weight
     Cout, Cin = w.shape[0], w.shape[1]
-    w3 = w.new_zeros(Cout, Cin, 2, 2, 3, 3)                       # [co, c, py, px, a + 1, b + 1]
-    tap = ((0, 1), (1, 0), (1, 1), (2, 0))                        # ky -> (a + 1, py)
-    for ky in range(4):
-        for kx in range(4):
-            (ay, py), (ax, px) = tap[ky], tap[kx]
-            w3[:, :, py, px, ay, ax] = w[:, :, ky, kx]
-    return _ConvFn.apply(F.pixel_unshuffle(x, 2), w3.reshape(Cout, 4 * Cin, 3, 3), conv.bias, _weight_exp(w))
+    # ONE gather for the re-layout (and one index_add in its backward): 16 sliced assignments were ~50 small launches per Downsample and step
+    # on a training step that is bound by its launch count
+    w3 = F.pad(w.reshape(Cout, Cin, 16), (0, 1)).index_select(2, _k4_index(w.device)).reshape(Cout, 4 * Cin, 3, 3)
+    return _ConvFn.apply(F.pixel_unshuffle(x, 2), w3, conv.bias, _weight_exp(w))
+
+
+_K4_INDEX = {}
+
+
+def _k4_index(dev) -> torch.Tensor:
+    """[py, px, a + 1, b + 1] flattened -> 4 ky + kx of the stride-2 kernel's tap, 16 (a zero column appended to the taps) where there is none"""
+    key = str(dev)
+    if key not in _K4_INDEX:
+        idx = torch.full((2, 2, 3, 3), 16, dtype=torch.long)
+        tap = ((0, 1), (1, 0), (1, 1), (2, 0))                        # ky -> (a + 1, py)
+        for ky in range(4):
+            for kx in range(4):
+                (ay, py), (ax, px) = tap[ky], tap[kx]
+                idx[py, px, ay, ax] = 4 * ky + kx
+        _K4_INDEX[key] = idx.reshape(-1).to(dev)
+    return _K4_INDEX[key]
 
 
 def conv_shape_supported(cin: int, cout: int, W: int, groups: int = 0) -> bool:

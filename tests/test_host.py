@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in minimagen_hip.h but not exported"
     lib.mi_backend.restype = ctypes.c_char_p
-    assert lib.mi_backend() == b"hip-gfx950" and lib.mi_abi_version() == 11
+    assert lib.mi_backend() == b"hip-gfx950" and lib.mi_abi_version() == 12
 
 
 def test_struct_layouts_match_the_library():

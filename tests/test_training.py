@@ -166,6 +166,32 @@ def test_pack_conv3_on_the_device_matches_the_host_packing(backend, shape):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
+def test_pack_conv3_multi_equals_the_single_launches(backend):
+    """mi_pack_conv3_multi (ABI 12: every conv weight of a U-Net, both directions, in ONE launch from a device-resident descriptor table --
+    begin_step's lagged mode) writes exactly what one mi_pack_conv3 per weight and direction writes"""
+    import numpy as np
+    from minimagen_amd import _lib as L, packing as P, train_ops
+    dev = setup(backend)
+    lib = L.lib()
+    g = torch.Generator().manual_seed(5)
+    ws = [(torch.randn(co, ci, 3, 3, generator=g) * sc).to(dev) for co, ci, sc in ((8, 8, 0.1), (16, 32, 3.0), (3, 8, 1e-3), (16, 24, 0.5), (8, 3, 0.2))]
+    single, multi, rows = [], [], []
+    for w in ws:
+        exp = P.rp_weight_exponent(float(w.abs().max()))
+        for adjoint in (False, True):
+            single.append(train_ops._Pack(w, exp, adjoint))
+            pk = train_ops._Pack(w, exp, adjoint, launch=False)
+            pk.frag.fill_(7.0); pk.generic.fill_(7.0)
+            multi.append(pk)
+            rows.append(pk.desc(w, adjoint))
+    table = torch.from_numpy(np.array(rows, dtype=train_ops._DESC_DTYPE).view(np.uint8).reshape(-1).copy()).to(dev)
+    L.check(lib.mi_pack_conv3_multi(table.data_ptr(), len(rows), 16, L.current_stream()), "mi_pack_conv3_multi")
+    for a, b in zip(single, multi):
+        assert torch.equal(a.generic, b.generic) and torch.equal(a.frag.view(torch.int16), b.frag.view(torch.int16))
+    assert lib.mi_pack_conv3_multi(0, 1, 16, L.current_stream()) != 0 and lib.mi_pack_conv3_multi(table.data_ptr(), 0, 16, L.current_stream()) != 0
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
 @pytest.mark.parametrize("case", [(2, 6, 16, 32, (3, 7, 15), (4, 2, 2), 3), (1, 3, 11, 40, (3, 7, 15), (4, 2, 2), 2), (1, 4, 9, 9, (3, 5), (6, 2), 1),
                                   (2, 6, 64, 64, (3, 7, 15), (4, 2, 2), 64)])
 def test_crossembed_wgrad_kernel(backend, case):
