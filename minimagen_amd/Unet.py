@@ -249,6 +249,18 @@ class Unet(nn.Module):
             t = t + torch.where(keep[:, None], text_hiddens, self.null_text_hidden.to(t.dtype))
             c = torch.cat((tokens, text_tokens), dim=-2)
         c = self.norm_cond(c)
+        if dev_path:
+            # the step is bound by its launch count: the ResnetBlocks' time MLPs (SiLU -> Linear(time_cond_dim, 2 dim_out), layers.py:386-391, one
+            # per block, all of the same t) run as ONE linear layer over the stacked weights -- 4 launches instead of 2 per block, and one
+            # matrix product per direction in the backward instead of two per block; each block reads its slice (ResnetBlock.forward)
+            rbs = self.__dict__.get("_mi_time_blocks")
+            if rbs is None:
+                rbs = self.__dict__["_mi_time_blocks"] = [m for m in self.modules() if isinstance(m, ResnetBlock) and m.time_mlp is not None]
+            if len(rbs) > 1:
+                lins = [m.time_mlp[1] for m in rbs]
+                allss = F.linear(F.silu(t), torch.cat([l.weight for l in lins], 0), torch.cat([l.bias for l in lins], 0))
+                for m, part in zip(rbs, allss.split([l.out_features for l in lins], dim=1)):
+                    m.__dict__["_mi_scale_shift"] = part
         # ---- trunk (Unet.py:396-472)
         lowres = lowres_cond_img if self.lowres_cond else None
         if dev_path and train_ops.crossembed_supported(self.init_conv, x, lowres):
@@ -279,6 +291,9 @@ class Unet(nn.Module):
             x = attn(x)
             x = conv3(up[1], up[0](x)) if isinstance(up, nn.Sequential) else up(x)
         x = self.final_res_block(x, t)
+        if dev_path:
+            for m in self.__dict__.get("_mi_time_blocks", ()):          # (a block that did not run must not keep a slice of this step's graph)
+                m.__dict__.pop("_mi_scale_shift", None)
         return conv3(self.final_conv, x)
 
     def forward_with_cond_scale(self, *args, cond_scale: float = 1., **kwargs) -> torch.Tensor:

@@ -306,8 +306,10 @@ class ResnetBlock(_Container):
     def forward(self, x, time_emb=None, cond=None):
         """layers.py:417-439"""
         scale_shift = None
+        pre = self.__dict__.pop("_mi_scale_shift", None)       # Unet._forward_train on the device: every block's time MLP as ONE stacked linear layer
         if exists(self.time_mlp) and exists(time_emb):
-            scale_shift = self.time_mlp(time_emb)[:, :, None, None].chunk(2, dim=1)
+            ss = pre if pre is not None else self.time_mlp(time_emb)
+            scale_shift = ss[:, :, None, None].chunk(2, dim=1)
         h = self.block1(x)
         if exists(self.cross_attn):
             assert exists(cond)
