@@ -9,6 +9,7 @@
 //                             over the chunk's tokens (staged in LDS, broadcast reads); chunk partials are added by the caller (fixed order)
 // exp through the hardware exp2 on log2(e)-scaled scores (fp32 throughout).
 #include "common.hip.h"
+#include <cstdlib>
 
 namespace {
 
@@ -164,6 +165,236 @@ __global__ __launch_bounds__(1024) void folded_attn_dkv_kernel(mi_folded_attn_pa
     }
 }
 
+
+// ---- matrix cores for the forward at C = 16 (the BASELINE U-Nets' bottleneck cross-attention): exact-fp32 products on v_mfma_f32_16x16x4_f32, the
+// arithmetic class of the VALU kernel above at twice its multiply-add rate and without its per-score LDS traffic.  A wave owns TT tiles of 16 tokens;
+// per tile of 16 context rows:    S^T[j][i] = sum_c kf[j][c] q[i][c]     A = kf[j0 + lq][4 lg + kb], B = q[i0 + lq][4 lg + kb], kb = 0 .. 3
+// -- the contraction index is (kb, lg) -> c = 4 lg + kb, so either operand is ONE 16-byte read per lane -- leaving lane (lq, lg) with the scores of
+// token i0 + lq against rows j0 + 4 lg + r.  Those four registers are, as they lie, the B operands of    out^T[c'][i] += sum_j vf[j][c'] P^T[j][i]
+// (instruction r contracts over j = j0 + 4 lg + r; A = vf[j0 + 4 lg + r][lq] from the [J/4][16][4] copy of vf: one 16-byte read), so the
+// probabilities never move between lanes; the per-token running maximum is shared by the four lanes of a token with two cross-lane steps per tile,
+// the running sum stays a per-lane partial until the head is done.  Online softmax as above (rescale once per 16 rows).
+constexpr int ATM_KP = 20;                   // floats per kf row in LDS: the 16-byte reads of 16 consecutive rows spread over all banks
+
+template <int TT, int NJT_MAX, int NW>
+__global__ __launch_bounds__(64 * NW) void folded_attn_fwd_mfma_kernel(mi_folded_attn_params p) {
+    constexpr int JP = 16 * NJT_MAX;
+    __shared__ __attribute__((aligned(16))) float ks[JP * ATM_KP], vt[JP * 16], bias[JP];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lq = lane & 15, lg = lane >> 4;
+    constexpr int NT = 64 * NW;
+    const int b = blockIdx.y, tok0 = (blockIdx.x * NW + wave) * (16 * TT);
+    const int njt = (p.J + 15) >> 4;
+    for (int j = tid; j < 16 * njt; j += NT) bias[j] = (j < p.J && (p.mask == nullptr || p.mask[(size_t)b * p.J + j])) ? 0.f : -INFINITY;
+    float4 q4[TT];
+    f32x4 otot[TT];
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+        const int i = tok0 + 16 * t + lq;
+        const float4 u = mi_ldg4(p.q + ((size_t)b * p.n + (i < p.n ? i : p.n - 1)) * 16 + 4 * lg);
+        q4[t] = make_float4(u.x * AT_LOG2E, u.y * AT_LOG2E, u.z * AT_LOG2E, u.w * AT_LOG2E);
+        otot[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int h = 0; h < p.H; ++h) {
+        __syncthreads();
+        const size_t base = ((size_t)b * p.H + h) * p.J * 16;
+        for (int e = tid; e < 16 * njt * 4; e += NT) {                   // one 16-byte chunk (row j, channels 4 c4 ..) per work-item and turn
+            const int j = e >> 2, c4 = e & 3;
+            float4 k = make_float4(0.f, 0.f, 0.f, 0.f), v = k;
+            if (j < p.J) { k = mi_ldg4(p.kf + base + (size_t)j * 16 + 4 * c4); v = mi_ldg4(p.vf + base + (size_t)j * 16 + 4 * c4); }
+            *reinterpret_cast<float4*>(&ks[j * ATM_KP + 4 * c4]) = k;
+            float* d = &vt[((j >> 2) * 16 + 4 * c4) * 4 + (j & 3)];      // vt[j / 4][c][j % 4]
+            d[0] = v.x; d[4] = v.y; d[8] = v.z; d[12] = v.w;
+        }
+        __syncthreads();
+        // NP token tiles side by side: two independent (scores -> maximum -> exponentials -> P V) chains per wave hide each other's matrix-pipe
+        // and cross-lane latencies (two workgroups per CU = two waves per SIMD do not)
+        constexpr int NP = TT >= 2 ? 2 : 1;
+#pragma unroll
+        for (int t0 = 0; t0 < TT; t0 += NP) {
+            if (tok0 + 16 * t0 >= p.n) break;                                // wave-uniform
+            float m[NP], l[NP];
+            f32x4 acc[NP];
+#pragma unroll
+            for (int u = 0; u < NP; ++u) { m[u] = -INFINITY; l[u] = 0.f; acc[u] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            for (int jt = 0; jt < njt; ++jt) {
+                const float4 ka = *reinterpret_cast<const float4*>(&ks[(16 * jt + lq) * ATM_KP + 4 * lg]);
+                const float4 bb = *reinterpret_cast<const float4*>(&bias[16 * jt + 4 * lg]);
+                const float4 va = *reinterpret_cast<const float4*>(&vt[((4 * jt + lg) * 16 + lq) * 4]);
+                const float kv[4] = {ka.x, ka.y, ka.z, ka.w};
+                f32x4 sc[NP];
+#pragma unroll
+                for (int u = 0; u < NP; ++u) sc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                    for (int u = 0; u < NP; ++u) {
+                        const float qv = kb == 0 ? q4[t0 + u].x : (kb == 1 ? q4[t0 + u].y : (kb == 2 ? q4[t0 + u].z : q4[t0 + u].w));
+                        sc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(kv[kb], qv, sc[u], 0, 0, 0);
+                    }
+                float pr[NP][4];
+#pragma unroll
+                for (int u = 0; u < NP; ++u) {
+                    const float s0 = sc[u][0] + bb.x, s1 = sc[u][1] + bb.y, s2 = sc[u][2] + bb.z, s3 = sc[u][3] + bb.w;
+                    float tm = fmaxf(fmaxf(s0, s1), fmaxf(s2, s3));
+                    tm = fmaxf(tm, __shfl_xor(tm, 16));
+                    tm = fmaxf(tm, __shfl_xor(tm, 32));
+                    const float mn = fmaxf(m[u], tm);
+                    const float mu = (mn == -INFINITY) ? 0.f : mn;           // nothing live so far for this token: every exponent below is -inf -> 0
+                    const float alpha = __builtin_amdgcn_exp2f(m[u] - mu);
+                    m[u] = mn;
+                    pr[u][0] = __builtin_amdgcn_exp2f(s0 - mu); pr[u][1] = __builtin_amdgcn_exp2f(s1 - mu);
+                    pr[u][2] = __builtin_amdgcn_exp2f(s2 - mu); pr[u][3] = __builtin_amdgcn_exp2f(s3 - mu);
+                    l[u] = fmaf(l[u], alpha, (pr[u][0] + pr[u][1]) + (pr[u][2] + pr[u][3]));
+                    acc[u][0] *= alpha; acc[u][1] *= alpha; acc[u][2] *= alpha; acc[u][3] *= alpha;
+                }
+                const float vv[4] = {va.x, va.y, va.z, va.w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int u = 0; u < NP; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv[r], pr[u][r], acc[u], 0, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < NP; ++u) {
+                const int t = t0 + u;
+                float lt = l[u];
+                lt += __shfl_xor(lt, 16);
+                lt += __shfl_xor(lt, 32);
+                const float inv = 1.0f / lt;
+                const int i = tok0 + 16 * t + lq;
+                const float4 oh4 = make_float4(acc[u][0] * inv, acc[u][1] * inv, acc[u][2] * inv, acc[u][3] * inv);     // out^T rows c' = 4 lg + r of token i
+                otot[t][0] += oh4.x; otot[t][1] += oh4.y; otot[t][2] += oh4.z; otot[t][3] += oh4.w;
+                if (i < p.n) {
+                    if (p.oh) mi_stg4(p.oh + (((size_t)b * p.n + i) * p.H + h) * 16 + 4 * lg, oh4);
+                    if (lg == 0) p.lse[((size_t)b * p.n + i) * p.H + h] = m[u] + log2f(lt);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+        const int i = tok0 + 16 * t + lq;
+        if (i < p.n) mi_stg4(p.out + ((size_t)b * p.n + i) * 16 + 4 * lg, make_float4(otot[t][0], otot[t][1], otot[t][2], otot[t][3]));
+    }
+}
+
+template <int TT, int NW>
+int launch_folded_fwd_mfma(const mi_folded_attn_params& p, hipStream_t st) {
+    const dim3 grid((p.n + 16 * NW * TT - 1) / (16 * NW * TT), p.B);
+    if (p.J <= 16 * 17) hipLaunchKernelGGL(HIP_KERNEL_NAME(folded_attn_fwd_mfma_kernel<TT, 17, NW>), grid, dim3(64 * NW), 0, st, p);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(folded_attn_fwd_mfma_kernel<TT, 24, NW>), grid, dim3(64 * NW), 0, st, p);
+    return mi_check_launch("folded_attn_fwd_mfma_kernel");
+}
+
+
+// ---- the token-side backward on the matrix cores (C = 16, per-head outputs saved by the forward): per tile of 16 context rows three products of the
+// forward's shapes -- S^T = kf q^T (probabilities p = exp2(S^T - lse)), dP^T = vf dO^T, and dq^T[c][i] += sum_j kf[j][c] dS^T[j][i] with
+// dS = p (dP - D), D_i = dO_i . O_hi -- the four dS registers of a lane being the B operands of the third as they lie.
+template <int TT, int NJT_MAX, int NW>
+__global__ __launch_bounds__(64 * NW) void folded_attn_dq_mfma_kernel(mi_folded_attn_params p) {
+    constexpr int JP = 16 * NJT_MAX, NT = 64 * NW;
+    __shared__ __attribute__((aligned(16))) float ks[JP * ATM_KP], vs[JP * ATM_KP], kt[JP * 16], bias[JP];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lq = lane & 15, lg = lane >> 4;
+    const int b = blockIdx.y, tok0 = (blockIdx.x * NW + wave) * (16 * TT);
+    const int njt = (p.J + 15) >> 4;
+    for (int j = tid; j < 16 * njt; j += NT) bias[j] = (j < p.J && (p.mask == nullptr || p.mask[(size_t)b * p.J + j])) ? 0.f : -INFINITY;
+    float4 q4[TT], g4[TT];
+    f32x4 dqa[TT];
+    size_t rowi[TT];
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+        const int i = tok0 + 16 * t + lq;
+        rowi[t] = (size_t)b * p.n + (i < p.n ? i : p.n - 1);
+        const float4 u = mi_ldg4(p.q + rowi[t] * 16 + 4 * lg);
+        q4[t] = make_float4(u.x * AT_LOG2E, u.y * AT_LOG2E, u.z * AT_LOG2E, u.w * AT_LOG2E);
+        g4[t] = mi_ldg4(p.dout + rowi[t] * 16 + 4 * lg);
+        dqa[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int h = 0; h < p.H; ++h) {
+        __syncthreads();
+        const size_t base = ((size_t)b * p.H + h) * p.J * 16;
+        for (int e = tid; e < 16 * njt * 4; e += NT) {
+            const int j = e >> 2, c4 = e & 3;
+            float4 k = make_float4(0.f, 0.f, 0.f, 0.f), v = k;
+            if (j < p.J) { k = mi_ldg4(p.kf + base + (size_t)j * 16 + 4 * c4); v = mi_ldg4(p.vf + base + (size_t)j * 16 + 4 * c4); }
+            *reinterpret_cast<float4*>(&ks[j * ATM_KP + 4 * c4]) = k;
+            *reinterpret_cast<float4*>(&vs[j * ATM_KP + 4 * c4]) = v;
+            float* d = &kt[((j >> 2) * 16 + 4 * c4) * 4 + (j & 3)];      // kt[j / 4][c][j % 4]
+            d[0] = k.x; d[4] = k.y; d[8] = k.z; d[12] = k.w;
+        }
+        __syncthreads();
+        constexpr int NP = TT >= 2 ? 2 : 1;
+#pragma unroll
+        for (int t0 = 0; t0 < TT; t0 += NP) {
+            if (tok0 + 16 * t0 >= p.n) break;                                // wave-uniform
+            float lse[NP], D[NP];
+            f32x4 acc[NP];
+#pragma unroll
+            for (int u = 0; u < NP; ++u) {
+                lse[u] = p.lse[rowi[t0 + u] * p.H + h];
+                const float4 o = mi_ldg4(p.oh + (rowi[t0 + u] * p.H + h) * 16 + 4 * lg);
+                const float4 g = g4[t0 + u];
+                float d = fmaf(g.x, o.x, fmaf(g.y, o.y, fmaf(g.z, o.z, g.w * o.w)));
+                d += __shfl_xor(d, 16);
+                d += __shfl_xor(d, 32);
+                D[u] = d;
+                acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            for (int jt = 0; jt < njt; ++jt) {
+                const float4 ka = *reinterpret_cast<const float4*>(&ks[(16 * jt + lq) * ATM_KP + 4 * lg]);
+                const float4 va = *reinterpret_cast<const float4*>(&vs[(16 * jt + lq) * ATM_KP + 4 * lg]);
+                const float4 bb = *reinterpret_cast<const float4*>(&bias[16 * jt + 4 * lg]);
+                const float4 ta = *reinterpret_cast<const float4*>(&kt[((4 * jt + lg) * 16 + lq) * 4]);
+                const float kv[4] = {ka.x, ka.y, ka.z, ka.w}, vv[4] = {va.x, va.y, va.z, va.w}, tv[4] = {ta.x, ta.y, ta.z, ta.w};
+                f32x4 sc[NP], dp[NP];
+#pragma unroll
+                for (int u = 0; u < NP; ++u) { sc[u] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[u] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                    for (int u = 0; u < NP; ++u) {
+                        const float4 qq = q4[t0 + u], gg = g4[t0 + u];
+                        const float qv = kb == 0 ? qq.x : (kb == 1 ? qq.y : (kb == 2 ? qq.z : qq.w));
+                        const float gv = kb == 0 ? gg.x : (kb == 1 ? gg.y : (kb == 2 ? gg.z : gg.w));
+                        sc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(kv[kb], qv, sc[u], 0, 0, 0);
+                        dp[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv[kb], gv, dp[u], 0, 0, 0);
+                    }
+                float ds[NP][4];
+                const float bv[4] = {bb.x, bb.y, bb.z, bb.w};
+#pragma unroll
+                for (int u = 0; u < NP; ++u)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float pj = __builtin_amdgcn_exp2f(sc[u][r] + bv[r] - lse[u]);      // masked / padded rows: exp2(-inf) = 0
+                        ds[u][r] = pj * (dp[u][r] - D[u]);
+                    }
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int u = 0; u < NP; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(tv[r], ds[u][r], acc[u], 0, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < NP; ++u) {
+                const int t = t0 + u, i = tok0 + 16 * t + lq;
+                dqa[t][0] += acc[u][0]; dqa[t][1] += acc[u][1]; dqa[t][2] += acc[u][2]; dqa[t][3] += acc[u][3];
+                if (i < p.n && lg == 0) p.dsum[rowi[t] * p.H + h] = D[u];
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+        const int i = tok0 + 16 * t + lq;
+        if (i < p.n) mi_stg4(p.dq + rowi[t] * 16 + 4 * lg, make_float4(dqa[t][0], dqa[t][1], dqa[t][2], dqa[t][3]));
+    }
+}
+
+template <int TT, int NW>
+int launch_folded_dq_mfma(const mi_folded_attn_params& p, hipStream_t st) {
+    const dim3 grid((p.n + 16 * NW * TT - 1) / (16 * NW * TT), p.B);
+    if (p.J <= 16 * 17) hipLaunchKernelGGL(HIP_KERNEL_NAME(folded_attn_dq_mfma_kernel<TT, 17, NW>), grid, dim3(64 * NW), 0, st, p);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(folded_attn_dq_mfma_kernel<TT, 24, NW>), grid, dim3(64 * NW), 0, st, p);
+    return mi_check_launch("folded_attn_dq_mfma_kernel");
+}
+
 template <int CC>
 int launch_folded(const mi_folded_attn_params& p, int which, hipStream_t st) {
     const dim3 gtok((p.n + 255) / 256, p.B);
@@ -179,6 +410,21 @@ int folded_dispatch(const mi_folded_attn_params* q, int which, void* stream) {
     if (which == 0 && !q->out) { mi_set_error("mi_folded_attn_fwd: out missing"); return MI_ERR_INVALID; }
     if (which >= 1 && (!q->dout || !q->dsum)) { mi_set_error("mi_folded_attn_bwd: dout / dsum missing"); return MI_ERR_INVALID; }
     hipStream_t st = (hipStream_t)stream;
+    static const bool valu_fwd = getenv("MI_FOLDED_ATTN_VALU") != nullptr;          // A/B knob: the fp32 VALU kernels at C = 16 too
+    if (which == 0 && q->C == 16 && q->J <= 16 * 24 && !valu_fwd) {
+        // 256 tokens per workgroup where that still leaves two workgroups per CU: eight waves of two token tiles share one staged (kf, vf) -- four
+        // waves per SIMD instead of two; smaller problems: four waves of two / one tile(s)
+        const long long wg256 = (long long)((q->n + 255) / 256) * q->B;
+        if (wg256 >= 512) return launch_folded_fwd_mfma<2, 8>(*q, st);        // (four waves of four tiles: 265-270 against 235-240 us at the SR shape)
+        if (2 * wg256 >= 512) return launch_folded_fwd_mfma<2, 4>(*q, st);
+        return launch_folded_fwd_mfma<1, 4>(*q, st);
+    }
+    if (which == 1 && q->C == 16 && q->J <= 16 * 24 && q->oh && !valu_fwd) {
+        const long long wg256 = (long long)((q->n + 255) / 256) * q->B;
+        if (wg256 >= 512) return launch_folded_dq_mfma<2, 8>(*q, st);
+        if (2 * wg256 >= 512) return launch_folded_dq_mfma<2, 4>(*q, st);
+        return launch_folded_dq_mfma<1, 4>(*q, st);
+    }
     switch (q->C) {
         case 8: return launch_folded<8>(*q, which, st);
         case 16: return launch_folded<16>(*q, which, st);
