@@ -395,6 +395,106 @@ int launch_folded_dq_mfma(const mi_folded_attn_params& p, hipStream_t st) {
     return mi_check_launch("folded_attn_dq_mfma_kernel");
 }
 
+
+// ---- the context-side backward on the matrix cores (C = 16): a workgroup per (token chunk, head, image) as above; its NW waves own the tiles of 16
+// context rows (tile jt -> wave jt % NW: kf / vf fragments and the tile's dkf^T / dvf^T accumulators stay in registers) and walk the chunk's tokens
+// together, 64 at a time through LDS.  Per (token tile, context tile):   S[i][j] = q_i . kf_j  and  dP[i][j] = dO_i . vf_j  (A = the token side: rows
+// i0 + lq, channels 4 lg + kb), p = exp2(S - lse_i), dS = p (dP - D_i) for the lane's tokens i0 + 4 lg + r, then
+//     dkf^T[c][j] += sum_i q[i][c] dS[i][j],   dvf^T[c][j] += sum_i dO[i][c] p[i][j]      (A = q / dO of token i0 + 4 lg + r, channel lq: the [i/4][16][4] copies)
+// with the four dS / p registers as B operands as they lie.
+template <int NJT_MAX, int NW>
+__global__ __launch_bounds__(64 * NW) void folded_attn_dkv_mfma_kernel(mi_folded_attn_params p) {
+    constexpr int NT = 64 * NW, TPW = (NJT_MAX + NW - 1) / NW;           // context tiles per wave
+    __shared__ __attribute__((aligned(16))) float qs[64 * ATM_KP], gs[64 * ATM_KP], qt[64 * 16], gt[64 * 16], ls[64], dsm[64];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lq = lane & 15, lg = lane >> 4;
+    const int chunk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int njt = (p.J + 15) >> 4;
+    const size_t base = ((size_t)b * p.H + h) * p.J * 16;
+    float4 kb4[TPW], vb4[TPW];
+    float bj[TPW];
+    f32x4 dk[TPW], dv[TPW];
+#pragma unroll
+    for (int w = 0; w < TPW; ++w) {
+        const int j = 16 * (wave + NW * w) + lq;
+        const bool in = j < p.J;
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 k = in ? mi_ldg4(p.kf + base + (size_t)j * 16 + 4 * lg) : z;
+        kb4[w] = make_float4(k.x * AT_LOG2E, k.y * AT_LOG2E, k.z * AT_LOG2E, k.w * AT_LOG2E);
+        vb4[w] = in ? mi_ldg4(p.vf + base + (size_t)j * 16 + 4 * lg) : z;
+        bj[w] = (in && (p.mask == nullptr || p.mask[(size_t)b * p.J + j])) ? 0.f : -INFINITY;
+        dk[w] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dv[w] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int per = (p.n + gridDim.x - 1) / gridDim.x;
+    const int i0 = chunk * per, i1 = (i0 + per < p.n) ? i0 + per : p.n;
+    for (int t0 = i0; t0 < i1; t0 += 64) {
+        __syncthreads();
+        for (int e = tid; e < 64 * 4; e += NT) {                            // one 16-byte chunk (token, channels 4 c4 ..) of q and of dO per turn
+            const int i = e >> 2, c4 = e & 3;
+            float4 qv = make_float4(0.f, 0.f, 0.f, 0.f), gv = qv;
+            if (t0 + i < i1) { qv = mi_ldg4(p.q + ((size_t)b * p.n + t0 + i) * 16 + 4 * c4); gv = mi_ldg4(p.dout + ((size_t)b * p.n + t0 + i) * 16 + 4 * c4); }
+            *reinterpret_cast<float4*>(&qs[i * ATM_KP + 4 * c4]) = qv;
+            *reinterpret_cast<float4*>(&gs[i * ATM_KP + 4 * c4]) = gv;
+            float* dq_ = &qt[((i >> 2) * 16 + 4 * c4) * 4 + (i & 3)];
+            dq_[0] = qv.x; dq_[4] = qv.y; dq_[8] = qv.z; dq_[12] = qv.w;
+            float* dg_ = &gt[((i >> 2) * 16 + 4 * c4) * 4 + (i & 3)];
+            dg_[0] = gv.x; dg_[4] = gv.y; dg_[8] = gv.z; dg_[12] = gv.w;
+        }
+        for (int i = tid; i < 64; i += NT) {
+            const bool in = t0 + i < i1;
+            ls[i] = in ? p.lse[((size_t)b * p.n + t0 + i) * p.H + h] : INFINITY;      // a token beyond the chunk: p = exp2(S - inf) = 0
+            dsm[i] = in ? p.dsum[((size_t)b * p.n + t0 + i) * p.H + h] : 0.f;
+        }
+        __syncthreads();
+        const int nit = (i1 - t0 + 15) >> 4 < 4 ? (i1 - t0 + 15) >> 4 : 4;
+        for (int it = 0; it < nit; ++it) {
+            const float4 qa = *reinterpret_cast<const float4*>(&qs[(16 * it + lq) * ATM_KP + 4 * lg]);
+            const float4 ga = *reinterpret_cast<const float4*>(&gs[(16 * it + lq) * ATM_KP + 4 * lg]);
+            const float4 qta = *reinterpret_cast<const float4*>(&qt[((4 * it + lg) * 16 + lq) * 4]);
+            const float4 gta = *reinterpret_cast<const float4*>(&gt[((4 * it + lg) * 16 + lq) * 4]);
+            const float4 l4 = *reinterpret_cast<const float4*>(&ls[16 * it + 4 * lg]);
+            const float4 d4 = *reinterpret_cast<const float4*>(&dsm[16 * it + 4 * lg]);
+            const float qv[4] = {qa.x, qa.y, qa.z, qa.w}, gv[4] = {ga.x, ga.y, ga.z, ga.w}, qtv[4] = {qta.x, qta.y, qta.z, qta.w}, gtv[4] = {gta.x, gta.y, gta.z, gta.w};
+            const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dvv[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+            for (int w = 0; w < TPW; ++w) {
+                if (wave + NW * w >= njt) break;                            // wave-uniform
+                const float kv[4] = {kb4[w].x, kb4[w].y, kb4[w].z, kb4[w].w}, vv[4] = {vb4[w].x, vb4[w].y, vb4[w].z, vb4[w].w};
+                f32x4 sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) {
+                    sc = __builtin_amdgcn_mfma_f32_16x16x4f32(qv[kb], kv[kb], sc, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_16x16x4f32(gv[kb], vv[kb], dp, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pj = __builtin_amdgcn_exp2f(sc[r] + bj[w] - lv[r]);
+                    const float ds = pj * (dp[r] - dvv[r]);
+                    dk[w] = __builtin_amdgcn_mfma_f32_16x16x4f32(qtv[r], ds, dk[w], 0, 0, 0);
+                    dv[w] = __builtin_amdgcn_mfma_f32_16x16x4f32(gtv[r], pj, dv[w], 0, 0, 0);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int w = 0; w < TPW; ++w) {
+        const int j = 16 * (wave + NW * w) + lq;                             // D rows c = 4 lg + r of context row j
+        if (j < p.J) {
+            const size_t o = ((((size_t)chunk * gridDim.z + b) * p.H + h) * p.J + j) * 16 + 4 * lg;
+            mi_stg4(p.dkf + o, make_float4(dk[w][0], dk[w][1], dk[w][2], dk[w][3]));
+            mi_stg4(p.dvf + o, make_float4(dv[w][0], dv[w][1], dv[w][2], dv[w][3]));
+        }
+    }
+}
+
+int launch_folded_dkv_mfma(const mi_folded_attn_params& p, hipStream_t st) {
+    const dim3 grid(p.nchunk, p.H, p.B);
+    if (p.J <= 16 * 12) hipLaunchKernelGGL(HIP_KERNEL_NAME(folded_attn_dkv_mfma_kernel<12, 4>), grid, dim3(256), 0, st, p);
+    else if (p.J <= 16 * 18) hipLaunchKernelGGL(HIP_KERNEL_NAME(folded_attn_dkv_mfma_kernel<18, 6>), grid, dim3(384), 0, st, p);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(folded_attn_dkv_mfma_kernel<24, 8>), grid, dim3(512), 0, st, p);
+    return mi_check_launch("folded_attn_dkv_mfma_kernel");
+}
+
 template <int CC>
 int launch_folded(const mi_folded_attn_params& p, int which, hipStream_t st) {
     const dim3 gtok((p.n + 255) / 256, p.B);
@@ -425,6 +525,7 @@ int folded_dispatch(const mi_folded_attn_params* q, int which, void* stream) {
         if (2 * wg256 >= 512) return launch_folded_dq_mfma<2, 4>(*q, st);
         return launch_folded_dq_mfma<1, 4>(*q, st);
     }
+    if (which == 2 && q->C == 16 && q->J <= 16 * 24 && !valu_fwd) return launch_folded_dkv_mfma(*q, st);
     switch (q->C) {
         case 8: return launch_folded<8>(*q, which, st);
         case 16: return launch_folded<16>(*q, which, st);
