@@ -1,13 +1,15 @@
 // Training path: the core of the FOLDED cross-attention (layers.py:220-251 with keys / values mapped into the token's
 // channel space, layers.CrossAttention._forward_folded) forward and backward without ever materialising the [tokens x heads x context] score
 // tensor:      out_i = sum_h sum_j softmax_j(q_i . kf_hj) vf_hj ,          q [B][n][C], kf / vf [B][H][J][C] (C = 8 / 16 / 32), mask [B][J].
-// The problem is tiny per score (C multiply-adds) and has no reuse the matrix cores could exploit at C = 16, so these are fp32 VALU kernels:
+// The problem is tiny per score (C multiply-adds).  C = 8 / 32 (and MI_FOLDED_ATTN_VALU=1, for A/B runs): fp32 VALU kernels --
 //   folded_attn_fwd_kernel    a work-item per token, kf / vf of one (row, head) in LDS read as broadcasts, online softmax over blocks of 8
 //                             context rows; saves the logsumexp and the head's own output per (token, head)
 //   folded_attn_dq_kernel     a work-item per token: recomputes the probabilities, D = dO . O_h, dq = sum_h sum_j p (dP - D) kf_hj; saves D
 //   folded_attn_dkv_kernel    a work-item per context row j of one (row, head, token chunk): dkf_j = sum_i dS_ij q_i, dvf_j = sum_i p_ij dO_i
 //                             over the chunk's tokens (staged in LDS, broadcast reads); chunk partials are added by the caller (fixed order)
 // exp through the hardware exp2 on log2(e)-scaled scores (fp32 throughout).
+// C = 16 (the BASELINE U-Nets): the same three kernels on v_mfma_f32_16x16x4_f32 (exact fp32 products), further down: folded_attn_fwd_mfma_kernel,
+// folded_attn_dq_mfma_kernel, folded_attn_dkv_mfma_kernel.
 #include "common.hip.h"
 #include <cstdlib>
 

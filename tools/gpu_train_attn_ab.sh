@@ -1,5 +1,5 @@
 #!/bin/bash
-# one box: the folded cross-attention forward of the training path at the SR U-Net's shape (B 32, 4096 tokens, 8 heads, C 16, 261 context rows) on
+# one box: the folded cross-attention kernels of the training path (forward isolated; forward + dq + dkv inside the step) at the SR U-Net's shape (B 32, 4096 tokens, 8 heads, C 16, 261 context rows) on
 # the matrix cores against the fp32 VALU kernel (MI_FOLDED_ATTN_VALU=1), isolated (50 launches) and inside the SR training step; GPU tests first
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out/train_attn; out=gpurun_out/train_attn
@@ -20,9 +20,9 @@ for B, n in ((32, 4096), (32, 1024)):
         for _ in range(50): o = train_ops.folded_attention(q, kf, vf, mask)
         torch.cuda.synchronize(); print(f"B {B} tokens {n}: forward {(time.perf_counter() - t0) / 50 * 1e6:.1f} us, checksum {float(o.abs().sum()):.1f}")
 PY
-for tag in valu mfma form1 mfma_b form1_b; do
-  unset MI_FOLDED_ATTN_VALU MI_FOLDED_ATTN_FORM
-  case $tag in valu*) export MI_FOLDED_ATTN_VALU=1;; form1*) export MI_FOLDED_ATTN_FORM=1;; esac
+for tag in valu mfma valu_b mfma_b; do
+  unset MI_FOLDED_ATTN_VALU
+  case $tag in valu*) export MI_FOLDED_ATTN_VALU=1;; esac
   echo "== $tag"; timeout 120 python /tmp/ub.py 2>&1 | tail -2
   timeout 600 python bench.py --train-step-only > $out/train_$tag.json 2> $out/train_$tag.err
   python - <<PY
