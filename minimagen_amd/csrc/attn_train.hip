@@ -512,7 +512,7 @@ int folded_dispatch(const mi_folded_attn_params* q, int which, void* stream) {
     if (which == 0 && !q->out) { mi_set_error("mi_folded_attn_fwd: out missing"); return MI_ERR_INVALID; }
     if (which >= 1 && (!q->dout || !q->dsum)) { mi_set_error("mi_folded_attn_bwd: dout / dsum missing"); return MI_ERR_INVALID; }
     hipStream_t st = (hipStream_t)stream;
-    static const bool valu_fwd = getenv("MI_FOLDED_ATTN_VALU") != nullptr;          // A/B knob: the fp32 VALU kernels at C = 16 too
+    const bool valu_fwd = getenv("MI_FOLDED_ATTN_VALU") != nullptr;    // (read per call: the GPU test flips it in-process)          // A/B knob: the fp32 VALU kernels at C = 16 too
     if (which == 0 && q->C == 16 && q->J <= 16 * 24 && !valu_fwd) {
         // 256 tokens per workgroup where that still leaves two workgroups per CU: eight waves of two token tiles share one staged (kf, vf) -- four
         // waves per SIMD instead of two; smaller problems: four waves of two / one tile(s)

@@ -563,6 +563,39 @@ def test_folded_attention_kernels(backend, case):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B", [32, 16])
+def test_folded_attention_matrix_core_forms_at_the_benched_shapes(B):
+    """the launch forms the SR training step takes at its benched batch (eight waves x two token tiles at B = 32, four waves x two at B = 16; the
+    fp64 case above reaches only the one-tile form): forward, dq, dkf, dvf of the matrix-core kernels against the fp32 VALU kernels of the same
+    library (MI_FOLDED_ATTN_VALU, read per call) on the SR U-Net's shape -- same arithmetic class, another summation order"""
+    from minimagen_amd import train_ops
+    dev = setup("gpu")
+    n, H, Cc, J = 4096, 8, 16, 261
+    g = torch.Generator().manual_seed(11)
+    q = torch.randn(B, n, Cc, generator=g).to(dev)
+    kf = (torch.randn(B, H, J, Cc, generator=g) * 0.5).to(dev)
+    vf = torch.randn(B, H, J, Cc, generator=g).to(dev)
+    mask = (torch.arange(J)[None, :] < torch.tensor([J - (7 * r) % 40 for r in range(B)])[:, None]).to(dev)
+    gy = torch.randn(B, n, Cc, generator=g).to(dev)
+    res = {}
+    for valu in (False, True):
+        if valu:
+            os.environ["MI_FOLDED_ATTN_VALU"] = "1"
+        try:
+            qh, kh, vh = (t.clone().requires_grad_() for t in (q, kf, vf))
+            out = train_ops.folded_attention(qh, kh, vh, mask)
+            out.backward(gy)
+            torch.cuda.synchronize()
+            res[valu] = [t.detach().clone() for t in (out, qh.grad, kh.grad, vh.grad)]
+        finally:
+            os.environ.pop("MI_FOLDED_ATTN_VALU", None)
+    for name, a, b in zip(("out", "dq", "dkf", "dvf"), res[False], res[True]):
+        assert torch.isfinite(a).all()
+        assert (a - b).abs().max() <= 2e-5 * max(1.0, float(b.abs().max())), (name, float((a - b).abs().max()), float(b.abs().max()))
+    assert not torch.equal(res[False][0], res[True][0])          # (two different kernels did run)
+
+
+@pytest.mark.gpu
 def test_allreduce_gradients_over_rccl(tmp_path):
     """the same data-parallel step with one rank per GPU over RCCL (backend "nccl"), the training graph on the HIP kernels: runs only where
     two devices are visible (the single-GPU test tier skips it)"""
