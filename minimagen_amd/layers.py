@@ -178,14 +178,17 @@ class Block(_Container):
         self.activation = nn.SiLU()
         self.project = nn.Conv2d(dim, dim_out, 3, padding=1)
 
-    def forward(self, x, scale_shift=None):
+    def forward(self, x, scale_shift=None, residual=None):
+        """``residual`` (not in the reference's signature): added to the output -- ResnetBlock hands its skip term here so that the device training
+        path can add it in the conv's epilogue"""
         if torch.is_grad_enabled() and train_ops.active(x) and train_ops.block_supported(self, x):        # training on the device: fused HIP forward, HIP dgrad / wgrad
-            return train_ops.block_forward(self, x, scale_shift)
+            return train_ops.block_forward(self, x, scale_shift, residual)
         x = self.groupnorm(x)
         if exists(scale_shift):
             scale, shift = scale_shift
             x = x * (scale + 1) + shift
-        return self.project(self.activation(x))
+        out = self.project(self.activation(x))
+        return out if residual is None else out + residual
 
 
 def ChanFeedForward(dim: int, mult: int = 2) -> nn.Sequential:
@@ -314,9 +317,10 @@ class ResnetBlock(_Container):
         if exists(self.cross_attn):
             assert exists(cond)
             h = self.cross_attn(h, context=cond) + h
+        if torch.is_grad_enabled() and train_ops.active(x):     # training on the device: the skip term goes into block2's conv epilogue where it can
+            res = train_ops.conv1x1_forward(self.res_conv, x) if train_ops.is_conv1x1(self.res_conv, x) else self.res_conv(x)
+            return self.block2(h, scale_shift=scale_shift, residual=res.contiguous())
         h = self.block2(h, scale_shift=scale_shift)
-        if torch.is_grad_enabled() and train_ops.active(x) and train_ops.is_conv1x1(self.res_conv, x):      # training on the device: the HIP 3x3 kernels
-            return h + train_ops.conv1x1_forward(self.res_conv, x)
         return h + self.res_conv(x)
 
 

@@ -237,7 +237,7 @@ def _zero_bias(n: int, dev) -> torch.Tensor:
     return _ZEROS[key]
 
 
-def _conv3x3(x: torch.Tensor, pack: _Pack, bias, gn=None, ss=None, stats=None, want_stats: bool = False):
+def _conv3x3(x: torch.Tensor, pack: _Pack, bias, gn=None, ss=None, stats=None, want_stats: bool = False, res=None):
     """one mi_conv_fwd launch: out = conv3x3(act(x)) + bias with act = SiLU(GroupNorm(x) * (scale + 1) + shift) when ``gn`` is given"""
     lib = L.lib()
     B, Cin, H, W = x.shape
@@ -261,6 +261,10 @@ def _conv3x3(x: torch.Tensor, pack: _Pack, bias, gn=None, ss=None, stats=None, w
         if ss is not None:
             p.scale_shift, p.ss_stride, p.ss_off = ss.data_ptr(), ss.shape[1], 0
     rp = pack.rp and W % 4 == 0
+    if res is not None:             # identity residual added in the epilogue (row-paired narrow family only: residual_fusable); out_stats describe the SUM
+        assert rp and Cin <= 64 and Cout <= 32 and res.shape == out.shape and res.is_contiguous()
+        p.res0 = L.MiAct(res.data_ptr(), Cout, 0, 0, 1.0, 0, 0)
+        keep.append(res)
     if rp:
         wide = not (Cin <= 64 and Cout <= 32)
         cfg = 6
@@ -339,7 +343,7 @@ class _BlockFn(torch.autograd.Function):
     operand staging.  Saved for the backward: the block's input, its channel statistics and the scale|shift table -- nothing else."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, scale, shift, weight, bias, groups, eps, x_stats):
+    def forward(ctx, x, gamma, beta, scale, shift, weight, bias, groups, eps, x_stats, residual=None):
         x = x.contiguous()
         fwd, _ = _packs(weight)
         g, b = gamma.detach().contiguous(), beta.detach().contiguous()
@@ -348,8 +352,10 @@ class _BlockFn(torch.autograd.Function):
             B = x.shape[0]
             ss = torch.cat((scale.detach().reshape(B, -1), shift.detach().reshape(B, -1)), 1).contiguous()
         stats = x_stats if x_stats is not None else _chan_stats(x)        # left by the producing Block's epilogue, or one statistics pass
-        out, out_stats = _conv3x3(x, fwd, None if bias is None else bias.detach(), gn=(g, b, groups, eps), ss=ss, stats=stats, want_stats=True)
+        out, out_stats = _conv3x3(x, fwd, None if bias is None else bias.detach(), gn=(g, b, groups, eps), ss=ss, stats=stats, want_stats=True,
+                                  res=None if residual is None else residual.detach())
         ctx.save_for_backward(x, g, b, ss, stats, weight)
+        ctx.has_res = residual is not None
         ctx.groups, ctx.eps, ctx.has_bias, ctx.ss_shape = groups, eps, bias is not None, (None if scale is None else scale.shape)
         ctx.mark_non_differentiable(out_stats)
         return out, out_stats
@@ -373,7 +379,7 @@ class _BlockFn(torch.autograd.Function):
             dw, db = _wgrad(x, dy, ctx.has_bias and need[6], act=(stats, gamma, beta, ctx.groups, ctx.eps, ss))
         pick = lambda g, n: g if n else None
         return (pick(dx, need[0]), pick(dgamma, need[1]), pick(dbeta, need[2]), pick(dscale, need[3]), pick(dshift, need[4]),
-                pick(dw, need[5]), db, None, None, None)
+                pick(dw, need[5]), db, None, None, None, (dy if (ctx.has_res and need[10]) else None))
 
 
 class _ConvFn(torch.autograd.Function):
@@ -609,19 +615,32 @@ def layer_norm(x: torch.Tensor, weight, bias, eps: float = 1e-5) -> torch.Tensor
     return torch.nn.functional.layer_norm(x, x.shape[-1:], weight, bias, eps)
 
 
-def block_forward(block, x: torch.Tensor, scale_shift=None) -> torch.Tensor:
-    """``Block.forward`` (layers.py:131-145) through _BlockFn"""
+def residual_fusable(block, x: torch.Tensor, residual) -> bool:
+    """the conv epilogue can add ``residual`` (ResnetBlock: h + res_conv(x), layers.py:439): narrow row-paired family, same shape, fp32, contiguous"""
+    conv = block.project
+    return (residual is not None and isinstance(block.groupnorm, torch.nn.GroupNorm) and conv.in_channels % 8 == 0 and x.shape[-1] % 4 == 0
+            and conv.in_channels <= 64 and conv.out_channels <= 32 and residual.dtype == torch.float32 and residual.is_contiguous()
+            and tuple(residual.shape) == (x.shape[0], conv.out_channels, x.shape[2], x.shape[3]))
+
+
+def block_forward(block, x: torch.Tensor, scale_shift=None, residual=None) -> torch.Tensor:
+    """``Block.forward`` (layers.py:131-145) through _BlockFn; ``residual`` (optional) is added to the output -- in the conv's epilogue where the
+    kernel family allows (one launch and one statistics pass less per ResnetBlock: the next Block reads the statistics of the SUM)"""
     gnm = block.groupnorm
     conv = block.project
     scale, shift = scale_shift if scale_shift is not None else (None, None)
     if not isinstance(gnm, torch.nn.GroupNorm):             # Block(norm=False): not a layer of the reference's U-Nets; keep the semantics
         h = x if scale is None else x * (scale + 1) + shift
-        return _ConvFn.apply(F.silu(h), conv.weight, conv.bias)
+        out = _ConvFn.apply(F.silu(h), conv.weight, conv.bias)
+        return out if residual is None else out + residual
     # statistics handed over by the Block that produced x (block1 -> block2 of a ResnetBlock without cross-attention): valid for this very tensor
     # object while it has not been written since
     tag = getattr(x, "_mi_stats", None)
     x_stats = tag[0] if (tag is not None and tag[1] == x._version and x.is_contiguous() and tag[0].shape[:2] == x.shape[:2]) else None
-    out, out_stats = _BlockFn.apply(x, gnm.weight, gnm.bias, scale, shift, conv.weight, conv.bias, gnm.num_groups, gnm.eps, x_stats)
+    fuse = residual_fusable(block, x, residual)
+    out, out_stats = _BlockFn.apply(x, gnm.weight, gnm.bias, scale, shift, conv.weight, conv.bias, gnm.num_groups, gnm.eps, x_stats, residual if fuse else None)
+    if residual is not None and not fuse:
+        return out + residual
     out._mi_stats = (out_stats, out._version)
     return out
 
