@@ -98,7 +98,9 @@ def _packs(weight: torch.Tensor, exp=None):
 
 
 def begin_step(module: torch.nn.Module):
-    """Once per training step: re-pack every conv weight under ``module`` whose VALUES changed.  The version counter and the storage pointer
+    """Once per training step.  Weights on the GPU (default): ``_begin_step_lagged`` -- every pack rebuilt from the current values by ONE launch, the
+    fragment scaling from the previous step's asynchronously copied maxima, no host / GPU synchronisation.  Host tensors (the emulator) and
+    MINIMAGEN_TRAIN_LAGGED_SCALES=0: re-pack every conv weight under ``module`` whose VALUES changed.  The version counter and the storage pointer
     (``_pack_key``) miss updates made through ``p.data`` (EMA copy-in, ``.data.mul_`` / ``.data.copy_``, hand-written SGD, an optimiser step
     replayed from a captured graph), so every weight also carries a content fingerprint (max |w|, ||w||_2): two fused multi-tensor launches
     and ONE device -> host copy for all layers -- the same copy that brings the exponents of the weights that need a new pack."""

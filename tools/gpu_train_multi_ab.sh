@@ -1,3 +1,7 @@
+#!/bin/bash
+# one box: GPU tests of the training path and the host-side ABI checks, the SR training step (bench.py --train-step-only) twice, then the host profile of
+# the step (tools/gpu_train_hostprof.py: time to issue ten steps against the time with the GPU drained, cProfile of the calling thread)
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out/train_multi; out=gpurun_out/train_multi
 timeout 1200 python -m pytest tests/test_training.py tests/test_training_loop.py tests/test_host.py -x -q -m gpu -p no:cacheprovider > $out/pytest.log 2>&1; echo "pytest rc=$?"; tail -3 $out/pytest.log
 for tag in a b; do
